@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's dilithium-256/ interface on batches.
+
+Same names, argument meaning and in-place behaviour as the reference functions
+(ref_ntt.h:30-36, ref_ntt2x2.h:31-33, ntt2x2.h:30-34), lifted from one `data_t[256]` to a
+dense batch `[..., 256]`:
+
+  * torch CUDA int32 tensors  -> device entry points (asynchronous, on torch's current stream)
+  * numpy int32 arrays        -> host entry points (synchronous H2D / kernel / D2H)
+
+All results are canonical residues in [0, q).  There is no CPU implementation here: without
+the HIP library and a GPU every call raises DilError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from . import LEVELS, N
+
+try:  # torch is plumbing (device memory, streams); numpy-only use does not need it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_tensor(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=None, name="tensor"):
+    if not (t.is_cuda and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous CUDA tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must have dtype {dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _batch(t):
+    n = t.numel() if _is_tensor(t) else t.size
+    if n % N:
+        raise ValueError("size must be a multiple of 256")
+    return n // N
+
+
+def _np(a):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.int32 and a.flags.c_contiguous):
+        raise ValueError("expected a C-contiguous numpy int32 array")
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def init(device: int = -1) -> None:
+    _lib.check(_lib.load().dil_init(device), "dil_init")
+
+
+# ---- H2/H3/H5 -----------------------------------------------------------------------------------
+def ntt(a):
+    """in-place forward NTT of every polynomial of `a` (ref_ntt.cpp:28-47)"""
+    L = _lib.load()
+    if _is_tensor(a):
+        _lib.check(L.dil_ntt_dev(_dev(a, torch.int32, "a"), _batch(a), _stream()), "dil_ntt_dev")
+    else:
+        _lib.check(L.dil_ntt_host(_np(a), _batch(a)), "dil_ntt_host")
+    return a
+
+
+def invntt(a):
+    """in-place inverse NTT incl. the 256^-1 scaling (ref_ntt.cpp:59-87)"""
+    L = _lib.load()
+    if _is_tensor(a):
+        _lib.check(L.dil_invntt_dev(_dev(a, torch.int32, "a"), _batch(a), _stream()), "dil_invntt_dev")
+    else:
+        _lib.check(L.dil_invntt_host(_np(a), _batch(a)), "dil_invntt_host")
+    return a
+
+
+# the radix-2x2 reference computes the same maps (ref_ntt2x2.cpp:37-82,100-145)
+ntt2x2_ref = ntt
+invntt2x2_ref = invntt
+
+
+def pointwise_barrett(c, a, b):
+    """c = a o b (ref_ntt.cpp:49-57); c may alias a"""
+    L = _lib.load()
+    if _is_tensor(a):
+        _lib.check(L.dil_pointwise_dev(_dev(c, torch.int32), _dev(a, torch.int32), _dev(b, torch.int32),
+                                       _batch(a), _stream()), "dil_pointwise_dev")
+    else:
+        _lib.check(L.dil_pointwise_host(_np(c), _np(a), _np(b), _batch(a)), "dil_pointwise_host")
+    return c
+
+
+def pointwise_acc(c, acc, a, b):
+    """c = acc + a o b : the RTL's MULT mode is a multiply-accumulate (butterfly.v:144-150)"""
+    _lib.check(_lib.load().dil_pointwise_acc_dev(_dev(c, torch.int32), _dev(acc, torch.int32), _dev(a, torch.int32),
+                                                 _dev(b, torch.int32), _batch(a), _stream()), "dil_pointwise_acc_dev")
+    return c
+
+
+def poly_add(c, a, b):
+    _lib.check(_lib.load().dil_poly_add_dev(_dev(c, torch.int32), _dev(a, torch.int32), _dev(b, torch.int32),
+                                            _batch(a), _stream()), "dil_poly_add_dev")
+    return c
+
+
+def poly_sub(c, a, b):
+    _lib.check(_lib.load().dil_poly_sub_dev(_dev(c, torch.int32), _dev(a, torch.int32), _dev(b, torch.int32),
+                                            _batch(a), _stream()), "dil_poly_sub_dev")
+    return c
+
+
+# ---- H6: hardware-model API on bram ([..., 64, 4]) ---------------------------------------------
+def ntt2x2_fwdntt(ram, mapping):
+    L = _lib.load()
+    if _is_tensor(ram):
+        _lib.check(L.dil_bram_fwdntt_dev(_dev(ram, torch.int32), _batch(ram), int(mapping), _stream()), "dil_bram_fwdntt_dev")
+    else:
+        _lib.check(L.dil_bram_fwdntt_host(_np(ram), _batch(ram), int(mapping)), "dil_bram_fwdntt_host")
+    return ram
+
+
+def ntt2x2_invntt(ram, mapping):
+    L = _lib.load()
+    if _is_tensor(ram):
+        _lib.check(L.dil_bram_invntt_dev(_dev(ram, torch.int32), _batch(ram), int(mapping), _stream()), "dil_bram_invntt_dev")
+    else:
+        _lib.check(L.dil_bram_invntt_host(_np(ram), _batch(ram), int(mapping)), "dil_bram_invntt_host")
+    return ram
+
+
+def ntt2x2_mul(ram, mul_ram, mapping):
+    L = _lib.load()
+    if _is_tensor(ram):
+        _lib.check(L.dil_bram_mul_dev(_dev(ram, torch.int32), _dev(mul_ram, torch.int32), _batch(ram), int(mapping),
+                                      _stream()), "dil_bram_mul_dev")
+    else:
+        _lib.check(L.dil_bram_mul_host(_np(ram), _np(mul_ram), _batch(ram), int(mapping)), "dil_bram_mul_host")
+    return ram
+
+
+# ---- H8-H10: fused Dilithium pipelines (device tensors only) -------------------------------------
+def _kl(level):
+    if level not in LEVELS:
+        raise ValueError("level must be 2, 3 or 5")
+    return LEVELS[level]
+
+
+def matvec(A, y, level, shared_A=False, out=None):
+    """w = INTT(A o NTT(y)); A [B|1,K,L,256], y [B,L,256] -> w [B,K,256]"""
+    K, Lv = _kl(level)
+    B = y.numel() // (Lv * N)
+    w = out if out is not None else torch.empty((B, K, N), dtype=torch.int32, device=y.device)
+    _lib.check(_lib.load().dil_matvec_dev(_dev(w, torch.int32), _dev(A, torch.int32), _dev(y, torch.int32), level, B,
+                                          int(shared_A), _stream()), "dil_matvec_dev")
+    return w
+
+
+def verify_core(A, z, c, t1, h, level, shared_pk=False, out=None):
+    """w1 = UseHint(h, INTT(A o NTT(z) - NTT(c) o NTT(t1 2^13))) -> uint8 [B,K,256]"""
+    K, Lv = _kl(level)
+    B = z.numel() // (Lv * N)
+    w1 = out if out is not None else torch.empty((B, K, N), dtype=torch.uint8, device=z.device)
+    _lib.check(_lib.load().dil_verify_core_dev(_dev(w1, torch.uint8), _dev(A, torch.int32), _dev(z, torch.int32),
+                                               _dev(c, torch.int32), _dev(t1, torch.int32), _dev(h, torch.uint8),
+                                               level, B, int(shared_pk), _stream()), "dil_verify_core_dev")
+    return w1
+
+
+def sign_phase1(A, y, level, shared_key=False):
+    K, Lv = _kl(level)
+    B = y.numel() // (Lv * N)
+    w1 = torch.empty((B, K, N), dtype=torch.uint8, device=y.device)
+    w0 = torch.empty((B, K, N), dtype=torch.int32, device=y.device)
+    _lib.check(_lib.load().dil_sign_phase1_dev(_dev(w1, torch.uint8), _dev(w0, torch.int32), _dev(A, torch.int32),
+                                               _dev(y, torch.int32), level, B, int(shared_key), _stream()),
+               "dil_sign_phase1_dev")
+    return w1, w0
+
+
+def sign_phase2(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False):
+    K, Lv = _kl(level)
+    B = y.numel() // (Lv * N)
+    z = torch.empty((B, Lv, N), dtype=torch.int32, device=y.device)
+    h = torch.empty((B, K, N), dtype=torch.uint8, device=y.device)
+    flags = torch.empty((B,), dtype=torch.int32, device=y.device)
+    _lib.check(_lib.load().dil_sign_phase2_dev(_dev(z, torch.int32), _dev(h, torch.uint8), _dev(flags, torch.int32),
+                                               _dev(c, torch.int32), _dev(y, torch.int32), _dev(w0, torch.int32),
+                                               _dev(w1, torch.uint8), _dev(s1hat, torch.int32), _dev(s2hat, torch.int32),
+                                               _dev(t0hat, torch.int32), level, B, int(shared_key), _stream()),
+               "dil_sign_phase2_dev")
+    return z, h, flags

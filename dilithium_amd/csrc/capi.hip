@@ -1,0 +1,360 @@
+// capi.hip -- the extern "C" boundary of libdil256.so (declared in include/dil256.h) and the
+// host runtime behind it: twiddle-table construction, device selection, scratch management
+// for the host-pointer entry points.  Host language is C++ because the reference's
+// dilithium-256/ is C++; nothing here is a CPU fallback -- every arithmetic entry
+// point launches a HIP kernel and returns the hipError_t if that is not possible.
+#include "../../include/dil256.h"
+#include "kernels.hpp"
+
+#include <mutex>
+#include <string.h>
+
+namespace {
+
+constexpr int64_t Q = DIL_Q;
+
+// ---- twiddles: zeta^brv8(k), zeta = 1753 (consts.cpp:64-97; zetas.txt holds them mod q) ----
+unsigned brv8(unsigned x)
+{
+    unsigned r = 0;
+    for (int i = 0; i < 8; i++) r |= ((x >> i) & 1u) << (7 - i);
+    return r;
+}
+int64_t powmod(int64_t b, unsigned e)
+{
+    int64_t r = 1;
+    for (b %= Q; e; e >>= 1, b = b * b % Q)
+        if (e & 1) r = r * b % Q;
+    return r;
+}
+void canonical_zetas(uint32_t z[256])
+{
+    z[0] = 0;
+    for (unsigned k = 1; k < 256; k++) z[k] = (uint32_t)powmod(1753, brv8(k));
+}
+inline uint32_t shoup24(uint32_t w) { return (uint32_t)(((uint64_t)w << 24) / (uint64_t)Q); }
+
+// forward: pass p, lane -> k1 = 4^p + (lane >> (6 - 2p)); entry {z[k1], ', z[2k1], ', z[2k1+1], ', 0, 0}
+//          (ref_ntt2x2.cpp:50-55 == twiddle_resolver.v:106-130 under the lane layout of ntt_core.hpp)
+// inverse: pass p, block t = lane >> 2p (0 in the last pass), base = 256 >> 2p:
+//          ka = base-1-2t, ka-1, kb = base/2-1-t, each negated (ref_ntt2x2.cpp:113-118 ==
+//          twiddle_resolver.v:87-105); last pass: wb *= 256^-1 and f = 256^-1 rides in slots 6,7
+void build_tables(uint32_t* fwd, uint32_t* inv)
+{
+    uint32_t z[256];
+    canonical_zetas(z);
+    const uint32_t f = 8347681u;
+    for (int p = 0; p < 4; p++) {
+        for (int lane = 0; lane < 64; lane++) {
+            uint32_t* e = fwd + (p * 64 + lane) * 8;
+            const unsigned k1 = (1u << (2 * p)) + ((unsigned)lane >> (6 - 2 * p));
+            const uint32_t wf[3] = {z[k1], z[2 * k1], z[2 * k1 + 1]};
+            for (int i = 0; i < 3; i++) {
+                e[2 * i] = wf[i];
+                e[2 * i + 1] = shoup24(wf[i]);
+            }
+            e[6] = e[7] = 0;
+
+            uint32_t* d = inv + (p * 64 + lane) * 8;
+            const unsigned t = (p < 3) ? ((unsigned)lane >> (2 * p)) : 0u;
+            const unsigned base = 256u >> (2 * p);
+            const unsigned ka = base - 1 - 2 * t, kb = (base >> 1) - 1 - t;
+            uint32_t wi[4] = {(uint32_t)((Q - z[ka]) % Q), (uint32_t)((Q - z[ka - 1]) % Q),
+                              (uint32_t)((Q - z[kb]) % Q), f};
+            if (p == 3) wi[2] = (uint32_t)((uint64_t)wi[2] * f % (uint64_t)Q);
+            for (int i = 0; i < 4; i++) {
+                d[2 * i] = wi[i];
+                d[2 * i + 1] = shoup24(wi[i]);
+            }
+        }
+    }
+}
+
+struct State {
+    std::mutex mu;
+    bool ready = false;
+    int device = -1;
+    uint32_t* d_tables = nullptr;   // fwd | inv
+    dil::Tables t;
+    void* scratch = nullptr;        // for *_host entry points
+    size_t scratch_bytes = 0;
+};
+State g;
+
+#define DIL_TRY(expr)                          \
+    do {                                       \
+        hipError_t e__ = (expr);               \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+int ensure_init()
+{
+    if (g.ready) return 0;
+    return dil_init(-1);
+}
+
+int ensure_scratch(size_t bytes)
+{
+    if (bytes <= g.scratch_bytes) return 0;
+    if (g.scratch) {
+        DIL_TRY(hipFree(g.scratch));
+        g.scratch = nullptr;
+        g.scratch_bytes = 0;
+    }
+    DIL_TRY(hipMalloc(&g.scratch, bytes));
+    g.scratch_bytes = bytes;
+    return 0;
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// host wrapper: copy n polys in, run fn on the device copy, copy back
+template <class F>
+int host_inplace(int32_t* h, size_t batch, F&& fn)
+{
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    const size_t bytes = batch * 1024;
+    rc = ensure_scratch(bytes);
+    if (rc) return rc;
+    DIL_TRY(hipMemcpy(g.scratch, h, bytes, hipMemcpyHostToDevice));
+    rc = fn(static_cast<int32_t*>(g.scratch));
+    if (rc) return rc;
+    DIL_TRY(hipDeviceSynchronize());
+    DIL_TRY(hipMemcpy(h, g.scratch, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void dil_host_twiddle_tables(uint32_t* fwd, uint32_t* inv) { build_tables(fwd, inv); }
+
+void dil_host_zetas(int32_t* zetas)
+{
+    uint32_t z[256];
+    canonical_zetas(z);
+    for (int k = 0; k < 256; k++) zetas[k] = (int32_t)(z[k] > (uint32_t)(Q - 1) / 2 ? (int64_t)z[k] - Q : z[k]);
+}
+
+int dil_device_count(int* count) { return (int)hipGetDeviceCount(count); }
+
+int dil_num_cus(void) { return g.ready ? g.t.num_cus : -1; }
+
+const char* dil_error_string(int code) { return hipGetErrorString((hipError_t)code); }
+
+int dil_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    int cur = 0;
+    if (device < 0) {
+        DIL_TRY(hipGetDevice(&cur));
+        device = cur;
+    }
+    if (g.ready && g.device == device) return 0;
+    DIL_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    DIL_TRY(hipGetDeviceProperties(&prop, device));
+    if (g.d_tables) {
+        (void)hipFree(g.d_tables);
+        g.d_tables = nullptr;
+    }
+    if (g.scratch) {
+        (void)hipFree(g.scratch);
+        g.scratch = nullptr;
+        g.scratch_bytes = 0;
+    }
+    static uint32_t h_tab[2 * 2048];
+    build_tables(h_tab, h_tab + 2048);
+    DIL_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_tables), sizeof(h_tab)));
+    DIL_TRY(hipMemcpy(g.d_tables, h_tab, sizeof(h_tab), hipMemcpyHostToDevice));
+    g.t.fwd = g.d_tables;
+    g.t.inv = g.d_tables + 2048;
+    g.t.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g.device = device;
+    g.ready = true;
+    return 0;
+}
+
+int dil_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.ready) return 0;
+    if (g.d_tables) (void)hipFree(g.d_tables);
+    if (g.scratch) (void)hipFree(g.scratch);
+    g.d_tables = nullptr;
+    g.scratch = nullptr;
+    g.scratch_bytes = 0;
+    g.ready = false;
+    return 0;
+}
+
+// ---- transforms ---------------------------------------------------------------------------
+int dil_ntt_dev(int32_t* polys, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, polys, batch, g.t, S(stream));
+}
+int dil_invntt_dev(int32_t* polys, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, polys, batch, g.t, S(stream));
+}
+int dil_ntt_host(int32_t* polys, size_t batch)
+{
+    return host_inplace(polys, batch, [&](int32_t* d) { return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, d, batch, g.t, 0); });
+}
+int dil_invntt_host(int32_t* polys, size_t batch)
+{
+    return host_inplace(polys, batch, [&](int32_t* d) { return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, d, batch, g.t, 0); });
+}
+
+// ---- element-wise ---------------------------------------------------------------------------
+int dil_pointwise_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_pointwise(dil::OP_MUL, c, a, b, nullptr, batch, g.t, S(stream));
+}
+int dil_pointwise_acc_dev(int32_t* c, const int32_t* acc, const int32_t* a, const int32_t* b, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_pointwise(dil::OP_MAC, c, a, b, acc, batch, g.t, S(stream));
+}
+int dil_poly_add_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_pointwise(dil::OP_ADD, c, a, b, nullptr, batch, g.t, S(stream));
+}
+int dil_poly_sub_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_pointwise(dil::OP_SUB, c, a, b, nullptr, batch, g.t, S(stream));
+}
+int dil_pointwise_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
+{
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    const size_t bytes = batch * 1024;
+    rc = ensure_scratch(2 * bytes);
+    if (rc) return rc;
+    int32_t* da = static_cast<int32_t*>(g.scratch);
+    int32_t* db = da + batch * 256;
+    DIL_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    DIL_TRY(dil::launch_pointwise(dil::OP_MUL, da, da, db, nullptr, batch, g.t, 0));
+    DIL_TRY(hipDeviceSynchronize());
+    DIL_TRY(hipMemcpy(c, da, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- bram (hardware-model API) -----------------------------------------------------------------
+static int check_mapping(int m) { return (m < 0 || m > 2) ? (int)hipErrorInvalidValue : 0; }
+
+int dil_bram_fwdntt_dev(int32_t* ram, size_t batch, int mapping, void* stream)
+{
+    int rc = ensure_init();
+    if (rc || (rc = check_mapping(mapping))) return rc;
+    return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, ram, batch, g.t, S(stream));
+}
+int dil_bram_invntt_dev(int32_t* ram, size_t batch, int mapping, void* stream)
+{
+    int rc = ensure_init();
+    if (rc || (rc = check_mapping(mapping))) return rc;
+    return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, ram, batch, g.t, S(stream));
+}
+int dil_bram_mul_dev(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, void* stream)
+{
+    int rc = ensure_init();
+    if (rc || (rc = check_mapping(mapping))) return rc;
+    return (int)dil::launch_bram_mul(ram, mul_ram, batch, mapping, g.t, S(stream));
+}
+int dil_bram_fwdntt_host(int32_t* ram, size_t batch, int mapping)
+{
+    int rc = check_mapping(mapping);
+    if (rc) return rc;
+    return host_inplace(ram, batch, [&](int32_t* d) { return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, d, batch, g.t, 0); });
+}
+int dil_bram_invntt_host(int32_t* ram, size_t batch, int mapping)
+{
+    int rc = check_mapping(mapping);
+    if (rc) return rc;
+    return host_inplace(ram, batch, [&](int32_t* d) { return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, d, batch, g.t, 0); });
+}
+int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping)
+{
+    if (batch == 0) return 0;
+    int rc = check_mapping(mapping);
+    if (rc || (rc = ensure_init())) return rc;
+    std::lock_guard<std::mutex> lk(g.mu);
+    const size_t bytes = batch * 1024;
+    rc = ensure_scratch(2 * bytes);
+    if (rc) return rc;
+    int32_t* da = static_cast<int32_t*>(g.scratch);
+    int32_t* db = da + batch * 256;
+    DIL_TRY(hipMemcpy(da, ram, bytes, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(db, mul_ram, bytes, hipMemcpyHostToDevice));
+    DIL_TRY(dil::launch_bram_mul(da, db, batch, mapping, g.t, 0));
+    DIL_TRY(hipDeviceSynchronize());
+    DIL_TRY(hipMemcpy(ram, da, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- fused pipelines ---------------------------------------------------------------------------
+int dil_matvec_dev(int32_t* w, const int32_t* A, const int32_t* y, int level, size_t batch, int shared_A, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, y, batch, shared_A, g.t, S(stream));
+}
+int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
+                        const uint8_t* h, int level, size_t batch, int shared_pk, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, g.t, S(stream));
+}
+int dil_sign_phase1_dev(uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y, int level, size_t batch,
+                        int shared_key, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_matvec(level, dil::OUT_W1W0, nullptr, w1, w0, A, y, batch, shared_key, g.t, S(stream));
+}
+int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, const int32_t* w0,
+                        const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
+                        size_t batch, int shared_key, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, S(stream));
+}
+
+// ---- events --------------------------------------------------------------------------------------
+int dil_event_create(void** ev)
+{
+    hipEvent_t e;
+    DIL_TRY(hipEventCreate(&e));
+    *ev = e;
+    return 0;
+}
+int dil_event_destroy(void* ev) { return (int)hipEventDestroy(static_cast<hipEvent_t>(ev)); }
+int dil_event_record(void* ev, void* stream) { return (int)hipEventRecord(static_cast<hipEvent_t>(ev), S(stream)); }
+int dil_event_elapsed_ms(float* ms, void* start, void* stop)
+{
+    DIL_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+    return (int)hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop));
+}
+int dil_stream_sync(void* stream) { return (int)hipStreamSynchronize(S(stream)); }
+
+}  // extern "C"

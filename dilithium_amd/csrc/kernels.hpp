@@ -1,0 +1,32 @@
+// kernels.hpp -- launcher interface between the C-ABI (capi.hip) and the kernels (kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dil {
+
+enum { MAP_NATURAL = 0, MAP_AFTER_NTT = 1, MAP_AFTER_INVNTT = 2 };   // config.h:45-50 (enum MAPPING)
+enum { LAYOUT_POLY = 0, LAYOUT_BRAM = 1 };
+enum { OP_MUL = 0, OP_MAC = 1, OP_ADD = 2, OP_SUB = 3 };              // butterfly.v modes MULT / ADD / SUB
+enum { OUT_W = 0, OUT_W1W0 = 1 };
+
+struct Tables {
+    const uint32_t* fwd = nullptr;   // device, [4][64][8]
+    const uint32_t* inv = nullptr;   // device, [4][64][8]
+    int num_cus = 256;
+};
+
+hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, size_t batch, const Tables& t, hipStream_t s);
+hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t* b, const int32_t* acc, size_t batch,
+                            const Tables& t, hipStream_t s);
+hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);
+hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
+                         size_t batch, int shared_A, const Tables& t, hipStream_t s);
+hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
+                         const uint8_t* h, size_t batch, int shared_pk, const Tables& t, hipStream_t s);
+hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
+                        const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
+                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s);
+
+}  // namespace dil

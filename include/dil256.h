@@ -1,0 +1,121 @@
+/*
+ * dil256.h -- C-ABI of libdil256.so: the MI355X (gfx950) drop-in for the NTT hot path of
+ * GMUCERG/Dilithium's dilithium-256/ C++ code and of the polynomial-ALU sequences of its RTL.
+ *
+ * Plain C: pointers, sizes, ints.  No torch / C++ types.  Every entry point returns 0 on
+ * success or a hipError_t value (see dil_error_string).  Callers own every buffer; the library
+ * never retains, frees or reallocates them (the reference's ownership rule: fixed-size,
+ * in-place, caller-owned -- ref_ntt.h:30-36, ntt2x2.h:30-34).
+ *
+ * Data model
+ *   polynomial  = int32_t[256] = 1024 B          (data_t[DILITHIUM_N], params.h:30-35)
+ *   bram        = int32_t[64][4], row r = coefficients 4r..4r+3   (config.h:29-36, util.cpp:61-72)
+ *   batches are dense arrays of polynomials: [batch][256], [batch][L][256], [batch][K][L][256] ...
+ *   *_dev entry points take DEVICE pointers + a hipStream_t (as void*, NULL = default stream)
+ *   and are asynchronous; *_host entry points take host pointers and are synchronous
+ *   (H2D copy, kernel, D2H copy).
+ * Value domain
+ *   time-domain inputs (a, y, z, c, w0): any int32 in [-q, 2^31); NTT-domain inputs
+ *   (A, s1hat, s2hat, t0hat, b of pointwise ops) in (-q, q) for the pointwise ops and canonical
+ *   [0, q) for the fused pipelines.  ALL outputs are canonical residues in [0, q) -- the RTL's
+ *   convention (butterfly.v:194-195); the reference C++ returns (-q, q) and its own tests
+ *   compare canonically (util.cpp:98-112, ref_test_ntt_ntt2x2.cpp:31-42).
+ */
+#ifndef DIL256_H
+#define DIL256_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIL_Q 8380417
+#define DIL_N 256
+
+/* enum MAPPING of the hardware model (config.h:45-50) */
+#define DIL_MAP_NATURAL 0
+#define DIL_MAP_AFTER_NTT 1
+#define DIL_MAP_AFTER_INVNTT 2
+
+/* ---- life cycle --------------------------------------------------------------------- */
+/* Select `device`, build + upload the twiddle tables (derived from zeta = 1753; identical
+ * to consts.cpp:64-97 / zetas.txt mod q).  Idempotent; -1 = keep the current device. */
+int dil_init(int device);
+int dil_shutdown(void);
+int dil_device_count(int* count);
+int dil_num_cus(void);
+const char* dil_error_string(int code);
+/* Host-only (no GPU needed): the twiddle tables the kernels use, [4 passes][64 lanes][8] uint32
+ * each; and the plain 256-entry table (zetas_barrett of consts.h:30, centred). */
+void dil_host_twiddle_tables(uint32_t* fwd /*2048*/, uint32_t* inv /*2048*/);
+void dil_host_zetas(int32_t* zetas /*256*/);
+
+/* ---- H2/H3/H5: batched transforms, in place, [batch][256] ------------------------------
+ * dil_ntt_*    == ntt() / ntt2x2_ref()        (ref_ntt.cpp:28-47, ref_ntt2x2.cpp:37-82)
+ * dil_invntt_* == invntt() / invntt2x2_ref()  (ref_ntt.cpp:59-87, ref_ntt2x2.cpp:100-145) */
+int dil_ntt_dev(int32_t* polys, size_t batch, void* stream);
+int dil_invntt_dev(int32_t* polys, size_t batch, void* stream);
+int dil_ntt_host(int32_t* polys, size_t batch);
+int dil_invntt_host(int32_t* polys, size_t batch);
+
+/* ---- H4 + butterfly.v MULT(-ACC)/ADD/SUB modes: element-wise on [batch][256] ------------
+ * pointwise: c = a*b (pointwise_barrett, ref_ntt.cpp:49-57; c may alias a or b)
+ * mac:       c = acc + a*b (butterfly.v:144-150,224-230; c may alias acc)
+ * add / sub: c = a +- b (butterfly.v ADD_MODE / SUB_MODE) */
+int dil_pointwise_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream);
+int dil_pointwise_acc_dev(int32_t* c, const int32_t* acc, const int32_t* a, const int32_t* b, size_t batch, void* stream);
+int dil_poly_add_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream);
+int dil_poly_sub_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream);
+int dil_pointwise_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batch);
+
+/* ---- H6: the hardware-model API on `bram` ([batch][64][4]) -----------------------------
+ * `mapping` is the model's address translation (address_encoder_decoder.cpp:34-55).
+ * fwd: NATURAL in -> AFTER_NTT out (ntt2x2_fwdntt.cpp:32-157, ntt2x2_test.cpp:41-58)
+ * inv: NATURAL -> AFTER_INVNTT, AFTER_NTT -> NATURAL (ntt2x2_invntt.cpp:38-161, ntt2x2_test.cpp:64-81,129-132)
+ * mul: ram[map(l)][k] *= mul_ram[l][k] (ntt2x2_mul.cpp:33-59) */
+int dil_bram_fwdntt_dev(int32_t* ram, size_t batch, int mapping, void* stream);
+int dil_bram_invntt_dev(int32_t* ram, size_t batch, int mapping, void* stream);
+int dil_bram_mul_dev(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, void* stream);
+int dil_bram_fwdntt_host(int32_t* ram, size_t batch, int mapping);
+int dil_bram_invntt_host(int32_t* ram, size_t batch, int mapping);
+int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping);
+
+/* ---- H9: mat-vec  w[k] = INTT(sum_l A[k][l] o NTT(y[l]))  (combined_top.v:1850-1933) -----
+ * level in {2,3,5} selects (K,L) = (4,4)/(6,5)/(8,7).  A: [batch|1][K][L][256] NTT domain,
+ * row-major as the RTL stores it (combined_top.v:1370); shared_A != 0 -> one A for the batch.
+ * y: [batch][L][256]; w: [batch][K][256]. */
+int dil_matvec_dev(int32_t* w, const int32_t* A, const int32_t* y, int level, size_t batch, int shared_A, void* stream);
+
+/* ---- H8: verify core (combined_top.v:1207-1469) -----------------------------------------
+ * w1[k] = UseHint(h[k], INTT(sum_l A[k][l] o NTT(z[l]) - NTT(c) o NTT(t1[k] * 2^13)))
+ * z: [batch][L][256]; c: [batch][256] (+-1 as 1 / q-1 or -1); t1: [batch|1][K][256] 10-bit,
+ * UNscaled (the 2^13 of decoder.v:96-100 is applied on device); h: [batch][K][256] bytes 0/1;
+ * w1 out: [batch][K][256] bytes (values < 44 / < 16).  shared_pk != 0 -> one (A, t1). */
+int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
+                        const uint8_t* h, int level, size_t batch, int shared_pk, void* stream);
+
+/* ---- H10: sign inner loop (combined_top.v:1830-2229) --------------------------------------
+ * phase 1 (FSM1 + DECOMP): w = INTT(A o NTT(y)); (w1, w0) = Decompose(w); w0 as residue in [0,q).
+ * phase 2 (FSM2): z = y + c*s1, r0 = w0 - c*s2, ct0 = c*t0, h = MakeHint(r0 + ct0, w1);
+ *   flags[i]: bit0 ||z|| >= gamma1-beta, bit1 ||r0|| >= gamma2-beta, bit2 ||ct0|| >= gamma2,
+ *   bit3 #hints > omega  (norm_check.v:84-105, makehint.v:98-99,176-177); 0 = accept.
+ * s1hat [batch|1][L][256], s2hat / t0hat [batch|1][K][256]: NTT domain, canonical. */
+int dil_sign_phase1_dev(uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y, int level, size_t batch,
+                        int shared_key, void* stream);
+int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, const int32_t* w0,
+                        const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
+                        size_t batch, int shared_key, void* stream);
+
+/* ---- timing helpers (hipEvent on the caller's stream; used by bench.py) ------------------ */
+int dil_event_create(void** ev);
+int dil_event_destroy(void* ev);
+int dil_event_record(void* ev, void* stream);
+int dil_event_elapsed_ms(float* ms, void* start, void* stop);   /* synchronises on `stop` */
+int dil_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIL256_H */
