@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json metric on MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[1] -- batched forward + inverse NTT,
+n = 256, q = 8380417, batch = 65536 polynomials per GPU (64 MiB).  One STEP = one forward-NTT
+launch + one inverse-NTT launch over one batch = 131072 transforms.  Inputs are resident in
+HBM before the timed region; steps rotate over --rotate distinct batches (default 8 = 512 MiB,
+twice the 256 MiB Infinity Cache) so that the number is an HBM-streaming number and not an
+L3-resident one (the L3-resident rate is reported beside it as `llc_resident_value`).
+metric value = transforms / second over all GPUs (weak scaling: per-GPU work fixed).
+
+Also reported on the same JSON line:
+  roofline      dominant kernel (forward NTT): algorithmic bytes (2048 B x 65536 per launch) /
+                its average duration, measured with HIP events on the launch stream inside the
+                timed region; peak 8 TB/s (MI355X_MICROARCH.md); traffic from the committed
+                rocprofv3 PMC pass (profiles/), or null.
+  cpu_baseline  the reference's own ntt()+invntt() (oracle/_ref, kind "reference") -- or our C
+                restatement (kind "port") -- on one host core, bounded sample.
+  secondary     Dilithium-3 verify cores / s (configs[3], batch 8192, distinct pk) with its own
+                roofline fraction; and the final RCCL gather time when N > 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NTT_BYTES = 2048               # 1 KiB read + 1 KiB written per transform
+VERIFY3_BYTES = 45 * 1024 + 0  # z 5 + c 1 + t1 6 + A 30 KiB + h 1.5 + w1 1.5 KiB (distinct pk)
+BATCH = 65536
+VBATCH = 8192
+
+
+def cpu_baseline(sample_polys=4096, target_s=10.0):
+    """reference ntt()+invntt() on ONE host core, bounded to ~target_s seconds"""
+    from oracle.oracle import Oracle, Reference, splitmix64_polys
+    o = Oracle()
+    a = splitmix64_polys(sample_polys, seed=1)
+    if Reference.available():
+        r = Reference()
+        f_ntt, f_inv, kind = r.addr("ntt"), r.addr("invntt"), "reference"
+    else:
+        f_ntt, f_inv, kind = o.fn_addr("orc_ntt"), o.fn_addr("orc_invntt"), "port"
+    buf = a.copy()
+    t1 = o.time_poly_fn(f_ntt, buf, 1) + o.time_poly_fn(f_inv, buf, 1)      # calibrate
+    reps = max(1, int(target_s / max(t1, 1e-6)))
+    buf = a.copy()
+    t = 0.0
+    for _ in range(reps):        # alternate so values stay bounded like the GPU run
+        t += o.time_poly_fn(f_ntt, buf, 1)
+        t += o.time_poly_fn(f_inv, buf, 1)
+    n = 2 * reps * sample_polys
+    return {"value": n / t, "unit": "NTT/s", "cores": 1, "kind": kind,
+            "sample": f"{reps} x (ntt + invntt) over {sample_polys} polynomials = {n} transforms in {t:.1f} s, "
+                      f"1 thread of {os.cpu_count()} host CPUs"}
+
+
+def cpu_baseline_verify(target_s=5.0):
+    from oracle.oracle import Oracle
+    o = Oracle()
+    A, z, c, t1, h = synth_verify(64, 3)
+    t = o.time_verify_core(3, A, z, c, t1, h)
+    reps = max(1, int(target_s / max(t, 1e-6)))
+    tt = sum(o.time_verify_core(3, A, z, c, t1, h) for _ in range(reps))
+    return {"value": 64 * reps / tt, "unit": "verify/s", "cores": 1, "kind": "port",
+            "sample": f"{64 * reps} level-3 verify cores (oracle C restatement) in {tt:.1f} s, 1 thread"}
+
+
+def synth_verify(n, seed):
+    from oracle.oracle import splitmix64_polys, Q, N
+    K, L, tau, g1 = 6, 5, 49, 1 << 19
+    rng = np.random.default_rng(seed)
+    A = splitmix64_polys(n * K * L, seed=seed).reshape(n, K, L, N)
+    z = np.mod(rng.integers(-(g1 - 1), g1 + 1, (n, L, N)), Q).astype(np.int32)
+    c = np.zeros((n, N), np.int32)
+    cols = np.argsort(rng.random((n, N)), axis=1)[:, :tau]
+    sg = np.where(rng.integers(0, 2, (n, tau)) == 1, 1, Q - 1).astype(np.int32)
+    np.put_along_axis(c, cols, sg, axis=1)
+    t1 = rng.integers(0, 1 << 10, (n, K, N)).astype(np.int32)
+    h = (rng.random((n, K, N)) < 0.03).astype(np.uint8)
+    return A, z, c, t1, h
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), if any"""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        return json.load(open(p)).get(kernel_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rotate", type=int, default=8, help="distinct resident batches the steps rotate over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    from dilithium_amd import api, sharding
+    from dilithium_amd import lib as dlib
+    import ctypes as C
+
+    rank, world, local = sharding.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    api.init(local)
+    L = dlib.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def ev():
+        e = C.c_void_p()
+        dlib.check(L.dil_event_create(C.byref(e)))
+        return e
+
+    def elapsed(a, b):
+        ms = C.c_float()
+        dlib.check(L.dil_event_elapsed_ms(C.byref(ms), a, b))
+        return float(ms.value)
+
+    # ---- inputs, resident in HBM ------------------------------------------------------------
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    R = max(1, args.rotate)
+    bufs = [torch.randint(0, 8380417, (BATCH, 256), dtype=torch.int32, device="cuda", generator=g) for _ in range(R)]
+    check = bufs[0][:64].clone()
+
+    ptrs = [C.c_void_p(b.data_ptr()) for b in bufs]      # direct C-ABI calls: minimal host overhead
+
+    def step(i):
+        p = ptrs[i % R]
+        dlib.check(L.dil_ntt_dev(p, BATCH, stream))
+        dlib.check(L.dil_invntt_dev(p, BATCH, stream))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    K = args.steps
+    evs = [(ev(), ev(), ev()) for _ in range(K)]
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = 0
+    for i in range(K):
+        p = ptrs[i % R]
+        e0, e1, e2 = evs[i]
+        L.dil_event_record(e0, stream)
+        rc |= L.dil_ntt_dev(p, BATCH, stream)
+        L.dil_event_record(e1, stream)
+        rc |= L.dil_invntt_dev(p, BATCH, stream)
+        L.dil_event_record(e2, stream)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    dt = time.perf_counter() - t0
+    dlib.check(rc, "timed NTT launches")
+    dt = sharding.max_over_ranks(dt)
+    fwd_ms = float(np.mean([elapsed(e0, e1) for e0, e1, _ in evs]))
+    inv_ms = float(np.mean([elapsed(e1, e2) for _, e1, e2 in evs]))
+    assert torch.equal(bufs[0][:64], check), "fwd+inv round trip is not the identity"
+    value = world * K * 2 * BATCH / dt
+
+    # LLC-resident variant (same 64 MiB batch every step) for context
+    for i in range(5):
+        step(0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(K):
+        L.dil_ntt_dev(ptrs[0], BATCH, stream)
+        L.dil_invntt_dev(ptrs[0], BATCH, stream)
+    torch.cuda.synchronize()
+    llc_value = world * K * 2 * BATCH / sharding.max_over_ranks(time.perf_counter() - t1)
+
+    fwd_gbs = NTT_BYTES * BATCH / (fwd_ms * 1e-3) / 1e9
+    out = {
+        "metric": "ntt256_transforms_per_sec", "value": value, "unit": "NTT/s", "n_gpus": world, "steps": K,
+        "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batched forward+inverse NTT, n=256, q=8380417, "
+                               "batch=65536 polynomials per GPU; step = 1 fwd launch + 1 inv launch",
+                   "batch_per_gpu": BATCH, "rotating_resident_batches": R, "parallelism": f"shard x{world}",
+                   "bytes_per_transform": NTT_BYTES},
+        "roofline": {"bound": "hbm", "kernel": "ntt_fwd_kernel<LAYOUT_POLY>", "achieved": fwd_gbs,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fwd_gbs / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("ntt_fwd_kernel"), "avg_launch_ms": fwd_ms,
+                     "algorithmic_bytes_per_launch": NTT_BYTES * BATCH,
+                     "inverse_kernel": {"avg_launch_ms": inv_ms,
+                                        "achieved": NTT_BYTES * BATCH / (inv_ms * 1e-3) / 1e9}},
+        "llc_resident_value": llc_value,
+    }
+
+    # ---- secondary: Dilithium-3 verify core, configs[3] ----------------------------------------
+    if not args.no_secondary:
+        A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank)
+        cu = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
+        dA, dz, dc, dt1, dh = cu(A), cu(z), cu(c), cu(t1_), cu(h)
+        w1 = torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")
+        vs = max(10, K // 4)
+        for _ in range(3):
+            api.verify_core(dA, dz, dc, dt1, dh, 3, out=w1)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        e0, e1 = ev(), ev()
+        tv = time.perf_counter()
+        L.dil_event_record(e0, stream)
+        for _ in range(vs):
+            api.verify_core(dA, dz, dc, dt1, dh, 3, out=w1)
+        L.dil_event_record(e1, stream)
+        torch.cuda.synchronize()
+        sharding.barrier()
+        tv = sharding.max_over_ranks(time.perf_counter() - tv)
+        v_ms = elapsed(e0, e1) / vs
+        v_gbs = VERIFY3_BYTES * VBATCH / (v_ms * 1e-3) / 1e9
+        sec = {"metric": "dilithium3_verify_cores_per_sec", "value": world * vs * VBATCH / tv, "unit": "verify/s",
+               "config": {"workload": "BASELINE configs[3]: level-3 verify core (NTT z, A.z - c.t1.2^d, INTT, "
+                                      "UseHint -> w1), batch=8192 per GPU, distinct pk (A, t1 per item)",
+                          "bytes_per_verify": VERIFY3_BYTES},
+               "roofline": {"bound": "hbm", "kernel": "verify_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("verify_kernel"),
+                            "avg_launch_ms": v_ms}}
+        # the one collective of the design: final gather of the result slabs over RCCL/xGMI
+        if world > 1:
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            allw1 = sharding.gather_slabs(w1, world * VBATCH)
+            torch.cuda.synchronize()
+            sec["final_gather_ms"] = (time.perf_counter() - tg) * 1e3
+            sec["final_gather_bytes"] = int(allw1.numel())
+        out["secondary"] = sec
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            if not args.no_secondary:
+                out["secondary"]["cpu_baseline"] = cpu_baseline_verify()
+        print(json.dumps(out))
+    sharding.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+"""GPU parity: the HIP transforms / element-wise ops / bram API through the C-ABI vs the oracle
+and the committed reference goldens.  Bit-exact (canonical residues) -- integer work."""
+import numpy as np
+import pytest
+
+from oracle.oracle import AFTER_INVNTT, AFTER_NTT, NATURAL, N, Q, canon, splitmix64_polys
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def test_native_library_is_loaded(gpu):
+    """the tests below must run the in-tree HIP library, not a fallback"""
+    import dilithium_amd
+    lib = dilithium_amd.load()
+    assert lib.dil_num_cus() > 0
+    maps = open("/proc/self/maps").read()
+    assert "dilithium_amd/libdil256.so" in maps
+
+
+@pytest.mark.parametrize("op", ["ntt", "invntt", "ntt2x2_ref", "invntt2x2_ref"])
+def test_golden_vectors(gpu, golden, op):
+    from dilithium_amd import api
+    t = dev(gpu, golden["a"])
+    getattr(api, op)(t)
+    key = {"ntt": "ntt", "invntt": "invntt", "ntt2x2_ref": "ntt2x2", "invntt2x2_ref": "invntt2x2"}[op]
+    assert (host(t) == canon(golden[key])).all()
+
+
+@pytest.mark.parametrize("batch", [0, 1, 2, 3, 5, 63, 64, 257, 1001, 8191])
+def test_ragged_batches_vs_oracle(gpu, oracle, batch):
+    from dilithium_amd import api
+    a = splitmix64_polys(max(batch, 1), seed=100 + batch)[:batch]
+    f, i = dev(gpu, a), dev(gpu, a)
+    api.ntt(f)
+    api.invntt(i)
+    if batch:
+        assert (host(f) == oracle.ntt(a)).all()
+        assert (host(i) == oracle.invntt(a)).all()
+
+
+def test_edge_values(gpu, oracle):
+    from dilithium_amd import api
+    rows = [np.full(N, Q - 1), np.full(N, -(Q - 1)), np.zeros(N), np.full(N, 1), np.full(N, -1),
+            np.tile([0, Q - 1], 128), np.tile([Q - 1, -(Q - 1)], 128), np.arange(N), -np.arange(N)]
+    for idx in (0, 1, 63, 64, 127, 128, 255):
+        e = np.zeros(N)
+        e[idx] = Q - 1
+        rows.append(e)
+    a = np.array(rows, dtype=np.int32)
+    f, i = dev(gpu, a), dev(gpu, a)
+    api.ntt(f)
+    api.invntt(i)
+    assert (host(f) == oracle.ntt(a)).all()
+    assert (host(i) == oracle.invntt(a)).all()
+
+
+def test_signed_inputs(gpu, oracle):
+    """the reference is correct for any |x| < q (SURVEY 8b value domain)"""
+    from dilithium_amd import api
+    a = splitmix64_polys(512, seed=77, lo=-(Q - 1), hi=Q)
+    f, i = dev(gpu, a), dev(gpu, a)
+    api.ntt(f)
+    api.invntt(i)
+    assert (host(f) == oracle.ntt(a)).all()
+    assert (host(i) == oracle.invntt(a)).all()
+
+
+def test_full_config2_batch_parity_and_roundtrip(gpu, oracle):
+    """BASELINE.json configs[1]: batch = 65536.  All outputs vs the oracle, round trip == identity"""
+    from dilithium_amd import api
+    a = splitmix64_polys(65536, seed=0)
+    t = dev(gpu, a)
+    api.ntt(t)
+    assert (host(t) == oracle.ntt(a)).all()
+    api.invntt(t)
+    assert (host(t) == a).all()
+    api.invntt(t)
+    assert (host(t) == oracle.invntt(a)).all()
+
+
+def test_linearity_property(gpu):
+    """size-independent property: NTT(a + b) == NTT(a) + NTT(b) (mod q), 1M polynomials"""
+    from dilithium_amd import api
+    torch = gpu
+    n = 1 << 18
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randint(0, Q, (n, N), dtype=torch.int32, device="cuda", generator=g)
+    b = torch.randint(0, Q, (n, N), dtype=torch.int32, device="cuda", generator=g)
+    s = (a + b) % Q
+    api.ntt(a), api.ntt(b), api.ntt(s)
+    assert torch.equal((a + b) % Q, s)
+    assert int(s.min()) >= 0 and int(s.max()) < Q
+
+
+def test_pointwise_mac_add_sub(gpu, oracle, golden):
+    from dilithium_amd import api
+    torch = gpu
+    a, b = golden["a"], golden["b"]
+    ta, tb = dev(torch, a), dev(torch, b)
+    tc = torch.empty_like(ta)
+    api.pointwise_barrett(tc, ta, tb)
+    assert (host(tc) == canon(golden["pointwise"])).all()
+    # aliasing c == a (ntt2x2_test.cpp:102)
+    t2 = ta.clone()
+    api.pointwise_barrett(t2, t2, tb)
+    assert (host(t2) == canon(golden["pointwise"])).all()
+    acc = splitmix64_polys(a.shape[0], seed=5, lo=-(Q - 1), hi=Q)
+    tacc = dev(torch, acc)
+    api.pointwise_acc(tc, tacc, ta, tb)
+    want = np.mod(acc.astype(np.int64) + a.astype(np.int64) * b.astype(np.int64), Q)
+    assert (host(tc) == want).all()
+    api.poly_add(tc, ta, tb)
+    assert (host(tc) == np.mod(a.astype(np.int64) + b, Q)).all()
+    api.poly_sub(tc, ta, tb)
+    assert (host(tc) == np.mod(a.astype(np.int64) - b, Q)).all()
+    # large random batch vs oracle
+    x, y = splitmix64_polys(4099, seed=8), splitmix64_polys(4099, seed=9, lo=-(Q - 1), hi=Q)
+    tx, ty = dev(torch, x), dev(torch, y)
+    api.pointwise_barrett(tx, tx, ty)
+    assert (host(tx) == oracle.pointwise(x, y)).all()
+
+
+@pytest.mark.parametrize("mapping", [NATURAL, AFTER_NTT, AFTER_INVNTT])
+def test_bram_api_vs_reference_golden(gpu, golden, mapping):
+    from dilithium_amd import api
+    ram, mul = golden["ram"], golden["mul_ram"]
+    t = dev(gpu, ram)
+    api.ntt2x2_fwdntt(t, mapping)
+    assert (host(t) == canon(golden[f"bram_fwd_{mapping}"])).all()
+    t = dev(gpu, ram)
+    api.ntt2x2_invntt(t, mapping)
+    assert (host(t) == canon(golden[f"bram_inv_{mapping}"])).all()
+    t = dev(gpu, ram)
+    api.ntt2x2_mul(t, dev(gpu, mul), mapping)
+    assert (host(t) == canon(golden[f"bram_mul_{mapping}"])).all()
+
+
+def test_bram_polymul_chain_like_reference_test(gpu, oracle, golden):
+    """ntt2x2_test.cpp:109-137 polymul(): fwd, fwd, mul, inv under AFTER_NTT == plain product;
+    b = 31 a as in the reference's main (:171-172)"""
+    from dilithium_amd import api
+    a = splitmix64_polys(2000, seed=31)
+    b = np.mod(a.astype(np.int64) * 31, Q).astype(np.int32)
+    ta, tb = dev(gpu, a), dev(gpu, b)
+    api.ntt2x2_fwdntt(ta, NATURAL)
+    api.ntt2x2_fwdntt(tb, NATURAL)
+    assert (host(ta) == oracle.bram_fwdntt(a, NATURAL)).all()
+    api.ntt2x2_mul(ta, tb, NATURAL)
+    api.ntt2x2_invntt(ta, AFTER_NTT)
+    plain = oracle.invntt(oracle.pointwise(oracle.ntt(a), oracle.ntt(b)))
+    assert (host(ta) == plain).all()
+    g = dev(gpu, golden["ram"])
+    gm = dev(gpu, golden["mul_ram"])
+    api.ntt2x2_fwdntt(g, NATURAL)
+    api.ntt2x2_fwdntt(gm, NATURAL)
+    api.ntt2x2_mul(g, gm, NATURAL)
+    api.ntt2x2_invntt(g, AFTER_NTT)
+    assert (host(g) == canon(golden["bram_polymul"])).all()
+
+
+def test_host_pointer_entry_points(gpu, oracle):
+    """the *_host entry points (what the reference-signature wrappers call)"""
+    from dilithium_amd import api
+    a = splitmix64_polys(33, seed=12)
+    x = a.copy()
+    api.ntt(x)
+    assert (x == oracle.ntt(a)).all()
+    api.invntt(x)
+    assert (x == a).all()
+    b = splitmix64_polys(33, seed=13)
+    c = np.empty_like(a)
+    api.pointwise_barrett(c, a, b)
+    assert (c == oracle.pointwise(a, b)).all()
+    r = a.copy()
+    api.ntt2x2_fwdntt(r, NATURAL)
+    assert (r == oracle.bram_fwdntt(a, NATURAL)).all()
