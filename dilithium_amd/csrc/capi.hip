@@ -32,39 +32,46 @@ void canonical_zetas(uint32_t z[256])
     z[0] = 0;
     for (unsigned k = 1; k < 256; k++) z[k] = (uint32_t)powmod(1753, brv8(k));
 }
-inline uint32_t shoup24(uint32_t w) { return (uint32_t)(((uint64_t)w << 24) / (uint64_t)Q); }
+// Montgomery form of a table constant w: wt = centred(w * 2^32 mod q), wq = wt * q^-1 mod 2^32
+constexpr uint32_t QINV = 58728449u;
+inline void mont_const(uint32_t w, uint32_t* out)
+{
+    int64_t wt = (int64_t)(((unsigned __int128)w << 32) % (uint64_t)Q);
+    if (wt > (Q - 1) / 2) wt -= Q;
+    out[0] = (uint32_t)(int32_t)wt;
+    out[1] = (uint32_t)(int32_t)wt * QINV;
+}
 
-// forward: pass p, lane -> k1 = 4^p + (lane >> (6 - 2p)); entry {z[k1], ', z[2k1], ', z[2k1+1], ', 0, 0}
+// forward: pass p, lane -> k1 = 4^p + (lane >> (6 - 2p)); entry {z[k1], z[2k1], z[2k1+1]} x (wt, wq), 0, 0
 //          (ref_ntt2x2.cpp:50-55 == twiddle_resolver.v:106-130 under the lane layout of ntt_core.hpp)
 // inverse: pass p, block t = lane >> 2p (0 in the last pass), base = 256 >> 2p:
 //          ka = base-1-2t, ka-1, kb = base/2-1-t, each negated (ref_ntt2x2.cpp:113-118 ==
-//          twiddle_resolver.v:87-105); last pass: wb *= 256^-1 and f = 256^-1 rides in slots 6,7
-void build_tables(uint32_t* fwd, uint32_t* inv)
+//          twiddle_resolver.v:87-105); last pass: wb *= f and f rides in slots 6,7, with
+//          f = 256^-1 (standalone) or 2^32 * 256^-1 (pipelines, see kernels.hpp)
+void build_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe)
 {
     uint32_t z[256];
     canonical_zetas(z);
-    const uint32_t f = 8347681u;
+    const uint64_t f_std = 8347681u;
+    const uint64_t f_pipe = f_std * ((1ull << 32) % (uint64_t)Q) % (uint64_t)Q;
     for (int p = 0; p < 4; p++) {
         for (int lane = 0; lane < 64; lane++) {
             uint32_t* e = fwd + (p * 64 + lane) * 8;
             const unsigned k1 = (1u << (2 * p)) + ((unsigned)lane >> (6 - 2 * p));
             const uint32_t wf[3] = {z[k1], z[2 * k1], z[2 * k1 + 1]};
-            for (int i = 0; i < 3; i++) {
-                e[2 * i] = wf[i];
-                e[2 * i + 1] = shoup24(wf[i]);
-            }
+            for (int i = 0; i < 3; i++) mont_const(wf[i], e + 2 * i);
             e[6] = e[7] = 0;
 
-            uint32_t* d = inv + (p * 64 + lane) * 8;
             const unsigned t = (p < 3) ? ((unsigned)lane >> (2 * p)) : 0u;
             const unsigned base = 256u >> (2 * p);
             const unsigned ka = base - 1 - 2 * t, kb = (base >> 1) - 1 - t;
-            uint32_t wi[4] = {(uint32_t)((Q - z[ka]) % Q), (uint32_t)((Q - z[ka - 1]) % Q),
-                              (uint32_t)((Q - z[kb]) % Q), f};
-            if (p == 3) wi[2] = (uint32_t)((uint64_t)wi[2] * f % (uint64_t)Q);
-            for (int i = 0; i < 4; i++) {
-                d[2 * i] = wi[i];
-                d[2 * i + 1] = shoup24(wi[i]);
+            for (int flavour = 0; flavour < 2; flavour++) {
+                uint32_t* d = (flavour ? inv_pipe : inv) + (p * 64 + lane) * 8;
+                const uint64_t f = flavour ? f_pipe : f_std;
+                uint64_t wi[4] = {(uint64_t)((Q - z[ka]) % Q), (uint64_t)((Q - z[ka - 1]) % Q),
+                                  (uint64_t)((Q - z[kb]) % Q), f};
+                if (p == 3) wi[2] = wi[2] * f % (uint64_t)Q;
+                for (int i = 0; i < 4; i++) mont_const((uint32_t)wi[i], d + 2 * i);
             }
         }
     }
@@ -74,7 +81,7 @@ struct State {
     std::mutex mu;
     bool ready = false;
     int device = -1;
-    uint32_t* d_tables = nullptr;   // fwd | inv
+    uint32_t* d_tables = nullptr;   // fwd | inv | inv_pipe
     dil::Tables t;
     void* scratch = nullptr;        // for *_host entry points
     size_t scratch_bytes = 0;
@@ -131,7 +138,7 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)
 
 extern "C" {
 
-void dil_host_twiddle_tables(uint32_t* fwd, uint32_t* inv) { build_tables(fwd, inv); }
+void dil_host_twiddle_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe) { build_tables(fwd, inv, inv_pipe); }
 
 void dil_host_zetas(int32_t* zetas)
 {
@@ -167,12 +174,13 @@ int dil_init(int device)
         g.scratch = nullptr;
         g.scratch_bytes = 0;
     }
-    static uint32_t h_tab[2 * 2048];
-    build_tables(h_tab, h_tab + 2048);
+    static uint32_t h_tab[3 * 2048];
+    build_tables(h_tab, h_tab + 2048, h_tab + 4096);
     DIL_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_tables), sizeof(h_tab)));
     DIL_TRY(hipMemcpy(g.d_tables, h_tab, sizeof(h_tab), hipMemcpyHostToDevice));
     g.t.fwd = g.d_tables;
     g.t.inv = g.d_tables + 2048;
+    g.t.inv_pipe = g.d_tables + 4096;
     g.t.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g.device = device;
     g.ready = true;

@@ -1,8 +1,8 @@
 // kernels.hip -- hand-written CDNA4 (gfx950) kernels for the Dilithium NTT hot path.
 //
 // One 64-lane wavefront owns one polynomial (256 x int32 = 1 KiB): 4 coefficients per lane,
-// butterflies in VGPRs, exchanges by cross-lane ops (ntt_core.hpp), 24-bit full-rate
-// multiplies (modarith.hpp).  No MFMA: this is 32-bit integer work bounded by HBM bandwidth
+// butterflies in VGPRs, exchanges by cross-lane ops (ntt_core.hpp), signed Montgomery
+// arithmetic on 32-bit multiplies (modarith.hpp).  No MFMA: this is 32-bit integer work bounded by HBM bandwidth
 // and VALU issue.  Every polynomial crosses HBM exactly once per kernel.
 //
 // Reference behaviour implemented (file:line relative to GMUCERG/Dilithium):
@@ -61,7 +61,8 @@ __device__ __forceinline__ int inv_out_off(int i, int mapping)
 }
 
 // ---------------------------------------------------------------------------------------
-// H2/H5/H6 forward NTT, batched, in place.  Persistent waves, grid-stride over polynomials.
+// H2/H5/H6 forward NTT, batched, in place.  Persistent waves, grid-stride over polynomials,
+// the next polynomial's loads are issued before the current one is transformed.
 // HBM traffic: 1 KiB in (4 coalesced 256-B dword loads per wave) + 1 KiB out (one 1-KiB
 // dwordx4 store per wave) per polynomial.
 // ---------------------------------------------------------------------------------------
@@ -72,20 +73,31 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
     const int lane = threadIdx.x & 63;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t nwaves = (size_t)gridDim.x * 4;
+    if (wave >= batch) return;
+    int off[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) off[m] = fwd_in_off<LAYOUT>(lane + 64 * m, mapping);
+    const int out_off = fwd_out_row_off<LAYOUT>(lane, mapping);
+    int32_t nxt[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) nxt[m] = polys[wave * 256 + off[m]];
     TwRegs tw;
     tw.load(tw_tab, lane);
+    const LaneMasks lm(lane);
     for (size_t p = wave; p < batch; p += nwaves) {
-        int32_t* a = polys + p * 256;
-        uint32_t r[4];
+        int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+        const size_t pn = p + nwaves;
+        if (pn < batch) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) r[m] = (uint32_t)a[fwd_in_off<LAYOUT>(lane + 64 * m, mapping)] + Q;
-        ntt_fwd_core(r, tw, lane);
-        uint4 o = make_uint4(canon(r[0]), canon(r[1]), canon(r[2]), canon(r[3]));
-        *reinterpret_cast<uint4*>(a + fwd_out_row_off<LAYOUT>(lane, mapping)) = o;
+            for (int m = 0; m < 4; m++) nxt[m] = polys[pn * 256 + off[m]];
+        }
+        ntt_fwd_core(r, tw, lm);
+        *reinterpret_cast<uint4*>(polys + p * 256 + out_off) =
+            make_uint4(canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
     }
 }
 
-// H3/H5/H6 inverse NTT (x 256^-1), batched, in place.
+// H3/H5/H6 inverse NTT (x 256^-1), batched, in place.  Inputs in (-q, q) (or canonical).
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ polys, size_t batch,
                                                        const uint32_t* __restrict__ tw_tab, int mapping)
@@ -93,15 +105,22 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ poly
     const int lane = threadIdx.x & 63;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t nwaves = (size_t)gridDim.x * 4;
+    if (wave >= batch) return;
+    const int in_off = inv_in_row_off<LAYOUT>(lane, mapping);
+    int off[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) off[m] = inv_out_off<LAYOUT>(lane + 64 * m, mapping);
+    int4 nxt = *reinterpret_cast<const int4*>(polys + wave * 256 + in_off);
     TwRegs tw;
     tw.load(tw_tab, lane);
+    const LaneMasks lm(lane);
     for (size_t p = wave; p < batch; p += nwaves) {
-        int32_t* a = polys + p * 256;
-        uint4 v = *reinterpret_cast<const uint4*>(a + inv_in_row_off<LAYOUT>(lane, mapping));
-        uint32_t r[4] = {red(v.x + Q), red(v.y + Q), red(v.z + Q), red(v.w + Q)};
-        ntt_inv_core(r, tw, lane);
+        int32_t r[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+        const size_t pn = p + nwaves;
+        if (pn < batch) nxt = *reinterpret_cast<const int4*>(polys + pn * 256 + in_off);
+        ntt_inv_core(r, tw, lm);
 #pragma unroll
-        for (int m = 0; m < 4; m++) a[inv_out_off<LAYOUT>(lane + 64 * m, mapping)] = (int32_t)csub(r[m]);
+        for (int m = 0; m < 4; m++) polys[p * 256 + off[m]] = (int32_t)canon_small(r[m]);
     }
 }
 
@@ -110,31 +129,35 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ poly
 // 4 coefficients (16 B) per thread, grid-stride.  c may alias a (ntt2x2_test.cpp:102).
 //   OP_MUL: c = a*b        OP_MAC: c = acc + a*b        OP_ADD: c = a+b       OP_SUB: c = a-b
 // ---------------------------------------------------------------------------------------
+// true product of two residues given as any int32 with |a|,|b| < 2^31 / ... (here: < 2^24):
+// Montgomery-reduce the 64-bit product, then multiply by 2^64 mod q to cancel the 2^-32.
+__device__ __forceinline__ int32_t mulmod_true(int32_t a, int32_t b) { return mont_tw(mont_mul(a, b), R2_WT, R2_WQ); }
+
 template <int OP>
 __global__ __launch_bounds__(256) void pointwise_kernel(int32_t* c, const int32_t* a, const int32_t* b,
                                                          const int32_t* acc, size_t nvec4)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec4; i += stride) {
-        int4 va = reinterpret_cast<const int4*>(a)[i];
-        int4 vb = reinterpret_cast<const int4*>(b)[i];
-        uint32_t x[4] = {canon_signed(va.x), canon_signed(va.y), canon_signed(va.z), canon_signed(va.w)};
-        uint32_t y[4] = {canon_signed(vb.x), canon_signed(vb.y), canon_signed(vb.z), canon_signed(vb.w)};
+        const int4 va = reinterpret_cast<const int4*>(a)[i];
+        const int4 vb = reinterpret_cast<const int4*>(b)[i];
+        const int32_t x[4] = {va.x, va.y, va.z, va.w};
+        const int32_t y[4] = {vb.x, vb.y, vb.z, vb.w};
         uint32_t o[4];
         if (OP == OP_MUL) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = mulmod(x[k], y[k]);
+            for (int k = 0; k < 4; k++) o[k] = canon_small(mulmod_true(x[k], y[k]));
         } else if (OP == OP_MAC) {
-            int4 vc = reinterpret_cast<const int4*>(acc)[i];
-            uint32_t z[4] = {canon_signed(vc.x), canon_signed(vc.y), canon_signed(vc.z), canon_signed(vc.w)};
+            const int4 vc = reinterpret_cast<const int4*>(acc)[i];
+            const int32_t z[4] = {vc.x, vc.y, vc.z, vc.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = canon(z[k] + mulmod_lazy(x[k], y[k]));
+            for (int k = 0; k < 4; k++) o[k] = canon_any(z[k] + mulmod_true(x[k], y[k]));
         } else if (OP == OP_ADD) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = csub(x[k] + y[k]);
+            for (int k = 0; k < 4; k++) o[k] = canon_any(x[k] + y[k]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = csub(x[k] + Q - y[k]);
+            for (int k = 0; k < 4; k++) o[k] = canon_any(x[k] - y[k]);
         }
         reinterpret_cast<uint4*>(c)[i] = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -148,13 +171,13 @@ __global__ __launch_bounds__(256) void bram_mul_kernel(int32_t* ram, const int32
         const size_t p = i >> 6;
         const int l = (int)(i & 63);
         int4* dst = reinterpret_cast<int4*>(ram + p * 256 + 4 * resolve_row(mapping, l));
-        int4 va = *dst;
-        int4 vb = *reinterpret_cast<const int4*>(mul_ram + p * 256 + 4 * l);
+        const int4 va = *dst;
+        const int4 vb = *reinterpret_cast<const int4*>(mul_ram + p * 256 + 4 * l);
         int4 o;
-        o.x = (int32_t)mulmod(canon_signed(va.x), canon_signed(vb.x));
-        o.y = (int32_t)mulmod(canon_signed(va.y), canon_signed(vb.y));
-        o.z = (int32_t)mulmod(canon_signed(va.z), canon_signed(vb.z));
-        o.w = (int32_t)mulmod(canon_signed(va.w), canon_signed(vb.w));
+        o.x = (int32_t)canon_small(mulmod_true(va.x, vb.x));
+        o.y = (int32_t)canon_small(mulmod_true(va.y, vb.y));
+        o.z = (int32_t)canon_small(mulmod_true(va.z, vb.z));
+        o.w = (int32_t)canon_small(mulmod_true(va.w, vb.w));
         *dst = o;
     }
 }
@@ -187,14 +210,14 @@ __device__ __forceinline__ void decompose(uint32_t a, uint32_t& a1, int32_t& a0)
 {
     uint32_t t = (a + 127) >> 7;
     if (LEVEL == 2) {
-        t = (mul24(t, 11275) + (1u << 23)) >> 24;
+        t = (t * 11275u + (1u << 23)) >> 24;
         t ^= (uint32_t)(((int32_t)(43 - t)) >> 31) & t;
     } else {
-        t = (mul24(t, 1025) + (1u << 21)) >> 22;
+        t = (t * 1025u + (1u << 21)) >> 22;
         t &= 15;
     }
-    int32_t r = (int32_t)a - (int32_t)mul24(t, 2 * Par<LEVEL>::GAMMA2);
-    r -= (((int32_t)(Q - 1) / 2 - r) >> 31) & (int32_t)Q;
+    int32_t r = (int32_t)a - (int32_t)t * (2 * Par<LEVEL>::GAMMA2);
+    r -= (((Q - 1) / 2 - r) >> 31) & Q;
     a1 = t;
     a0 = r;
 }
@@ -220,14 +243,16 @@ __device__ __forceinline__ uint32_t make_hint(uint32_t s, uint32_t a1)   // make
 
 __device__ __forceinline__ bool norm_reject(uint32_t x, uint32_t bound)   // norm_check.v:84-105
 {
-    return x >= bound && x <= Q - bound;
+    return x >= bound && x <= (uint32_t)Q - bound;
 }
 
 // ---------------------------------------------------------------------------------------
 // Fused pipelines.  One workgroup per item (signature / verification), one wave per
-// polynomial row; NTT-domain vectors shared through LDS; twiddles LDS-resident.
-// LDS map (dwords): [0,2048) fwd twiddles | [2048,4096) inv twiddles | [4096, 4096+8*256) vec
-// | chat[256] | flags[4]
+// polynomial row; NTT-domain vectors shared through LDS as LAZY signed residues (no
+// canonicalisation between stages); twiddles LDS-resident; pointwise products accumulate as
+// 64-bit integers (v_mad_i64_i32) and are Montgomery-reduced once per output coefficient --
+// the 2^-32 this leaves is cancelled by the pipeline-flavour inverse table (f = 2^32 / 256).
+// LDS map (dwords): [0,2048) fwd twiddles | [2048,4096) inv twiddles | 8*256 vec | chat[256] | flags[4]
 // ---------------------------------------------------------------------------------------
 constexpr int LDS_VEC = 2 * TW_TABLE_DWORDS;
 constexpr int LDS_CHAT = LDS_VEC + 8 * 256;
@@ -243,28 +268,34 @@ __device__ __forceinline__ void stage_tables(uint32_t* lds, const uint32_t* __re
     }
 }
 
-// strided load of one polynomial (natural order, any int32 in [-q, 2^31)) into NTT-input regs
-__device__ __forceinline__ void load_strided(uint32_t (&r)[4], const int32_t* __restrict__ a, int lane)
+// strided load of one polynomial (natural order) into NTT-input registers
+__device__ __forceinline__ void load_strided(int32_t (&r)[4], const int32_t* __restrict__ a, int lane)
 {
 #pragma unroll
-    for (int m = 0; m < 4; m++) r[m] = (uint32_t)a[lane + 64 * m] + Q;
+    for (int m = 0; m < 4; m++) r[m] = a[lane + 64 * m];
 }
 
-// accumulate sum_l A[k][l] o vhat[l] for the lane's 4 coefficients, lazily (each term < 2q)
 template <int L>
-__device__ __forceinline__ void mac_row(uint32_t (&acc)[4], const int32_t* __restrict__ Arow,
-                                        const uint32_t* vec_lds, int lane)
-{
-    uint4 av[L];
+struct ARow {
+    int4 v[L];
+    __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane)
+    {
 #pragma unroll
-    for (int l = 0; l < L; l++) av[l] = *reinterpret_cast<const uint4*>(Arow + l * 256 + 4 * lane);
+        for (int l = 0; l < L; l++) v[l] = *reinterpret_cast<const int4*>(Arow + l * 256 + 4 * lane);
+    }
+};
+
+// acc += sum_l A[k][l] o vhat[l] for the lane's 4 coefficients, as 64-bit integers
+template <int L>
+__device__ __forceinline__ void mac_row(int64_t (&acc)[4], const ARow<L>& A, const uint32_t* vec_lds, int lane)
+{
 #pragma unroll
     for (int l = 0; l < L; l++) {
-        uint4 z = *reinterpret_cast<const uint4*>(vec_lds + l * 256 + 4 * lane);
-        acc[0] += mulmod_lazy(av[l].x, z.x);
-        acc[1] += mulmod_lazy(av[l].y, z.y);
-        acc[2] += mulmod_lazy(av[l].z, z.z);
-        acc[3] += mulmod_lazy(av[l].w, z.w);
+        const int4 z = *reinterpret_cast<const int4*>(vec_lds + l * 256 + 4 * lane);
+        acc[0] += (int64_t)A.v[l].x * z.x;
+        acc[1] += (int64_t)A.v[l].y * z.y;
+        acc[2] += (int64_t)A.v[l].z * z.z;
+        acc[3] += (int64_t)A.v[l].w * z.w;
     }
 }
 
@@ -280,27 +311,27 @@ __global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
     stage_tables(lds, fwd_tab, inv_tab);
     __syncthreads();
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
     uint32_t* vec = lds + LDS_VEC;
     for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
+        ARow<L> Ar;
+        if (wv < K) Ar.load(A + ((shared_A ? 0 : it * K) + wv) * (size_t)L * 256, lane);
         if (wv < L) {
-            uint32_t r[4];
+            int32_t r[4];
             load_strided(r, y + (it * L + wv) * 256, lane);
-            ntt_fwd_core(r, twf, lane);
-            *reinterpret_cast<uint4*>(vec + wv * 256 + 4 * lane) =
-                make_uint4(canon(r[0]), canon(r[1]), canon(r[2]), canon(r[3]));
+            ntt_fwd_core(r, twf, lm);
+            *reinterpret_cast<int4*>(vec + wv * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
         }
         __syncthreads();
         if (wv < K) {
-            const int32_t* Arow = A + ((shared_A ? 0 : it * K) + wv) * (size_t)L * 256;
-            uint32_t acc[4] = {0, 0, 0, 0};
-            mac_row<L>(acc, Arow, vec, lane);
-#pragma unroll
-            for (int m = 0; m < 4; m++) acc[m] = red(acc[m]);
-            ntt_inv_core(acc, twi, lane);
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, vec, lane);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            ntt_inv_core(r, twi, lm);
             const size_t o = (it * K + wv) * 256;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                uint32_t v = csub(acc[m]);
+                const uint32_t v = canon_small(r[m]);
                 if (OUT == OUT_W) {
                     w_out[o + lane + 64 * m] = (int32_t)v;
                 } else {
@@ -308,7 +339,7 @@ __global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
                     int32_t a0;
                     decompose<LEVEL>(v, a1, a0);
                     w1_out[o + lane + 64 * m] = (uint8_t)a1;
-                    w0_out[o + lane + 64 * m] = a0 < 0 ? a0 + (int32_t)Q : a0;
+                    w0_out[o + lane + 64 * m] = a0 + ((a0 >> 31) & Q);
                 }
             }
         }
@@ -333,46 +364,49 @@ void verify_kernel(uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A,
     stage_tables(lds, fwd_tab, inv_tab);
     __syncthreads();
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
     uint32_t* vec = lds + LDS_VEC;
     uint32_t* chat = lds + LDS_CHAT;
     for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
-        if (wv <= L) {   // waves 0..L-1: z_l ; wave L: c
-            uint32_t r[4];
-            const int32_t* src = (wv < L) ? z + (it * L + wv) * 256 : c + it * 256;
-            load_strided(r, src, lane);
-            ntt_fwd_core(r, twf, lane);
-            uint32_t* dst = (wv < L) ? vec + wv * 256 : chat;
-            *reinterpret_cast<uint4*>(dst + 4 * lane) =
-                make_uint4(canon(r[0]), canon(r[1]), canon(r[2]), canon(r[3]));
-        }
-        uint32_t th[4] = {0, 0, 0, 0};
-        if (wv < K) {    // t1_k * 2^13 (decoder.v:96-100), t1 is 10 bits
+        ARow<L> Ar;
+        int32_t th[4] = {0, 0, 0, 0};
+        uint32_t hb[4] = {0, 0, 0, 0};
+        const size_t o = (it * K + wv) * 256;
+        if (wv < K) {    // issue this row's loads first: A (L x 1 KiB), t1, h
+            Ar.load(A + ((shared_pk ? 0 : it * K) + wv) * (size_t)L * 256, lane);
             const int32_t* src = t1 + ((shared_pk ? 0 : it * K) + wv) * 256;
 #pragma unroll
-            for (int m = 0; m < 4; m++) th[m] = ((uint32_t)src[lane + 64 * m] & 0x3FFu) << 13;
-            ntt_fwd_core(th, twf, lane);
+            for (int m = 0; m < 4; m++) th[m] = src[lane + 64 * m];
 #pragma unroll
-            for (int m = 0; m < 4; m++) th[m] = canon(th[m]);
+            for (int m = 0; m < 4; m++) hb[m] = h[o + lane + 64 * m];
+        }
+        if (wv <= L) {   // waves 0..L-1: z_l ; wave L: c
+            int32_t r[4];
+            const int32_t* src = (wv < L) ? z + (it * L + wv) * 256 : c + it * 256;
+            load_strided(r, src, lane);
+            ntt_fwd_core(r, twf, lm);
+            uint32_t* dst = (wv < L) ? vec + wv * 256 : chat;
+            *reinterpret_cast<int4*>(dst + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        if (wv < K) {    // t1_k * 2^13 (decoder.v:96-100), t1 is 10 bits
+#pragma unroll
+            for (int m = 0; m < 4; m++) th[m] = (th[m] & 0x3FF) << 13;
+            ntt_fwd_core(th, twf, lm);
         }
         __syncthreads();
         if (wv < K) {
-            const int32_t* Arow = A + ((shared_pk ? 0 : it * K) + wv) * (size_t)L * 256;
-            uint32_t acc[4] = {0, 0, 0, 0};
-            mac_row<L>(acc, Arow, vec, lane);
-            uint4 ch = *reinterpret_cast<const uint4*>(chat + 4 * lane);
-            acc[0] += Q2 - mulmod_lazy(ch.x, th[0]);
-            acc[1] += Q2 - mulmod_lazy(ch.y, th[1]);
-            acc[2] += Q2 - mulmod_lazy(ch.z, th[2]);
-            acc[3] += Q2 - mulmod_lazy(ch.w, th[3]);
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, vec, lane);
+            const int4 ch = *reinterpret_cast<const int4*>(chat + 4 * lane);
+            acc[0] -= (int64_t)ch.x * th[0];
+            acc[1] -= (int64_t)ch.y * th[1];
+            acc[2] -= (int64_t)ch.z * th[2];
+            acc[3] -= (int64_t)ch.w * th[3];
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            ntt_inv_core(r, twi, lm);
 #pragma unroll
-            for (int m = 0; m < 4; m++) acc[m] = red(acc[m]);
-            ntt_inv_core(acc, twi, lane);
-            const size_t o = (it * K + wv) * 256;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                uint32_t hb = h[o + lane + 64 * m];
-                w1_out[o + lane + 64 * m] = (uint8_t)use_hint<LEVEL>(csub(acc[m]), hb);
-            }
+            for (int m = 0; m < 4; m++)
+                w1_out[o + lane + 64 * m] = (uint8_t)use_hint<LEVEL>(canon_small(r[m]), hb[m]);
         }
         __syncthreads();
     }
@@ -399,28 +433,28 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
     if (threadIdx.x < 4) lds[LDS_FLAGS + threadIdx.x] = 0;
     __syncthreads();
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
     uint32_t* chat = lds + LDS_CHAT;
     uint32_t* fl = lds + LDS_FLAGS;   // [0] reject bits, [1] hint count
     for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
         if (wv == L) {
-            uint32_t r[4];
+            int32_t r[4];
             load_strided(r, c + it * 256, lane);
-            ntt_fwd_core(r, twf, lane);
-            *reinterpret_cast<uint4*>(chat + 4 * lane) =
-                make_uint4(canon(r[0]), canon(r[1]), canon(r[2]), canon(r[3]));
+            ntt_fwd_core(r, twf, lm);
+            *reinterpret_cast<int4*>(chat + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
         }
         __syncthreads();
-        const uint4 ch = *reinterpret_cast<const uint4*>(chat + 4 * lane);
+        const int4 ch = *reinterpret_cast<const int4*>(chat + 4 * lane);
         uint32_t bits = 0, nh = 0;
         if (wv < L) {
-            const uint4 s = *reinterpret_cast<const uint4*>(s1hat + ((shared_key ? 0 : it * L) + wv) * 256 + 4 * lane);
-            uint32_t r[4] = {mulmod_lazy(ch.x, s.x), mulmod_lazy(ch.y, s.y), mulmod_lazy(ch.z, s.z), mulmod_lazy(ch.w, s.w)};
-            ntt_inv_core(r, twi, lane);
+            const int4 s = *reinterpret_cast<const int4*>(s1hat + ((shared_key ? 0 : it * L) + wv) * 256 + 4 * lane);
+            int32_t r[4] = {mont_mul(ch.x, s.x), mont_mul(ch.y, s.y), mont_mul(ch.z, s.z), mont_mul(ch.w, s.w)};
+            ntt_inv_core(r, twi, lm);
             const size_t o = (it * L + wv) * 256;
             bool rej = false;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                uint32_t v = csub(csub(r[m]) + canon_signed(y[o + lane + 64 * m]));
+                const uint32_t v = canon_any(r[m] + y[o + lane + 64 * m]);
                 rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
                 z_out[o + lane + 64 * m] = (int32_t)v;
             }
@@ -428,21 +462,23 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
         }
         if (wv < K) {
             const size_t ko = ((shared_key ? 0 : it * K) + wv) * 256 + 4 * lane;
-            const uint4 s2 = *reinterpret_cast<const uint4*>(s2hat + ko);
-            const uint4 t0 = *reinterpret_cast<const uint4*>(t0hat + ko);
-            uint32_t a[4] = {mulmod_lazy(ch.x, s2.x), mulmod_lazy(ch.y, s2.y), mulmod_lazy(ch.z, s2.z), mulmod_lazy(ch.w, s2.w)};
-            uint32_t b[4] = {mulmod_lazy(ch.x, t0.x), mulmod_lazy(ch.y, t0.y), mulmod_lazy(ch.z, t0.z), mulmod_lazy(ch.w, t0.w)};
-            ntt_inv_core(a, twi, lane);
-            ntt_inv_core(b, twi, lane);
+            const int4 s2 = *reinterpret_cast<const int4*>(s2hat + ko);
+            const int4 t0 = *reinterpret_cast<const int4*>(t0hat + ko);
+            int32_t a[4] = {mont_mul(ch.x, s2.x), mont_mul(ch.y, s2.y), mont_mul(ch.z, s2.z), mont_mul(ch.w, s2.w)};
+            int32_t b[4] = {mont_mul(ch.x, t0.x), mont_mul(ch.y, t0.y), mont_mul(ch.z, t0.z), mont_mul(ch.w, t0.w)};
+            ntt_inv_core(a, twi, lm);
+            ntt_inv_core(b, twi, lm);
             const size_t o = (it * K + wv) * 256;
             bool rej1 = false, rej2 = false;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                uint32_t cs2 = csub(a[m]), ct0 = csub(b[m]);
-                uint32_t r0 = csub(canon_signed(w0[o + lane + 64 * m]) + Q - cs2);
+                const uint32_t ct0 = canon_small(b[m]);
+                const uint32_t r0 = canon_any(w0[o + lane + 64 * m] - a[m]);
                 rej1 |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
                 rej2 |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
-                uint32_t hb = make_hint<LEVEL>(csub(r0 + ct0), w1[o + lane + 64 * m]);
+                uint32_t s = r0 + ct0;
+                s -= (s >= (uint32_t)Q) ? (uint32_t)Q : 0u;
+                const uint32_t hb = make_hint<LEVEL>(s, w1[o + lane + 64 * m]);
                 h_out[o + lane + 64 * m] = (uint8_t)hb;
                 nh += __popcll(__ballot(hb));
             }
@@ -478,7 +514,7 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
 {
     if (batch == 0) return hipSuccess;
     const int grid = grid_for((batch + 3) / 4, t.num_cus * 8);
-    const uint32_t* tab = inverse ? t.inv : t.fwd;
+    const uint32_t* tab = inverse ? t.inv : t.fwd;   // standalone flavour of the inverse table
     if (!inverse) {
         if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_POLY>, grid, 256, 0, s, polys, batch, tab, mapping);
         else hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_BRAM>, grid, 256, 0, s, polys, batch, tab, mapping);
@@ -521,7 +557,7 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     const int grid = grid_for(batch, t.num_cus * 4);
     hipLaunchKernelGGL((matvec_kernel<K, L, LEVEL, OUT>), grid, 64 * (K > L ? K : L), 0, s, w, w1, w0, A, y, batch,
-                       shared_A, t.fwd, t.inv);
+                       shared_A, t.fwd, t.inv_pipe);
     return hipGetLastError();
 }
 
@@ -550,7 +586,7 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
 #define DIL_VY(LV)                                                                                             \
     hipLaunchKernelGGL(verify_kernel<LV>, grid,                                                                \
                        64 * (Par<LV>::K > Par<LV>::L + 1 ? Par<LV>::K : Par<LV>::L + 1), 0, s, w1, A, z, c, t1, \
-                       h, batch, shared_pk, t.fwd, t.inv);                                                     \
+                       h, batch, shared_pk, t.fwd, t.inv_pipe);                                                     \
     break
     switch (level) {
     case 2: DIL_VY(2);
@@ -571,7 +607,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
 #define DIL_S2(LV)                                                                                             \
     hipLaunchKernelGGL(sign2_kernel<LV>, grid,                                                                 \
                        64 * (Par<LV>::K > Par<LV>::L + 1 ? Par<LV>::K : Par<LV>::L + 1), 0, s, z, h, flags, c, \
-                       y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv);                       \
+                       y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe);                       \
     break
     switch (level) {
     case 2: DIL_S2(2);

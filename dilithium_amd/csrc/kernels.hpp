@@ -13,7 +13,8 @@ enum { OUT_W = 0, OUT_W1W0 = 1 };
 
 struct Tables {
     const uint32_t* fwd = nullptr;   // device, [4][64][8]
-    const uint32_t* inv = nullptr;   // device, [4][64][8]
+    const uint32_t* inv = nullptr;   // device, [4][64][8]  standalone inverse (f = 1/256)
+    const uint32_t* inv_pipe = nullptr;   // same, f = 2^32/256: cancels the 2^-32 of the fused pointwise stage
     int num_cus = 256;
 };
 

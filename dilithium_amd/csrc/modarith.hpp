@@ -1,106 +1,79 @@
-// modarith.hpp -- 23-bit modular arithmetic for q = 8380417 on CDNA4 (gfx950) VALUs.
+// modarith.hpp -- modular arithmetic for q = 8380417 on CDNA4 (gfx950) VALUs.
 //
-// Design rule: 32-bit integer multiplies (v_mul_lo_u32 / v_mul_hi_u32) are quarter rate on
-// CDNA; the 24-bit forms v_mul_u32_u24 / v_mul_hi_u32_u24 / v_mad_u32_u24 are full rate.
-// q < 2^23 and 2q < 2^24, so every multiplier operand is kept below 2^24 and every product
-// is taken with the 24-bit instructions.  hipcc selects them from the masked C expressions
-// below (the masks themselves fold away: the instructions ignore bits 31:24).
+// Measured on MI355X (profiles/r01_ubench_valu_rates.txt): v_add/v_sub/v_and/v_xor/shifts-right
+// issue at ~2.5 cycles per wave64 instruction; EVERY other integer op -- v_mul_lo_u32,
+// v_mul_hi_{u,i}32, the 24-bit multiplies, v_mad_*, v_min/max, v_add3, v_bfi, v_cndmask(e64),
+// DPP moves -- issues at ~4.4 cycles, v_mad_{u,i}64_{u,i}32 at ~5.2, and VCC-form v_cndmask at
+// ~22.  So 32-bit multiplies cost the same as 24-bit ones, a 64-bit multiply-accumulate costs
+// barely more than one multiply, and the cheapest exact reduction is signed Montgomery with
+// R = 2^32 (3 multiplies + 1 subtract for a constant operand, no range fix-ups):
 //
-// Arithmetic spec being matched (bit-exact mod q): Barrett_8380417.v:146-283 (modmul),
-// butterfly.v:27-250 (op set), ref_ntt.cpp:28-87 (C model).  Values are "lazy" residues:
-// any uint32 congruent to the true value; canonical [0,q) only at kernel outputs.
+//     mont_tw(y, w)      = y * w            (w stored as w~ = w * 2^32 mod q, and w~ * q^-1)
+//     mont_red64(p)      = p * 2^-32 mod q  (p a 64-bit sum of products)
+//
+// Arithmetic spec being matched bit-exactly mod q: Barrett_8380417.v:146-283 (modmul),
+// butterfly.v:27-250 (op set), ref_ntt.cpp:28-87 (C model).  Values in flight are lazy signed
+// residues (any int32 congruent to the true value); canonical [0, q) only at kernel outputs
+// (the RTL convention, butterfly.v:194-195).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace dil {
 
-constexpr uint32_t Q = 8380417u;        // 2^23 - 2^13 + 1   (params.h:33)
-constexpr uint32_t Q2 = 2u * Q;
-constexpr uint32_t MU46 = 8396807u;     // floor(2^46 / q)   (Barrett_8380417.v:189-219)
-constexpr uint32_t F256 = 8347681u;     // 256^-1 mod q      (ref_ntt.cpp:64)
+constexpr int32_t Q = 8380417;             // 2^23 - 2^13 + 1   (params.h:33)
+constexpr uint32_t QINV = 58728449u;       // q^-1 mod 2^32
+constexpr int32_t F256 = 8347681;          // 256^-1 mod q      (ref_ntt.cpp:64)
 
-__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b)
+// y * w for a table constant w = (wt, wq):  wt = centred(w * 2^32 mod q), wq = wt * q^-1 mod 2^32.
+// Any int32 y; |result| < q (|y * wt| < 2^31 * q/2).      v_mul_lo_u32, 2 x v_mul_hi_i32, v_sub
+__device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
 {
-    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);                       // v_mul_u32_u24
-}
-__device__ __forceinline__ uint32_t mulhi24(uint32_t a, uint32_t b)
-{
-    return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) >> 32);  // v_mul_hi_u32_u24
-}
-// keep a value opaque to the optimiser (stops it re-associating a 24-bit product into a
-// quarter-rate 32-bit multiply by a negative constant)
-__device__ __forceinline__ uint32_t opaque(uint32_t x)
-{
-    asm("" : "+v"(x));
-    return x;
+    const int32_t m = (int32_t)((uint32_t)y * wq);
+    return __mulhi(y, wt) - __mulhi(m, Q);
 }
 
-// any uint32 x  ->  x - floor(x / 2^23) * q  in [0, 2^23 + 2^22)  (2 instructions)
-// (Barrett with the quotient estimate x>>23: q = 2^23 - 2^13 + 1, so the remainder is
-//  x mod 2^23 + (x>>23) * 8191.)
-__device__ __forceinline__ uint32_t red(uint32_t x)
+// p * 2^-32 mod q for |p| < 2^31 * q;  |result| < q.
+__device__ __forceinline__ int32_t mont_red64(int64_t p)
 {
-    return x + (uint32_t)((int)(x >> 23) * (-(int)Q));
+    const int32_t m = (int32_t)((uint32_t)p * QINV);
+    return (int32_t)(p >> 32) - __mulhi(m, Q);
 }
 
-// [0, 2q) -> [0, q)
-__device__ __forceinline__ uint32_t csub(uint32_t x)
+// a * b * 2^-32 mod q (generic Montgomery product; v_mad_i64_i32 gives the 64-bit product)
+__device__ __forceinline__ int32_t mont_mul(int32_t a, int32_t b) { return mont_red64((int64_t)a * (int64_t)b); }
+
+// (-q, q) -> [0, q)
+__device__ __forceinline__ uint32_t canon_small(int32_t t) { return (uint32_t)(t + ((t >> 31) & Q)); }
+
+// any int32 with |x| < 2^31 - 2^22 -> [0, q):  x - round(x / 2^23) * q lies in (-q, q)
+__device__ __forceinline__ uint32_t canon_any(int32_t x)
 {
-    uint32_t y = x - Q;
-    return y < x ? y : x;                                           // v_min_u32(x, x - q)
+    const int32_t k = (x + (1 << 22)) >> 23;
+    return canon_small(x - k * Q);
 }
 
-// any uint32 -> canonical [0, q)
-__device__ __forceinline__ uint32_t canon(uint32_t x) { return csub(red(x)); }
+// 2^64 mod q as a table constant: mont_tw(mont_mul(a, b), R2_WT, R2_WQ) == a * b mod q
+constexpr int32_t R2_WT = 1593613;             // centred(2^64 * 2^32 mod q)
+constexpr uint32_t R2_WQ = 3082416397u;        // R2_WT * q^-1 mod 2^32   (checked in tests/test_model_and_cabi.py)
 
-// int32 in (-q, q) (or already canonical) -> canonical [0, q): min(x, x + q) as unsigned
-__device__ __forceinline__ uint32_t canon_signed(int32_t v)
+// Cooley-Tukey butterfly (ref_ntt.cpp:39-44 / butterfly.v FORWARD_NTT_MODE), lazy signed:
+//   x' = x + w*y,  y' = x - w*y.   |w*y| < 0.75 q, so each layer widens x by < q.
+__device__ __forceinline__ void ct_bfly(int32_t& x, int32_t& y, int32_t wt, uint32_t wq)
 {
-    uint32_t x = (uint32_t)v, y = x + Q;
-    return y < x ? y : x;
+    const int32_t t = mont_tw(y, wt, wq);
+    y = x - t;
+    x = x + t;
 }
 
-// Shoup / Harvey multiplication by a constant w < q with companion wp = floor(w * 2^24 / q):
-//   y < 2^24  ->  y * w mod q  in [0, 2q).   5 full-rate instructions.
-__device__ __forceinline__ uint32_t shoup_mul(uint32_t y, uint32_t w, uint32_t wp)
+// Gentleman-Sande butterfly (ref_ntt.cpp:76-81 / butterfly.v INVERSE_NTT_MODE), lazy signed:
+//   x' = x + y,  y' = (x - y) * w.   The sums double per layer: 8 layers from |x| < q stay
+//   below 256 q < 2^31.
+__device__ __forceinline__ void gs_bfly(int32_t& x, int32_t& y, int32_t wt, uint32_t wq)
 {
-    uint32_t qe = __builtin_amdgcn_alignbit(mulhi24(y, wp), mul24(y, wp), 24);
-    return mul24(y, w) - opaque(mul24(qe, Q));
-}
-
-// Cooley-Tukey butterfly (ref_ntt.cpp:39-44 / butterfly.v FORWARD_NTT_MODE), lazy:
-//   x' = x + w*y,  y' = x - w*y + 2q.   x, y any uint32 small enough not to overflow
-//   (each layer adds at most 2q); y is pulled below 2^24 by red() for the multiplier.
-__device__ __forceinline__ void ct_bfly(uint32_t& x, uint32_t& y, uint32_t w, uint32_t wp)
-{
-    uint32_t yr = red(y);
-    uint32_t qe = __builtin_amdgcn_alignbit(mulhi24(yr, wp), mul24(yr, wp), 24);
-    uint32_t xn = (mul24(yr, w) + x) - opaque(mul24(qe, Q));        // v_mad_u32_u24 + v_sub
-    uint32_t b = opaque((x << 1) + Q2);                             // v_lshl_add_u32
-    y = b - xn;
-    x = xn;
-}
-
-// Gentleman-Sande butterfly (ref_ntt.cpp:76-81 / butterfly.v INVERSE_NTT_MODE), lazy:
-//   x' = x + y,  y' = (x - y) * w.   BY = static bound on y in units of q.
-template <uint32_t BY>
-__device__ __forceinline__ void gs_bfly(uint32_t& x, uint32_t& y, uint32_t w, uint32_t wp)
-{
-    uint32_t d = x + (BY * Q) - y;
+    const int32_t d = x - y;
     x = x + y;
-    y = shoup_mul(red(d), w, wp);
+    y = mont_tw(d, wt, wq);
 }
-
-// Barrett product of two canonical residues, exactly the RTL datapath
-// (Barrett_8380417.v: quo = ((x >> 22) * 8396807) >> 24): a, b in [0, q) -> a*b mod q in [0, 2q)
-__device__ __forceinline__ uint32_t mulmod_lazy(uint32_t a, uint32_t b)
-{
-    uint32_t lo = mul24(a, b), hi = mulhi24(a, b);
-    uint32_t xs = __builtin_amdgcn_alignbit(hi, lo, 22);
-    uint32_t qe = __builtin_amdgcn_alignbit(mulhi24(xs, MU46), mul24(xs, MU46), 24);
-    return lo - opaque(mul24(qe, Q));
-}
-__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) { return csub(mulmod_lazy(a, b)); }
 
 }  // namespace dil

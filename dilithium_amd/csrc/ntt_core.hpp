@@ -8,12 +8,12 @@
 // transposes between the register index and one lane bit-pair:
 //     lane bits 5:4  ->  v_permlane32_swap + v_permlane16_swap   (gfx950)
 //     lane bits 3:2  ->  DPP row_shr/row_shl with bank masks
-//     lane bits 1:0  ->  DPP quad_perm + v_cndmask
+//     lane bits 1:0  ->  DPP quad_perm + v_bfi
 // No LDS traffic, no barriers inside a transform.
 //
 // Index bookkeeping (pos = coefficient index, P3..P0 = its four bit-pairs, P3 = bits 7:6):
 //   forward  load   lane = (P2,P1,P0) reg = P3      a[lane + 64 m]        (4 coalesced dword loads)
-//            pass 0 (len 64,32... layers 128/64)    twiddle k1 = 1
+//            pass 0 (layers len 128, 64)            twiddle k1 = 1
 //            xchg 5:4 -> lane = (P3,P1,P0) reg = P2 ; pass 1, k1 = 4  + (lane >> 4)
 //            xchg 3:2 -> lane = (P3,P2,P0) reg = P1 ; pass 2, k1 = 16 + (lane >> 2)
 //            xchg 1:0 -> lane = (P3,P2,P1) reg = P0 ; pass 3, k1 = 64 + lane
@@ -25,9 +25,9 @@
 
 namespace dil {
 
-// per-lane twiddles of one pass: 8 dwords = two 16-byte loads
-//   forward: {wa, wa', wb0, wb0', wb1, wb1', -, -}
-//   inverse: {wa0, wa0', wa1, wa1', wb, wb', f, f'}   (f = 256^-1, used by the last pass only)
+// per-lane twiddles of one pass, Montgomery form: 8 dwords = two 16-byte loads
+//   forward: {wa~, waq, wb0~, wb0q, wb1~, wb1q, -, -}
+//   inverse: {wa0~, wa0q, wa1~, wa1q, wb~, wbq, f~, fq}   (f = 256^-1 [* 2^32], last pass only)
 struct Tw8 {
     uint32_t v[8];
 };
@@ -35,19 +35,23 @@ struct Tw8 {
 constexpr int TW_PASS_STRIDE = 64 * 8;      // dwords per pass in a table: [pass][lane][8]
 constexpr int TW_TABLE_DWORDS = 4 * TW_PASS_STRIDE;
 
+__device__ __forceinline__ Tw8 load_tw8(const uint32_t* p)
+{
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    Tw8 t;
+    t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
+    t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w;
+    return t;
+}
+
 // twiddle providers ------------------------------------------------------------------
-// registers: the 4 passes' twiddles live in 32 VGPRs for the lifetime of a persistent wave
+// registers: the 4 passes' twiddles live in VGPRs for the lifetime of a persistent wave
 struct TwRegs {
     Tw8 p[4];
     __device__ __forceinline__ void load(const uint32_t* __restrict__ tab, int lane)
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint4* src = reinterpret_cast<const uint4*>(tab + i * TW_PASS_STRIDE + lane * 8);
-            uint4 a = src[0], b = src[1];
-            p[i].v[0] = a.x; p[i].v[1] = a.y; p[i].v[2] = a.z; p[i].v[3] = a.w;
-            p[i].v[4] = b.x; p[i].v[5] = b.y; p[i].v[6] = b.z; p[i].v[7] = b.w;
-        }
+        for (int i = 0; i < 4; i++) p[i] = load_tw8(tab + i * TW_PASS_STRIDE + lane * 8);
     }
     template <int PASS>
     __device__ __forceinline__ Tw8 get() const { return p[PASS]; }
@@ -60,125 +64,127 @@ struct TwLds {
     const uint32_t* tab;   // LDS pointer, [4][64][8]
     int lane;
     template <int PASS>
-    __device__ __forceinline__ Tw8 get() const
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(tab + PASS * TW_PASS_STRIDE + lane * 8);
-        uint4 a = src[0], b = src[1];
-        Tw8 t;
-        t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
-        t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w;
-        return t;
-    }
+    __device__ __forceinline__ Tw8 get() const { return load_tw8(tab + PASS * TW_PASS_STRIDE + lane * 8); }
 };
 
 // cross-lane 4x4 transposes -----------------------------------------------------------
 // 2x2 step on a register pair (X = index bit 0, Y = index bit 1) against one lane bit:
 //   X[lanes with bit = 1]  <->  Y[partner lanes with bit = 0]
-__device__ __forceinline__ void swap_b5(uint32_t& x, uint32_t& y)
+__device__ __forceinline__ void swap_b5(int32_t& x, int32_t& y)
 {
-    auto s = __builtin_amdgcn_permlane32_swap(x, y, false, false);
-    x = s[0];
-    y = s[1];
+    auto s = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)y, false, false);
+    x = (int32_t)s[0];
+    y = (int32_t)s[1];
 }
-__device__ __forceinline__ void swap_b4(uint32_t& x, uint32_t& y)
+__device__ __forceinline__ void swap_b4(int32_t& x, int32_t& y)
 {
-    auto s = __builtin_amdgcn_permlane16_swap(x, y, false, false);
-    x = s[0];
-    y = s[1];
+    auto s = __builtin_amdgcn_permlane16_swap((uint32_t)x, (uint32_t)y, false, false);
+    x = (int32_t)s[0];
+    y = (int32_t)s[1];
 }
 template <int M>   // M = 8 (lane bit 3) or 4 (lane bit 2): DPP within a row of 16 lanes
-__device__ __forceinline__ void swap_row(uint32_t& x, uint32_t& y)
+__device__ __forceinline__ void swap_row(int32_t& x, int32_t& y)
 {
     constexpr int SHR = 0x110 | M, SHL = 0x100 | M;
     constexpr int BANK1 = (M == 8) ? 0xC : 0xA, BANK0 = (M == 8) ? 0x3 : 0x5;
-    uint32_t nx = __builtin_amdgcn_update_dpp(x, y, SHR, 0xF, BANK1, false);
-    uint32_t ny = __builtin_amdgcn_update_dpp(y, x, SHL, 0xF, BANK0, false);
+    const int32_t nx = __builtin_amdgcn_update_dpp(x, y, SHR, 0xF, BANK1, false);
+    const int32_t ny = __builtin_amdgcn_update_dpp(y, x, SHL, 0xF, BANK0, false);
     x = nx;
     y = ny;
 }
-template <int M>   // M = 2 (lane bit 1) or 1 (lane bit 0): DPP quad_perm + select
-__device__ __forceinline__ void swap_quad(uint32_t& x, uint32_t& y, bool bit)
+// M = 2 (lane bit 1) or 1 (lane bit 0): DPP quad_perm + bit-field insert under a per-lane mask
+// (v_bfi_b32: VCC-form v_cndmask measured 5x slower on gfx950, see modarith.hpp)
+__device__ __forceinline__ int32_t bfi(uint32_t mask, int32_t a, int32_t b)   // mask ? a : b, bitwise
+{
+    int32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+template <int M>
+__device__ __forceinline__ void swap_quad(int32_t& x, int32_t& y, uint32_t mask)
 {
     constexpr int PERM = (M == 1) ? 0xB1 : 0x4E;   // quad_perm [1,0,3,2] / [2,3,0,1]
-    uint32_t ys = __builtin_amdgcn_mov_dpp(y, PERM, 0xF, 0xF, true);
-    uint32_t xs = __builtin_amdgcn_mov_dpp(x, PERM, 0xF, 0xF, true);
-    uint32_t nx = bit ? ys : x;
-    uint32_t ny = bit ? y : xs;
+    const int32_t ys = __builtin_amdgcn_mov_dpp(y, PERM, 0xF, 0xF, true);
+    const int32_t xs = __builtin_amdgcn_mov_dpp(x, PERM, 0xF, 0xF, true);
+    const int32_t nx = bfi(mask, ys, x);
+    const int32_t ny = bfi(mask, y, xs);
     x = nx;
     y = ny;
 }
 
-__device__ __forceinline__ void xchg_54(uint32_t (&r)[4])
+// per-lane constants of the exchanges (computed once per wave)
+struct LaneMasks {
+    uint32_t b1, b0;   // all-ones where lane bit 1 / bit 0 is set
+    __device__ __forceinline__ explicit LaneMasks(int lane) : b1(0u - ((lane >> 1) & 1)), b0(0u - (lane & 1)) {}
+};
+
+__device__ __forceinline__ void xchg_54(int32_t (&r)[4])
 {
     swap_b5(r[0], r[2]);
     swap_b5(r[1], r[3]);
     swap_b4(r[0], r[1]);
     swap_b4(r[2], r[3]);
 }
-__device__ __forceinline__ void xchg_32(uint32_t (&r)[4])
+__device__ __forceinline__ void xchg_32(int32_t (&r)[4])
 {
     swap_row<8>(r[0], r[2]);
     swap_row<8>(r[1], r[3]);
     swap_row<4>(r[0], r[1]);
     swap_row<4>(r[2], r[3]);
 }
-__device__ __forceinline__ void xchg_10(uint32_t (&r)[4], int lane)
+__device__ __forceinline__ void xchg_10(int32_t (&r)[4], const LaneMasks& lm)
 {
-    const bool b1 = lane & 2, b0 = lane & 1;
-    swap_quad<2>(r[0], r[2], b1);
-    swap_quad<2>(r[1], r[3], b1);
-    swap_quad<1>(r[0], r[1], b0);
-    swap_quad<1>(r[2], r[3], b0);
+    swap_quad<2>(r[0], r[2], lm.b1);
+    swap_quad<2>(r[1], r[3], lm.b1);
+    swap_quad<1>(r[0], r[1], lm.b0);
+    swap_quad<1>(r[2], r[3], lm.b0);
 }
 
 // one forward radix-2x2 pass on the lane's 4-tuple (ref_ntt2x2.cpp:57-79 / butterfly2x2.v)
-__device__ __forceinline__ void fwd_pass(uint32_t (&r)[4], const Tw8& t)
+__device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
 {
-    ct_bfly(r[0], r[2], t.v[0], t.v[1]);
-    ct_bfly(r[1], r[3], t.v[0], t.v[1]);
-    ct_bfly(r[0], r[1], t.v[2], t.v[3]);
-    ct_bfly(r[2], r[3], t.v[4], t.v[5]);
+    ct_bfly(r[0], r[2], (int32_t)t.v[0], t.v[1]);
+    ct_bfly(r[1], r[3], (int32_t)t.v[0], t.v[1]);
+    ct_bfly(r[0], r[1], (int32_t)t.v[2], t.v[3]);
+    ct_bfly(r[2], r[3], (int32_t)t.v[4], t.v[5]);
 }
 
-// Forward NTT.  In: r[m] = lazy residue (< 2^31) of a[lane + 64 m].  Out: r[m] = lazy
-// residue (< 2^28) of ntt(a)[4 lane + m]; canonicalise with canon() if it leaves the chip.
+// Forward NTT.  In: r[m] = a[lane + 64 m], any int32 with |a| < 2^31 - 6q.
+// Out: r[m] = lazy residue (|.| < |in| + 6q) of ntt(a)[4 lane + m]; canon_any() to leave the chip.
 template <class TW>
-__device__ __forceinline__ void ntt_fwd_core(uint32_t (&r)[4], const TW& tw, int lane)
+__device__ __forceinline__ void ntt_fwd_core(int32_t (&r)[4], const TW& tw, const LaneMasks& lm)
 {
     fwd_pass(r, tw.template get<0>());
     xchg_54(r);
     fwd_pass(r, tw.template get<1>());
     xchg_32(r);
     fwd_pass(r, tw.template get<2>());
-    xchg_10(r, lane);
+    xchg_10(r, lm);
     fwd_pass(r, tw.template get<3>());
 }
 
-// one inverse pass: every register enters below 2q (ref_ntt2x2.cpp:122-140, without the
-// per-butterfly halving -- the 2^-8 is applied once, folded into the last pass)
+// one inverse pass (ref_ntt2x2.cpp:122-140, without the per-butterfly halving -- the 2^-8 is
+// applied once, folded into the last pass's constants)
 template <bool LAST>
-__device__ __forceinline__ void inv_pass(uint32_t (&r)[4], const Tw8& t)
+__device__ __forceinline__ void inv_pass(int32_t (&r)[4], const Tw8& t)
 {
-    gs_bfly<2>(r[0], r[1], t.v[0], t.v[1]);       // r0: 4q, r1: 2q
-    gs_bfly<2>(r[2], r[3], t.v[2], t.v[3]);       // r2: 4q, r3: 2q
-    gs_bfly<4>(r[0], r[2], t.v[4], t.v[5]);       // r0: 8q, r2: 2q
-    gs_bfly<2>(r[1], r[3], t.v[4], t.v[5]);       // r1: 4q, r3: 2q
+    gs_bfly(r[0], r[1], (int32_t)t.v[0], t.v[1]);
+    gs_bfly(r[2], r[3], (int32_t)t.v[2], t.v[3]);
+    gs_bfly(r[0], r[2], (int32_t)t.v[4], t.v[5]);
+    gs_bfly(r[1], r[3], (int32_t)t.v[4], t.v[5]);
     if (LAST) {
-        r[0] = shoup_mul(red(r[0]), t.v[6], t.v[7]);
-        r[1] = shoup_mul(red(r[1]), t.v[6], t.v[7]);
-    } else {
-        r[0] = red(r[0]);                         // back under 2q before the exchange mixes registers
-        r[1] = red(r[1]);
+        r[0] = mont_tw(r[0], (int32_t)t.v[6], t.v[7]);
+        r[1] = mont_tw(r[1], (int32_t)t.v[6], t.v[7]);
     }
 }
 
-// Inverse NTT.  In: r[m] = residue BELOW 2q of a[4 lane + m].  Out: r[m] in [0, 2q) congruent
-// to invntt(a)[lane + 64 m] (the 256^-1 of ref_ntt.cpp:83-86 included); csub() for canonical.
+// Inverse NTT.  In: r[m] = a[4 lane + m] with |a| < q.  Out: r[m] in (-q, q) congruent to
+// invntt(a)[lane + 64 m] (the 256^-1 of ref_ntt.cpp:83-86 included); canon_small() for [0, q).
 template <class TW>
-__device__ __forceinline__ void ntt_inv_core(uint32_t (&r)[4], const TW& tw, int lane)
+__device__ __forceinline__ void ntt_inv_core(int32_t (&r)[4], const TW& tw, const LaneMasks& lm)
 {
     inv_pass<false>(r, tw.template get<0>());
-    xchg_10(r, lane);
+    xchg_10(r, lm);
     inv_pass<false>(r, tw.template get<1>());
     xchg_32(r);
     inv_pass<false>(r, tw.template get<2>());

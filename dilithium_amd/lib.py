@@ -23,7 +23,7 @@ SIGNATURES = {
     "dil_device_count": [C.POINTER(C.c_int)],
     "dil_num_cus": [],
     "dil_error_string": [C.c_int],
-    "dil_host_twiddle_tables": [_u32p, _u32p],
+    "dil_host_twiddle_tables": [_u32p, _u32p, _u32p],
     "dil_host_zetas": [_i32p],
     "dil_ntt_dev": [_vp, _sz, _vp],
     "dil_invntt_dev": [_vp, _sz, _vp],

@@ -1,177 +1,225 @@
 """Executable spec of the HIP kernels' wave-level dataflow (numpy, 64 lanes x 4 registers).
 
-TEST INFRASTRUCTURE.  Mirrors dilithium_amd/csrc/ntt_core.hpp step for step -- same lane
-layout, same cross-lane exchanges, same lazy-reduction schedule, same twiddle tables --
-so that layout / twiddle-index / overflow-bound mistakes are caught on CPU (no GPU in the
-dev container).  Every multiply asserts its 24-bit operand contract; every add asserts
-no 32-bit overflow.
+TEST INFRASTRUCTURE.  Mirrors dilithium_amd/csrc/{modarith,ntt_core}.hpp step for step --
+same lane layout, same cross-lane exchanges, same signed-Montgomery arithmetic (R = 2^32),
+same twiddle tables -- so that layout / twiddle-index / overflow mistakes are caught on CPU
+(the dev container has no GPU).  Every intermediate asserts that it fits in int32 and every
+Montgomery product asserts its |a*b| < 2^31 * q contract.
 """
 import numpy as np
 
 Q = 8380417
 N = 256
 LANES = 64
-F256 = 8347681  # 256^-1 mod q (ref_ntt.cpp:64)
+F256 = 8347681            # 256^-1 mod q (ref_ntt.cpp:64)
+R = 1 << 32
+QINV = pow(Q, -1, R)      # 58728449
+assert QINV == 58728449
 
 
 def brv8(x):
     return int(f"{x:08b}"[::-1], 2)
 
 
-ZETA = [0] + [pow(1753, brv8(k), Q) for k in range(1, N)]  # canonical zetas (== zetas.txt)
+ZETA = [0] + [pow(1753, brv8(k), Q) for k in range(1, N)]   # canonical zetas (== zetas.txt)
 
 
-def shoup(w):
-    return (w << 24) // Q
+def centered(x):
+    x %= Q
+    return x - Q if x > (Q - 1) // 2 else x
 
 
-# ---- arithmetic primitives (uint32 semantics, checked) -------------------------------
-def mul24(a, b):
-    a = np.asarray(a, dtype=np.uint64)
-    b = np.asarray(b, dtype=np.uint64)
-    assert (a < (1 << 24)).all() and (b < (1 << 24)).all(), "u24 operand out of range"
-    return a * b  # full 48-bit product (caller takes what it needs)
+def mont_const(w):
+    """(w~, wq): w~ = centred(w * 2^32 mod q),  wq = w~ * q^-1 mod 2^32 (as a 32-bit pattern)"""
+    wt = centered(w * R % Q)
+    return wt, (wt * QINV) % R
 
 
-def red(x):
-    """x - (x>>23)*q : any uint32 -> [0, 2^23 + 2^22)"""
-    x = np.asarray(x, dtype=np.uint64)
-    assert (x < (1 << 32)).all(), "32-bit overflow"
-    r = x - (x >> np.uint64(23)) * np.uint64(Q)
-    assert (r < (1 << 23) + (1 << 22)).all()
-    return r
+def i32(x):
+    x = np.asarray(x, dtype=np.int64)
+    assert (x >= -(1 << 31)).all() and (x < (1 << 31)).all(), "int32 overflow"
+    return x
 
 
-def shoup_mul(y, w, wp):
-    """y < 2^24, w < q, wp = floor(w 2^24 / q) -> y*w mod q in [0, 2q)"""
-    p = mul24(y, wp)
-    qe = p >> np.uint64(24)
-    r = (mul24(y, w) - mul24(qe, Q))
-    assert (r < 2 * Q).all()
-    return r
+def wrap32(x):
+    """two's-complement wrap of an int64 array to signed 32 bit"""
+    x = np.asarray(x, dtype=np.int64) & 0xFFFFFFFF
+    return np.where(x >= (1 << 31), x - (1 << 32), x)
 
 
-def canon_final(x):
-    r = red(x)
-    return np.where(r >= Q, r - Q, r)
+def mulhi(a, b):
+    return (np.asarray(a, dtype=np.int64) * np.asarray(b, dtype=np.int64)) >> 32   # floor, like v_mul_hi_i32
+
+
+def mont_tw(y, wt, wq):
+    """y * w (true product, w given in Montgomery form): 3 multiplies + 1 subtract.  |result| < q"""
+    y = i32(y)
+    wt = np.asarray(wt, dtype=np.int64)
+    assert (np.abs(y * wt) < (1 << 31) * Q).all()
+    m = wrap32(y * np.asarray(wq, dtype=np.int64))
+    t = mulhi(y, wt) - mulhi(m, Q)
+    assert (np.abs(t) < Q).all()
+    return t
+
+
+def mont_red64(p):
+    """p (int64, |p| < 2^31 q) -> p * 2^-32 mod q, |result| < q"""
+    p = np.asarray(p, dtype=np.int64)
+    assert (np.abs(p) < (1 << 31) * Q).all()
+    lo = wrap32(p)
+    m = wrap32(lo * QINV)
+    t = (p >> 32) - mulhi(m, Q)
+    assert (np.abs(t) < Q).all()
+    return t
+
+
+def canon_any(x):
+    """any int32 -> [0, q)"""
+    x = i32(x)
+    k = (x + (1 << 22)) >> 23
+    r = x - k * Q
+    assert (np.abs(r) < Q).all()
+    return np.where(r < 0, r + Q, r)
+
+
+def canon_small(t):
+    """(-q, q) -> [0, q)"""
+    assert (np.abs(t) < Q).all()
+    return np.where(t < 0, t + Q, t)
 
 
 # ---- cross-lane exchanges: 4x4 transpose between register index and a lane bit-pair ---
 def xchg(r, shift):
-    """r: [4][64].  Transpose reg index (2 bits) with lane bits [shift+1:shift]."""
     out = np.empty_like(r)
     lane = np.arange(LANES)
     grp = (lane >> shift) & 3
-    for m in range(4):            # new register index m
-        for c in range(4):        # lanes whose group == c receive old register c from lane with group m
+    for m in range(4):
+        for c in range(4):
             sel = grp == c
             src_lane = (lane & ~(3 << shift)) | (m << shift)
             out[m][sel] = r[c][src_lane[sel]]
     return out
 
 
-# ---- twiddle tables, exactly as the host library builds them ---------------------------
+# ---- twiddle tables, exactly as the host library builds them: [pass][lane][8] ------------
 def fwd_table():
-    """[4 passes][6 = (wa, wa', wb0, wb0', wb1, wb1')][64 lanes]"""
-    t = np.zeros((4, 6, LANES), dtype=np.uint64)
+    t = np.zeros((4, LANES, 8), dtype=np.int64)
     for p in range(4):
         for lane in range(LANES):
             k1 = (1 << (2 * p)) + (lane >> (6 - 2 * p))
-            ws = [ZETA[k1], ZETA[2 * k1], ZETA[2 * k1 + 1]]
-            for i, w in enumerate(ws):
-                t[p, 2 * i, lane] = w
-                t[p, 2 * i + 1, lane] = shoup(w)
+            for i, w in enumerate([ZETA[k1], ZETA[2 * k1], ZETA[2 * k1 + 1]]):
+                t[p, lane, 2 * i], t[p, lane, 2 * i + 1] = mont_const(w)
     return t
 
 
-def inv_table():
-    """[4 passes][8 = (wa0, wa0', wa1, wa1', wb, wb', f, f')][64 lanes]; the last pass's wb is
-    pre-multiplied by f = 256^-1 and f itself rides along (the 1/256 of ref_ntt.cpp:83-86)."""
-    t = np.zeros((4, 8, LANES), dtype=np.uint64)
+def inv_table(pipeline):
+    """last pass: wb *= f and slots 6,7 = f  (f = 256^-1; x 2^32 more in the pipeline flavour,
+    which cancels the 2^-32 left by the Montgomery reduction of the pointwise products)"""
+    t = np.zeros((4, LANES, 8), dtype=np.int64)
+    f = F256 * (R % Q) % Q if pipeline else F256
     for p in range(4):
         for lane in range(LANES):
             blk = lane >> (2 * p) if p < 3 else 0
             base = N >> (2 * p)
             ka = base - 1 - 2 * blk
             kb = (base >> 1) - 1 - blk
-            ws = [(Q - ZETA[ka]) % Q, (Q - ZETA[ka - 1]) % Q, (Q - ZETA[kb]) % Q]
+            ws = [(Q - ZETA[ka]) % Q, (Q - ZETA[ka - 1]) % Q, (Q - ZETA[kb]) % Q, f]
             if p == 3:
-                ws[2] = ws[2] * F256 % Q
-            ws.append(F256)
+                ws[2] = ws[2] * f % Q
             for i, w in enumerate(ws):
-                t[p, 2 * i, lane] = w
-                t[p, 2 * i + 1, lane] = shoup(w)
+                t[p, lane, 2 * i], t[p, lane, 2 * i + 1] = mont_const(w)
     return t
 
 
 FWD = fwd_table()
-INV = inv_table()
+INV = inv_table(False)
+INV_PIPE = inv_table(True)
+
+
+def table_u32(t):
+    return (t & 0xFFFFFFFF).astype(np.uint32)
 
 
 # ---- butterflies ---------------------------------------------------------------------------
-def ct(x, y, w, wp):
-    t = shoup_mul(red(y), w, wp)
-    xn = x + t
-    yn = x + np.uint64(2 * Q) - t
-    assert (xn < (1 << 32)).all() and (yn < (1 << 32)).all()
-    return xn, yn
+def ct(x, y, wt, wq):
+    t = mont_tw(y, wt, wq)
+    return i32(x + t), i32(x - t)
 
 
-def gs(x, y, w, wp, by):
-    """by = static bound (in units of q) on y"""
-    s = x + y
-    d = x + np.uint64(by * Q) - y
-    assert (s < (1 << 32)).all() and (d < (1 << 32)).all() and (y <= by * Q).all()
-    return s, shoup_mul(red(d), w, wp)
+def gs(x, y, wt, wq):
+    return i32(x + y), mont_tw(i32(x - y), wt, wq)
 
 
-# ---- forward NTT: natural in (any int32 in [-q, 2^31)) -> reference order, canonical ----------
-def ntt_wave(a, exchanges_out=None):
-    """a: int array[256].  Returns (r [4][64] with lane j holding out[4j..4j+3], out[256])."""
-    a = np.asarray(a, dtype=np.int64)
-    lane = np.arange(LANES)
-    r = np.stack([(a[lane + 64 * m] + Q).astype(np.uint64) for m in range(4)])  # strided load, +q
-    assert (r < (1 << 32)).all()
+def fwd_core(r):
     for p in range(4):
-        wa, wap, wb0, wb0p, wb1, wb1p = FWD[p]
-        r0, r2 = ct(r[0], r[2], wa, wap)
-        r1, r3 = ct(r[1], r[3], wa, wap)
-        r0, r1 = ct(r0, r1, wb0, wb0p)
-        r2, r3 = ct(r2, r3, wb1, wb1p)
+        T = FWD[p].T
+        r0, r2 = ct(r[0], r[2], T[0], T[1])
+        r1, r3 = ct(r[1], r[3], T[0], T[1])
+        r0, r1 = ct(r0, r1, T[2], T[3])
+        r2, r3 = ct(r2, r3, T[4], T[5])
         r = np.stack([r0, r1, r2, r3])
         if p < 3:
             r = xchg(r, 4 - 2 * p)
-    r = np.stack([canon_final(x) for x in r])
+    return r
+
+
+def inv_core(r, table):
+    for p in range(4):
+        T = table[p].T
+        r0, r1 = gs(r[0], r[1], T[0], T[1])
+        r2, r3 = gs(r[2], r[3], T[2], T[3])
+        r0, r2 = gs(r0, r2, T[4], T[5])
+        r1, r3 = gs(r1, r3, T[4], T[5])
+        if p < 3:
+            r = xchg(np.stack([r0, r1, r2, r3]), 2 * p)
+        else:
+            r = np.stack([mont_tw(r0, T[6], T[7]), mont_tw(r1, T[6], T[7]), r2, r3])
+    return r
+
+
+def ntt_wave(a):
+    """forward NTT: natural in (int32) -> reference order, canonical"""
+    a = i32(a)
+    lane = np.arange(LANES)
+    r = fwd_core(np.stack([a[lane + 64 * m] for m in range(4)]))
+    r = np.stack([canon_any(x) for x in r])
     out = np.empty(N, dtype=np.int64)
     for m in range(4):
         out[4 * lane + m] = r[m]
     return r, out
 
 
-# ---- inverse NTT: reference order in (lane j holds a[4j..4j+3]) -> natural, canonical ----------
-def invntt_wave(a):
-    a = np.asarray(a, dtype=np.int64)
+def invntt_wave(a, table=None):
+    """inverse NTT: reference order in, |a| < q -> natural order, canonical"""
+    a = i32(a)
+    assert (np.abs(a) < Q).all()
     lane = np.arange(LANES)
-    r = np.stack([(a[4 * lane + m] + Q).astype(np.uint64) for m in range(4)])
-    for p in range(4):
-        wa0, wa0p, wa1, wa1p, wb, wbp, f, fp = INV[p]
-        # every register enters a pass below 2q (loads: x+q; later passes: see the reds below)
-        s01, m01 = gs(r[0], r[1], wa0, wa0p, 2)
-        s23, m23 = gs(r[2], r[3], wa1, wa1p, 2)       # s: 4q, m: 2q
-        if p < 3:
-            s02, m02 = gs(s01, s23, wb, wbp, 4)       # 8q, 2q
-            s13, m13 = gs(m01, m23, wb, wbp, 2)       # 4q, 2q
-            # the sums carry 8q / 4q: pull them under 2q BEFORE the exchange mixes registers
-            r = np.stack([red(s02), red(s13), m02, m13])
-            r = xchg(r, 2 * p)
-        else:
-            s02, m02 = gs(s01, s23, wb, wbp, 4)
-            s13, m13 = gs(m01, m23, wb, wbp, 2)
-            s02 = shoup_mul(red(s02), f, fp)
-            s13 = shoup_mul(red(s13), f, fp)
-            r = np.stack([s02, s13, m02, m13])
-    r = np.stack([np.where(x >= Q, x - Q, x) for x in r])   # [0,2q) -> [0,q)
+    r = inv_core(np.stack([a[4 * lane + m] for m in range(4)]), INV if table is None else table)
+    r = np.stack([canon_small(x) for x in r])
     out = np.empty(N, dtype=np.int64)
     for m in range(4):
         out[lane + 64 * m] = r[m]
     return r, out
+
+
+def matvec_wave(A, y):
+    """w[k] = INTT(sum_l A[k][l] o NTT(y[l])) the way the fused kernels do it: lazy NTT outputs,
+    64-bit multiply-accumulate, one Montgomery reduction, pipeline-flavour inverse table"""
+    K, L = A.shape[:2]
+    lane = np.arange(LANES)
+    yh = []
+    for l in range(L):
+        r = fwd_core(np.stack([i32(y[l])[lane + 64 * m] for m in range(4)]))     # lazy, |x| <= 7q
+        yh.append(r)
+    out = np.empty((K, N), dtype=np.int64)
+    for k in range(K):
+        acc = np.zeros((4, LANES), dtype=np.int64)
+        for l in range(L):
+            Arow = np.stack([A[k, l][4 * lane + m] for m in range(4)]).astype(np.int64)
+            acc += Arow * yh[l]
+        r = np.stack([mont_red64(x) for x in acc])
+        r = inv_core(r, INV_PIPE)
+        r = np.stack([canon_small(x) for x in r])
+        for m in range(4):
+            out[k, lane + 64 * m] = r[m]
+    return out

@@ -31,11 +31,22 @@ def test_header_symbols_exported(lib):
 
 
 def test_host_tables_match_model(lib):
-    f = np.zeros(2048, np.uint32)
-    i = np.zeros(2048, np.uint32)
-    lib.dil_host_twiddle_tables(f.ctypes.data_as(C.POINTER(C.c_uint32)), i.ctypes.data_as(C.POINTER(C.c_uint32)))
-    assert (f.reshape(4, 64, 8)[:, :, :6].transpose(0, 2, 1) == wm.FWD).all()
-    assert (i.reshape(4, 64, 8).transpose(0, 2, 1) == wm.INV).all()
+    """the C++ host library's twiddle tables (Montgomery form) == the model's, bit for bit"""
+    u32p = C.POINTER(C.c_uint32)
+    f, i, ip = (np.zeros(2048, np.uint32) for _ in range(3))
+    lib.dil_host_twiddle_tables(f.ctypes.data_as(u32p), i.ctypes.data_as(u32p), ip.ctypes.data_as(u32p))
+    assert (f.reshape(4, 64, 8) == wm.table_u32(wm.FWD)).all()
+    assert (i.reshape(4, 64, 8) == wm.table_u32(wm.INV)).all()
+    assert (ip.reshape(4, 64, 8) == wm.table_u32(wm.INV_PIPE)).all()
+
+
+def test_montgomery_constants():
+    """constants hard-coded in modarith.hpp"""
+    src = open(os.path.join(ROOT, "dilithium_amd/csrc/modarith.hpp")).read()
+    wt, wq = wm.mont_const(pow(2, 64, Q))
+    assert f"R2_WT = {wt};" in src and f"R2_WQ = {wq}u;" in src
+    assert f"QINV = {wm.QINV}u;" in src and (wm.QINV * Q) % (1 << 32) == 1
+    assert (wm.F256 * 256) % Q == 1 and f"F256 = {wm.F256};" in src
 
 
 def test_host_zetas_match_rom_and_oracle(lib, oracle):
@@ -55,6 +66,16 @@ def test_wave_model_matches_oracle(oracle):
     for k, a in enumerate(polys):
         assert (wm.ntt_wave(a)[1] == good[k]).all()
         assert (wm.invntt_wave(a)[1] == goodi[k]).all()
+    # widest forward input domain, and the fused mat-vec dataflow incl. its worst-case bounds
+    for v in (2**31 - 6 * Q - 1, -(2**31 - 6 * Q - 1), 20 * Q + 5):
+        a = np.full(256, v)
+        assert (wm.ntt_wave(a)[1] == oracle.ntt(np.mod(a, Q).astype(np.int32))).all()
+    A = splitmix64_polys(30, seed=9).reshape(6, 5, 256)
+    y = splitmix64_polys(5, seed=10)
+    assert (wm.matvec_wave(A, y) == oracle.matvec(6, 5, A, y)[0]).all()
+    A2 = np.full((8, 7, 256), Q - 1, dtype=np.int32)
+    y2 = np.full((7, 256), Q - 1, dtype=np.int32)
+    assert (wm.matvec_wave(A2, y2) == oracle.matvec(8, 7, A2, y2)[0]).all()
 
 
 def test_no_cpu_fallback_without_gpu(lib):
