@@ -7,6 +7,7 @@
 #include "kernels.hpp"
 
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -182,6 +183,8 @@ int dil_init(int device)
     g.t.inv = g.d_tables + 2048;
     g.t.inv_pipe = g.d_tables + 4096;
     g.t.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("DIL_NTT_BPC")) g.t.ntt_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.ntt_blocks_per_cu;
+    if (const char* e = getenv("DIL_FUSED_WGPC")) g.t.fused_wgs_per_cu = atoi(e) > 0 ? atoi(e) : g.t.fused_wgs_per_cu;
     g.device = device;
     g.ready = true;
     return 0;

@@ -60,6 +60,28 @@ __device__ __forceinline__ int inv_out_off(int i, int mapping)
     return 4 * resolve_row(mapping, resolve_row(MAP_AFTER_INVNTT, i >> 2)) + (i & 3);
 }
 
+// Streaming accesses use the non-temporal cache policy: every polynomial is touched exactly
+// once per kernel, and measured on MI355X nt loads + stores lift the in-place 1 KiB-in /
+// 1 KiB-out stream from 4.7 to 5.2 TB/s (profiles/r01_tune_ntt.txt).
+__device__ __forceinline__ int32_t ld_nt(const int32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_nt(int32_t* p, int32_t v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ int4 ld_nt4(const int32_t* p)
+{
+    int4 v;
+    v.x = __builtin_nontemporal_load(p);
+    v.y = __builtin_nontemporal_load(p + 1);
+    v.z = __builtin_nontemporal_load(p + 2);
+    v.w = __builtin_nontemporal_load(p + 3);
+    return v;      // hipcc merges the four into one global_load_dwordx4 ... nt
+}
+__device__ __forceinline__ void st_nt4(int32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    __builtin_nontemporal_store((int32_t)a, p);
+    __builtin_nontemporal_store((int32_t)b, p + 1);
+    __builtin_nontemporal_store((int32_t)c, p + 2);
+    __builtin_nontemporal_store((int32_t)d, p + 3);
+}
+
 // ---------------------------------------------------------------------------------------
 // H2/H5/H6 forward NTT, batched, in place.  Persistent waves, grid-stride over polynomials,
 // the next polynomial's loads are issued before the current one is transformed.
@@ -80,7 +102,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
     const int out_off = fwd_out_row_off<LAYOUT>(lane, mapping);
     int32_t nxt[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++) nxt[m] = polys[wave * 256 + off[m]];
+    for (int m = 0; m < 4; m++) nxt[m] = ld_nt(polys + wave * 256 + off[m]);
     TwRegs tw;
     tw.load(tw_tab, lane);
     const LaneMasks lm(lane);
@@ -89,11 +111,10 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
         const size_t pn = p + nwaves;
         if (pn < batch) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) nxt[m] = polys[pn * 256 + off[m]];
+            for (int m = 0; m < 4; m++) nxt[m] = ld_nt(polys + pn * 256 + off[m]);
         }
         ntt_fwd_core(r, tw, lm);
-        *reinterpret_cast<uint4*>(polys + p * 256 + out_off) =
-            make_uint4(canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
+        st_nt4(polys + p * 256 + out_off, canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
     }
 }
 
@@ -110,17 +131,17 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ poly
     int off[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) off[m] = inv_out_off<LAYOUT>(lane + 64 * m, mapping);
-    int4 nxt = *reinterpret_cast<const int4*>(polys + wave * 256 + in_off);
+    int4 nxt = ld_nt4(polys + wave * 256 + in_off);
     TwRegs tw;
     tw.load(tw_tab, lane);
     const LaneMasks lm(lane);
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
         const size_t pn = p + nwaves;
-        if (pn < batch) nxt = *reinterpret_cast<const int4*>(polys + pn * 256 + in_off);
+        if (pn < batch) nxt = ld_nt4(polys + pn * 256 + in_off);
         ntt_inv_core(r, tw, lm);
 #pragma unroll
-        for (int m = 0; m < 4; m++) polys[p * 256 + off[m]] = (int32_t)canon_small(r[m]);
+        for (int m = 0; m < 4; m++) st_nt(polys + p * 256 + off[m], (int32_t)canon_small(r[m]));
     }
 }
 
@@ -272,16 +293,22 @@ __device__ __forceinline__ void stage_tables(uint32_t* lds, const uint32_t* __re
 __device__ __forceinline__ void load_strided(int32_t (&r)[4], const int32_t* __restrict__ a, int lane)
 {
 #pragma unroll
-    for (int m = 0; m < 4; m++) r[m] = a[lane + 64 * m];
+    for (int m = 0; m < 4; m++) r[m] = ld_nt(a + lane + 64 * m);
 }
 
 template <int L>
 struct ARow {
     int4 v[L];
-    __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane)
+    // stream = true: this row is read once (per-item A): non-temporal; false: shared A, keep it cached
+    __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane, bool stream)
     {
+        if (stream) {
 #pragma unroll
-        for (int l = 0; l < L; l++) v[l] = *reinterpret_cast<const int4*>(Arow + l * 256 + 4 * lane);
+            for (int l = 0; l < L; l++) v[l] = ld_nt4(Arow + l * 256 + 4 * lane);
+        } else {
+#pragma unroll
+            for (int l = 0; l < L; l++) v[l] = *reinterpret_cast<const int4*>(Arow + l * 256 + 4 * lane);
+        }
     }
 };
 
@@ -315,7 +342,7 @@ __global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
     uint32_t* vec = lds + LDS_VEC;
     for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
         ARow<L> Ar;
-        if (wv < K) Ar.load(A + ((shared_A ? 0 : it * K) + wv) * (size_t)L * 256, lane);
+        if (wv < K) Ar.load(A + ((shared_A ? 0 : it * K) + wv) * (size_t)L * 256, lane, !shared_A);
         if (wv < L) {
             int32_t r[4];
             load_strided(r, y + (it * L + wv) * 256, lane);
@@ -373,7 +400,7 @@ void verify_kernel(uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A,
         uint32_t hb[4] = {0, 0, 0, 0};
         const size_t o = (it * K + wv) * 256;
         if (wv < K) {    // issue this row's loads first: A (L x 1 KiB), t1, h
-            Ar.load(A + ((shared_pk ? 0 : it * K) + wv) * (size_t)L * 256, lane);
+            Ar.load(A + ((shared_pk ? 0 : it * K) + wv) * (size_t)L * 256, lane, !shared_pk);
             const int32_t* src = t1 + ((shared_pk ? 0 : it * K) + wv) * 256;
 #pragma unroll
             for (int m = 0; m < 4; m++) th[m] = src[lane + 64 * m];
@@ -513,7 +540,7 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
                       const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = grid_for((batch + 3) / 4, t.num_cus * 8);
+    const int grid = grid_for((batch + 3) / 4, t.num_cus * t.ntt_blocks_per_cu);
     const uint32_t* tab = inverse ? t.inv : t.fwd;   // standalone flavour of the inverse table
     if (!inverse) {
         if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_POLY>, grid, 256, 0, s, polys, batch, tab, mapping);
@@ -555,7 +582,7 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
                                       size_t batch, int shared_A, const Tables& t, hipStream_t s)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    const int grid = grid_for(batch, t.num_cus * 4);
+    const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
     hipLaunchKernelGGL((matvec_kernel<K, L, LEVEL, OUT>), grid, 64 * (K > L ? K : L), 0, s, w, w1, w0, A, y, batch,
                        shared_A, t.fwd, t.inv_pipe);
     return hipGetLastError();
@@ -582,7 +609,7 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
                          const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = grid_for(batch, t.num_cus * 4);
+    const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
 #define DIL_VY(LV)                                                                                             \
     hipLaunchKernelGGL(verify_kernel<LV>, grid,                                                                \
                        64 * (Par<LV>::K > Par<LV>::L + 1 ? Par<LV>::K : Par<LV>::L + 1), 0, s, w1, A, z, c, t1, \
@@ -603,7 +630,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
                         const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = grid_for(batch, t.num_cus * 4);
+    const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
 #define DIL_S2(LV)                                                                                             \
     hipLaunchKernelGGL(sign2_kernel<LV>, grid,                                                                 \
                        64 * (Par<LV>::K > Par<LV>::L + 1 ? Par<LV>::K : Par<LV>::L + 1), 0, s, z, h, flags, c, \

@@ -16,6 +16,8 @@ struct Tables {
     const uint32_t* inv = nullptr;   // device, [4][64][8]  standalone inverse (f = 1/256)
     const uint32_t* inv_pipe = nullptr;   // same, f = 2^32/256: cancels the 2^-32 of the fused pointwise stage
     int num_cus = 256;
+    int ntt_blocks_per_cu = 8;    // persistent 256-thread blocks per CU for the NTT kernels   (env DIL_NTT_BPC)
+    int fused_wgs_per_cu = 4;     // persistent workgroups per CU for the fused pipelines      (env DIL_FUSED_WGPC)
 };
 
 hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, size_t batch, const Tables& t, hipStream_t s);

@@ -25,19 +25,28 @@ constexpr int32_t Q = 8380417;             // 2^23 - 2^13 + 1   (params.h:33)
 constexpr uint32_t QINV = 58728449u;       // q^-1 mod 2^32
 constexpr int32_t F256 = 8347681;          // 256^-1 mod q      (ref_ntt.cpp:64)
 
+// signed high product as ONE v_mul_hi_i32.  (Left to itself hipcc sometimes hoists the sign
+// extension of a loop-invariant operand and then expands the product into 3 multiplies + fix-ups.)
+__device__ __forceinline__ int32_t mulhi_i32(int32_t a, int32_t b)
+{
+    int32_t d;
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // y * w for a table constant w = (wt, wq):  wt = centred(w * 2^32 mod q), wq = wt * q^-1 mod 2^32.
 // Any int32 y; |result| < q (|y * wt| < 2^31 * q/2).      v_mul_lo_u32, 2 x v_mul_hi_i32, v_sub
 __device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
 {
     const int32_t m = (int32_t)((uint32_t)y * wq);
-    return __mulhi(y, wt) - __mulhi(m, Q);
+    return mulhi_i32(y, wt) - mulhi_i32(m, Q);
 }
 
 // p * 2^-32 mod q for |p| < 2^31 * q;  |result| < q.
 __device__ __forceinline__ int32_t mont_red64(int64_t p)
 {
     const int32_t m = (int32_t)((uint32_t)p * QINV);
-    return (int32_t)(p >> 32) - __mulhi(m, Q);
+    return (int32_t)(p >> 32) - mulhi_i32(m, Q);
 }
 
 // a * b * 2^-32 mod q (generic Montgomery product; v_mad_i64_i32 gives the 64-bit product)
@@ -53,9 +62,9 @@ __device__ __forceinline__ uint32_t canon_any(int32_t x)
     return canon_small(x - k * Q);
 }
 
-// 2^64 mod q as a table constant: mont_tw(mont_mul(a, b), R2_WT, R2_WQ) == a * b mod q
-constexpr int32_t R2_WT = 1593613;             // centred(2^64 * 2^32 mod q)
-constexpr uint32_t R2_WQ = 3082416397u;        // R2_WT * q^-1 mod 2^32   (checked in tests/test_model_and_cabi.py)
+// the constant 2^32 mod q in table form (wt = 2^64 mod q centred): mont_tw(mont_mul(a, b), R2_WT, R2_WQ) == a * b mod q
+constexpr int32_t R2_WT = 2365951;
+constexpr uint32_t R2_WQ = 2145647103u;        // R2_WT * q^-1 mod 2^32   (checked in tests/test_model_and_cabi.py)
 
 // Cooley-Tukey butterfly (ref_ntt.cpp:39-44 / butterfly.v FORWARD_NTT_MODE), lazy signed:
 //   x' = x + w*y,  y' = x - w*y.   |w*y| < 0.75 q, so each layer widens x by < q.
