@@ -49,6 +49,9 @@ inline void mont_const(uint32_t w, uint32_t* out)
 //          ka = base-1-2t, ka-1, kb = base/2-1-t, each negated (ref_ntt2x2.cpp:113-118 ==
 //          twiddle_resolver.v:87-105); last pass: wb *= f and f rides in slots 6,7, with
 //          f = 256^-1 (standalone) or 2^32 * 256^-1 (pipelines, see kernels.hpp)
+// slot i (0..7) of (pass p, lane) in the [pass][half][lane][4] layout the kernels read
+inline uint32_t* slot(uint32_t* tab, int p, int lane, int i) { return tab + p * 512 + (i >> 2) * 256 + lane * 4 + (i & 3); }
+
 void build_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe)
 {
     uint32_t z[256];
@@ -57,22 +60,30 @@ void build_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe)
     const uint64_t f_pipe = f_std * ((1ull << 32) % (uint64_t)Q) % (uint64_t)Q;
     for (int p = 0; p < 4; p++) {
         for (int lane = 0; lane < 64; lane++) {
-            uint32_t* e = fwd + (p * 64 + lane) * 8;
             const unsigned k1 = (1u << (2 * p)) + ((unsigned)lane >> (6 - 2 * p));
             const uint32_t wf[3] = {z[k1], z[2 * k1], z[2 * k1 + 1]};
-            for (int i = 0; i < 3; i++) mont_const(wf[i], e + 2 * i);
-            e[6] = e[7] = 0;
+            uint32_t pr[2];
+            for (int i = 0; i < 3; i++) {
+                mont_const(wf[i], pr);
+                *slot(fwd, p, lane, 2 * i) = pr[0];
+                *slot(fwd, p, lane, 2 * i + 1) = pr[1];
+            }
+            *slot(fwd, p, lane, 6) = *slot(fwd, p, lane, 7) = 0;
 
             const unsigned t = (p < 3) ? ((unsigned)lane >> (2 * p)) : 0u;
             const unsigned base = 256u >> (2 * p);
             const unsigned ka = base - 1 - 2 * t, kb = (base >> 1) - 1 - t;
             for (int flavour = 0; flavour < 2; flavour++) {
-                uint32_t* d = (flavour ? inv_pipe : inv) + (p * 64 + lane) * 8;
+                uint32_t* d = flavour ? inv_pipe : inv;
                 const uint64_t f = flavour ? f_pipe : f_std;
                 uint64_t wi[4] = {(uint64_t)((Q - z[ka]) % Q), (uint64_t)((Q - z[ka - 1]) % Q),
                                   (uint64_t)((Q - z[kb]) % Q), f};
                 if (p == 3) wi[2] = wi[2] * f % (uint64_t)Q;
-                for (int i = 0; i < 4; i++) mont_const((uint32_t)wi[i], d + 2 * i);
+                for (int i = 0; i < 4; i++) {
+                    mont_const((uint32_t)wi[i], pr);
+                    *slot(d, p, lane, 2 * i) = pr[0];
+                    *slot(d, p, lane, 2 * i + 1) = pr[1];
+                }
             }
         }
     }

@@ -32,12 +32,15 @@ struct Tw8 {
     uint32_t v[8];
 };
 
-constexpr int TW_PASS_STRIDE = 64 * 8;      // dwords per pass in a table: [pass][lane][8]
+// table layout [pass][half][lane][4]: each of the two 16-byte reads is lane-linear (stride 16 B),
+// which is conflict-free for ds_read_b128 and one 1-KiB coalesced global_load_dwordx4
+constexpr int TW_PASS_STRIDE = 64 * 8;      // dwords per pass
 constexpr int TW_TABLE_DWORDS = 4 * TW_PASS_STRIDE;
 
-__device__ __forceinline__ Tw8 load_tw8(const uint32_t* p)
+__device__ __forceinline__ Tw8 load_tw8(const uint32_t* pass_base, int lane)
 {
-    const uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];
+    const uint4 a = *reinterpret_cast<const uint4*>(pass_base + 4 * lane);
+    const uint4 b = *reinterpret_cast<const uint4*>(pass_base + 256 + 4 * lane);
     Tw8 t;
     t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
     t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w;
@@ -51,7 +54,7 @@ struct TwRegs {
     __device__ __forceinline__ void load(const uint32_t* __restrict__ tab, int lane)
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) p[i] = load_tw8(tab + i * TW_PASS_STRIDE + lane * 8);
+        for (int i = 0; i < 4; i++) p[i] = load_tw8(tab + i * TW_PASS_STRIDE, lane);
     }
     template <int PASS>
     __device__ __forceinline__ Tw8 get() const { return p[PASS]; }
@@ -61,10 +64,10 @@ struct TwRegs {
 // lane-linear, conflict-free).  Used by the fused pipelines, where VGPRs are better spent on
 // polynomial state.
 struct TwLds {
-    const uint32_t* tab;   // LDS pointer, [4][64][8]
+    const uint32_t* tab;   // LDS pointer, [4][2][64][4]
     int lane;
     template <int PASS>
-    __device__ __forceinline__ Tw8 get() const { return load_tw8(tab + PASS * TW_PASS_STRIDE + lane * 8); }
+    __device__ __forceinline__ Tw8 get() const { return load_tw8(tab + PASS * TW_PASS_STRIDE, lane); }
 };
 
 // cross-lane 4x4 transposes -----------------------------------------------------------

@@ -47,7 +47,7 @@ int dil_shutdown(void);
 int dil_device_count(int* count);
 int dil_num_cus(void);
 const char* dil_error_string(int code);
-/* Host-only (no GPU needed): the twiddle tables the kernels use, [4 passes][64 lanes][8] uint32
+/* Host-only (no GPU needed): the twiddle tables the kernels use, [4 passes][2 halves][64 lanes][4] uint32
  * each (Montgomery form; inv = standalone inverse, inv_pipe = inverse inside the fused
  * pipelines); and the plain 256-entry table (zetas_barrett of consts.h:30, centred). */
 void dil_host_twiddle_tables(uint32_t* fwd /*2048*/, uint32_t* inv /*2048*/, uint32_t* inv_pipe /*2048*/);

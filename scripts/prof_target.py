@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Small fixed workloads for rocprofv3 (kernel trace or --pmc passes):
+   prof_target.py ntt | verify | verify_shared | sign | all   [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from dilithium_amd import api  # noqa: E402
+
+Q = 8380417
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    api.init(0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: torch.randint(0, Q, s, dtype=torch.int32, device="cuda", generator=g)  # noqa: E731
+    if what in ("ntt", "all"):
+        bufs = [rnd(65536, 256) for _ in range(8)]           # 512 MiB rotating: HBM, not LLC
+        for i in range(reps * 8):
+            api.ntt(bufs[i % 8])
+            api.invntt(bufs[i % 8])
+    if what in ("verify", "verify_shared", "all"):
+        n, K, L = 8192, 6, 5
+        A, z, c = rnd(n, K, L, 256), rnd(n, L, 256), rnd(n, 256)
+        t1 = torch.randint(0, 1024, (n, K, 256), dtype=torch.int32, device="cuda", generator=g)
+        h = (torch.rand((n, K, 256), device="cuda", generator=g) < 0.03).to(torch.uint8)
+        w1 = torch.empty((n, K, 256), dtype=torch.uint8, device="cuda")
+        for _ in range(reps):
+            if what != "verify_shared":
+                api.verify_core(A, z, c, t1, h, 3, out=w1)
+            if what != "verify":
+                api.verify_core(A[:1], z, c, t1[:1], h, 3, shared_pk=True, out=w1)
+    if what in ("sign", "all"):
+        n, K, L = 8192, 8, 7
+        A, y, c = rnd(1, K, L, 256), rnd(n, L, 256), rnd(n, 256)
+        s1h, s2h, t0h = rnd(1, L, 256), rnd(1, K, 256), rnd(1, K, 256)
+        for _ in range(reps):
+            w1, w0 = api.sign_phase1(A, y, 5, shared_key=True)
+            api.sign_phase2(c, y, w0, w1, s1h, s2h, t0h, 5, shared_key=True)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,13 +19,16 @@ def main():
         lines.append(f"{r[0][:72]:72s} {r[1]:6d} {r[2] / 1e3:9.2f} {r[3] / 1e3:9.2f} {r[4] / 1e3:9.2f} {r[5] / 1e6:9.3f} "
                      f"{100 * r[5] / tot:6.2f} {r[6]:5d} {r[7]:5d} {r[8]:6d} {r[9]:8d} {r[10]:5d}")
     try:
-        pm = cur.execute("select k.name, p.counter_name, avg(p.value), count(*) from pmc_events p "
-                         "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+        pm = cur.execute(
+            "select name, counter_name, avg(v), count(*) from (select substr(name, 1, 60) as name, counter_name, "
+            "dispatch_id, sum(counter_value) as v from pmc_events group by dispatch_id, counter_name) "
+            "group by name, counter_name").fetchall()
         if pm:
             lines.append("")
-            lines.append("PMC (average per dispatch)")
+            lines.append("PMC (summed over SEs/XCCs, average per dispatch)")
             for name, cn, v, n in pm:
-                lines.append(f"{name[:72]:72s} {cn:28s} {v:18.1f}  (n={n})")
+                if name.startswith("void dil::") or "--all" in sys.argv:
+                    lines.append(f"{name:60s} {cn:28s} {v:18.1f}  (dispatches={n})")
     except Exception as e:  # noqa: BLE001
         lines.append(f"(no PMC table: {e})")
     out = "\n".join(lines) + "\n"

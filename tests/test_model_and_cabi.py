@@ -35,9 +35,11 @@ def test_host_tables_match_model(lib):
     u32p = C.POINTER(C.c_uint32)
     f, i, ip = (np.zeros(2048, np.uint32) for _ in range(3))
     lib.dil_host_twiddle_tables(f.ctypes.data_as(u32p), i.ctypes.data_as(u32p), ip.ctypes.data_as(u32p))
-    assert (f.reshape(4, 64, 8) == wm.table_u32(wm.FWD)).all()
-    assert (i.reshape(4, 64, 8) == wm.table_u32(wm.INV)).all()
-    assert (ip.reshape(4, 64, 8) == wm.table_u32(wm.INV_PIPE)).all()
+    # device layout is [pass][half][lane][4]; the model keeps [pass][lane][8]
+    dev = lambda t: t.reshape(4, 2, 64, 4).transpose(0, 2, 1, 3).reshape(4, 64, 8)  # noqa: E731
+    assert (dev(f) == wm.table_u32(wm.FWD)).all()
+    assert (dev(i) == wm.table_u32(wm.INV)).all()
+    assert (dev(ip) == wm.table_u32(wm.INV_PIPE)).all()
 
 
 def test_montgomery_constants():
