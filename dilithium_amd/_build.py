@@ -11,8 +11,10 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdil256.so")
+REF_LIB = os.path.join(PKG, "libdil256_ref.so")     # reference-identical C++ signatures (include/dil256_ref.hpp)
 SOURCES = ["kernels.hip", "capi.hip"]
-HEADERS = ["modarith.hpp", "ntt_core.hpp", "kernels.hpp", os.path.join("..", "..", "include", "dil256.h")]
+HEADERS = ["modarith.hpp", "ntt_core.hpp", "kernels.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
+           os.path.join("..", "..", "include", "dil256_ref.hpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall"]
 
 
@@ -26,6 +28,8 @@ def _stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
+        if not os.path.exists(REF_LIB):
+            build_ref(verbose)
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -34,7 +38,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_ref(verbose)
     return LIB
+
+
+def build_ref(verbose: bool = False) -> str:
+    """libdil256_ref.so: host-only C++ (no device code), links against libdil256.so next to it"""
+    cxx = shutil.which("g++") or shutil.which("hipcc")
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", os.path.join(CSRC, "ref_api.cpp"),
+           "-L" + PKG, "-ldil256", "-Wl,-rpath,$ORIGIN", "-o", REF_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return REF_LIB
 
 
 if __name__ == "__main__":

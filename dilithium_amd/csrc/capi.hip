@@ -195,6 +195,8 @@ int dil_init(int device)
     g.t.inv_pipe = g.d_tables + 4096;
     g.t.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("DIL_NTT_BPC")) g.t.ntt_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.ntt_blocks_per_cu;
+    if (const char* e = getenv("DIL_WPI_BPC")) g.t.wpi_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.wpi_blocks_per_cu;
+    if (const char* e = getenv("DIL_FUSED_MODE")) g.t.fused_mode = atoi(e);
     if (const char* e = getenv("DIL_FUSED_WGPC")) g.t.fused_wgs_per_cu = atoi(e) > 0 ? atoi(e) : g.t.fused_wgs_per_cu;
     g.device = device;
     g.ready = true;

@@ -528,8 +528,241 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
 }
 
 // ---------------------------------------------------------------------------------------
+// Wave-per-item variants of the fused pipelines (large batches).
+// One wavefront carries one whole item through every stage: the L NTT-domain vectors stay in
+// its registers (4L VGPRs), the matrix rows stream through, no LDS data exchange and no
+// barrier after the one-time twiddle staging.  Rows are software-prefetched: the loads of row
+// k+1 are issued as soon as the MACs of row k have consumed the row registers, and fly under
+// NTT(t1_k) + INTT(row k).  With batch >= 8 items per SIMD this keeps the VALUs busier than
+// the workgroup-per-item kernels above (which remain the low-latency path for small batches).
+// ---------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void mac_row_regs(int64_t (&acc)[4], const ARow<L>& A, const int32_t (&vh)[L][4])
+{
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        acc[0] += (int64_t)A.v[l].x * vh[l][0];
+        acc[1] += (int64_t)A.v[l].y * vh[l][1];
+        acc[2] += (int64_t)A.v[l].z * vh[l][2];
+        acc[3] += (int64_t)A.v[l].w * vh[l][3];
+    }
+}
+
+// forward-transform L consecutive polynomials (+ optionally one extra from `tail`) into
+// registers, loading polynomial l+1 while l is being transformed
+template <int L, bool TAIL, class TW>
+__device__ __forceinline__ void fwd_vector(int32_t (&vh)[L][4], int32_t (&th)[4], const int32_t* __restrict__ v,
+                                           const int32_t* __restrict__ tail, const TW& twf, const LaneMasks& lm, int lane)
+{
+    int32_t cur[4], nxt[4] = {0, 0, 0, 0};
+    load_strided(cur, v, lane);
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        if (l + 1 < L) load_strided(nxt, v + (l + 1) * 256, lane);
+        else if (TAIL) load_strided(nxt, tail, lane);
+        ntt_fwd_core(cur, twf, lm);
+#pragma unroll
+        for (int m = 0; m < 4; m++) { vh[l][m] = cur[m]; cur[m] = nxt[m]; }
+    }
+    if (TAIL) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) th[m] = cur[m];     // loaded, NOT yet transformed
+    }
+}
+
+template <int K, int L, int LEVEL, int OUT>
+__global__ __launch_bounds__(256) void matvec_wpi_kernel(
+    int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
+    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
+    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS];
+    const int lane = threadIdx.x & 63;
+    stage_tables(lds, fwd_tab, inv_tab);
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+        const int32_t* Ait = A + (shared_A ? 0 : it * K) * (size_t)L * 256;
+        ARow<L> Ar;
+        Ar.load(Ait, lane, !shared_A);
+        int32_t vh[L][4], dummy[4];
+        fwd_vector<L, false>(vh, dummy, y + it * L * 256, nullptr, twf, lm, lane);
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row_regs<L>(acc, Ar, vh);
+            if (k + 1 < K) Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_A);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            ntt_inv_core(r, twi, lm);
+            const size_t o = (it * K + k) * 256;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t v = canon_small(r[m]);
+                if (OUT == OUT_W) {
+                    st_nt(w_out + o + lane + 64 * m, (int32_t)v);
+                } else {
+                    uint32_t a1;
+                    int32_t a0;
+                    decompose<LEVEL>(v, a1, a0);
+                    w1_out[o + lane + 64 * m] = (uint8_t)a1;
+                    st_nt(w0_out + o + lane + 64 * m, a0 + ((a0 >> 31) & Q));
+                }
+            }
+        }
+    }
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void verify_wpi_kernel(
+    uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
+    const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint8_t* __restrict__ h, size_t batch,
+    int shared_pk, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS];
+    const int lane = threadIdx.x & 63;
+    stage_tables(lds, fwd_tab, inv_tab);
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+        const int32_t* Ait = A + (shared_pk ? 0 : it * K) * (size_t)L * 256;
+        const int32_t* t1it = t1 + (shared_pk ? 0 : it * K) * 256;
+        const uint8_t* hit = h + it * K * 256;
+        int32_t zh[L][4], ch[4];
+        fwd_vector<L, true>(zh, ch, z + it * L * 256, c + it * 256, twf, lm, lane);
+        // row 0 operands fly under NTT(c)
+        ARow<L> Ar;
+        Ar.load(Ait, lane, !shared_pk);
+        int32_t tn[4];
+        uint32_t hn[4];
+        load_strided(tn, t1it, lane);
+#pragma unroll
+        for (int m = 0; m < 4; m++) hn[m] = hit[lane + 64 * m];
+        ntt_fwd_core(ch, twf, lm);
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row_regs<L>(acc, Ar, zh);
+            int32_t th[4];
+            uint32_t hb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) { th[m] = (tn[m] & 0x3FF) << 13; hb[m] = hn[m]; }   // decoder.v:96-100
+            if (k + 1 < K) {
+                Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_pk);
+                load_strided(tn, t1it + (k + 1) * 256, lane);
+#pragma unroll
+                for (int m = 0; m < 4; m++) hn[m] = hit[(k + 1) * 256 + lane + 64 * m];
+            }
+            ntt_fwd_core(th, twf, lm);
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            ntt_inv_core(r, twi, lm);
+            const size_t o = (it * K + k) * 256;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                w1_out[o + lane + 64 * m] = (uint8_t)use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+        }
+    }
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void sign2_wpi_kernel(
+    int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
+    const int32_t* __restrict__ c, const int32_t* __restrict__ y, const int32_t* __restrict__ w0,
+    const uint8_t* __restrict__ w1, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
+    const int32_t* __restrict__ t0hat, size_t batch, int shared_key, const uint32_t* __restrict__ fwd_tab,
+    const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS];
+    const int lane = threadIdx.x & 63;
+    stage_tables(lds, fwd_tab, inv_tab);
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+        const int32_t* s1 = s1hat + (shared_key ? 0 : it * L) * 256;
+        const int32_t* s2 = s2hat + (shared_key ? 0 : it * K) * 256;
+        const int32_t* t0 = t0hat + (shared_key ? 0 : it * K) * 256;
+        int32_t ch[4];
+        load_strided(ch, c + it * 256, lane);
+        int4 sn = *reinterpret_cast<const int4*>(s1 + 4 * lane);
+        ntt_fwd_core(ch, twf, lm);
+        uint32_t bits = 0, nh = 0;
+        for (int l = 0; l < L; l++) {
+            const int4 s = sn;
+            const size_t o = (it * L + l) * 256;
+            int32_t yv[4];
+            load_strided(yv, y + o, lane);
+            if (l + 1 < L) sn = *reinterpret_cast<const int4*>(s1 + (l + 1) * 256 + 4 * lane);
+            int32_t r[4] = {mont_mul(ch[0], s.x), mont_mul(ch[1], s.y), mont_mul(ch[2], s.z), mont_mul(ch[3], s.w)};
+            ntt_inv_core(r, twi, lm);
+            bool rej = false;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t v = canon_any(r[m] + yv[m]);
+                rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
+                st_nt(z_out + o + lane + 64 * m, (int32_t)v);
+            }
+            if (__ballot(rej)) bits |= 1;
+        }
+        for (int k = 0; k < K; k++) {
+            const int4 a2 = *reinterpret_cast<const int4*>(s2 + k * 256 + 4 * lane);
+            const int4 b0 = *reinterpret_cast<const int4*>(t0 + k * 256 + 4 * lane);
+            const size_t o = (it * K + k) * 256;
+            int32_t wv0[4];
+            uint32_t wv1[4];
+            load_strided(wv0, w0 + o, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) wv1[m] = w1[o + lane + 64 * m];
+            int32_t a[4] = {mont_mul(ch[0], a2.x), mont_mul(ch[1], a2.y), mont_mul(ch[2], a2.z), mont_mul(ch[3], a2.w)};
+            int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
+            ntt_inv_core(a, twi, lm);
+            ntt_inv_core(b, twi, lm);
+            bool rej1 = false, rej2 = false;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t ct0 = canon_small(b[m]);
+                const uint32_t r0 = canon_any(wv0[m] - a[m]);
+                rej1 |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
+                rej2 |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
+                uint32_t s = r0 + ct0;
+                s -= (s >= (uint32_t)Q) ? (uint32_t)Q : 0u;
+                const uint32_t hb = make_hint<LEVEL>(s, wv1[m]);
+                h_out[o + lane + 64 * m] = (uint8_t)hb;
+                nh += __popcll(__ballot(hb));
+            }
+            if (__ballot(rej1)) bits |= 2;
+            if (__ballot(rej2)) bits |= 4;
+        }
+        if (lane == 0) flags_out[it] = (int32_t)(bits | (nh > (uint32_t)Par<LEVEL>::OMEGA ? 8u : 0u));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+// resident blocks per CU of a kernel (occupancy API, cached per kernel): persistent grids are
+// sized to what is actually co-resident so that no block waits for another to retire
+template <class KernelT>
+static int resident_blocks_per_cu(KernelT kernel, int block_threads, int cap)
+{
+    static int cached = 0;          // one instance per KernelT instantiation... but KernelT is a type:
+    static const void* cached_for = nullptr;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    if (cached_for != key) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block_threads, 0) != hipSuccess || n < 1) n = 1;
+        cached = n;
+        cached_for = key;
+    }
+    return cached < cap ? cached : cap;
+}
+
 static inline int grid_for(size_t work_blocks, int max_blocks)
 {
     if (work_blocks < 1) work_blocks = 1;
@@ -577,11 +810,27 @@ hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, i
     return hipGetLastError();
 }
 
+// wave-per-item pays once every SIMD has several items to interleave; below that the
+// workgroup-per-item kernels expose more parallelism per item (lower latency)
+static inline bool use_wpi(size_t batch, const Tables& t)
+{
+    if (t.fused_mode == 1) return false;
+    if (t.fused_mode == 2) return true;
+    return batch >= (size_t)t.num_cus * 8;
+}
+
 template <int LEVEL, int OUT>
 static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
                                       size_t batch, int shared_A, const Tables& t, hipStream_t s)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    if (use_wpi(batch, t)) {
+        const int g = grid_for((batch + 3) / 4,
+                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT>, 256, t.wpi_blocks_per_cu));
+        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, t.fwd,
+                           t.inv_pipe);
+        return hipGetLastError();
+    }
     const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
     hipLaunchKernelGGL((matvec_kernel<K, L, LEVEL, OUT>), grid, 64 * (K > L ? K : L), 0, s, w, w1, w0, A, y, batch,
                        shared_A, t.fwd, t.inv_pipe);
@@ -609,6 +858,15 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
                          const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
+    if (use_wpi(batch, t)) {
+        switch (level) {
+        case 2: hipLaunchKernelGGL(verify_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<2>, 256, t.wpi_blocks_per_cu)), 256, 0, s, w1, A, z, c, t1, h, batch, shared_pk, t.fwd, t.inv_pipe); break;
+        case 3: hipLaunchKernelGGL(verify_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<3>, 256, t.wpi_blocks_per_cu)), 256, 0, s, w1, A, z, c, t1, h, batch, shared_pk, t.fwd, t.inv_pipe); break;
+        case 5: hipLaunchKernelGGL(verify_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<5>, 256, t.wpi_blocks_per_cu)), 256, 0, s, w1, A, z, c, t1, h, batch, shared_pk, t.fwd, t.inv_pipe); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
 #define DIL_VY(LV)                                                                                             \
     hipLaunchKernelGGL(verify_kernel<LV>, grid,                                                                \
@@ -630,6 +888,15 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
                         const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
+    if (use_wpi(batch, t)) {
+        switch (level) {
+        case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
+        case 3: hipLaunchKernelGGL(sign2_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<3>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
+        case 5: hipLaunchKernelGGL(sign2_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<5>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
 #define DIL_S2(LV)                                                                                             \
     hipLaunchKernelGGL(sign2_kernel<LV>, grid,                                                                 \

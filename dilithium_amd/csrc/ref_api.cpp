@@ -1,0 +1,99 @@
+// ref_api.cpp -- libdil256_ref.so: the reference-identical C++ signatures (include/dil256_ref.hpp)
+// as thin batch-of-one wrappers over the C-ABI.  No arithmetic happens here: every function
+// forwards to a HIP kernel through include/dil256.h and aborts loudly if that fails (the
+// reference's functions are void and cannot report errors -- SURVEY 8b).
+#include "../../include/dil256.h"
+#include "../../include/dil256_ref.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace {
+
+[[noreturn]] void die(const char* what, int rc)
+{
+    fprintf(stderr, "libdil256_ref: %s failed: hipError %d (%s) -- no CPU fallback\n", what, rc, dil_error_string(rc));
+    abort();
+}
+inline void ok(const char* what, int rc)
+{
+    if (rc) die(what, rc);
+}
+
+// zeta^brv8(k), zeta = 1753, centred -- the table of consts.cpp:64-97, computed at compile time
+constexpr int64_t Qc = DILITHIUM_Q;
+constexpr unsigned brv8(unsigned x)
+{
+    unsigned r = 0;
+    for (int i = 0; i < 8; i++) r |= ((x >> i) & 1u) << (7 - i);
+    return r;
+}
+constexpr int64_t powmod(int64_t b, unsigned e)
+{
+    int64_t r = 1;
+    b %= Qc;
+    while (e) {
+        if (e & 1) r = r * b % Qc;
+        b = b * b % Qc;
+        e >>= 1;
+    }
+    return r;
+}
+struct ZetaTable {
+    data_t v[DILITHIUM_N];
+    constexpr ZetaTable() : v()
+    {
+        v[0] = 0;
+        for (unsigned k = 1; k < DILITHIUM_N; k++) {
+            int64_t z = powmod(1753, brv8(k));
+            v[k] = (data_t)(z > (Qc - 1) / 2 ? z - Qc : z);
+        }
+    }
+};
+constexpr ZetaTable ZT{};
+
+}  // namespace
+
+#define Z(i) ZT.v[i]
+#define Z8(i) Z(i), Z(i + 1), Z(i + 2), Z(i + 3), Z(i + 4), Z(i + 5), Z(i + 6), Z(i + 7)
+#define Z64(i) Z8(i), Z8(i + 8), Z8(i + 16), Z8(i + 24), Z8(i + 32), Z8(i + 40), Z8(i + 48), Z8(i + 56)
+extern const data_t zetas_barrett[DILITHIUM_N] = {Z64(0), Z64(64), Z64(128), Z64(192)};
+
+void ntt(data_t a[DILITHIUM_N]) { ok("ntt", dil_ntt_host(a, 1)); }
+void invntt(data_t a[DILITHIUM_N]) { ok("invntt", dil_invntt_host(a, 1)); }
+void pointwise_barrett(data_t c[DILITHIUM_N], const data_t a[DILITHIUM_N], const data_t b[DILITHIUM_N])
+{
+    ok("pointwise_barrett", dil_pointwise_host(c, a, b, 1));
+}
+void ntt2x2_ref(data_t a[DILITHIUM_N]) { ok("ntt2x2_ref", dil_ntt_host(a, 1)); }
+void invntt2x2_ref(data_t a[DILITHIUM_N]) { ok("invntt2x2_ref", dil_invntt_host(a, 1)); }
+
+// the `mode` argument only selects the datapath inside each reference function
+// (ntt2x2_fwdntt.cpp:122-129); each entry point has exactly one meaningful mode
+void ntt2x2_fwdntt(bram* ram, enum OPERATION, enum MAPPING mapping)
+{
+    ok("ntt2x2_fwdntt", dil_bram_fwdntt_host(&ram->coeffs[0][0], 1, (int)mapping));
+}
+void ntt2x2_invntt(bram* ram, enum OPERATION, enum MAPPING mapping)
+{
+    ok("ntt2x2_invntt", dil_bram_invntt_host(&ram->coeffs[0][0], 1, (int)mapping));
+}
+void ntt2x2_mul(bram* ram, const bram* mul_ram, enum MAPPING mapping)
+{
+    ok("ntt2x2_mul", dil_bram_mul_host(&ram->coeffs[0][0], &mul_ram->coeffs[0][0], 1, (int)mapping));
+}
+
+unsigned resolve_address(enum MAPPING mapping, unsigned addr)   // address_encoder_decoder.cpp:34-55
+{
+    switch (mapping) {
+    case AFTER_INVNTT: return (addr % 16) * 4 + addr / 16;
+    case AFTER_NTT: return (addr % 4) * 16 + addr / 4;
+    default: return addr;
+    }
+}
+
+void reshape(bram* ram, const data_t in[DILITHIUM_N])           // util.cpp:61-72: row i = coefficients 4i..4i+3
+{
+    for (int i = 0; i < BRAM_DEPT; i++)
+        for (int j = 0; j < 4; j++) ram->coeffs[i][j] = in[4 * i + j];
+}

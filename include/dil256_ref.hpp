@@ -1,0 +1,56 @@
+// dil256_ref.hpp -- the reference's dilithium-256/ C++ surface, re-declared for the drop-in.
+//
+// A translation unit written against the reference's headers
+//     params.h:30-35        data_t, data2_t, DILITHIUM_Q / _N / _LOGN
+//     consts.h:30           extern const data_t zetas_barrett[DILITHIUM_N]
+//     ref_ntt.h:30-36       ntt, pointwise_barrett, invntt
+//     ref_ntt2x2.h:31-33    ntt2x2_ref, invntt2x2_ref
+//     config.h:29-51        BRAM<T>, bram, enum OPERATION, enum MAPPING
+//     ntt2x2.h:30-34        ntt2x2_fwdntt, ntt2x2_mul, ntt2x2_invntt
+//     address_encoder_decoder.h   resolve_address
+//     util.h                reshape
+// compiles against this header and links against libdil256_ref.so + libdil256.so instead:
+// same names, same C++ linkage, same in-place / caller-owns-buffers contract.  Every call runs
+// on the GPU (batch = 1 through the host-pointer C-ABI of include/dil256.h); results are the
+// canonical residues in [0, q) -- congruent mod q to what the reference returns, which is the
+// equality its own tests use (ref_test_ntt_ntt2x2.cpp:31-42, util.cpp:98-112).  For throughput
+// use the batched entry points of dil256.h; this header exists for source compatibility.
+#ifndef DIL256_REF_HPP
+#define DIL256_REF_HPP
+
+#include <stdint.h>
+
+typedef int32_t data_t;
+typedef int64_t data2_t;
+
+#define DILITHIUM_Q 8380417
+#define DILITHIUM_N 256
+#define DILITHIUM_LOGN 8
+#define BRAM_DEPT (DILITHIUM_N / 4)
+
+template <typename T>
+struct BRAM {
+    T coeffs[BRAM_DEPT][4];
+};
+typedef BRAM<data_t> bram;
+
+enum OPERATION { FORWARD_NTT_MODE, INVERSE_NTT_MODE, MUL_MODE };
+enum MAPPING { NATURAL, AFTER_NTT, AFTER_INVNTT };
+
+extern const data_t zetas_barrett[DILITHIUM_N];
+
+void ntt(data_t a[DILITHIUM_N]);
+void invntt(data_t a[DILITHIUM_N]);
+void pointwise_barrett(data_t c[DILITHIUM_N], const data_t a[DILITHIUM_N], const data_t b[DILITHIUM_N]);
+
+void ntt2x2_ref(data_t a[DILITHIUM_N]);
+void invntt2x2_ref(data_t a[DILITHIUM_N]);
+
+void ntt2x2_fwdntt(bram* ram, enum OPERATION mode, enum MAPPING mapping);
+void ntt2x2_mul(bram* ram, const bram* mul_ram, enum MAPPING mapping);
+void ntt2x2_invntt(bram* ram, enum OPERATION mode, enum MAPPING mapping);
+
+unsigned resolve_address(enum MAPPING mapping, unsigned addr);
+void reshape(bram* ram, const data_t in[DILITHIUM_N]);
+
+#endif

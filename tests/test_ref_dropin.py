@@ -1,0 +1,49 @@
+"""The drop-in surface: libdil256_ref.so exports the reference's C++ signatures
+(include/dil256_ref.hpp); our mains for the reference's two C++ tests run against it on the GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+# Itanium-mangled names of the reference's functions (what a TU built against its headers imports)
+MANGLED = ["_Z3nttPi", "_Z6invnttPi", "_Z17pointwise_barrettPiPKiS1_", "_Z10ntt2x2_refPi", "_Z13invntt2x2_refPi",
+           "_Z13ntt2x2_fwdnttP4BRAMIiE9OPERATION7MAPPING", "_Z13ntt2x2_invnttP4BRAMIiE9OPERATION7MAPPING",
+           "_Z10ntt2x2_mulP4BRAMIiEPKS0_7MAPPING", "_Z15resolve_address7MAPPINGj", "_Z7reshapeP4BRAMIiEPKi"]
+
+
+def _build():
+    import dilithium_amd
+    dilithium_amd.load()
+    from oracle import oracle as orc
+    orc.build()
+    subprocess.check_call(["make", "-C", CPP], stdout=subprocess.DEVNULL)
+
+
+def test_ref_library_exports_reference_symbols(oracle):
+    """same mangled names as the compiled reference (cf. oracle/oracle.py Reference.SYMS)"""
+    _build()
+    from dilithium_amd import _build as b
+    lib = C.CDLL(b.REF_LIB)
+    for name in MANGLED:
+        assert hasattr(lib, name), name
+    z = np.ctypeslib.as_array((C.c_int32 * 256).in_dll(lib, "zetas_barrett"))
+    assert (z == oracle.zetas()).all()
+    ra = lib._Z15resolve_address7MAPPINGj
+    ra.restype = C.c_uint
+    for m in range(3):
+        for a in range(64):
+            assert ra(m, a) == oracle.lib.orc_resolve_address(m, a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exe", ["test_ref_ntt_ntt2x2", "test_ntt2x2_hw"])
+def test_reference_style_cpp_mains(gpu, exe):
+    _build()
+    out = subprocess.run([os.path.join(CPP, exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout and "ERROR" not in out.stdout
