@@ -151,26 +151,31 @@ def main():
         step(i)
     torch.cuda.synchronize()
     K = args.steps
-    evs = [(ev(), ev(), ev()) for _ in range(K)]
+    EV_EVERY = 4                      # bracket the kernels of every 4th step with HIP events (less perturbation)
+    evs = {i: (ev(), ev(), ev()) for i in range(0, K, EV_EVERY)}
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rc = 0
     for i in range(K):
         p = ptrs[i % R]
-        e0, e1, e2 = evs[i]
-        L.dil_event_record(e0, stream)
-        rc |= L.dil_ntt_dev(p, BATCH, stream)
-        L.dil_event_record(e1, stream)
-        rc |= L.dil_invntt_dev(p, BATCH, stream)
-        L.dil_event_record(e2, stream)
+        if i in evs:
+            e0, e1, e2 = evs[i]
+            L.dil_event_record(e0, stream)
+            rc |= L.dil_ntt_dev(p, BATCH, stream)
+            L.dil_event_record(e1, stream)
+            rc |= L.dil_invntt_dev(p, BATCH, stream)
+            L.dil_event_record(e2, stream)
+        else:
+            rc |= L.dil_ntt_dev(p, BATCH, stream)
+            rc |= L.dil_invntt_dev(p, BATCH, stream)
     torch.cuda.synchronize()
     sharding.barrier()
     dt = time.perf_counter() - t0
     dlib.check(rc, "timed NTT launches")
     dt = sharding.max_over_ranks(dt)
-    fwd_ms = float(np.mean([elapsed(e0, e1) for e0, e1, _ in evs]))
-    inv_ms = float(np.mean([elapsed(e1, e2) for _, e1, e2 in evs]))
+    fwd_ms = float(np.mean([elapsed(e0, e1) for e0, e1, _ in evs.values()]))
+    inv_ms = float(np.mean([elapsed(e1, e2) for _, e1, e2 in evs.values()]))
     assert torch.equal(bufs[0][:64], check), "fwd+inv round trip is not the identity"
     value = world * K * 2 * BATCH / dt
 
@@ -229,7 +234,7 @@ def main():
                "config": {"workload": "BASELINE configs[3]: level-3 verify core (NTT z, A.z - c.t1.2^d, INTT, "
                                       "UseHint -> w1), batch=8192 per GPU, distinct pk (A, t1 per item)",
                           "bytes_per_verify": VERIFY3_BYTES},
-               "roofline": {"bound": "hbm", "kernel": "verify_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
+               "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("verify_kernel"),
                             "avg_launch_ms": v_ms}}
         # the one collective of the design: final gather of the result slabs over RCCL/xGMI

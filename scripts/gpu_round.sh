@@ -19,7 +19,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o ${TAG} -- py
 echo "prof exit $?" >> $OUT/${TAG}_prof.log
 # HBM traffic: separate --pmc passes, kernel trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/${TAG}_pmc_$ctr -o p -- python $GRAFT_REPO_ROOT/scripts/prof_target.py all 2 > $OUT/${TAG}_pmc_$ctr.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $OUT/${TAG}_pmc_$ctr -o p -- python $GRAFT_REPO_ROOT/scripts/prof_target.py bench 2 > $OUT/${TAG}_pmc_$ctr.log 2>&1
   echo "pmc $ctr exit $?" >> $OUT/${TAG}_prof.log
 done
 cd $GRAFT_REPO_ROOT

@@ -18,12 +18,14 @@ def main():
     api.init(0)
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randint(0, Q, s, dtype=torch.int32, device="cuda", generator=g)  # noqa: E731
-    if what in ("ntt", "all"):
+    if what == "bench":            # exactly the two workloads bench.py times: configs[1] and configs[3] (distinct pk)
+        what = "ntt+verify"
+    if what in ("ntt", "all", "ntt+verify"):
         bufs = [rnd(65536, 256) for _ in range(8)]           # 512 MiB rotating: HBM, not LLC
         for i in range(reps * 8):
             api.ntt(bufs[i % 8])
             api.invntt(bufs[i % 8])
-    if what in ("verify", "verify_shared", "all"):
+    if what in ("verify", "verify_shared", "all", "ntt+verify"):
         n, K, L = 8192, 6, 5
         A, z, c = rnd(n, K, L, 256), rnd(n, L, 256), rnd(n, 256)
         t1 = torch.randint(0, 1024, (n, K, 256), dtype=torch.int32, device="cuda", generator=g)
@@ -32,7 +34,7 @@ def main():
         for _ in range(reps):
             if what != "verify_shared":
                 api.verify_core(A, z, c, t1, h, 3, out=w1)
-            if what != "verify":
+            if what not in ("verify", "ntt+verify"):
                 api.verify_core(A[:1], z, c, t1[:1], h, 3, shared_pk=True, out=w1)
     if what in ("sign", "all"):
         n, K, L = 8192, 8, 7
