@@ -613,6 +613,22 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     }
 }
 
+#define DIL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// raw (time-domain) inputs of one item, prefetched a whole row phase ahead
+template <int NP>
+struct RawPolys {
+    int32_t v[NP][4];
+    __device__ __forceinline__ void load(const int32_t* __restrict__ base, int lane)
+    {
+#pragma unroll
+        for (int p = 0; p < NP; p++) load_strided(v[p], base + p * 256, lane);
+    }
+};
+
+// verify, wave-per-item.  Per item:  issue row-0 operand loads | z-phase: L+1 forward NTTs on
+// registers that were loaded during the PREVIOUS item's row phase, z^ -> this wave's LDS slice |
+// issue the NEXT item's z/c loads | K rows: MAC from LDS, prefetch row k+1, NTT(t1_k), INTT, UseHint.
 template <int LEVEL>
 __global__ __launch_bounds__(256) void verify_wpi_kernel(
     uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
@@ -620,20 +636,26 @@ __global__ __launch_bounds__(256) void verify_wpi_kernel(
     int shared_pk, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256];
     const int lane = threadIdx.x & 63;
     stage_tables(lds, fwd_tab, inv_tab);
-    __syncthreads();
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
     const LaneMasks lm(lane);
+    uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * (L * 256);   // this wave's private slice
     const size_t nwaves = (size_t)gridDim.x * 4;
-    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+    size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    RawPolys<L> zr;
+    int32_t cr[4] = {0, 0, 0, 0};
+    if (it < batch) {
+        zr.load(z + it * L * 256, lane);
+        load_strided(cr, c + it * 256, lane);
+    }
+    __syncthreads();                               // tables staged (the only barrier)
+    for (; it < batch; it += nwaves) {
         const int32_t* Ait = A + (shared_pk ? 0 : it * K) * (size_t)L * 256;
         const int32_t* t1it = t1 + (shared_pk ? 0 : it * K) * 256;
         const uint8_t* hit = h + it * K * 256;
-        int32_t zh[L][4], ch[4];
-        fwd_vector<L, true>(zh, ch, z + it * L * 256, c + it * 256, twf, lm, lane);
-        // row 0 operands fly under NTT(c)
+        // row 0 operands fly under the z-phase
         ARow<L> Ar;
         Ar.load(Ait, lane, !shared_pk);
         int32_t tn[4];
@@ -641,10 +663,24 @@ __global__ __launch_bounds__(256) void verify_wpi_kernel(
         load_strided(tn, t1it, lane);
 #pragma unroll
         for (int m = 0; m < 4; m++) hn[m] = hit[lane + 64 * m];
+        // z-phase
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            ntt_fwd_core(zr.v[l], twf, lm);
+            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zr.v[l][0], zr.v[l][1], zr.v[l][2], zr.v[l][3]);
+        }
+        int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
         ntt_fwd_core(ch, twf, lm);
+        DIL_SCHED_FENCE();
+        // next item's time-domain inputs: a whole row phase to land
+        const size_t itn = it + nwaves;
+        if (itn < batch) {
+            zr.load(z + itn * L * 256, lane);
+            load_strided(cr, c + itn * 256, lane);
+        }
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
-            mac_row_regs<L>(acc, Ar, zh);
+            mac_row<L>(acc, Ar, zl, lane);
             int32_t th[4];
             uint32_t hb[4];
 #pragma unroll
@@ -655,11 +691,15 @@ __global__ __launch_bounds__(256) void verify_wpi_kernel(
 #pragma unroll
                 for (int m = 0; m < 4; m++) hn[m] = hit[(k + 1) * 256 + lane + 64 * m];
             }
+            DIL_SCHED_FENCE();     // keep the stages from being interleaved (register pressure, not ILP, is the limit)
             ntt_fwd_core(th, twf, lm);
+            DIL_SCHED_FENCE();
 #pragma unroll
             for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE();
             ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE();
             const size_t o = (it * K + k) * 256;
 #pragma unroll
             for (int m = 0; m < 4; m++)

@@ -154,16 +154,27 @@ __device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
 
 // Forward NTT.  In: r[m] = a[lane + 64 m], any int32 with |a| < 2^31 - 6q.
 // Out: r[m] = lazy residue (|.| < |in| + 6q) of ntt(a)[4 lane + m]; canon_any() to leave the chip.
+// Twiddles are fetched ONE PASS AHEAD and pinned there with a scheduling fence: with
+// LDS-resident tables (TwLds) each fetch is two ds_read_b128 whose latency would otherwise sit
+// exposed at the head of every pass (hipcc sinks the loads to their first use).
+#define DIL_TW_FENCE() __builtin_amdgcn_sched_barrier(0)
 template <class TW>
 __device__ __forceinline__ void ntt_fwd_core(int32_t (&r)[4], const TW& tw, const LaneMasks& lm)
 {
-    fwd_pass(r, tw.template get<0>());
+    const Tw8 t0 = tw.template get<0>();
+    const Tw8 t1 = tw.template get<1>();
+    DIL_TW_FENCE();
+    fwd_pass(r, t0);
     xchg_54(r);
-    fwd_pass(r, tw.template get<1>());
+    const Tw8 t2 = tw.template get<2>();
+    DIL_TW_FENCE();
+    fwd_pass(r, t1);
     xchg_32(r);
-    fwd_pass(r, tw.template get<2>());
+    const Tw8 t3 = tw.template get<3>();
+    DIL_TW_FENCE();
+    fwd_pass(r, t2);
     xchg_10(r, lm);
-    fwd_pass(r, tw.template get<3>());
+    fwd_pass(r, t3);
 }
 
 // one inverse pass (ref_ntt2x2.cpp:122-140, without the per-butterfly halving -- the 2^-8 is
@@ -186,13 +197,20 @@ __device__ __forceinline__ void inv_pass(int32_t (&r)[4], const Tw8& t)
 template <class TW>
 __device__ __forceinline__ void ntt_inv_core(int32_t (&r)[4], const TW& tw, const LaneMasks& lm)
 {
-    inv_pass<false>(r, tw.template get<0>());
+    const Tw8 t0 = tw.template get<0>();
+    const Tw8 t1 = tw.template get<1>();
+    DIL_TW_FENCE();
+    inv_pass<false>(r, t0);
     xchg_10(r, lm);
-    inv_pass<false>(r, tw.template get<1>());
+    const Tw8 t2 = tw.template get<2>();
+    DIL_TW_FENCE();
+    inv_pass<false>(r, t1);
     xchg_32(r);
-    inv_pass<false>(r, tw.template get<2>());
+    const Tw8 t3 = tw.template get<3>();
+    DIL_TW_FENCE();
+    inv_pass<false>(r, t2);
     xchg_54(r);
-    inv_pass<true>(r, tw.template get<3>());
+    inv_pass<true>(r, t3);
 }
 
 }  // namespace dil

@@ -64,8 +64,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if build_if_missing:
+    path = os.environ.get("DIL_LIB_PATH", _build.LIB)      # tuning builds; default = the in-tree library
+    if build_if_missing and path == _build.LIB:
         try:
             _build.build()
         except Exception:

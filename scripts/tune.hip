@@ -232,6 +232,11 @@ int main(int argc, char** argv)
     RUNI(2, 4, 4, "INV nt lds-transpose wpb4 bpc4");
     RUN(V_COPY, 4, 8, "copy-only  wpb4 bpc8 ");
     RUN(V_COPY, 4, 4, "copy-only  wpb4 bpc4 ");
+    RUN(V_COMPUTE, 4, 1, "compute-only wpb4 bpc1");
+    RUN(V_COMPUTE, 4, 2, "compute-only wpb4 bpc2");
+    RUN(V_COMPUTE, 4, 3, "compute-only wpb4 bpc3");
+    RUN(V_COMPUTE, 4, 5, "compute-only wpb4 bpc5");
+    RUN(V_COMPUTE, 4, 6, "compute-only wpb4 bpc6");
     RUN(V_COMPUTE, 4, 8, "compute-only wpb4 bpc8");
     RUN(V_COMPUTE, 4, 4, "compute-only wpb4 bpc4");
     {
