@@ -127,23 +127,74 @@ int ensure_scratch(size_t bytes)
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// host wrapper: copy n polys in, run fn on the device copy, copy back
+// host wrapper: the reference's callers hold HOST buffers.  Small batches: copy in, run, copy
+// out on the default stream.  Large batches: chunks of HOST_CHUNK polynomials round-robin over
+// HOST_STREAMS streams, each chunk H2D -> kernel -> D2H on its own stream, so the PCIe transfers of
+// one chunk overlap the kernel and the opposite-direction transfer of its neighbours.  With
+// DIL_HOST_PIN=1 the caller's buffer is page-locked (hipHostRegister) for the duration of the call
+// so that the copies are true asynchronous DMA.
+constexpr size_t HOST_CHUNK = 16384;     // polynomials per chunk (16 MiB)
+constexpr int HOST_STREAMS = 3;
+
+struct HostPipe {
+    hipStream_t stream[HOST_STREAMS] = {nullptr, nullptr, nullptr};
+    int32_t* dev[HOST_STREAMS] = {nullptr, nullptr, nullptr};
+    bool ready = false;
+    int pin = -1;
+};
+HostPipe hp;
+
+int ensure_pipe()
+{
+    if (hp.ready) return 0;
+    for (int i = 0; i < HOST_STREAMS; i++) {
+        DIL_TRY(hipStreamCreateWithFlags(&hp.stream[i], hipStreamNonBlocking));
+        DIL_TRY(hipMalloc(reinterpret_cast<void**>(&hp.dev[i]), HOST_CHUNK * 1024));
+    }
+    const char* e = getenv("DIL_HOST_PIN");
+    hp.pin = (e && atoi(e) != 0) ? 1 : 0;
+    hp.ready = true;
+    return 0;
+}
+
 template <class F>
-int host_inplace(int32_t* h, size_t batch, F&& fn)
+int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, stream) -> int
 {
     if (batch == 0) return 0;
     int rc = ensure_init();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(g.mu);
-    const size_t bytes = batch * 1024;
-    rc = ensure_scratch(bytes);
+    if (batch <= HOST_CHUNK) {
+        const size_t bytes = batch * 1024;
+        rc = ensure_scratch(bytes);
+        if (rc) return rc;
+        DIL_TRY(hipMemcpy(g.scratch, h, bytes, hipMemcpyHostToDevice));
+        rc = fn(static_cast<int32_t*>(g.scratch), batch, (hipStream_t)0);
+        if (rc) return rc;
+        DIL_TRY(hipDeviceSynchronize());
+        DIL_TRY(hipMemcpy(h, g.scratch, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    rc = ensure_pipe();
     if (rc) return rc;
-    DIL_TRY(hipMemcpy(g.scratch, h, bytes, hipMemcpyHostToDevice));
-    rc = fn(static_cast<int32_t*>(g.scratch));
-    if (rc) return rc;
-    DIL_TRY(hipDeviceSynchronize());
-    DIL_TRY(hipMemcpy(h, g.scratch, bytes, hipMemcpyDeviceToHost));
-    return 0;
+    bool pinned = false;
+    if (hp.pin) pinned = hipHostRegister(h, batch * 1024, hipHostRegisterDefault) == hipSuccess;
+    int err = 0;
+    size_t c = 0;
+    for (size_t off = 0; off < batch && !err; off += HOST_CHUNK, c++) {
+        const int s = (int)(c % HOST_STREAMS);
+        const size_t n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
+        int32_t* hc = h + off * 256;
+        err = (int)hipMemcpyAsync(hp.dev[s], hc, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
+        if (!err) err = fn(hp.dev[s], n, hp.stream[s]);
+        if (!err) err = (int)hipMemcpyAsync(hc, hp.dev[s], n * 1024, hipMemcpyDeviceToHost, hp.stream[s]);
+    }
+    for (int i = 0; i < HOST_STREAMS; i++) {
+        const hipError_t e = hipStreamSynchronize(hp.stream[i]);
+        if (!err && e != hipSuccess) err = (int)e;
+    }
+    if (pinned) (void)hipHostUnregister(h);
+    return err;
 }
 
 }  // namespace
@@ -209,6 +260,13 @@ int dil_shutdown(void)
     if (!g.ready) return 0;
     if (g.d_tables) (void)hipFree(g.d_tables);
     if (g.scratch) (void)hipFree(g.scratch);
+    if (hp.ready) {
+        for (int i = 0; i < HOST_STREAMS; i++) {
+            (void)hipFree(hp.dev[i]);
+            (void)hipStreamDestroy(hp.stream[i]);
+        }
+        hp = HostPipe{};
+    }
     g.d_tables = nullptr;
     g.scratch = nullptr;
     g.scratch_bytes = 0;
@@ -231,11 +289,11 @@ int dil_invntt_dev(int32_t* polys, size_t batch, void* stream)
 }
 int dil_ntt_host(int32_t* polys, size_t batch)
 {
-    return host_inplace(polys, batch, [&](int32_t* d) { return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, d, batch, g.t, 0); });
+    return host_inplace(polys, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, d, n, g.t, st); });
 }
 int dil_invntt_host(int32_t* polys, size_t batch)
 {
-    return host_inplace(polys, batch, [&](int32_t* d) { return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, d, batch, g.t, 0); });
+    return host_inplace(polys, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, d, n, g.t, st); });
 }
 
 // ---- element-wise ---------------------------------------------------------------------------
@@ -307,13 +365,13 @@ int dil_bram_fwdntt_host(int32_t* ram, size_t batch, int mapping)
 {
     int rc = check_mapping(mapping);
     if (rc) return rc;
-    return host_inplace(ram, batch, [&](int32_t* d) { return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, d, batch, g.t, 0); });
+    return host_inplace(ram, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, d, n, g.t, st); });
 }
 int dil_bram_invntt_host(int32_t* ram, size_t batch, int mapping)
 {
     int rc = check_mapping(mapping);
     if (rc) return rc;
-    return host_inplace(ram, batch, [&](int32_t* d) { return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, d, batch, g.t, 0); });
+    return host_inplace(ram, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, d, n, g.t, st); });
 }
 int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping)
 {

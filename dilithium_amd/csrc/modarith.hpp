@@ -34,6 +34,15 @@ __device__ __forceinline__ int32_t mulhi_i32(int32_t a, int32_t b)
     return d;
 }
 
+// sign mask (all-ones iff x < 0) as ONE v_ashrrev_i32, opaque to the optimiser: left visible,
+// LLVM canonicalises (x >> 31) & c into v_cmp + VCC-form v_cndmask, which issues ~5x slower here.
+__device__ __forceinline__ int32_t sgn(int32_t x)
+{
+    int32_t m;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(m) : "v"(x));
+    return m;
+}
+
 // y * w for a table constant w = (wt, wq):  wt = centred(w * 2^32 mod q), wq = wt * q^-1 mod 2^32.
 // Any int32 y; |result| < q (|y * wt| < 2^31 * q/2).      v_mul_lo_u32, 2 x v_mul_hi_i32, v_sub
 __device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
@@ -53,7 +62,7 @@ __device__ __forceinline__ int32_t mont_red64(int64_t p)
 __device__ __forceinline__ int32_t mont_mul(int32_t a, int32_t b) { return mont_red64((int64_t)a * (int64_t)b); }
 
 // (-q, q) -> [0, q)
-__device__ __forceinline__ uint32_t canon_small(int32_t t) { return (uint32_t)(t + ((t >> 31) & Q)); }
+__device__ __forceinline__ uint32_t canon_small(int32_t t) { return (uint32_t)(t + (sgn(t) & Q)); }
 
 // any int32 with |x| < 2^31 - 2^22 -> [0, q):  x - round(x / 2^23) * q lies in (-q, q)
 __device__ __forceinline__ uint32_t canon_any(int32_t x)

@@ -1,0 +1,200 @@
+// pipeline_common.hpp -- device helpers of the fused Dilithium pipelines (pipelines.hip):
+// parameter sets, Decompose / UseHint / MakeHint / norm checks, LDS table staging, matrix-row
+// streaming and the 64-bit multiply-accumulate.
+#pragma once
+#include "device_common.hpp"
+#include "kernels.hpp"
+#include "ntt_core.hpp"
+
+namespace dil {
+
+// ---------------------------------------------------------------------------------------
+// Dilithium element-wise tail: Decompose / UseHint / MakeHint / norm checks
+// ---------------------------------------------------------------------------------------
+template <int LEVEL>
+struct Par;
+template <>
+struct Par<2> {
+    static constexpr int K = 4, L = 4, OMEGA = 80, BETA = 78;
+    static constexpr int32_t GAMMA1 = 1 << 17, GAMMA2 = (Q - 1) / 88;
+};
+template <>
+struct Par<3> {
+    static constexpr int K = 6, L = 5, OMEGA = 55, BETA = 196;
+    static constexpr int32_t GAMMA1 = 1 << 19, GAMMA2 = (Q - 1) / 32;
+};
+template <>
+struct Par<5> {
+    static constexpr int K = 8, L = 7, OMEGA = 75, BETA = 120;
+    static constexpr int32_t GAMMA1 = 1 << 19, GAMMA2 = (Q - 1) / 32;
+};
+
+// a canonical -> (a1 = HighBits, a0 = LowBits centred in (-gamma2, gamma2]); equals the RTL's
+// threshold map decomp_map1.v:37-171 + coeff_decomposer.v:70-89 (checked over all of [0,q))
+template <int LEVEL>
+__device__ __forceinline__ void decompose(uint32_t a, uint32_t& a1, int32_t& a0)
+{
+    uint32_t t = (a + 127) >> 7;
+    if (LEVEL == 2) {
+        t = (t * 11275u + (1u << 23)) >> 24;
+        t ^= (uint32_t)sgn((int32_t)(43 - t)) & t;
+    } else {
+        t = (t * 1025u + (1u << 21)) >> 22;
+        t &= 15;
+    }
+    int32_t r = (int32_t)a - (int32_t)t * (2 * Par<LEVEL>::GAMMA2);
+    r -= sgn((Q - 1) / 2 - r) & Q;
+    a1 = t;
+    a0 = r;
+}
+
+// UseHint (usehint.v:140-159), compare-free: VCC-form v_cndmask costs ~22 cycles on gfx950
+// (profiles/r01_ubench_valu_rates.txt), so every select below is sign-bit arithmetic.
+//   a1' = a1 + 1 if a0 > 0 else a1 - 1 (mod 16 / mod 44), taken only where hint = 1
+template <int LEVEL>
+__device__ __forceinline__ uint32_t use_hint(uint32_t a, uint32_t hint)
+{
+    uint32_t a1;
+    int32_t a0;
+    decompose<LEVEL>(a, a1, a0);
+    const int32_t pos = sgn(-a0);                          // all-ones iff a0 > 0
+    int32_t n = (int32_t)a1 + ((pos & 2) - 1);             // a1 +- 1
+    if (LEVEL == 2) {
+        n += sgn(n) & 44;                                  // -1 -> 43
+        n -= sgn(43 - n) & 44;                             // 44 -> 0
+    } else {
+        n &= 15;
+    }
+    uint32_t hm = 0u - (hint & 1u);                        // all-ones iff hinted
+    asm("" : "+v"(hm));                                   // keep it a mask (no compare + select)
+    return a1 ^ ((a1 ^ (uint32_t)n) & hm);
+}
+
+// MakeHint (makehint.v:98-99), compare-free: hint unless s <= g2, or s > q - g2, or (s == q - g2 and a1 == 0)
+template <int LEVEL>
+__device__ __forceinline__ uint32_t make_hint(uint32_t s, uint32_t a1)
+{
+    constexpr int32_t G2 = Par<LEVEL>::GAMMA2;
+    const int32_t v = (int32_t)s;                          // s in [0, q)
+    const int32_t le = ~sgn(G2 - v);                       // s <= g2
+    const int32_t gt = sgn((Q - G2) - v);                  // s >  q - g2
+    const int32_t d = v - (Q - G2);
+    const int32_t eq = ~sgn(d | -d);                       // s == q - g2
+    const int32_t z1 = ~sgn((int32_t)a1 | -(int32_t)a1);   // a1 == 0
+    const int32_t none = le | gt | (eq & z1);
+    return (uint32_t)(~none) & 1u;
+}
+
+__device__ __forceinline__ bool norm_reject(uint32_t x, uint32_t bound)   // norm_check.v:84-105
+{
+    return x >= bound && x <= (uint32_t)Q - bound;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused pipelines.  One workgroup per item (signature / verification), one wave per
+// polynomial row; NTT-domain vectors shared through LDS as LAZY signed residues (no
+// canonicalisation between stages); twiddles LDS-resident; pointwise products accumulate as
+// 64-bit integers (v_mad_i64_i32) and are Montgomery-reduced once per output coefficient --
+// the 2^-32 this leaves is cancelled by the pipeline-flavour inverse table (f = 2^32 / 256).
+// LDS map (dwords): [0,2048) fwd twiddles | [2048,4096) inv twiddles | 8*256 vec | chat[256] | flags[4]
+// ---------------------------------------------------------------------------------------
+constexpr int LDS_VEC = 2 * TW_TABLE_DWORDS;
+constexpr int LDS_CHAT = LDS_VEC + 8 * 256;
+constexpr int LDS_FLAGS = LDS_CHAT + 256;
+constexpr int LDS_SCR = LDS_FLAGS + 4;                 // 64 dwords of byte-plane scratch per wave (<= 8 waves)
+constexpr int LDS_DWORDS = LDS_SCR + 8 * 64;
+
+__device__ __forceinline__ void stage_tables(uint32_t* lds, const uint32_t* __restrict__ fwd_tab,
+                                             const uint32_t* __restrict__ inv_tab)
+{
+    for (int i = threadIdx.x; i < TW_TABLE_DWORDS / 4; i += blockDim.x) {
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(fwd_tab)[i];
+        reinterpret_cast<uint4*>(lds + TW_TABLE_DWORDS)[i] = reinterpret_cast<const uint4*>(inv_tab)[i];
+    }
+}
+
+// Byte planes (h, w1) move as whole dwords: 64 lanes x 4 bytes = one coalesced 256-B row per
+// instruction.  global_store_byte / global_load_ubyte of 64-byte runs measured 2x the whole
+// kernel's time (profiles/r01_fused_ablation.txt), so the re-layout between the INTT's strided
+// order (lane + 64 m) and packed order (4 lane + j) goes through a 256-B per-wave LDS scratch.
+__device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out_row, const uint32_t (&v)[4], uint32_t* scratch, int lane)
+{
+    uint8_t* sc = reinterpret_cast<uint8_t*>(scratch);
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[lane + 64 * m] = (uint8_t)v[m];
+    reinterpret_cast<uint32_t*>(out_row)[lane] = scratch[lane];
+}
+__device__ __forceinline__ uint32_t load_row_u8(const uint8_t* __restrict__ row, int lane)   // issue early, unpack late
+{
+    return reinterpret_cast<const uint32_t*>(row)[lane];
+}
+__device__ __forceinline__ void unpack_row_u8(uint32_t (&v)[4], uint32_t packed, uint32_t* scratch, int lane)
+{
+    const uint8_t* sc = reinterpret_cast<const uint8_t*>(scratch);
+    scratch[lane] = packed;
+#pragma unroll
+    for (int m = 0; m < 4; m++) v[m] = sc[lane + 64 * m];
+}
+
+// Output stage of one mat-vec row: r[] = INTT output (|r| < q, strided order) ->
+//   OUT_W   : w row, canonical int32             (matvec)
+//   OUT_W1W0: w1 = HighBits as bytes, w0 = LowBits as residue in [0,q)  (sign phase 1, DECOMP :1946)
+template <int LEVEL, int OUT>
+__device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out,
+                                                int32_t* __restrict__ w0_out, size_t o, const int32_t (&r)[4],
+                                                uint32_t* scratch, int lane)
+{
+    uint32_t wb[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const uint32_t v = canon_small(r[m]);
+        if (OUT == OUT_W) {
+            st_nt(w_out + o + lane + 64 * m, (int32_t)v);
+        } else {
+            int32_t a0;
+            decompose<LEVEL>(v, wb[m], a0);
+            st_nt(w0_out + o + lane + 64 * m, a0 + (sgn(a0) & Q));
+        }
+    }
+    if (OUT != OUT_W) store_row_u8(w1_out + o, wb, scratch, lane);
+}
+
+// strided load of one polynomial (natural order) into NTT-input registers
+__device__ __forceinline__ void load_strided(int32_t (&r)[4], const int32_t* __restrict__ a, int lane)
+{
+#pragma unroll
+    for (int m = 0; m < 4; m++) r[m] = ld_nt(a + lane + 64 * m);
+}
+
+template <int L>
+struct ARow {
+    int4 v[L];
+    // stream = true: this row is read once (per-item A): non-temporal; false: shared A, keep it cached
+    __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane, bool stream)
+    {
+        if (stream) {
+#pragma unroll
+            for (int l = 0; l < L; l++) v[l] = ld_nt4(Arow + l * 256 + 4 * lane);
+        } else {
+#pragma unroll
+            for (int l = 0; l < L; l++) v[l] = *reinterpret_cast<const int4*>(Arow + l * 256 + 4 * lane);
+        }
+    }
+};
+
+// acc += sum_l A[k][l] o vhat[l] for the lane's 4 coefficients, as 64-bit integers
+template <int L>
+__device__ __forceinline__ void mac_row(int64_t (&acc)[4], const ARow<L>& A, const uint32_t* vec_lds, int lane)
+{
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        const int4 z = *reinterpret_cast<const int4*>(vec_lds + l * 256 + 4 * lane);
+        acc[0] += (int64_t)A.v[l].x * z.x;
+        acc[1] += (int64_t)A.v[l].y * z.y;
+        acc[2] += (int64_t)A.v[l].z * z.z;
+        acc[3] += (int64_t)A.v[l].w * z.w;
+    }
+}
+
+
+}  // namespace dil

@@ -1,0 +1,752 @@
+// pipelines.hip -- fused Dilithium pipelines on top of the wavefront NTT (ntt_core.hpp):
+// mat-vec (H9), verify core (H8), sign inner loop phases 1 and 2 (H10).
+//   rtl_src/combined_top.v:1207-1469 (verify), :1850-1933 (mat-vec / FSM1), :1946-2229 (FSM2)
+// Two shapes: workgroup-per-item (small batches, low latency) and wave-per-item (large batches).
+#include "launch_util.hpp"
+#include "pipeline_common.hpp"
+
+namespace dil {
+
+// H9 mat-vec  w = INTT(A o NTT(y))   (OUT_W)   and sign phase 1 = mat-vec + Decompose (OUT_W1W0)
+template <int K, int L, int LEVEL, int OUT>
+__global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
+    int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
+    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
+    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DWORDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stage_tables(lds, fwd_tab, inv_tab);
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* sc = lds + LDS_SCR + wv * 64;      // this wave's byte-plane scratch
+    uint32_t* vec = lds + LDS_VEC;
+    for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
+        ARow<L> Ar;
+        if (wv < K) Ar.load(A + ((shared_A ? 0 : it * K) + wv) * (size_t)L * 256, lane, !shared_A);
+        if (wv < L) {
+            int32_t r[4];
+            load_strided(r, y + (it * L + wv) * 256, lane);
+            ntt_fwd_core(r, twf, lm);
+            *reinterpret_cast<int4*>(vec + wv * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        __syncthreads();
+        if (wv < K) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, vec, lane);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            ntt_inv_core(r, twi, lm);
+            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + wv) * 256, r, sc, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// H8 verify core:  w1 = UseHint(h, INTT(A o NTT(z) - NTT(c) o NTT(t1 * 2^13)))
+// (combined_top.v VY_NTT_Z :1207, VY_NTT_T1 :1259, VY_NTT_C :1314, VY_MULT_AZ :1347-1386,
+//  VY_MULT_CT1 :1387, VY_SUB_AZ_CT1 :1415, VY_INTT :1435, VY_GENW1 :1470)
+template <int LEVEL>
+__global__ __launch_bounds__(64 * (Par<LEVEL>::K > Par<LEVEL>::L + 1 ? Par<LEVEL>::K : Par<LEVEL>::L + 1))
+void verify_kernel(uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A,
+                   const int32_t* __restrict__ z, const int32_t* __restrict__ c,
+                   const int32_t* __restrict__ t1, const uint8_t* __restrict__ h, size_t batch,
+                   int shared_pk, const uint32_t* __restrict__ fwd_tab,
+                   const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DWORDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stage_tables(lds, fwd_tab, inv_tab);
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* sc = lds + LDS_SCR + wv * 64;      // this wave's byte-plane scratch
+    uint32_t* vec = lds + LDS_VEC;
+    uint32_t* chat = lds + LDS_CHAT;
+    for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
+        ARow<L> Ar;
+        int32_t th[4] = {0, 0, 0, 0};
+        uint32_t hb[4] = {0, 0, 0, 0};
+        const size_t o = (it * K + wv) * 256;
+        if (wv < K) {    // issue this row's loads first: A (L x 1 KiB), t1, h
+            Ar.load(A + ((shared_pk ? 0 : it * K) + wv) * (size_t)L * 256, lane, !shared_pk);
+            const int32_t* src = t1 + ((shared_pk ? 0 : it * K) + wv) * 256;
+#pragma unroll
+            for (int m = 0; m < 4; m++) th[m] = src[lane + 64 * m];
+            unpack_row_u8(hb, load_row_u8(h + o, lane), sc, lane);
+        }
+        if (wv <= L) {   // waves 0..L-1: z_l ; wave L: c
+            int32_t r[4];
+            const int32_t* src = (wv < L) ? z + (it * L + wv) * 256 : c + it * 256;
+            load_strided(r, src, lane);
+            ntt_fwd_core(r, twf, lm);
+            uint32_t* dst = (wv < L) ? vec + wv * 256 : chat;
+            *reinterpret_cast<int4*>(dst + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        if (wv < K) {    // t1_k * 2^13 (decoder.v:96-100), t1 is 10 bits
+#pragma unroll
+            for (int m = 0; m < 4; m++) th[m] = (th[m] & 0x3FF) << 13;
+            ntt_fwd_core(th, twf, lm);
+        }
+        __syncthreads();
+        if (wv < K) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, vec, lane);
+            const int4 ch = *reinterpret_cast<const int4*>(chat + 4 * lane);
+            acc[0] -= (int64_t)ch.x * th[0];
+            acc[1] -= (int64_t)ch.y * th[1];
+            acc[2] -= (int64_t)ch.z * th[2];
+            acc[3] -= (int64_t)ch.w * th[3];
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            ntt_inv_core(r, twi, lm);
+            uint32_t wb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+            store_row_u8(w1_out + o, wb, sc, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// H10 sign phase 2 (operator 1 of the RTL, FSM2 combined_top.v:1981-2229):
+//   c^ = NTT(c);  z_l = y_l + INTT(c^ o s1^_l)          reject ||z||  >= gamma1 - beta  (bit 0)
+//   r0 = w0_k - INTT(c^ o s2^_k)                         reject ||r0|| >= gamma2 - beta  (bit 1)
+//   ct0 = INTT(c^ o t0^_k)                               reject ||ct0||>= gamma2         (bit 2)
+//   h_k = MakeHint(r0 + ct0, w1_k)                       reject #h > omega               (bit 3)
+template <int LEVEL>
+__global__ __launch_bounds__(64 * (Par<LEVEL>::K > Par<LEVEL>::L + 1 ? Par<LEVEL>::K : Par<LEVEL>::L + 1))
+void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
+                  const int32_t* __restrict__ c, const int32_t* __restrict__ y,
+                  const int32_t* __restrict__ w0, const uint8_t* __restrict__ w1,
+                  const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
+                  const int32_t* __restrict__ t0hat, size_t batch, int shared_key,
+                  const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DWORDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stage_tables(lds, fwd_tab, inv_tab);
+    if (threadIdx.x < 4) lds[LDS_FLAGS + threadIdx.x] = 0;
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* sc = lds + LDS_SCR + wv * 64;      // this wave's byte-plane scratch
+    uint32_t* chat = lds + LDS_CHAT;
+    uint32_t* fl = lds + LDS_FLAGS;   // [0] reject bits, [1] hint count
+    for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
+        if (wv == L) {
+            int32_t r[4];
+            load_strided(r, c + it * 256, lane);
+            ntt_fwd_core(r, twf, lm);
+            *reinterpret_cast<int4*>(chat + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        __syncthreads();
+        const int4 ch = *reinterpret_cast<const int4*>(chat + 4 * lane);
+        uint32_t bits = 0, nh = 0;
+        if (wv < L) {
+            const int4 s = *reinterpret_cast<const int4*>(s1hat + ((shared_key ? 0 : it * L) + wv) * 256 + 4 * lane);
+            int32_t r[4] = {mont_mul(ch.x, s.x), mont_mul(ch.y, s.y), mont_mul(ch.z, s.z), mont_mul(ch.w, s.w)};
+            ntt_inv_core(r, twi, lm);
+            const size_t o = (it * L + wv) * 256;
+            bool rej = false;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t v = canon_any(r[m] + y[o + lane + 64 * m]);
+                rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
+                z_out[o + lane + 64 * m] = (int32_t)v;
+            }
+            if (__ballot(rej)) bits |= 1;
+        }
+        if (wv < K) {
+            const size_t ko = ((shared_key ? 0 : it * K) + wv) * 256 + 4 * lane;
+            const int4 s2 = *reinterpret_cast<const int4*>(s2hat + ko);
+            const int4 t0 = *reinterpret_cast<const int4*>(t0hat + ko);
+            int32_t a[4] = {mont_mul(ch.x, s2.x), mont_mul(ch.y, s2.y), mont_mul(ch.z, s2.z), mont_mul(ch.w, s2.w)};
+            int32_t b[4] = {mont_mul(ch.x, t0.x), mont_mul(ch.y, t0.y), mont_mul(ch.z, t0.z), mont_mul(ch.w, t0.w)};
+            ntt_inv_core(a, twi, lm);
+            ntt_inv_core(b, twi, lm);
+            const size_t o = (it * K + wv) * 256;
+            bool rej1 = false, rej2 = false;
+            uint32_t w1v[4], hv[4];
+            unpack_row_u8(w1v, load_row_u8(w1 + o, lane), sc, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t ct0 = canon_small(b[m]);
+                const uint32_t r0 = canon_any(w0[o + lane + 64 * m] - a[m]);
+                rej1 |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
+                rej2 |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
+                const uint32_t s = canon_small((int32_t)(r0 + ct0) - Q);
+                hv[m] = make_hint<LEVEL>(s, w1v[m]);
+                nh += __popcll(__ballot(hv[m]));
+            }
+            store_row_u8(h_out + o, hv, sc, lane);
+            if (__ballot(rej1)) bits |= 2;
+            if (__ballot(rej2)) bits |= 4;
+        }
+        if (lane == 0) {
+            if (bits) atomicOr(&fl[0], bits);
+            if (nh) atomicAdd(&fl[1], nh);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t f = fl[0] | (fl[1] > (uint32_t)Par<LEVEL>::OMEGA ? 8u : 0u);
+            flags_out[it] = (int32_t)f;
+            fl[0] = 0;
+            fl[1] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Wave-per-item variants of the fused pipelines (large batches).
+// One wavefront carries one whole item through every stage: the L NTT-domain vectors stay in
+// its registers (4L VGPRs), the matrix rows stream through, no LDS data exchange and no
+// barrier after the one-time twiddle staging.  Rows are software-prefetched: the loads of row
+// k+1 are issued as soon as the MACs of row k have consumed the row registers, and fly under
+// NTT(t1_k) + INTT(row k).  With batch >= 8 items per SIMD this keeps the VALUs busier than
+// the workgroup-per-item kernels above (which remain the low-latency path for small batches).
+// ---------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void mac_row_regs(int64_t (&acc)[4], const ARow<L>& A, const int32_t (&vh)[L][4])
+{
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        acc[0] += (int64_t)A.v[l].x * vh[l][0];
+        acc[1] += (int64_t)A.v[l].y * vh[l][1];
+        acc[2] += (int64_t)A.v[l].z * vh[l][2];
+        acc[3] += (int64_t)A.v[l].w * vh[l][3];
+    }
+}
+
+// forward-transform L consecutive polynomials (+ optionally one extra from `tail`) into
+// registers, loading polynomial l+1 while l is being transformed
+template <int L, bool TAIL, class TW>
+__device__ __forceinline__ void fwd_vector(int32_t (&vh)[L][4], int32_t (&th)[4], const int32_t* __restrict__ v,
+                                           const int32_t* __restrict__ tail, const TW& twf, const LaneMasks& lm, int lane)
+{
+    int32_t cur[4], nxt[4] = {0, 0, 0, 0};
+    load_strided(cur, v, lane);
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        if (l + 1 < L) load_strided(nxt, v + (l + 1) * 256, lane);
+        else if (TAIL) load_strided(nxt, tail, lane);
+        ntt_fwd_core(cur, twf, lm);
+#pragma unroll
+        for (int m = 0; m < 4; m++) { vh[l][m] = cur[m]; cur[m] = nxt[m]; }
+    }
+    if (TAIL) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) th[m] = cur[m];     // loaded, NOT yet transformed
+    }
+}
+
+// raw (time-domain) inputs of one item, prefetched a whole row phase ahead
+template <int NP>
+struct RawPolys {
+    int32_t v[NP][4];
+    __device__ __forceinline__ void load(const int32_t* __restrict__ base, int lane)
+    {
+#pragma unroll
+        for (int p = 0; p < NP; p++) load_strided(v[p], base + p * 256, lane);
+    }
+};
+
+#define DIL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// mat-vec / sign phase 1, wave-per-item.  Per item: issue row-0 loads | L forward NTTs on registers
+// loaded during the PREVIOUS item's row phase, y^ -> this wave's LDS slice | issue the NEXT item's y
+// loads | K rows: MAC from LDS, prefetch row k+1, INTT, (Decompose), store.
+template <int K, int L, int LEVEL, int OUT>
+__global__ __launch_bounds__(256) void matvec_wpi_kernel(
+    int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
+    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
+    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64];
+    const int lane = threadIdx.x & 63;
+    stage_tables(lds, fwd_tab, inv_tab);
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + (threadIdx.x >> 6) * 64;   // byte-plane scratch
+    uint32_t* yl = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * (L * 256);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    RawPolys<L> yr;
+    if (it < batch) yr.load(y + it * L * 256, lane);
+    __syncthreads();                               // tables staged (the only barrier)
+    for (; it < batch; it += nwaves) {
+        const int32_t* Ait = A + (shared_A ? 0 : it * K) * (size_t)L * 256;
+        ARow<L> Ar;
+        Ar.load(Ait, lane, !shared_A);
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            ntt_fwd_core(yr.v[l], twf, lm);
+            *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
+        }
+        DIL_SCHED_FENCE();
+        const size_t itn = it + nwaves;
+        if (itn < batch) yr.load(y + itn * L * 256, lane);
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, yl, lane);
+            if (k + 1 < K) Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_A);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE();
+            ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE();
+            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane);
+        }
+    }
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void verify_wpi_kernel(
+    uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
+    const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint8_t* __restrict__ h, size_t batch,
+    int shared_pk, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64];
+    const int lane = threadIdx.x & 63;
+    stage_tables(lds, fwd_tab, inv_tab);
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + (threadIdx.x >> 6) * 64;   // byte-plane scratch
+    uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * (L * 256);   // this wave's private slice
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    RawPolys<L> zr;
+    int32_t cr[4] = {0, 0, 0, 0};
+    if (it < batch) {
+        zr.load(z + it * L * 256, lane);
+        load_strided(cr, c + it * 256, lane);
+    }
+    __syncthreads();                               // tables staged (the only barrier)
+    for (; it < batch; it += nwaves) {
+        const int32_t* Ait = A + (shared_pk ? 0 : it * K) * (size_t)L * 256;
+        const int32_t* t1it = t1 + (shared_pk ? 0 : it * K) * 256;
+        const uint8_t* hit = h + it * K * 256;
+        // row 0 operands fly under the z-phase
+        ARow<L> Ar;
+        Ar.load(Ait, lane, !shared_pk);
+        int32_t tn[4];
+        uint32_t hn;
+        load_strided(tn, t1it, lane);
+        hn = load_row_u8(hit, lane);
+        // z-phase
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            ntt_fwd_core(zr.v[l], twf, lm);
+            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zr.v[l][0], zr.v[l][1], zr.v[l][2], zr.v[l][3]);
+        }
+        int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
+        ntt_fwd_core(ch, twf, lm);
+        DIL_SCHED_FENCE();
+        // next item's time-domain inputs: a whole row phase to land
+        const size_t itn = it + nwaves;
+        if (itn < batch) {
+            zr.load(z + itn * L * 256, lane);
+            load_strided(cr, c + itn * 256, lane);
+        }
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, zl, lane);
+            int32_t th[4];
+            uint32_t hb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
+            unpack_row_u8(hb, hn, sc, lane);
+            if (k + 1 < K) {
+                Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_pk);
+                load_strided(tn, t1it + (k + 1) * 256, lane);
+                hn = load_row_u8(hit + (k + 1) * 256, lane);
+            }
+            DIL_SCHED_FENCE();     // keep the stages from being interleaved (register pressure, not ILP, is the limit)
+            ntt_fwd_core(th, twf, lm);
+            DIL_SCHED_FENCE();
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE();
+            ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE();
+            const size_t o = (it * K + k) * 256;
+            uint32_t wb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+            store_row_u8(w1_out + o, wb, sc, lane);
+        }
+    }
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void sign2_wpi_kernel(
+    int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
+    const int32_t* __restrict__ c, const int32_t* __restrict__ y, const int32_t* __restrict__ w0,
+    const uint8_t* __restrict__ w1, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
+    const int32_t* __restrict__ t0hat, size_t batch, int shared_key, const uint32_t* __restrict__ fwd_tab,
+    const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64];
+    const int lane = threadIdx.x & 63;
+    stage_tables(lds, fwd_tab, inv_tab);
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * 64;   // byte-plane scratch
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+        const int32_t* s1 = s1hat + (shared_key ? 0 : it * L) * 256;
+        const int32_t* s2 = s2hat + (shared_key ? 0 : it * K) * 256;
+        const int32_t* t0 = t0hat + (shared_key ? 0 : it * K) * 256;
+        int32_t ch[4];
+        load_strided(ch, c + it * 256, lane);
+        int4 sn = *reinterpret_cast<const int4*>(s1 + 4 * lane);
+        ntt_fwd_core(ch, twf, lm);
+        uint32_t bits = 0, nh = 0;
+        for (int l = 0; l < L; l++) {
+            const int4 s = sn;
+            const size_t o = (it * L + l) * 256;
+            int32_t yv[4];
+            load_strided(yv, y + o, lane);
+            if (l + 1 < L) sn = *reinterpret_cast<const int4*>(s1 + (l + 1) * 256 + 4 * lane);
+            int32_t r[4] = {mont_mul(ch[0], s.x), mont_mul(ch[1], s.y), mont_mul(ch[2], s.z), mont_mul(ch[3], s.w)};
+            ntt_inv_core(r, twi, lm);
+            bool rej = false;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t v = canon_any(r[m] + yv[m]);
+                rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
+                st_nt(z_out + o + lane + 64 * m, (int32_t)v);
+            }
+            if (__ballot(rej)) bits |= 1;
+        }
+        for (int k = 0; k < K; k++) {
+            const int4 a2 = *reinterpret_cast<const int4*>(s2 + k * 256 + 4 * lane);
+            const int4 b0 = *reinterpret_cast<const int4*>(t0 + k * 256 + 4 * lane);
+            const size_t o = (it * K + k) * 256;
+            int32_t wv0[4];
+            uint32_t wv1[4], hv[4];
+            load_strided(wv0, w0 + o, lane);
+            const uint32_t w1p = load_row_u8(w1 + o, lane);
+            int32_t a[4] = {mont_mul(ch[0], a2.x), mont_mul(ch[1], a2.y), mont_mul(ch[2], a2.z), mont_mul(ch[3], a2.w)};
+            int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
+            ntt_inv_core(a, twi, lm);
+            ntt_inv_core(b, twi, lm);
+            bool rej1 = false, rej2 = false;
+            unpack_row_u8(wv1, w1p, sc, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t ct0 = canon_small(b[m]);
+                const uint32_t r0 = canon_any(wv0[m] - a[m]);
+                rej1 |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
+                rej2 |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
+                const uint32_t s = canon_small((int32_t)(r0 + ct0) - Q);
+                hv[m] = make_hint<LEVEL>(s, wv1[m]);
+                nh += __popcll(__ballot(hv[m]));
+            }
+            store_row_u8(h_out + o, hv, sc, lane);
+            if (__ballot(rej1)) bits |= 2;
+            if (__ballot(rej2)) bits |= 4;
+        }
+        if (lane == 0) flags_out[it] = (int32_t)(bits | (nh > (uint32_t)Par<LEVEL>::OMEGA ? 8u : 0u));
+    }
+}
+
+#ifndef DIL_SHARED_TWREG
+#define DIL_SHARED_TWREG 0
+#endif
+// ---------------------------------------------------------------------------------------
+// Shared-key wave-per-item kernels.  When one key serves the whole batch (one signer, or many
+// signatures under one public key) its NTT-domain material -- A [K][L] (+ t1^ for verify; s1^,
+// s2^, t0^ for sign phase 2) -- is staged ONCE per persistent workgroup into LDS (30-64 KiB)
+// and every multiply-accumulate reads both operands from LDS.  No per-item matrix traffic at
+// all: measured, re-reading an L2-resident A per item cost as much as streaming it from HBM.
+// Workgroups are as large as LDS allows (NW waves, 1 workgroup per CU).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_polys(uint32_t* lds_dst, const int32_t* __restrict__ src, int npolys)
+{
+    for (int i = threadIdx.x; i < npolys * 64; i += blockDim.x)
+        reinterpret_cast<uint4*>(lds_dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+}
+
+template <int L>
+__device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a_row, const uint32_t* vec, int lane)
+{
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        const int4 a = *reinterpret_cast<const int4*>(a_row + l * 256 + 4 * lane);
+        const int4 z = *reinterpret_cast<const int4*>(vec + l * 256 + 4 * lane);
+        acc[0] += (int64_t)a.x * z.x;
+        acc[1] += (int64_t)a.y * z.y;
+        acc[2] += (int64_t)a.z * z.z;
+        acc[3] += (int64_t)a.w * z.w;
+    }
+}
+
+template <int K, int L, int LEVEL, int OUT, int NW>
+__global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
+    int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
+    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch,
+    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + NW * L) * 256 + NW * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stage_tables(lds, fwd_tab, inv_tab);
+    uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
+    stage_polys(Al, A, K * L);
+#if DIL_SHARED_TWREG
+    TwRegs twf, twi;
+    twf.load(fwd_tab, lane);
+    twi.load(inv_tab, lane);
+#else
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+#endif
+    const LaneMasks lm(lane);
+    uint32_t* yl = Al + K * L * 256 + wv * (L * 256);
+    uint32_t* sc = Al + (K * L + NW * L) * 256 + wv * 64;   // byte-plane scratch
+    const size_t nwaves = (size_t)gridDim.x * NW;
+    size_t it = (size_t)blockIdx.x * NW + wv;
+    RawPolys<L> yr;
+    if (it < batch) yr.load(y + it * L * 256, lane);
+    __syncthreads();                               // tables + key staged (the only barrier)
+    for (; it < batch; it += nwaves) {
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            ntt_fwd_core(yr.v[l], twf, lm);
+            *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
+        }
+        DIL_SCHED_FENCE();
+        const size_t itn = it + nwaves;
+        if (itn < batch) yr.load(y + itn * L * 256, lane);
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row_lds<L>(acc, Al + k * L * 256, yl, lane);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE();
+            ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE();
+            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane);
+        }
+    }
+}
+
+// verify, shared public key: A and t1^ = NTT(t1 2^13) live in LDS; t1^ is computed once per
+// workgroup by its first K waves (VY_NTT_T1, combined_top.v:1259) -- cheaper than a second launch
+template <int LEVEL, int NW>
+__global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
+    uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
+    const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint8_t* __restrict__ h, size_t batch,
+    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K + NW * L) * 256 + NW * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stage_tables(lds, fwd_tab, inv_tab);
+    uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
+    uint32_t* Tl = Al + K * L * 256;
+    stage_polys(Al, A, K * L);
+#if DIL_SHARED_TWREG
+    TwRegs twf, twi;
+    twf.load(fwd_tab, lane);
+    twi.load(inv_tab, lane);
+#else
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+#endif
+    const LaneMasks lm(lane);
+    uint32_t* zl = Tl + K * 256 + wv * (L * 256);
+    uint32_t* sc = Tl + (K + NW * L) * 256 + wv * 64;        // byte-plane scratch
+    const size_t nwaves = (size_t)gridDim.x * NW;
+    size_t it = (size_t)blockIdx.x * NW + wv;
+    RawPolys<L> zr;
+    int32_t cr[4] = {0, 0, 0, 0};
+    if (it < batch) {
+        zr.load(z + it * L * 256, lane);
+        load_strided(cr, c + it * 256, lane);
+    }
+    __syncthreads();                               // tables + A staged
+    if (wv < K) {                                  // t1_k * 2^13 (decoder.v:96-100) -> NTT -> LDS, lazy residues
+        int32_t th[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) th[m] = (t1[wv * 256 + lane + 64 * m] & 0x3FF) << 13;
+        ntt_fwd_core(th, twf, lm);
+        *reinterpret_cast<int4*>(Tl + wv * 256 + 4 * lane) = make_int4(th[0], th[1], th[2], th[3]);
+    }
+    __syncthreads();
+    for (; it < batch; it += nwaves) {
+        const uint8_t* hit = h + it * K * 256;
+        uint32_t hn = load_row_u8(hit, lane);
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            ntt_fwd_core(zr.v[l], twf, lm);
+            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zr.v[l][0], zr.v[l][1], zr.v[l][2], zr.v[l][3]);
+        }
+        int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
+        ntt_fwd_core(ch, twf, lm);
+        DIL_SCHED_FENCE();
+        const size_t itn = it + nwaves;
+        if (itn < batch) {
+            zr.load(z + itn * L * 256, lane);
+            load_strided(cr, c + itn * 256, lane);
+        }
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row_lds<L>(acc, Al + k * L * 256, zl, lane);
+            const int4 th = *reinterpret_cast<const int4*>(Tl + k * 256 + 4 * lane);
+            acc[0] -= (int64_t)ch[0] * th.x;
+            acc[1] -= (int64_t)ch[1] * th.y;
+            acc[2] -= (int64_t)ch[2] * th.z;
+            acc[3] -= (int64_t)ch[3] * th.w;
+            uint32_t hb[4];
+            unpack_row_u8(hb, hn, sc, lane);
+            if (k + 1 < K) hn = load_row_u8(hit + (k + 1) * 256, lane);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE();
+            ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE();
+            const size_t o = (it * K + k) * 256;
+            uint32_t wb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+            store_row_u8(w1_out + o, wb, sc, lane);
+        }
+    }
+}
+
+// LDS budget (160 KiB): tables 16 KiB + key + NW * L KiB of per-wave vector slices
+template <int LEVEL> struct SharedNW;
+template <> struct SharedNW<2> { static constexpr int MATVEC = 16, VERIFY = 16; };   // 16+16(+4)+64  = 96 / 100 KiB
+template <> struct SharedNW<3> { static constexpr int MATVEC = 16, VERIFY = 16; };   // 16+30(+6)+80  = 126 / 132 KiB
+template <> struct SharedNW<5> { static constexpr int MATVEC = 12, VERIFY = 11; };   // 16+56(+8)+84/77 = 156 / 157 KiB
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+// wave-per-item pays once every SIMD has several items to interleave; below that the
+// workgroup-per-item kernels expose more parallelism per item (lower latency)
+static inline bool use_wpi(size_t batch, const Tables& t)
+{
+    if (t.fused_mode == 1) return false;
+    if (t.fused_mode == 2) return true;
+    return batch >= (size_t)t.num_cus * 8;
+}
+
+template <int LEVEL, int OUT>
+static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
+                                      size_t batch, int shared_A, const Tables& t, hipStream_t s)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    if (use_wpi(batch, t) && shared_A) {
+        constexpr int NW = SharedNW<LEVEL>::MATVEC;
+        const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
+        hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, t.fwd,
+                           t.inv_pipe);
+        return hipGetLastError();
+    }
+    if (use_wpi(batch, t)) {
+        const int g = grid_for((batch + 3) / 4,
+                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT>, 256, t.wpi_blocks_per_cu));
+        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, t.fwd,
+                           t.inv_pipe);
+        return hipGetLastError();
+    }
+    const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
+    hipLaunchKernelGGL((matvec_kernel<K, L, LEVEL, OUT>), grid, 64 * (K > L ? K : L), 0, s, w, w1, w0, A, y, batch,
+                       shared_A, t.fwd, t.inv_pipe);
+    return hipGetLastError();
+}
+
+hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A,
+                         const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+#define DIL_MV(LV)                                                                                   \
+    return out_mode == OUT_W ? launch_matvec_level<LV, OUT_W>(w, w1, w0, A, y, batch, shared_A, t, s) \
+                             : launch_matvec_level<LV, OUT_W1W0>(w, w1, w0, A, y, batch, shared_A, t, s)
+    switch (level) {
+    case 2: DIL_MV(2);
+    case 3: DIL_MV(3);
+    case 5: DIL_MV(5);
+    default: return hipErrorInvalidValue;
+    }
+#undef DIL_MV
+}
+
+template <int LEVEL>
+static void launch_verify_wpi(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
+                              const uint8_t* h, size_t batch, int shared_pk, const Tables& t, hipStream_t s)
+{
+    if (shared_pk) {
+        constexpr int NW = SharedNW<LEVEL>::VERIFY;
+        const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
+        hipLaunchKernelGGL((verify_shared_kernel<LEVEL, NW>), g, 64 * NW, 0, s, w1, A, z, c, t1, h, batch, t.fwd, t.inv_pipe);
+    } else {
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<LEVEL>, 256, t.wpi_blocks_per_cu));
+        hipLaunchKernelGGL((verify_wpi_kernel<LEVEL>), g, 256, 0, s, w1, A, z, c, t1, h, batch, shared_pk, t.fwd, t.inv_pipe);
+    }
+}
+
+hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c,
+                         const int32_t* t1, const uint8_t* h, size_t batch, int shared_pk,
+                         const Tables& t, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    if (use_wpi(batch, t)) {
+        switch (level) {
+        case 2: launch_verify_wpi<2>(w1, A, z, c, t1, h, batch, shared_pk, t, s); break;
+        case 3: launch_verify_wpi<3>(w1, A, z, c, t1, h, batch, shared_pk, t, s); break;
+        case 5: launch_verify_wpi<5>(w1, A, z, c, t1, h, batch, shared_pk, t, s); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
+#define DIL_VY(LV)                                                                                             \
+    hipLaunchKernelGGL(verify_kernel<LV>, grid,                                                                \
+                       64 * (Par<LV>::K > Par<LV>::L + 1 ? Par<LV>::K : Par<LV>::L + 1), 0, s, w1, A, z, c, t1, \
+                       h, batch, shared_pk, t.fwd, t.inv_pipe);                                                     \
+    break
+    switch (level) {
+    case 2: DIL_VY(2);
+    case 3: DIL_VY(3);
+    case 5: DIL_VY(5);
+    default: return hipErrorInvalidValue;
+    }
+#undef DIL_VY
+    return hipGetLastError();
+}
+
+hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
+                        const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
+                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    if (use_wpi(batch, t)) {
+        switch (level) {
+        case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
+        case 3: hipLaunchKernelGGL(sign2_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<3>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
+        case 5: hipLaunchKernelGGL(sign2_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<5>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
+#define DIL_S2(LV)                                                                                             \
+    hipLaunchKernelGGL(sign2_kernel<LV>, grid,                                                                 \
+                       64 * (Par<LV>::K > Par<LV>::L + 1 ? Par<LV>::K : Par<LV>::L + 1), 0, s, z, h, flags, c, \
+                       y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe);                       \
+    break
+    switch (level) {
+    case 2: DIL_S2(2);
+    case 3: DIL_S2(3);
+    case 5: DIL_S2(5);
+    default: return hipErrorInvalidValue;
+    }
+#undef DIL_S2
+    return hipGetLastError();
+}
+
+}  // namespace dil

@@ -36,6 +36,12 @@ def main():
                 api.verify_core(A, z, c, t1, h, 3, out=w1)
             if what not in ("verify", "ntt+verify"):
                 api.verify_core(A[:1], z, c, t1[:1], h, 3, shared_pk=True, out=w1)
+    if what in ("matvec_shared", "matvec"):
+        n, K, L = 8192, 6, 5
+        A, y = rnd(n if what == "matvec" else 1, K, L, 256), rnd(n, L, 256)
+        w = torch.empty((n, K, 256), dtype=torch.int32, device="cuda")
+        for _ in range(reps):
+            api.matvec(A, y, 3, shared_A=(what == "matvec_shared"), out=w)
     if what in ("sign", "all"):
         n, K, L = 8192, 8, 7
         A, y, c = rnd(1, K, L, 256), rnd(n, L, 256), rnd(n, 256)
