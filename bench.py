@@ -237,6 +237,54 @@ def main():
                "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("verify_kernel"),
                             "avg_launch_ms": v_ms}}
+        # same pipeline with ONE public key for the whole batch (A, t1 staged in LDS): VALU-bound, reported beside it
+        torch.cuda.synchronize()
+        e2, e3 = ev(), ev()
+        L.dil_event_record(e2, stream)
+        for _ in range(vs):
+            api.verify_core(dA[:1], dz, dc, dt1[:1], dh, 3, shared_pk=True, out=w1)
+        L.dil_event_record(e3, stream)
+        torch.cuda.synchronize()
+        s_ms = elapsed(e2, e3) / vs
+        sec["shared_pk"] = {"value": VBATCH / (s_ms * 1e-3), "unit": "verify/s per GPU", "avg_launch_ms": s_ms,
+                            "bytes_per_verify": 15 * 1024, "kernel": "verify_shared_kernel<3,16>",
+                            "bound": "valu (key material LDS-resident)"}
+        # configs[2] and configs[4] of BASELINE.json (parity-test configs; timed here for the record only)
+        try:
+            g2 = torch.Generator(device="cuda").manual_seed(5)
+            rnd = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=g2)  # noqa: E731
+            A2, y2 = rnd(4096, 4, 4, 256), rnd(4096, 4, 256)
+            wout = torch.empty((4096, 4, 256), dtype=torch.int32, device="cuda")
+            for _ in range(3):
+                api.matvec(A2, y2, 2, out=wout)
+            e4, e5 = ev(), ev()
+            L.dil_event_record(e4, stream)
+            for _ in range(vs):
+                api.matvec(A2, y2, 2, out=wout)
+            L.dil_event_record(e5, stream)
+            torch.cuda.synchronize()
+            m_ms = elapsed(e4, e5) / vs
+            A5, y5, c5 = rnd(1, 8, 7, 256), rnd(8192, 7, 256), rnd(8192, 256)
+            s1h, s2h, t0h = rnd(1, 7, 256), rnd(1, 8, 256), rnd(1, 8, 256)
+            w1s, w0s = api.sign_phase1(A5, y5, 5, shared_key=True)
+            for _ in range(2):
+                api.sign_phase1(A5, y5, 5, shared_key=True)
+                api.sign_phase2(c5, y5, w0s, w1s, s1h, s2h, t0h, 5, shared_key=True)
+            e6, e7 = ev(), ev()
+            L.dil_event_record(e6, stream)
+            for _ in range(vs):
+                api.sign_phase1(A5, y5, 5, shared_key=True)
+                api.sign_phase2(c5, y5, w0s, w1s, s1h, s2h, t0h, 5, shared_key=True)
+            L.dil_event_record(e7, stream)
+            torch.cuda.synchronize()
+            a_ms = elapsed(e6, e7) / vs
+            sec["other_configs"] = {
+                "configs[2] level-2 A.y matvec batch=4096 distinct A": {"matvecs_per_s": 4096 / (m_ms * 1e-3), "ms": m_ms,
+                                                                         "GBps": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9},
+                "configs[4] level-5 sign attempt (phase1+phase2) batch=8192 per GPU, shared key": {
+                    "attempts_per_s": 8192 / (a_ms * 1e-3), "ms": a_ms}}
+        except Exception as e:  # noqa: BLE001
+            sec["other_configs"] = {"error": repr(e)}
         # the one collective of the design: final gather of the result slabs over RCCL/xGMI
         if world > 1:
             torch.cuda.synchronize()
