@@ -194,3 +194,50 @@ def sign_phase2(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False):
                                                _dev(t0hat, torch.int32), level, B, int(shared_key), _stream()),
                "dil_sign_phase2_dev")
     return z, h, flags
+
+
+# ---- row N1: SHAKE-bound samplers on the device (uint8 / int32 CUDA tensors) -----------------------
+def shake256(data, out_bytes):
+    """out[i] = SHAKE256(data[i]); data uint8 [B, n] with n % 8 == 0, out_bytes % 8 == 0"""
+    B, n = data.shape
+    out = torch.empty((B, out_bytes), dtype=torch.uint8, device=data.device)
+    _lib.check(_lib.load().dil_shake256_dev(_dev(out, torch.uint8), out_bytes, _dev(data, torch.uint8), n, B, _stream()),
+               "dil_shake256_dev")
+    return out
+
+
+def expand_a(rho, level):
+    """A [B,K,L,256] from rho uint8 [B,32]"""
+    K, Lv = _kl(level)
+    B = rho.shape[0]
+    A = torch.empty((B, K, Lv, N), dtype=torch.int32, device=rho.device)
+    _lib.check(_lib.load().dil_expand_a_dev(_dev(A, torch.int32), _dev(rho, torch.uint8), level, B, _stream()), "dil_expand_a_dev")
+    return A
+
+
+def expand_mask(rhoprime, kappa, level):
+    """y [B,L,256] canonical from rho' uint8 [B,64] and int32 nonce base kappa [B]"""
+    K, Lv = _kl(level)
+    B = rhoprime.shape[0]
+    y = torch.empty((B, Lv, N), dtype=torch.int32, device=rhoprime.device)
+    _lib.check(_lib.load().dil_expand_mask_dev(_dev(y, torch.int32), _dev(rhoprime, torch.uint8), _dev(kappa, torch.int32),
+                                               level, B, _stream()), "dil_expand_mask_dev")
+    return y
+
+
+def sample_in_ball(ctilde, level):
+    """c [B,256] (+-1 as 1 / q-1) from c~ uint8 [B,32]"""
+    B = ctilde.shape[0]
+    c = torch.empty((B, N), dtype=torch.int32, device=ctilde.device)
+    _lib.check(_lib.load().dil_sample_in_ball_dev(_dev(c, torch.int32), _dev(ctilde, torch.uint8), level, B, _stream()),
+               "dil_sample_in_ball_dev")
+    return c
+
+
+def pack_w1(w1, level):
+    """[B,K,256] uint8 -> [B, K*128] (levels 3/5) or [B, K*192] (level 2) uint8"""
+    K, _ = _kl(level)
+    B = w1.shape[0]
+    out = torch.empty((B, K * (192 if level == 2 else 128)), dtype=torch.uint8, device=w1.device)
+    _lib.check(_lib.load().dil_pack_w1_dev(_dev(out, torch.uint8), _dev(w1, torch.uint8), level, B, _stream()), "dil_pack_w1_dev")
+    return out

@@ -422,6 +422,39 @@ int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c
     return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, S(stream));
 }
 
+// ---- row N1: samplers ---------------------------------------------------------------------------
+int dil_shake256_dev(uint8_t* out, size_t out_bytes, const uint8_t* in, size_t in_bytes, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_shake256(reinterpret_cast<uint64_t*>(out), (int)out_bytes, reinterpret_cast<const uint64_t*>(in),
+                                     (int)in_bytes, batch, S(stream));
+}
+int dil_expand_a_dev(int32_t* A, const uint8_t* rho, int level, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_expand_a(A, rho, level, batch, S(stream));
+}
+int dil_expand_mask_dev(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_expand_mask(y, rhoprime, kappa, level, batch, S(stream));
+}
+int dil_sample_in_ball_dev(int32_t* c, const uint8_t* ctilde, int level, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_sample_in_ball(c, ctilde, level, batch, S(stream));
+}
+int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, void* stream)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    return (int)dil::launch_pack_w1(out, w1, level, batch, g.t, S(stream));
+}
+
 // ---- events --------------------------------------------------------------------------------------
 int dil_event_create(void** ev)
 {

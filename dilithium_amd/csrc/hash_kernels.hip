@@ -1,0 +1,303 @@
+// hash_kernels.hip -- row N1 of SURVEY 8(f): the SHAKE-bound samplers of Dilithium on the GPU, so
+// that sign / verify batches no longer bounce through the host between kernels.
+//   ExpandA        gen_a_ext.v, sampler_a_ext.v:107,129 (nonce (i<<8)|j), rejection_a.v:67-73
+//   ExpandMask     expandmask_ext.v:98,131-185, sampler_y_ext.v:101,119, rejection_y.v:97-99
+//   SampleInBall   gen_c.v:163-196,318-339
+//   H(mu || w1)    keccak_top (3 instances, combined_top.v:225-231) + encoder.v:96-133 (w1 packing)
+// One sponge per lane (keccak.hpp).  Conventions are those the reference's KATs obey (round-3
+// v3.1); parity is checked against hashlib and the KAT vectors.
+#include "keccak.hpp"
+#include "kernels.hpp"
+
+namespace dil {
+
+constexpr uint32_t QU = 8380417u;
+
+// ---------------------------------------------------------------------------------------
+// generic batched SHAKE256 with one input length for the whole batch:
+//   out[i][0..out_bytes) = SHAKE256(in[i][0..in_bytes)),  in_bytes, out_bytes multiples of 8
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void shake256_batch_kernel(uint64_t* __restrict__ out, int out_words,
+                                                            const uint64_t* __restrict__ in, int in_words, size_t batch)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= batch) return;
+    Shake<17> sp;
+    sp.init();
+    const uint64_t* src = in + i * in_words;
+    int w = 0;
+    for (int k = 0; k < in_words; k++) {
+        const uint64_t v = src[k];
+#pragma unroll
+        for (int t = 0; t < 17; t++)
+            if (t == w) sp.s[t] ^= v;
+        if (++w == 17) {
+            sp.next_block();
+            w = 0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 17; t++)
+        if (t == w) sp.s[t] ^= 0x1Full;
+    sp.s[16] ^= 0x8000000000000000ull;
+    keccak_f1600(sp.s);
+    uint64_t* dst = out + i * out_words;
+    int o = 0;
+    for (int k = 0; k < out_words; k++) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 17; t++)
+            if (t == o) v = sp.s[t];
+        dst[k] = v;
+        if (++o == 17 && k + 1 < out_words) {
+            sp.next_block();
+            o = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ExpandA: A[item][i][j] = RejUniform(SHAKE128(rho || byte j || byte i)), 3-byte little-endian
+// candidates masked to 23 bits, accepted when < q.  One lane per polynomial.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit23(uint32_t v, int32_t* __restrict__ dst, int& cnt)
+{
+    v &= 0x7FFFFFu;
+    if (v < QU && cnt < 256) dst[cnt++] = (int32_t)v;
+}
+
+__global__ __launch_bounds__(64) void expand_a_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
+                                                      int K, int L, size_t nitems)
+{
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t total = nitems * (size_t)(K * L);
+    const bool live = p < total;
+    const size_t item = live ? p / (size_t)(K * L) : 0;
+    const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
+    Shake<21> sp;
+    sp.init();
+#pragma unroll
+    for (int w = 0; w < 4; w++) sp.s[w] = rho[item * 4 + w];
+    sp.s[4] = (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16);
+    sp.s[20] ^= 0x8000000000000000ull;
+    int32_t* dst = A + p * 256;
+    int cnt = live ? 0 : 256;
+    while (__any(cnt < 256)) {
+        keccak_f1600(sp.s);
+#pragma unroll
+        for (int g = 0; g < 7; g++) {
+            const uint64_t w0 = sp.s[3 * g], w1 = sp.s[3 * g + 1], w2 = sp.s[3 * g + 2];
+            emit23((uint32_t)w0, dst, cnt);
+            emit23((uint32_t)(w0 >> 24), dst, cnt);
+            emit23((uint32_t)((w0 >> 48) | (w1 << 16)), dst, cnt);
+            emit23((uint32_t)(w1 >> 8), dst, cnt);
+            emit23((uint32_t)(w1 >> 32), dst, cnt);
+            emit23((uint32_t)((w1 >> 56) | (w2 << 8)), dst, cnt);
+            emit23((uint32_t)(w2 >> 16), dst, cnt);
+            emit23((uint32_t)(w2 >> 40), dst, cnt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ExpandMask: y[item][l] = gamma1 - Unpack_B(SHAKE256(rho' || LE16(kappa[item] + l))),
+// B = 18 (gamma1 = 2^17) or 20 (2^19) bits.  Output canonical in [0, q).  One lane per polynomial.
+// ---------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(64) void expand_mask_kernel(int32_t* __restrict__ y, const uint64_t* __restrict__ rhoprime,
+                                                         const uint32_t* __restrict__ kappa, int L, size_t nitems)
+{
+    constexpr int32_t GAMMA1 = 1 << (B - 1);
+    constexpr uint64_t MASK = (1ull << B) - 1;
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= nitems * (size_t)L) return;
+    const size_t item = p / (size_t)L;
+    const uint32_t nonce = (kappa[item] + (uint32_t)(p % (size_t)L)) & 0xFFFFu;
+    Shake<17> sp;
+    sp.init();
+#pragma unroll
+    for (int w = 0; w < 8; w++) sp.s[w] = rhoprime[item * 8 + w];
+    sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
+    sp.s[16] ^= 0x8000000000000000ull;
+    int32_t* dst = y + p * 256;
+    uint64_t buf = 0;
+    int nbits = 0, cnt = 0;          // wave-uniform
+    while (cnt < 256) {
+        keccak_f1600(sp.s);
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+            const uint64_t word = sp.s[w];
+            // consume `word` (64 fresh bits) behind the nbits (< B) left in buf
+            int avail = 64;
+            if (nbits > 0 && cnt < 256) {
+                const int need = B - nbits;
+                const uint32_t t = (uint32_t)((buf | (word << nbits)) & MASK);
+                const int32_t v = GAMMA1 - (int32_t)t;
+                dst[cnt++] = v + ((v >> 31) & (int32_t)QU);
+                avail -= need;
+            }
+            uint64_t rest = (avail == 64) ? word : (word >> (64 - avail));
+            while (avail >= B && cnt < 256) {
+                const int32_t v = GAMMA1 - (int32_t)(rest & MASK);
+                dst[cnt++] = v + ((v >> 31) & (int32_t)QU);
+                rest >>= B;
+                avail -= B;
+            }
+            buf = rest;
+            nbits = avail;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// SampleInBall: c = tau coefficients +-1 from SHAKE256(c~): 8 sign bytes, then for
+// i = 256-tau..255 draw bytes until b <= i; c[i] = c[b]; c[b] = 1 - 2*sign.
+// One lane per item; the lane's c[] and its current rate block live in LDS, lane-interleaved.
+// Output canonical (+1 -> 1, -1 -> q-1).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sample_in_ball_kernel(int32_t* __restrict__ c_out, const uint64_t* __restrict__ ctilde,
+                                                            int tau, size_t nitems)
+{
+    __shared__ int8_t cl[256 * 64];           // c[idx][lane]
+    __shared__ uint8_t rb[136 * 64];          // rate block bytes [pos][lane]
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * 64;
+    const size_t item = base + lane;
+    const bool live = item < nitems;
+    for (int k = 0; k < 256; k++) cl[k * 64 + lane] = 0;
+    Shake<17> sp;
+    sp.init();
+#pragma unroll
+    for (int w = 0; w < 4; w++) sp.s[w] = live ? ctilde[item * 4 + w] : 0;
+    sp.s[4] = 0x1Full;
+    sp.s[16] ^= 0x8000000000000000ull;
+    keccak_f1600(sp.s);
+    uint64_t signs = sp.s[0];
+    auto spill = [&]() {
+#pragma unroll
+        for (int w = 0; w < 17; w++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) rb[(8 * w + b) * 64 + lane] = (uint8_t)(sp.s[w] >> (8 * b));
+    };
+    spill();
+    int pos = 8;
+    for (int i = 256 - tau; i < 256; i++) {
+        int b;
+        do {
+            if (pos == 136) {
+                keccak_f1600(sp.s);
+                spill();
+                pos = 0;
+            }
+            b = rb[pos * 64 + lane];
+            pos++;
+        } while (b > i);
+        cl[i * 64 + lane] = cl[b * 64 + lane];
+        cl[b * 64 + lane] = (int8_t)(1 - 2 * (int)(signs & 1));
+        signs >>= 1;
+    }
+    __syncthreads();
+    // coalesced write-out: item t of this block, coefficients lane + 64 m
+    for (int t = 0; t < 64; t++) {
+        if (base + t >= nitems) break;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int v = cl[(lane + 64 * m) * 64 + t];
+            c_out[(base + t) * 256 + lane + 64 * m] = v + ((v >> 31) & (int32_t)QU);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// w1 packing (encoder.v:96-133): [rows][256] bytes -> 4 bits (levels 3/5: 128 B per row) or
+// 6 bits (level 2: 192 B per row) little-endian bit stream.  16 coefficients per thread.
+// ---------------------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void pack_w1_kernel(uint32_t* __restrict__ out, const uint4* __restrict__ in, size_t nvec16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec16; i += stride) {
+        const uint4 v = in[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (BITS == 4) {
+            uint32_t o[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc |= ((w[2 * h + (k >> 2)] >> (8 * (k & 3))) & 0xFu) << (4 * k);
+                o[h] = acc;
+            }
+            reinterpret_cast<uint2*>(out)[i] = make_uint2(o[0], o[1]);
+        } else {
+            uint64_t lo = 0, hi = 0;     // 96 bits
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint64_t c = (w[k >> 2] >> (8 * (k & 3))) & 0x3Fu;
+                const int bit = 6 * k;
+                if (bit < 64) lo |= c << bit;
+                if (bit + 6 > 64) hi |= (bit >= 64) ? c << (bit - 64) : c >> (64 - bit);
+            }
+            out[3 * i] = (uint32_t)lo;
+            out[3 * i + 1] = (uint32_t)(lo >> 32);
+            out[3 * i + 2] = (uint32_t)hi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    if ((out_bytes & 7) || (in_bytes & 7) || out_bytes <= 0 || in_bytes < 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(shake256_batch_kernel, (int)((batch + 63) / 64), 64, 0, s, out, out_bytes / 8, in, in_bytes / 8, batch);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, int level, size_t nitems, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const size_t total = nitems * (size_t)(K * L);
+    hipLaunchKernelGGL(expand_a_kernel, (int)((total + 63) / 64), 64, 0, s, A, reinterpret_cast<const uint64_t*>(rho), K, L, nitems);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    const size_t total = nitems * (size_t)L;
+    const int grid = (int)((total + 63) / 64);
+    if (level == 2) hipLaunchKernelGGL(expand_mask_kernel<18>, grid, 64, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
+    else hipLaunchKernelGGL(expand_mask_kernel<20>, grid, 64, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    hipLaunchKernelGGL(sample_in_ball_kernel, (int)((nitems + 63) / 64), 64, 0, s, c, reinterpret_cast<const uint64_t*>(ctilde), tau, nitems);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
+    const size_t nvec = nitems * (size_t)K * 16;
+    const size_t blocks = (nvec + 255) / 256;
+    const int grid = (int)(blocks < (size_t)t.num_cus * 8 ? blocks : (size_t)t.num_cus * 8);
+    if (level == 2) hipLaunchKernelGGL(pack_w1_kernel<6>, grid, 256, 0, s, reinterpret_cast<uint32_t*>(out), reinterpret_cast<const uint4*>(w1), nvec);
+    else hipLaunchKernelGGL(pack_w1_kernel<4>, grid, 256, 0, s, reinterpret_cast<uint32_t*>(out), reinterpret_cast<const uint4*>(w1), nvec);
+    return hipGetLastError();
+}
+
+}  // namespace dil

@@ -1,0 +1,92 @@
+// keccak.hpp -- Keccak-f[1600] / SHAKE128 / SHAKE256, one sponge per LANE (64 independent
+// sponges per wavefront, the whole 1600-bit state in 50 VGPRs).  Row N1 of SURVEY 8(f): what the
+// reference does with three VHDL Keccak cores (keccak_*.vhd, sha3_*.vhd; control word
+// {final, mode, outbits, inbits}, keccak_datapath.vhd:97,116-117) feeding its samplers.
+// Written from FIPS 202; checked against hashlib (tests/test_gpu_hash.py) and, through the
+// samplers, against the reference's KAT vectors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dil {
+
+__device__ __constant__ uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+    0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+    0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+    0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// 24 rounds; the round body is fully unrolled (static lane indices keep the state in registers),
+// the round loop is not (2 KB of code instead of 50 KB)
+__device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25])
+{
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
+        uint64_t c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+        uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
+        uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+        uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+        const uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1),
+                       d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            a[y] ^= d0; a[y + 1] ^= d1; a[y + 2] ^= d2; a[y + 3] ^= d3; a[y + 4] ^= d4;
+        }
+        // rho + pi
+        uint64_t b[25];
+        b[0] = a[0];
+        b[10] = rotl64(a[1], 1);   b[20] = rotl64(a[2], 62);  b[5] = rotl64(a[3], 28);   b[15] = rotl64(a[4], 27);
+        b[16] = rotl64(a[5], 36);  b[1] = rotl64(a[6], 44);   b[11] = rotl64(a[7], 6);   b[21] = rotl64(a[8], 55);
+        b[6] = rotl64(a[9], 20);   b[7] = rotl64(a[10], 3);   b[17] = rotl64(a[11], 10); b[2] = rotl64(a[12], 43);
+        b[12] = rotl64(a[13], 25); b[22] = rotl64(a[14], 39); b[23] = rotl64(a[15], 41); b[8] = rotl64(a[16], 45);
+        b[18] = rotl64(a[17], 15); b[3] = rotl64(a[18], 21);  b[13] = rotl64(a[19], 8);  b[14] = rotl64(a[20], 18);
+        b[24] = rotl64(a[21], 2);  b[9] = rotl64(a[22], 61);  b[19] = rotl64(a[23], 56); b[4] = rotl64(a[24], 14);
+        // chi
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            a[y] = b[y] ^ (~b[y + 1] & b[y + 2]);
+            a[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]);
+            a[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]);
+            a[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]);
+            a[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]);
+        }
+        a[0] ^= KECCAK_RC[round];
+    }
+}
+
+// A sponge whose input is short and known up front: absorb `nbytes` (<= rate - 1) bytes given as
+// little-endian 64-bit words (zero padded), pad with the SHAKE suffix 0x1F ... 0x80, permute.
+// RATE_WORDS = 21 (SHAKE128, 168 B) or 17 (SHAKE256, 136 B).
+template <int RATE_WORDS>
+struct Shake {
+    uint64_t s[25];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < 25; i++) s[i] = 0;
+    }
+    // xor one input word into the state (caller guarantees word < RATE_WORDS)
+    __device__ __forceinline__ void absorb_word(int word, uint64_t v) { s[word] ^= v; }
+    // finish a message that ends after `total_bytes` bytes in the CURRENT block
+    __device__ __forceinline__ void finish(int bytes_in_block)
+    {
+        xor_byte(bytes_in_block, 0x1F);
+        s[RATE_WORDS - 1] ^= 0x8000000000000000ull;
+        keccak_f1600(s);
+    }
+    __device__ __forceinline__ void xor_byte(int pos, uint64_t v)
+    {
+        // pos is uniform/compile-time at every call site; the switch folds away
+#pragma unroll
+        for (int w = 0; w < RATE_WORDS; w++)
+            if (w == (pos >> 3)) s[w] ^= v << (8 * (pos & 7));
+    }
+    __device__ __forceinline__ void next_block() { keccak_f1600(s); }
+};
+
+}  // namespace dil

@@ -44,6 +44,11 @@ SIGNATURES = {
     "dil_verify_core_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase1_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase2_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_shake256_dev": [_vp, _sz, _vp, _sz, _sz, _vp],
+    "dil_expand_a_dev": [_vp, _vp, C.c_int, _sz, _vp],
+    "dil_expand_mask_dev": [_vp, _vp, _vp, C.c_int, _sz, _vp],
+    "dil_sample_in_ball_dev": [_vp, _vp, C.c_int, _sz, _vp],
+    "dil_pack_w1_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_event_create": [C.POINTER(_vp)],
     "dil_event_destroy": [_vp],
     "dil_event_record": [_vp, _vp],

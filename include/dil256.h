@@ -109,6 +109,20 @@ int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c
                         const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
                         size_t batch, int shared_key, void* stream);
 
+/* ---- SHAKE-bound samplers on the device ---------------------------------
+ * (round-3 v3.1 conventions, the ones the reference's KAT files obey; all buffers 8-byte aligned)
+ * shake256:        out[i] = SHAKE256(in[i]); one input length for the batch; in_bytes, out_bytes % 8 == 0
+ * expand_a:        A[i][k][l] from rho[i] (32 B)          gen_a_ext.v, sampler_a_ext.v:129, rejection_a.v:67-73
+ * expand_mask:     y[i][l] from rho'[i] (64 B), nonce kappa[i] + l; canonical [0,q)
+ *                                                          expandmask_ext.v:98, sampler_y_ext.v, rejection_y.v
+ * sample_in_ball:  c[i] (+-1 as 1 / q-1) from c~[i] (32 B) gen_c.v:163-196,318-339
+ * pack_w1:         [K][256] bytes -> 4-bit (levels 3/5) or 6-bit (level 2) stream   encoder.v:96-133 */
+int dil_shake256_dev(uint8_t* out, size_t out_bytes, const uint8_t* in, size_t in_bytes, size_t batch, void* stream);
+int dil_expand_a_dev(int32_t* A, const uint8_t* rho, int level, size_t batch, void* stream);
+int dil_expand_mask_dev(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t batch, void* stream);
+int dil_sample_in_ball_dev(int32_t* c, const uint8_t* ctilde, int level, size_t batch, void* stream);
+int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, void* stream);
+
 /* ---- timing helpers (hipEvent on the caller's stream; used by bench.py) ------------------ */
 int dil_event_create(void** ev);
 int dil_event_destroy(void* ev);
