@@ -241,3 +241,31 @@ def pack_w1(w1, level):
     out = torch.empty((B, K * (192 if level == 2 else 128)), dtype=torch.uint8, device=w1.device)
     _lib.check(_lib.load().dil_pack_w1_dev(_dev(out, torch.uint8), _dev(w1, torch.uint8), level, B, _stream()), "dil_pack_w1_dev")
     return out
+
+
+# ---- row N3 (first step): whole sequences as one call ----------------------------------------------
+def verify(A, ctilde, z, t1, h, mu, level, shared_pk=False):
+    """verdict int32 [B]: 0 accept; bit0 challenge mismatch; bit1 ||z|| too large"""
+    K, Lv = _kl(level)
+    B = z.numel() // (Lv * N)
+    verdict = torch.empty((B,), dtype=torch.int32, device=z.device)
+    _lib.check(_lib.load().dil_verify_dev(_dev(verdict, torch.int32), _dev(A, torch.int32), _dev(ctilde, torch.uint8),
+                                          _dev(z, torch.int32), _dev(t1, torch.int32), _dev(h, torch.uint8),
+                                          _dev(mu, torch.uint8), level, B, int(shared_pk), _stream()), "dil_verify_dev")
+    return verdict
+
+
+def sign_attempt(A, mu, rhoprime, kappa, s1hat, s2hat, t0hat, level, shared_key=False):
+    """one rejection-loop attempt for every item: returns (ctilde, z, h, flags)"""
+    K, Lv = _kl(level)
+    B = mu.shape[0]
+    ct = torch.empty((B, 32), dtype=torch.uint8, device=mu.device)
+    z = torch.empty((B, Lv, N), dtype=torch.int32, device=mu.device)
+    h = torch.empty((B, K, N), dtype=torch.uint8, device=mu.device)
+    fl = torch.empty((B,), dtype=torch.int32, device=mu.device)
+    _lib.check(_lib.load().dil_sign_attempt_dev(_dev(ct, torch.uint8), _dev(z, torch.int32), _dev(h, torch.uint8),
+                                                _dev(fl, torch.int32), _dev(A, torch.int32), _dev(mu, torch.uint8),
+                                                _dev(rhoprime, torch.uint8), _dev(kappa, torch.int32),
+                                                _dev(s1hat, torch.int32), _dev(s2hat, torch.int32), _dev(t0hat, torch.int32),
+                                                level, B, int(shared_key), _stream()), "dil_sign_attempt_dev")
+    return ct, z, h, fl

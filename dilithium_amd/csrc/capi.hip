@@ -455,6 +455,80 @@ int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, vo
     return (int)dil::launch_pack_w1(out, w1, level, batch, g.t, S(stream));
 }
 
+// ---- row N3 (first step): composite sequences, device-resident end to end -----------------------
+namespace {
+struct StreamScratch {       // stream-ordered temporaries, freed on the same stream
+    hipStream_t s;
+    void* p[8];
+    int n = 0;
+    explicit StreamScratch(hipStream_t st) : s(st) {}
+    int get(void** out, size_t bytes)
+    {
+        hipError_t e = hipMallocAsync(out, bytes, s);
+        if (e != hipSuccess) return (int)e;
+        p[n++] = *out;
+        return 0;
+    }
+    ~StreamScratch()
+    {
+        for (int i = 0; i < n; i++) (void)hipFreeAsync(p[i], s);
+    }
+};
+int level_kl(int level, int* K, int* L)
+{
+    switch (level) {
+    case 2: *K = 4; *L = 4; return 0;
+    case 3: *K = 6; *L = 5; return 0;
+    case 5: *K = 8; *L = 7; return 0;
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+}  // namespace
+
+int dil_verify_dev(int32_t* verdict, const int32_t* A, const uint8_t* ctilde, const int32_t* z, const int32_t* t1,
+                   const uint8_t* h, const uint8_t* mu, int level, size_t batch, int shared_pk, void* stream)
+{
+    int rc = ensure_init(), K, L;
+    if (rc || (rc = level_kl(level, &K, &L))) return rc;
+    if (batch == 0) return 0;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    void *c, *w1, *w1p;
+    const size_t wb = (size_t)K * (level == 2 ? 192 : 128);
+    if ((rc = ws.get(&c, batch * 1024)) || (rc = ws.get(&w1, batch * K * 256)) || (rc = ws.get(&w1p, batch * wb))) return rc;
+    DIL_TRY(dil::launch_z_norm(verdict, z, level, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(static_cast<int32_t*>(c), ctilde, level, batch, s));
+    DIL_TRY(dil::launch_verify(level, static_cast<uint8_t*>(w1), A, z, static_cast<int32_t*>(c), t1, h, batch, shared_pk, g.t, s));
+    DIL_TRY(dil::launch_pack_w1(static_cast<uint8_t*>(w1p), static_cast<uint8_t*>(w1), level, batch, g.t, s));
+    DIL_TRY(dil::launch_challenge_hash(nullptr, verdict, mu, static_cast<uint8_t*>(w1p), level, ctilde, batch, s));
+    return 0;
+}
+
+int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
+                         const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                         const int32_t* t0hat, int level, size_t batch, int shared_key, void* stream)
+{
+    int rc = ensure_init(), K, L;
+    if (rc || (rc = level_kl(level, &K, &L))) return rc;
+    if (batch == 0) return 0;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    void *y, *w1, *w0, *w1p, *c;
+    const size_t wb = (size_t)K * (level == 2 ? 192 : 128);
+    if ((rc = ws.get(&y, batch * L * 1024)) || (rc = ws.get(&w1, batch * K * 256)) || (rc = ws.get(&w0, batch * K * 1024)) ||
+        (rc = ws.get(&w1p, batch * wb)) || (rc = ws.get(&c, batch * 1024)))
+        return rc;
+    DIL_TRY(dil::launch_expand_mask(static_cast<int32_t*>(y), rhoprime, kappa, level, batch, s));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, static_cast<uint8_t*>(w1), static_cast<int32_t*>(w0), A,
+                               static_cast<int32_t*>(y), batch, shared_key, g.t, s));
+    DIL_TRY(dil::launch_pack_w1(static_cast<uint8_t*>(w1p), static_cast<uint8_t*>(w1), level, batch, g.t, s));
+    DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, static_cast<uint8_t*>(w1p), level, nullptr, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(static_cast<int32_t*>(c), ctilde, level, batch, s));
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, static_cast<int32_t*>(c), static_cast<int32_t*>(y), static_cast<int32_t*>(w0),
+                              static_cast<uint8_t*>(w1), s1hat, s2hat, t0hat, batch, shared_key, g.t, s));
+    return 0;
+}
+
 // ---- events --------------------------------------------------------------------------------------
 int dil_event_create(void** ev)
 {

@@ -246,8 +246,96 @@ __global__ __launch_bounds__(256) void pack_w1_kernel(uint32_t* __restrict__ out
 }
 
 // ---------------------------------------------------------------------------------------
+// c~ = SHAKE256(mu (64 B) || w1_packed (wbytes))  -- the challenge hash of sign and verify.
+// expect == nullptr : write the 32-byte digest to out32[i]
+// expect != nullptr : verdict[i] |= (digest != expect[i])        (VY_COMPARE, combined_top.v:1501)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void challenge_hash_kernel(uint64_t* __restrict__ out32, int32_t* __restrict__ verdict,
+                                                            const uint64_t* __restrict__ mu, const uint64_t* __restrict__ w1p,
+                                                            int w1_words, const uint64_t* __restrict__ expect, size_t batch)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= batch) return;
+    Shake<17> sp;
+    sp.init();
+#pragma unroll
+    for (int t = 0; t < 8; t++) sp.s[t] = mu[i * 8 + t];
+    int w = 8;
+    const uint64_t* src = w1p + i * (size_t)w1_words;
+    for (int k = 0; k < w1_words; k++) {
+        const uint64_t v = src[k];
+#pragma unroll
+        for (int t = 0; t < 17; t++)
+            if (t == w) sp.s[t] ^= v;
+        if (++w == 17) {
+            sp.next_block();
+            w = 0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 17; t++)
+        if (t == w) sp.s[t] ^= 0x1Full;
+    sp.s[16] ^= 0x8000000000000000ull;
+    keccak_f1600(sp.s);
+    if (expect) {
+        const uint64_t d = (sp.s[0] ^ expect[i * 4]) | (sp.s[1] ^ expect[i * 4 + 1]) | (sp.s[2] ^ expect[i * 4 + 2]) |
+                           (sp.s[3] ^ expect[i * 4 + 3]);
+        if (d) verdict[i] |= 1;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) out32[i * 4 + t] = sp.s[t];
+    }
+}
+
+// verdict[i] = 2 if ||z_i||_inf >= bound else 0 (norm_check.v:84-105 on canonical residues); one wave per item
+__global__ __launch_bounds__(256) void z_norm_kernel(int32_t* __restrict__ verdict, const int32_t* __restrict__ z, int npolys,
+                                                     uint32_t bound, size_t batch)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= batch) return;
+    bool rej = false;
+    const int4* src = reinterpret_cast<const int4*>(z + it * (size_t)npolys * 256);
+    for (int k = lane; k < npolys * 64; k += 64) {
+        const int4 v = src[k];
+        const int32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int32_t x = e[j] % (int32_t)QU;
+            x += (x >> 31) & (int32_t)QU;
+            rej |= ((uint32_t)x >= bound) && ((uint32_t)x <= QU - bound);
+        }
+    }
+    const bool any = __ballot(rej) != 0;
+    if (lane == 0) verdict[it] = any ? 2 : 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,
+                                 const uint8_t* expect, size_t batch, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
+    const int words = K * (level == 2 ? 192 : 128) / 8;
+    hipLaunchKernelGGL(challenge_hash_kernel, (int)((batch + 63) / 64), 64, 0, s, reinterpret_cast<uint64_t*>(out32), verdict,
+                       reinterpret_cast<const uint64_t*>(mu), reinterpret_cast<const uint64_t*>(w1p), words,
+                       reinterpret_cast<const uint64_t*>(expect), batch);
+    return hipGetLastError();
+}
+
+hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t batch, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    const uint32_t bound = (level == 2 ? (1u << 17) : (1u << 19)) - (level == 2 ? 78u : level == 3 ? 196u : 120u);
+    hipLaunchKernelGGL(z_norm_kernel, (int)((batch + 3) / 4), 256, 0, s, verdict, z, L, bound, batch);
+    return hipGetLastError();
+}
+
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;

@@ -40,5 +40,8 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, int level, size_t nit
 hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s);
 hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s);
+hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,
+                                 const uint8_t* expect, size_t batch, hipStream_t s);
+hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t batch, hipStream_t s);
 
 }  // namespace dil

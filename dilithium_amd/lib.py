@@ -49,6 +49,8 @@ SIGNATURES = {
     "dil_expand_mask_dev": [_vp, _vp, _vp, C.c_int, _sz, _vp],
     "dil_sample_in_ball_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_pack_w1_dev": [_vp, _vp, C.c_int, _sz, _vp],
+    "dil_verify_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_sign_attempt_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_event_create": [C.POINTER(_vp)],
     "dil_event_destroy": [_vp],
     "dil_event_record": [_vp, _vp],

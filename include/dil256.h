@@ -123,6 +123,24 @@ int dil_expand_mask_dev(int32_t* y, const uint8_t* rhoprime, const uint32_t* kap
 int dil_sample_in_ball_dev(int32_t* c, const uint8_t* ctilde, int level, size_t batch, void* stream);
 int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, void* stream);
 
+/* ---- SURVEY 8(f) row N3 (first step): whole verify / sign-attempt sequences as ONE call --------
+ * Everything between the wire-format codecs runs on the device, on `stream`, with no host round trip;
+ * temporaries come from the stream-ordered allocator (hipMallocAsync) and are freed on the stream.
+ *
+ * dil_verify_dev   (combined_top.v VY_* :1149-1534):  c = SampleInBall(c~);  w1 = verify core;
+ *                  c~' = SHAKE256(mu || pack(w1));  verdict[i] = 0 accept, bit0 c~' != c~, bit1 ||z|| >= gamma1-beta
+ *                  ctilde [B][32], mu [B][64] bytes; z, t1, h, A as for dil_verify_core_dev.
+ * dil_sign_attempt_dev (FSM1 + FSM2, :1830-2229): y = ExpandMask(rho', kappa);  (w1,w0) = phase 1;
+ *                  c~ = SHAKE256(mu || pack(w1));  c = SampleInBall(c~);  (z,h,flags) = phase 2.
+ *                  rhoprime [B][64], kappa [B] (nonce base of this attempt), outputs ctilde [B][32],
+ *                  z [B][L][256], h [B][K][256] bytes, flags [B] (0 = accept; the caller re-submits the
+ *                  rejected items with kappa += L). */
+int dil_verify_dev(int32_t* verdict, const int32_t* A, const uint8_t* ctilde, const int32_t* z, const int32_t* t1,
+                   const uint8_t* h, const uint8_t* mu, int level, size_t batch, int shared_pk, void* stream);
+int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
+                         const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                         const int32_t* t0hat, int level, size_t batch, int shared_key, void* stream);
+
 /* ---- timing helpers (hipEvent on the caller's stream; used by bench.py) ------------------ */
 int dil_event_create(void** ev);
 int dil_event_destroy(void* ev);

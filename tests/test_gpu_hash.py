@@ -160,3 +160,71 @@ def test_kat_sign_with_device_hashing(gpu, level, kat_msgs):
         assert dk.pack_z(p, oz[i]) == k["z"][i].tobytes()
         assert dk.pack_hint(p, oh[i]) == k["h"][i].tobytes()
     assert (at == k["attempts"]).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_kat_verify_single_call(gpu, level, kat_msgs):
+    """dil_verify_dev: SampleInBall + verify core + w1 packing + challenge hash + compare in ONE call"""
+    from dilithium_amd import api
+    torch = gpu
+    p = dk.PARAMS[level]
+    k, ver, _ = kat_items(level, kat_msgs)
+    rho = np.stack([np.frombuffer(it["rho"], np.uint8) for it in ver])
+    A = api.expand_a(cu(torch, rho), level)
+    ct = np.stack([np.frombuffer(it["ctilde"], np.uint8) for it in ver])
+    z = np.stack([dk.canon(dk.unpack_z(p, it["z_packed"])) for it in ver])
+    t1 = np.stack([dk.unpack_t1(p, it["t1_packed"]) for it in ver])
+    h = np.stack([dk.unpack_hint(p, it["h_packed"]) for it in ver])
+    mu = np.stack([np.frombuffer(dk.shake256(dk.shake256(it["rho"] + it["t1_packed"], 32) + it["msg"], 64), np.uint8)
+                   for it in ver])
+    args = (A, cu(torch, ct), cu(torch, z), cu(torch, t1), cu(torch, h, np.uint8), cu(torch, mu))
+    assert (api.verify(*args, level).cpu().numpy() == 0).all()
+    # tamper: flip one coefficient of z in item 5, the challenge in item 9, push one z over the norm bound in item 11
+    z2, ct2 = z.copy(), ct.copy()
+    z2[5, 0, 17] = (z2[5, 0, 17] + 1) % dk.Q
+    ct2[9, 0] ^= 1
+    z2[11, 1, 3] = p.gamma1 - p.beta
+    v = api.verify(A, cu(torch, ct2), cu(torch, z2), cu(torch, t1), cu(torch, h, np.uint8), cu(torch, mu), level).cpu().numpy()
+    assert v[5] & 1 and v[9] & 1 and v[11] & 2
+    good = np.ones(len(ver), bool)
+    good[[5, 9, 11]] = False
+    assert (v[good] == 0).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_kat_sign_single_call_attempts(gpu, level, kat_msgs):
+    """dil_sign_attempt_dev in a rejection loop reproduces all 100 KAT signatures byte for byte"""
+    from dilithium_amd import api
+    from tests.test_gpu_pipelines import HipEngine
+    torch = gpu
+    p = dk.PARAMS[level]
+    k, _, sig = kat_items(level, kat_msgs)
+    n = len(sig)
+    eng = HipEngine(torch)
+    rho = np.stack([np.frombuffer(it["rho"], np.uint8) for it in sig])
+    A = api.expand_a(cu(torch, rho), level)
+    s1h = cu(torch, np.stack([eng.ntt(dk.canon(dk.unpack_eta(p, it["s1_packed"], p.L))) for it in sig]))
+    s2h = cu(torch, np.stack([eng.ntt(dk.canon(dk.unpack_eta(p, it["s2_packed"], p.K))) for it in sig]))
+    t0h = cu(torch, np.stack([eng.ntt(dk.canon(dk.unpack_t0(p, it["t0_packed"]))) for it in sig]))
+    mu = [dk.shake256(it["tr"] + it["msg"], 64) for it in sig]
+    d_mu = cu(torch, np.stack([np.frombuffer(m, np.uint8) for m in mu]))
+    d_rhop = cu(torch, np.stack([np.frombuffer(dk.shake256(it["key"] + m, 64), np.uint8) for it, m in zip(sig, mu)]))
+    live = torch.arange(n, device="cuda")
+    kappa = torch.zeros(n, dtype=torch.int32, device="cuda")
+    res = {}
+    rounds = 0
+    while live.numel() and rounds < 64:
+        rounds += 1
+        sel = lambda t: t[live].contiguous()  # noqa: E731
+        ct, z, h, fl = api.sign_attempt(sel(A), sel(d_mu), sel(d_rhop), sel(kappa), sel(s1h), sel(s2h), sel(t0h), level)
+        kappa[live] += p.L
+        ok = (fl == 0).cpu().numpy()
+        idx = live.cpu().numpy()
+        for j in np.nonzero(ok)[0]:
+            res[int(idx[j])] = (ct[j].cpu().numpy().tobytes(), z[j].cpu().numpy(), h[j].cpu().numpy(), rounds)
+        live = live[torch.from_numpy(~ok).cuda()]
+    assert len(res) == n
+    for i in range(n):
+        c_, z_, h_, att = res[i]
+        assert c_ == k["ctilde"][i].tobytes() and dk.pack_z(p, z_) == k["z"][i].tobytes()
+        assert dk.pack_hint(p, h_) == k["h"][i].tobytes() and att == k["attempts"][i]
