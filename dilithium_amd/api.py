@@ -269,3 +269,89 @@ def sign_attempt(A, mu, rhoprime, kappa, s1hat, s2hat, t0hat, level, shared_key=
                                                 _dev(s1hat, torch.int32), _dev(s2hat, torch.int32), _dev(t0hat, torch.int32),
                                                 level, B, int(shared_key), _stream()), "dil_sign_attempt_dev")
     return ct, z, h, fl
+
+
+# ---- rows N2 / N4: wire-format codecs, ExpandS, keygen, wire-format verify --------------------------
+CODEC_T1, CODEC_T0, CODEC_S1, CODEC_S2, CODEC_Z = 0, 1, 2, 3, 4
+
+
+def _codec_polys(kind, level):
+    K, Lv = _kl(level)
+    return Lv if kind in (CODEC_S1, CODEC_Z) else K
+
+
+def pk_bytes(level):
+    return int(_lib.load().dil_pk_bytes(level))
+
+
+def sk_bytes(level):
+    return int(_lib.load().dil_sk_bytes(level))
+
+
+def sig_bytes(level):
+    return int(_lib.load().dil_sig_bytes(level))
+
+
+def unpack(buf, kind, level, offset=0):
+    """buf uint8 [B, stride] -> int32 [B, polys, 256] canonical; the field starts at byte `offset` of each row"""
+    B, stride = buf.shape
+    out = torch.empty((B, _codec_polys(kind, level), N), dtype=torch.int32, device=buf.device)
+    _lib.check(_lib.load().dil_unpack_dev(_dev(out, torch.int32), _dev(buf, torch.uint8), stride, offset, kind, level, B, _stream()),
+               "dil_unpack_dev")
+    return out
+
+
+def pack(polys, buf, kind, level, offset=0):
+    """int32 [B, polys, 256] -> packed field written at byte `offset` of each row of buf uint8 [B, stride]"""
+    B, stride = buf.shape
+    _lib.check(_lib.load().dil_pack_dev(_dev(buf, torch.uint8), stride, offset, _dev(polys, torch.int32), kind, level, B, _stream()),
+               "dil_pack_dev")
+    return buf
+
+
+def hint_unpack(buf, level, offset=0):
+    """-> (h uint8 [B,K,256], bad int32 [B])"""
+    K, _ = _kl(level)
+    B, stride = buf.shape
+    h = torch.empty((B, K, N), dtype=torch.uint8, device=buf.device)
+    bad = torch.empty((B,), dtype=torch.int32, device=buf.device)
+    _lib.check(_lib.load().dil_hint_unpack_dev(_dev(h, torch.uint8), _dev(bad, torch.int32), _dev(buf, torch.uint8), stride, offset,
+                                               level, B, _stream()), "dil_hint_unpack_dev")
+    return h, bad
+
+
+def hint_pack(h, buf, level, offset=0):
+    B, stride = buf.shape
+    _lib.check(_lib.load().dil_hint_pack_dev(_dev(buf, torch.uint8), stride, offset, _dev(h, torch.uint8), level, B, _stream()),
+               "dil_hint_pack_dev")
+    return buf
+
+
+def expand_s(rhoprime, level):
+    """(s1 [B,L,256], s2 [B,K,256]) canonical from rho' uint8 [B, >=64] (row stride = rhoprime.shape[1])"""
+    K, Lv = _kl(level)
+    B, stride = rhoprime.shape
+    s1 = torch.empty((B, Lv, N), dtype=torch.int32, device=rhoprime.device)
+    s2 = torch.empty((B, K, N), dtype=torch.int32, device=rhoprime.device)
+    _lib.check(_lib.load().dil_expand_s_dev(_dev(s1, torch.int32), _dev(s2, torch.int32), _dev(rhoprime, torch.uint8), stride,
+                                            level, B, _stream()), "dil_expand_s_dev")
+    return s1, s2
+
+
+def keygen(seed, level):
+    """seed uint8 [B,32] -> (pk uint8 [B,pk_bytes], sk uint8 [B,sk_bytes])"""
+    B = seed.shape[0]
+    pk = torch.empty((B, pk_bytes(level)), dtype=torch.uint8, device=seed.device)
+    sk = torch.empty((B, sk_bytes(level)), dtype=torch.uint8, device=seed.device)
+    _lib.check(_lib.load().dil_keygen_dev(_dev(pk, torch.uint8), _dev(sk, torch.uint8), _dev(seed, torch.uint8), level, B, _stream()),
+               "dil_keygen_dev")
+    return pk, sk
+
+
+def verify_sig(pk, sig, mu, level, shared_pk=False):
+    """wire-format verify: pk uint8 [B or 1, pk_bytes], sig uint8 [B, sig_bytes], mu uint8 [B,64] -> verdict int32 [B]"""
+    B = sig.shape[0]
+    verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
+    _lib.check(_lib.load().dil_verify_sig_dev(_dev(verdict, torch.int32), _dev(pk, torch.uint8), _dev(sig, torch.uint8),
+                                              _dev(mu, torch.uint8), level, B, int(shared_pk), _stream()), "dil_verify_sig_dev")
+    return verdict

@@ -434,7 +434,7 @@ int dil_expand_a_dev(int32_t* A, const uint8_t* rho, int level, size_t batch, vo
 {
     int rc = ensure_init();
     if (rc) return rc;
-    return (int)dil::launch_expand_a(A, rho, level, batch, S(stream));
+    return (int)dil::launch_expand_a(A, rho, 32, level, batch, S(stream));
 }
 int dil_expand_mask_dev(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t batch, void* stream)
 {
@@ -527,6 +527,144 @@ int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags
     DIL_TRY(dil::launch_sign2(level, z, h, flags, static_cast<int32_t*>(c), static_cast<int32_t*>(y), static_cast<int32_t*>(w0),
                               static_cast<uint8_t*>(w1), s1hat, s2hat, t0hat, batch, shared_key, g.t, s));
     return 0;
+}
+
+// ---- rows N2 / N4: codecs, keygen, wire-format verify -------------------------------------------------
+namespace {
+struct LevelPar { int K, L, eta, omega, zbits, eta_bits; int32_t gamma1; };
+int level_par(int level, LevelPar* p)
+{
+    switch (level) {
+    case 2: *p = {4, 4, 2, 80, 18, 3, 1 << 17}; return 0;
+    case 3: *p = {6, 5, 4, 55, 20, 4, 1 << 19}; return 0;
+    case 5: *p = {8, 7, 2, 75, 20, 3, 1 << 19}; return 0;
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+struct CodecDesc { int bits, polys, xf; int32_t offset; };
+int codec_desc(int kind, const LevelPar& p, CodecDesc* d)
+{
+    switch (kind) {
+    case DIL_CODEC_T1: *d = {10, p.K, dil::XF_PLAIN, 0}; return 0;
+    case DIL_CODEC_T0: *d = {13, p.K, dil::XF_OFFSET_MINUS, 1 << 12}; return 0;
+    case DIL_CODEC_S1: *d = {p.eta_bits, p.L, dil::XF_OFFSET_MINUS, p.eta}; return 0;
+    case DIL_CODEC_S2: *d = {p.eta_bits, p.K, dil::XF_OFFSET_MINUS, p.eta}; return 0;
+    case DIL_CODEC_Z: *d = {p.zbits, p.L, dil::XF_OFFSET_MINUS, p.gamma1}; return 0;
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+}  // namespace
+
+size_t dil_pk_bytes(int level) { LevelPar p; return level_par(level, &p) ? 0 : 32 + (size_t)p.K * 320; }
+size_t dil_sk_bytes(int level)
+{
+    LevelPar p;
+    return level_par(level, &p) ? 0 : 96 + (size_t)(p.L + p.K) * 32 * p.eta_bits + (size_t)p.K * 416;
+}
+size_t dil_sig_bytes(int level) { LevelPar p; return level_par(level, &p) ? 0 : 32 + (size_t)p.L * 32 * p.zbits + p.omega + p.K; }
+
+int dil_unpack_dev(int32_t* out, const uint8_t* in, size_t in_stride, size_t in_offset, int kind, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    CodecDesc d;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
+    return (int)dil::launch_unpack(d.bits, out, in, in_stride, in_offset, d.polys, d.xf, d.offset, batch, g.t, S(stream));
+}
+int dil_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int kind, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    CodecDesc d;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
+    return (int)dil::launch_pack(d.bits, out, out_stride, out_offset, in, d.polys, d.xf, d.offset, batch, g.t, S(stream));
+}
+int dil_hint_unpack_dev(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    return (int)dil::launch_hint_unpack(h, bad, in, in_stride, in_offset, p.K, p.omega, batch, S(stream));
+}
+int dil_hint_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    return (int)dil::launch_hint_pack(out, out_stride, out_offset, h, p.K, p.omega, batch, S(stream));
+}
+int dil_expand_s_dev(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t stride, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    DIL_TRY(dil::launch_expand_s(s1, rhoprime, stride, p.eta, 0, p.L, batch, S(stream)));
+    return (int)dil::launch_expand_s(s2, rhoprime, stride, p.eta, p.L, p.K, batch, S(stream));
+}
+
+int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    if (batch == 0) return 0;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    const size_t pkb = dil_pk_bytes(level), skb = dil_sk_bytes(level), sb = (size_t)32 * p.eta_bits;
+    void *exp, *A, *s1, *s2, *w, *t1, *t0, *tr;
+    if ((rc = ws.get(&exp, batch * 128)) || (rc = ws.get(&A, batch * p.K * p.L * 1024)) || (rc = ws.get(&s1, batch * p.L * 1024)) ||
+        (rc = ws.get(&s2, batch * p.K * 1024)) || (rc = ws.get(&w, batch * p.K * 1024)) || (rc = ws.get(&t1, batch * p.K * 1024)) ||
+        (rc = ws.get(&t0, batch * p.K * 1024)) || (rc = ws.get(&tr, batch * 32)))
+        return rc;
+    uint8_t* e = static_cast<uint8_t*>(exp);                       // rho(32) | rho'(64) | key(32)  (KG_*)
+    DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(exp), 128, reinterpret_cast<const uint64_t*>(seed), 32, batch, s));
+    DIL_TRY(dil::launch_expand_a(static_cast<int32_t*>(A), e, 128, level, batch, s));
+    DIL_TRY(dil::launch_expand_s(static_cast<int32_t*>(s1), e + 32, 128, p.eta, 0, p.L, batch, s));
+    DIL_TRY(dil::launch_expand_s(static_cast<int32_t*>(s2), e + 32, 128, p.eta, p.L, p.K, batch, s));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, static_cast<int32_t*>(w), nullptr, nullptr, static_cast<int32_t*>(A),
+                               static_cast<int32_t*>(s1), batch, 0, g.t, s));
+    DIL_TRY(dil::launch_power2round(static_cast<int32_t*>(t1), static_cast<int32_t*>(t0), static_cast<int32_t*>(w),
+                                    static_cast<int32_t*>(s2), batch * p.K * 256, g.t, s));
+    // pk = rho | t1
+    DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(10, pk, pkb, 32, static_cast<int32_t*>(t1), p.K, dil::XF_PLAIN, 0, batch, g.t, s));
+    // tr = SHAKE256(pk, 32)   (pk length is a multiple of 8 at every level)
+    DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, batch, s));
+    // sk = rho | key | tr | s1 | s2 | t0
+    DIL_TRY(dil::launch_copy_field(sk, skb, 0, e, 128, 0, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_copy_field(sk, skb, 32, e, 128, 96, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_copy_field(sk, skb, 64, static_cast<uint8_t*>(tr), 32, 0, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, static_cast<int32_t*>(s1), p.L, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, static_cast<int32_t*>(s2), p.K, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, static_cast<int32_t*>(t0), p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, g.t, s));
+    return 0;
+}
+
+int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                       int shared_pk, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    if (batch == 0) return 0;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
+    const size_t nk = shared_pk ? 1 : batch;
+    void *A, *t1, *z, *h, *bad, *ct;
+    if ((rc = ws.get(&A, nk * p.K * p.L * 1024)) || (rc = ws.get(&t1, nk * p.K * 1024)) || (rc = ws.get(&z, batch * p.L * 1024)) ||
+        (rc = ws.get(&h, batch * p.K * 256)) || (rc = ws.get(&bad, batch * 4)) || (rc = ws.get(&ct, batch * 32)))
+        return rc;
+    DIL_TRY(dil::launch_expand_a(static_cast<int32_t*>(A), pk, pkb, level, nk, s));
+    DIL_TRY(dil::launch_unpack(10, static_cast<int32_t*>(t1), pk, pkb, 32, p.K, dil::XF_PLAIN, 0, nk, g.t, s));
+    DIL_TRY(dil::launch_copy_field(static_cast<uint8_t*>(ct), 32, 0, sig, sgb, 0, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_unpack(p.zbits, static_cast<int32_t*>(z), sig, sgb, 32, p.L, dil::XF_OFFSET_MINUS, p.gamma1, batch, g.t, s));
+    DIL_TRY(dil::launch_hint_unpack(static_cast<uint8_t*>(h), static_cast<int32_t*>(bad), sig, sgb, 32 + zb, p.K, p.omega, batch, s));
+    rc = dil_verify_dev(verdict, static_cast<int32_t*>(A), static_cast<uint8_t*>(ct), static_cast<int32_t*>(z),
+                        static_cast<int32_t*>(t1), static_cast<uint8_t*>(h), mu, level, batch, shared_pk, stream);
+    if (rc) return rc;
+    // verdict |= bad << 2   (tiny element-wise op done with the pointwise machinery would be overkill: reuse copy kernel? no --)
+    return (int)dil::launch_or_flag(verdict, static_cast<int32_t*>(bad), 4, batch, g.t, s);
 }
 
 // ---- events --------------------------------------------------------------------------------------

@@ -1,0 +1,317 @@
+// codec_kernels.hip -- rows N2 and N4 of SURVEY 8(f): the reference's bit-packing codecs and the
+// keygen-side sampler on the device, in the wire formats its KAT files use (round-3 v3.1):
+//   decoder.v:89-143 / uncenter_coeff.v:49-65   t1 10 b | t0 13 b as 2^12 - t0 | s 3/4 b as eta - s |
+//                                               z 18/20 b as gamma1 - z        (-> canonical [0,q))
+//   encoder.v:96-133                            the inverse maps (w1 packing lives in hash_kernels.hip)
+//   usehint.v:92-114 / makehint.v:104-150       hint = omega position bytes + K cumulative counts
+//   gen_s.v, sampler_s.v, rejection_s.v:...     ExpandS: SHAKE256(rho' || LE16 nonce), nibble rejection
+// Buffers may sit at any byte alignment and stride (signatures are 3293 bytes at level 3), so the
+// codecs move bytes; they are a few KB per item next to the 30-56 KiB matrices.
+#include "keccak.hpp"
+#include "kernels.hpp"
+
+namespace dil {
+
+constexpr int32_t QC = 8380417;
+
+// XF_PLAIN: value = v   |   XF_OFFSET_MINUS: value = OFFSET - v   (kernels.hpp)
+
+// ---------------------------------------------------------------------------------------
+// unpack: out[item][poly][i] = canon(xf(bits [i*BITS, (i+1)*BITS) of the poly's stream))
+// ---------------------------------------------------------------------------------------
+template <int BITS>
+__device__ __forceinline__ uint32_t read_bits(const uint8_t* __restrict__ p, uint32_t bitpos)
+{
+    const uint32_t byte = bitpos >> 3, sh = bitpos & 7, nbytes = (sh + BITS + 7) >> 3;
+    uint32_t v = p[byte];
+    if (nbytes > 1) v |= (uint32_t)p[byte + 1] << 8;
+    if (nbytes > 2) v |= (uint32_t)p[byte + 2] << 16;
+    if (nbytes > 3) v |= (uint32_t)p[byte + 3] << 24;
+    return (v >> sh) & ((1u << BITS) - 1);
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void unpack_kernel(int32_t* __restrict__ out, const uint8_t* __restrict__ in,
+                                                     size_t in_stride, size_t in_offset, int polys, int xf, int32_t offset,
+                                                     size_t nitems)
+{
+    const size_t total = nitems * (size_t)polys * 256;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t item = g / ((size_t)polys * 256);
+        const uint32_t r = (uint32_t)(g % ((size_t)polys * 256)), poly = r >> 8, i = r & 255;
+        const uint8_t* p = in + item * in_stride + in_offset + (size_t)poly * (32 * BITS);
+        int32_t v = (int32_t)read_bits<BITS>(p, i * BITS);
+        if (xf == XF_OFFSET_MINUS) v = offset - v;
+        out[g] = v + ((v >> 31) & QC);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// pack: one thread per OUTPUT byte; value_i = xf(centred(in[i])) as a BITS-bit field
+// ---------------------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
+                                                   const int32_t* __restrict__ in, int polys, int xf, int32_t offset,
+                                                   size_t nitems)
+{
+    constexpr int PB = 32 * BITS;                 // bytes per packed polynomial
+    const size_t total = nitems * (size_t)polys * PB;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t item = g / ((size_t)polys * PB);
+        const uint32_t r = (uint32_t)(g % ((size_t)polys * PB)), poly = r / PB, j = r % PB;
+        const int32_t* src = in + (item * polys + poly) * 256;
+        const uint32_t bit0 = 8 * j;
+        uint32_t acc = 0;
+        for (uint32_t i = bit0 / BITS; i * BITS < bit0 + 8 && i < 256; i++) {
+            int32_t v = src[i] % QC;                                   // any representative
+            v += (v >> 31) & QC;                                       // canonical
+            v -= (((QC - 1) / 2 - v) >> 31) & QC;                      // centred
+            uint32_t f = (uint32_t)(xf == XF_OFFSET_MINUS ? offset - v : v) & ((1u << BITS) - 1);
+            const int rel = (int)(i * BITS) - (int)bit0;               // field start relative to this byte
+            acc |= rel >= 0 ? f << rel : f >> (-rel);
+        }
+        out[item * out_stride + out_offset + (size_t)poly * PB + j] = (uint8_t)acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// hints.  Wire form: omega position bytes then K cumulative counts (usehint.v:92-114).
+// unpack: one wave per item -> h [K][256] bytes 0/1; bad[item] = 1 when the encoding is malformed
+// (counts not monotone / > omega, positions not strictly increasing inside a row, non-zero padding).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hint_unpack_kernel(uint8_t* __restrict__ h, int32_t* __restrict__ bad,
+                                                          const uint8_t* __restrict__ in, size_t in_stride, size_t in_offset,
+                                                          int K, int omega, size_t nitems)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= nitems) return;
+    const uint8_t* src = in + it * in_stride + in_offset;
+    uint8_t* dst = h + it * (size_t)K * 256;
+    for (int k = lane; k < K * 64; k += 64) reinterpret_cast<uint32_t*>(dst)[k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    bool err = false;
+    int prev_cnt = 0;
+    for (int k = 0; k < K; k++) {
+        const int cnt = src[omega + k];
+        if (cnt < prev_cnt || cnt > omega) err = true;
+        prev_cnt = cnt;
+    }
+    const int total = err ? 0 : prev_cnt;
+    for (int t = lane; t < omega + ((64 - omega % 64) % 64); t += 64) {
+        if (t < omega) {
+            const int pos = src[t];
+            if (t < total) {
+                int row = 0, row_start = 0;
+                for (int k = 0; k < K; k++) {
+                    const int cnt = src[omega + k];
+                    if (cnt <= t) { row = k + 1; row_start = cnt; }
+                }
+                if (t > row_start && pos <= (int)src[t - 1]) err = true;
+                if (row < K) dst[row * 256 + pos] = 1;
+            } else if (pos != 0) {
+                err = true;
+            }
+        }
+    }
+    const bool any = __ballot(err) != 0;
+    if (lane == 0) bad[it] = any ? 1 : 0;
+}
+
+// pack: h [K][256] bytes -> omega + K bytes (makehint.v:104-150).  One wave per item.
+__global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
+                                                        const uint8_t* __restrict__ h, int K, int omega, size_t nitems)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= nitems) return;
+    uint8_t* dst = out + it * out_stride + out_offset;
+    const uint8_t* src = h + it * (size_t)K * 256;
+    for (int t = lane; t < omega + K; t += 64) dst[t] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    int count = 0;                                   // wave-uniform
+    for (int k = 0; k < K; k++) {
+        for (int chunk = 0; chunk < 4; chunk++) {
+            const int idx = chunk * 64 + lane;
+            const bool bit = src[k * 256 + idx] != 0;
+            const unsigned long long m = __ballot(bit);
+            const int before = __popcll(m & ((1ull << lane) - 1));
+            if (bit && count + before < omega) dst[count + before] = (uint8_t)idx;
+            count += __popcll(m);
+        }
+        if (lane == 0) dst[omega + k] = (uint8_t)(count < omega ? count : omega);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ExpandS (gen_s.v / rejection_s.v): s[item][n] = RejEta(SHAKE256(rho' || LE16(nonce0 + n))),
+// eta = 2: nibble < 15 -> 2 - (nibble mod 5);  eta = 4: nibble < 9 -> 4 - nibble.  Canonical out.
+// One lane per polynomial.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void expand_s_kernel(int32_t* __restrict__ s, const uint8_t* __restrict__ rhoprime,
+                                                      size_t rp_stride, int eta, int nonce0, int polys, size_t nitems)
+{
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool live = p < nitems * (size_t)polys;
+    const size_t item = live ? p / (size_t)polys : 0;
+    const uint32_t nonce = (uint32_t)(nonce0 + (int)(p % (size_t)polys));
+    Shake<17> sp;
+    sp.init();
+    const uint8_t* rp = rhoprime + item * rp_stride;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v |= (uint64_t)rp[8 * w + b] << (8 * b);
+        sp.s[w] = v;
+    }
+    sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
+    sp.s[16] ^= 0x8000000000000000ull;
+    int32_t* dst = s + p * 256;
+    int cnt = live ? 0 : 256;
+    while (__any(cnt < 256)) {
+        keccak_f1600(sp.s);
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+            uint64_t word = sp.s[w];
+#pragma unroll
+            for (int n = 0; n < 16; n++) {
+                const int nib = (int)(word & 15);
+                word >>= 4;
+                int v;
+                bool ok;
+                if (eta == 2) {
+                    ok = nib < 15;
+                    v = 2 - (nib - (205 * nib >> 10) * 5);
+                } else {
+                    ok = nib < 9;
+                    v = 4 - nib;
+                }
+                if (ok && cnt < 256) dst[cnt++] = v + ((v >> 31) & QC);
+            }
+        }
+    }
+}
+
+// t = w + s2 (mod q);  (t1, t0) = Power2Round(t), d = 13  (combined_top.v keygen :921-1079)
+// t1 out as 10-bit values, t0 out centred in (-2^12, 2^12]
+__global__ __launch_bounds__(256) void power2round_kernel(int32_t* __restrict__ t1, int32_t* __restrict__ t0,
+                                                          const int32_t* __restrict__ w, const int32_t* __restrict__ s2, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int32_t t = (w[i] % QC + s2[i] % QC) % QC;
+        t += (t >> 31) & QC;
+        const int32_t hi = (t + (1 << 12) - 1) >> 13;
+        t1[i] = hi;
+        t0[i] = t - (hi << 13);
+    }
+}
+
+// strided byte copy: dst[item][dst_off .. +n) = src[item][src_off .. +n)
+__global__ __launch_bounds__(256) void copy_field_kernel(uint8_t* __restrict__ dst, size_t dst_stride, size_t dst_off,
+                                                         const uint8_t* __restrict__ src, size_t src_stride, size_t src_off,
+                                                         int nbytes, size_t nitems)
+{
+    const size_t total = nitems * (size_t)nbytes;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t item = g / (size_t)nbytes, b = g % (size_t)nbytes;
+        dst[item * dst_stride + dst_off + b] = src[item * src_stride + src_off + b];
+    }
+}
+
+// verdict[i] |= flag[i] ? bit : 0
+__global__ __launch_bounds__(256) void or_flag_kernel(int32_t* __restrict__ verdict, const int32_t* __restrict__ flag, int bit, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) verdict[i] |= bit;
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+static inline int grid1d(size_t n, const Tables& t)
+{
+    const size_t blocks = (n + 255) / 256, cap = (size_t)t.num_cus * 8;
+    return (int)(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
+}
+
+hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t n, const Tables& t, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(or_flag_kernel, (int)((n + 255) / 256), 256, 0, s, verdict, flag, bit, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(int bits, int32_t* out, const uint8_t* in, size_t in_stride, size_t in_offset, int polys, int xf,
+                         int32_t offset, size_t nitems, const Tables& t, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    const int g = grid1d(nitems * (size_t)polys * 256, t);
+#define DIL_UP(B) case B: hipLaunchKernelGGL(unpack_kernel<B>, g, 256, 0, s, out, in, in_stride, in_offset, polys, xf, offset, nitems); break
+    switch (bits) {
+        DIL_UP(3); DIL_UP(4); DIL_UP(6); DIL_UP(10); DIL_UP(13); DIL_UP(18); DIL_UP(20);
+    default: return hipErrorInvalidValue;
+    }
+#undef DIL_UP
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(int bits, uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int polys, int xf,
+                       int32_t offset, size_t nitems, const Tables& t, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    const int g = grid1d(nitems * (size_t)polys * 32 * bits, t);
+#define DIL_PK(B) case B: hipLaunchKernelGGL(pack_kernel<B>, g, 256, 0, s, out, out_stride, out_offset, in, polys, xf, offset, nitems); break
+    switch (bits) {
+        DIL_PK(3); DIL_PK(4); DIL_PK(6); DIL_PK(10); DIL_PK(13); DIL_PK(18); DIL_PK(20);
+    default: return hipErrorInvalidValue;
+    }
+#undef DIL_PK
+    return hipGetLastError();
+}
+
+hipError_t launch_hint_unpack(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int K, int omega,
+                              size_t nitems, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    hipLaunchKernelGGL(hint_unpack_kernel, (int)((nitems + 3) / 4), 256, 0, s, h, bad, in, in_stride, in_offset, K, omega, nitems);
+    return hipGetLastError();
+}
+
+hipError_t launch_hint_pack(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int K, int omega, size_t nitems,
+                            hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    hipLaunchKernelGGL(hint_pack_kernel, (int)((nitems + 3) / 4), 256, 0, s, out, out_stride, out_offset, h, K, omega, nitems);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_stride, int eta, int nonce0, int polys, size_t nitems,
+                           hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    const size_t total = nitems * (size_t)polys;
+    hipLaunchKernelGGL(expand_s_kernel, (int)((total + 63) / 64), 64, 0, s, sout, rhoprime, rp_stride, eta, nonce0, polys, nitems);
+    return hipGetLastError();
+}
+
+hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const int32_t* s2, size_t n, const Tables& t, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(power2round_kernel, grid1d(n, t), 256, 0, s, t1, t0, w, s2, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,
+                             int nbytes, size_t nitems, const Tables& t, hipStream_t s)
+{
+    if (nitems == 0 || nbytes == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_field_kernel, grid1d(nitems * (size_t)nbytes, t), 256, 0, s, dst, dst_stride, dst_off, src, src_stride,
+                       src_off, nbytes, nitems);
+    return hipGetLastError();
+}
+
+}  // namespace dil

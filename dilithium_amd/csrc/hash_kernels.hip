@@ -67,7 +67,7 @@ __device__ __forceinline__ void emit23(uint32_t v, int32_t* __restrict__ dst, in
 }
 
 __global__ __launch_bounds__(64) void expand_a_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
-                                                      int K, int L, size_t nitems)
+                                                      size_t rho_stride_words, int K, int L, size_t nitems)
 {
     const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t total = nitems * (size_t)(K * L);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void expand_a_kernel(int32_t* __restrict__ A, c
     Shake<21> sp;
     sp.init();
 #pragma unroll
-    for (int w = 0; w < 4; w++) sp.s[w] = rho[item * 4 + w];
+    for (int w = 0; w < 4; w++) sp.s[w] = rho[item * rho_stride_words + w];
     sp.s[4] = (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16);
     sp.s[20] ^= 0x8000000000000000ull;
     int32_t* dst = A + p * 256;
@@ -344,13 +344,14 @@ hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int
     return hipGetLastError();
 }
 
-hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, int level, size_t nitems, hipStream_t s)
+hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s)
 {
+    if (rho_stride_bytes & 7) return hipErrorInvalidValue;
     if (nitems == 0) return hipSuccess;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const size_t total = nitems * (size_t)(K * L);
-    hipLaunchKernelGGL(expand_a_kernel, (int)((total + 63) / 64), 64, 0, s, A, reinterpret_cast<const uint64_t*>(rho), K, L, nitems);
+    hipLaunchKernelGGL(expand_a_kernel, (int)((total + 63) / 64), 64, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
     return hipGetLastError();
 }
 

@@ -36,12 +36,29 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
 
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
-hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, int level, size_t nitems, hipStream_t s);
+hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s);
 hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s);
 hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s);
 hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,
                                  const uint8_t* expect, size_t batch, hipStream_t s);
 hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t batch, hipStream_t s);
+
+// ---- rows N2 / N4: codecs, ExpandS, Power2Round (codec_kernels.hip) ----
+enum { XF_PLAIN = 0, XF_OFFSET_MINUS = 1 };
+hipError_t launch_unpack(int bits, int32_t* out, const uint8_t* in, size_t in_stride, size_t in_offset, int polys, int xf,
+                         int32_t offset, size_t nitems, const Tables& t, hipStream_t s);
+hipError_t launch_pack(int bits, uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int polys, int xf,
+                       int32_t offset, size_t nitems, const Tables& t, hipStream_t s);
+hipError_t launch_hint_unpack(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int K, int omega,
+                              size_t nitems, hipStream_t s);
+hipError_t launch_hint_pack(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int K, int omega, size_t nitems,
+                            hipStream_t s);
+hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_stride, int eta, int nonce0, int polys, size_t nitems,
+                           hipStream_t s);
+hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const int32_t* s2, size_t n, const Tables& t, hipStream_t s);
+hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t n, const Tables& t, hipStream_t s);
+hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,
+                             int nbytes, size_t nitems, const Tables& t, hipStream_t s);
 
 }  // namespace dil

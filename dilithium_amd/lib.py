@@ -49,6 +49,16 @@ SIGNATURES = {
     "dil_expand_mask_dev": [_vp, _vp, _vp, C.c_int, _sz, _vp],
     "dil_sample_in_ball_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_pack_w1_dev": [_vp, _vp, C.c_int, _sz, _vp],
+    "dil_unpack_dev": [_vp, _vp, _sz, _sz, C.c_int, C.c_int, _sz, _vp],
+    "dil_pack_dev": [_vp, _sz, _sz, _vp, C.c_int, C.c_int, _sz, _vp],
+    "dil_hint_unpack_dev": [_vp, _vp, _vp, _sz, _sz, C.c_int, _sz, _vp],
+    "dil_hint_pack_dev": [_vp, _sz, _sz, _vp, C.c_int, _sz, _vp],
+    "dil_expand_s_dev": [_vp, _vp, _vp, _sz, C.c_int, _sz, _vp],
+    "dil_keygen_dev": [_vp, _vp, _vp, C.c_int, _sz, _vp],
+    "dil_pk_bytes": [C.c_int],
+    "dil_sk_bytes": [C.c_int],
+    "dil_sig_bytes": [C.c_int],
+    "dil_verify_sig_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_verify_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_attempt_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_event_create": [C.POINTER(_vp)],
@@ -57,7 +67,8 @@ SIGNATURES = {
     "dil_event_elapsed_ms": [C.POINTER(C.c_float), _vp, _vp],
     "dil_stream_sync": [_vp],
 }
-_RESTYPE = {"dil_error_string": C.c_char_p, "dil_host_twiddle_tables": None, "dil_host_zetas": None}
+_RESTYPE = {"dil_error_string": C.c_char_p, "dil_host_twiddle_tables": None, "dil_host_zetas": None,
+            "dil_pk_bytes": C.c_size_t, "dil_sk_bytes": C.c_size_t, "dil_sig_bytes": C.c_size_t}
 
 _lib = None
 

@@ -123,6 +123,33 @@ int dil_expand_mask_dev(int32_t* y, const uint8_t* rhoprime, const uint32_t* kap
 int dil_sample_in_ball_dev(int32_t* c, const uint8_t* ctilde, int level, size_t batch, void* stream);
 int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, void* stream);
 
+/* ---- wire-format codecs, ExpandS, keygen ------------------------------
+ * Wire formats are those of the reference's KAT files (round-3 v3.1): pk = rho(32) | t1 (K x 320 B);
+ * sk = rho(32) | key(32) | tr(32) | s1 (L x 96|128 B) | s2 (K x 96|128) | t0 (K x 416);
+ * sig = c~(32) | z (L x 576|640 B) | hint (omega + K B).   Buffers: any alignment, `stride` bytes per item.
+ * kind: DIL_CODEC_*; unpack -> int32 [batch][polys][256] canonical; pack <- any residues. */
+#define DIL_CODEC_T1 0   /* 10 b, K polys                          decoder.v:96-100 (without the 2^13) */
+#define DIL_CODEC_T0 1   /* 13 b, K polys, 2^12 - t0               uncenter_coeff.v:49-65 */
+#define DIL_CODEC_S1 2   /* 3|4 b, L polys, eta - s */
+#define DIL_CODEC_S2 3   /* 3|4 b, K polys, eta - s */
+#define DIL_CODEC_Z 4    /* 18|20 b, L polys, gamma1 - z */
+int dil_unpack_dev(int32_t* out, const uint8_t* in, size_t in_stride, size_t in_offset, int kind, int level, size_t batch, void* stream);
+int dil_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int kind, int level, size_t batch, void* stream);
+/* hints: omega position bytes + K cumulative counts <-> h [batch][K][256] bytes 0/1; bad[i] = 1 if malformed */
+int dil_hint_unpack_dev(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int level, size_t batch, void* stream);
+int dil_hint_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int level, size_t batch, void* stream);
+/* ExpandS: s1 [batch][L][256], s2 [batch][K][256] canonical from rho' (64 B at rhoprime + i*stride)   gen_s.v */
+int dil_expand_s_dev(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t stride, int level, size_t batch, void* stream);
+/* key generation, seed (32 B) -> pk, sk in wire format (combined_top.v KG_* :754-1079), all on the device */
+int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch, void* stream);
+size_t dil_pk_bytes(int level);
+size_t dil_sk_bytes(int level);
+size_t dil_sig_bytes(int level);
+/* wire-format verification: verdict[i] = 0 accept; bit0 challenge mismatch, bit1 ||z|| bound, bit2 malformed hint.
+ * mu [batch][64] = SHAKE256(tr || message) (message hashing stays with the caller); shared_pk: one pk for all */
+int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                       int shared_pk, void* stream);
+
 /* ---- SURVEY 8(f) row N3 (first step): whole verify / sign-attempt sequences as ONE call --------
  * Everything between the wire-format codecs runs on the device, on `stream`, with no host round trip;
  * temporaries come from the stream-ordered allocator (hipMallocAsync) and are freed on the stream.

@@ -1,0 +1,241 @@
+"""GPU parity for SURVEY 8(f) rows N2 (bit-packed codecs on the device) and N4 (key generation):
+against the KAT harness's host codecs (oracle/dilithium_kat.py) on random data, on the reference's
+KAT byte strings, and end to end: seed -> (pk, sk) byte-identical to the KAT files, wire-format
+signatures verified from bytes."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import dilithium_kat as dk
+from tests.conftest import load_kat
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(torch, a, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).cuda()
+
+
+def kat_wire(level):
+    k = load_kat(level)
+    pk = np.concatenate([k["rho"], k["t1"]], axis=1)
+    sk = np.concatenate([k["rho"], k["key"], k["tr"], k["s1"], k["s2"], k["t0"]], axis=1)
+    sig = np.concatenate([k["ctilde"], k["z"], k["h"]], axis=1)
+    return k, pk, sk, sig
+
+
+def mus(k, msgs):
+    return np.stack([np.frombuffer(hashlib.shake_256(k["tr"][i].tobytes() + msgs[i]).digest(64), dtype=np.uint8)
+                     for i in range(len(msgs))])
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_sizes(gpu, level):
+    from dilithium_amd import api
+    assert (api.pk_bytes(level), api.sk_bytes(level), api.sig_bytes(level)) == \
+        {2: (1312, 2528, 2420), 3: (1952, 4000, 3293), 5: (2592, 4864, 4595)}[level]
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_unpack_kat_fields(gpu, level):
+    """every packed KAT field decodes as the host codec does, at odd offsets inside pk / sk / sig"""
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    k, pk, sk, sig = kat_wire(level)
+    sb = 32 * p.eta_bits
+    cases = [(pk, api.CODEC_T1, 32, lambda i: dk.unpack_t1(p, k["t1"][i].tobytes())),
+             (sk, api.CODEC_S1, 96, lambda i: dk.unpack_eta(p, k["s1"][i].tobytes(), p.L)),
+             (sk, api.CODEC_S2, 96 + p.L * sb, lambda i: dk.unpack_eta(p, k["s2"][i].tobytes(), p.K)),
+             (sk, api.CODEC_T0, 96 + (p.L + p.K) * sb, lambda i: dk.unpack_t0(p, k["t0"][i].tobytes())),
+             (sig, api.CODEC_Z, 32, lambda i: dk.unpack_z(p, k["z"][i].tobytes()))]
+    for buf, kind, off, want in cases:
+        got = api.unpack(cu(gpu, buf), kind, level, off).cpu().numpy()
+        assert got.min() >= 0 and got.max() < dk.Q
+        for i in range(100):
+            assert (got[i] == dk.canon(want(i))).all(), (kind, i)
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_pack_roundtrip_and_host_codec(gpu, level):
+    """random in-range values, canonical AND centred representatives: device pack == host pack; unpack(pack(x)) == x"""
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(100 + level)
+    n = 33
+    specs = [(api.CODEC_T1, p.K, 0, 1023, dk.pack_t1, 320),
+             (api.CODEC_T0, p.K, -(1 << 12) + 1, 1 << 12, dk.pack_t0, 416),
+             (api.CODEC_S1, p.L, -p.eta, p.eta, dk.pack_eta, 32 * p.eta_bits),
+             (api.CODEC_S2, p.K, -p.eta, p.eta, dk.pack_eta, 32 * p.eta_bits),
+             (api.CODEC_Z, p.L, -p.gamma1 + 1, p.gamma1, dk.pack_z, 32 * p.z_bits)]
+    for kind, polys, lo, hi, host_pack, pb in specs:
+        x = rng.integers(lo, hi + 1, (n, polys, 256)).astype(np.int32)
+        x[0, 0, :4] = [lo, hi, lo, hi]
+        stride, off = polys * pb + 11, 5           # odd stride and offset on purpose
+        for rep in (x, dk.canon(x).astype(np.int32)):
+            buf = gpu.full((n, stride), 0xA5, dtype=gpu.uint8, device="cuda")
+            api.pack(cu(gpu, rep), buf, kind, level, off)
+            b = buf.cpu().numpy()
+            assert (b[:, :off] == 0xA5).all() and (b[:, off + polys * pb:] == 0xA5).all()   # neighbours untouched
+            for i in range(n):
+                assert b[i, off:off + polys * pb].tobytes() == host_pack(p, x[i]), (kind, i)
+            back = api.unpack(buf, kind, level, off).cpu().numpy()
+            assert (back == dk.canon(x)).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_hint_codec(gpu, level):
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    k, _, _, sig = kat_wire(level)
+    hoff = 32 + p.L * 32 * p.z_bits
+    h, bad = api.hint_unpack(cu(gpu, sig), level, hoff)
+    h, bad = h.cpu().numpy(), bad.cpu().numpy()
+    assert (bad == 0).all()
+    for i in range(100):
+        assert (h[i] == dk.unpack_hint(p, k["h"][i].tobytes())).all()
+    # pack is the inverse on well-formed hints
+    out = gpu.zeros((100, p.omega + p.K + 3), dtype=gpu.uint8, device="cuda")
+    api.hint_pack(cu(gpu, h), out, level, 3)
+    assert (out.cpu().numpy()[:, 3:] == k["h"]).all()
+    # random hint sets incl. empty and exactly-omega
+    rng = np.random.default_rng(level)
+    hs = np.zeros((64, p.K, 256), dtype=np.uint8)
+    for i in range(64):
+        cnt = [0, p.omega, 1][i] if i < 3 else int(rng.integers(0, p.omega + 1))
+        idx = rng.choice(p.K * 256, cnt, replace=False)
+        hs[i].reshape(-1)[idx] = 1
+    out = gpu.zeros((64, p.omega + p.K), dtype=gpu.uint8, device="cuda")
+    api.hint_pack(cu(gpu, hs), out, level)
+    o = out.cpu().numpy()
+    for i in range(64):
+        assert o[i].tobytes() == dk.pack_hint(p, hs[i])
+    h2, bad2 = api.hint_unpack(out, level)
+    assert (bad2.cpu().numpy() == 0).all() and (h2.cpu().numpy() == hs).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_hint_malformed(gpu, level):
+    """every way the reference's decoder can reject a hint string (decoder.v hint checks; same cases as the host codec)"""
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    k = load_kat(level)
+    base = k["h"][:40].copy()
+    muts = []
+    for i in range(40):
+        b = base[i].copy()
+        cnts = b[p.omega:]
+        total = int(cnts[-1])
+        kind = i % 5
+        if kind == 0 and total >= 2:       # positions not increasing inside a row
+            row_end = next(int(c) for c in cnts if c >= 2)
+            b[row_end - 1], b[row_end - 2] = b[row_end - 2], b[row_end - 1]
+            if b[row_end - 1] == b[row_end - 2]:
+                kind = -1
+        elif kind == 1:                    # counts decreasing
+            b[p.omega] = int(cnts[1]) + 1
+        elif kind == 2:                    # count > omega
+            b[p.omega + p.K - 1] = p.omega + 1
+        elif kind == 3 and total < p.omega:  # non-zero padding
+            b[total] = 7
+        elif kind == 4 and total >= 2:     # duplicate position inside a row
+            row_end = next(int(c) for c in cnts if c >= 2)
+            b[row_end - 1] = b[row_end - 2]
+        muts.append(b)
+    muts = np.stack(muts)
+    want_bad = np.array([dk.unpack_hint(p, m.tobytes()) is None for m in muts])
+    assert want_bad.sum() >= 20
+    h, bad = api.hint_unpack(cu(gpu, muts), level)
+    assert ((bad.cpu().numpy() != 0) == want_bad).all()
+    good = ~want_bad
+    hh = h.cpu().numpy()
+    for i in np.nonzero(good)[0]:
+        assert (hh[i] == dk.unpack_hint(p, muts[i].tobytes())).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_expand_s(gpu, level):
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(40 + level)
+    n = 50
+    rp = rng.integers(0, 256, (n, 64 + 9), dtype=np.uint8)      # stride 73: unaligned rows
+    s1, s2 = api.expand_s(cu(gpu, rp), level)
+    s1, s2 = s1.cpu().numpy(), s2.cpu().numpy()
+    for i in range(n):
+        seed = rp[i, :64].tobytes()
+        for j in range(p.L):
+            assert (s1[i, j] == dk.canon(dk.expand_s_poly(p, seed, j))).all()
+        for j in range(p.K):
+            assert (s2[i, j] == dk.canon(dk.expand_s_poly(p, seed, p.L + j))).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_keygen_kat(gpu, level):
+    """seed -> pk, sk byte-identical to the reference's KAT files (PQCsignKAT_Dilithium{2,3,5}.rsp fields)"""
+    from dilithium_amd import api
+    k, pk, sk, _ = kat_wire(level)
+    gpk, gsk = api.keygen(cu(gpu, k["seed"]), level)
+    assert (gpk.cpu().numpy() == pk).all()
+    assert (gsk.cpu().numpy() == sk).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_keygen_large_batch_consistency(gpu, level):
+    """3000 random seeds: the keys the device makes verify... (property) t = A s1 + s2 recombines: t1*2^13 + t0 == NTT^-1(A NTT(s1)) + s2"""
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(level)
+    n = 3000
+    seed = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = api.keygen(cu(gpu, seed), level)
+    sb = 32 * p.eta_bits
+    t1 = api.unpack(pk, api.CODEC_T1, level, 32).long()
+    t0 = api.unpack(sk, api.CODEC_T0, level, 96 + (p.L + p.K) * sb).long()
+    s1 = api.unpack(sk, api.CODEC_S1, level, 96)
+    s2 = api.unpack(sk, api.CODEC_S2, level, 96 + p.L * sb).long()
+    A = api.expand_a(pk[:, :32].contiguous(), level)
+    w = api.matvec(A, s1, level).long()
+    assert bool((((t1 << 13) + t0 - w - s2) % dk.Q == 0).all())
+    assert (pk[:, :32] == sk[:, :32]).all()
+    # spot check against the host keygen
+    from oracle.oracle import Oracle
+    eng = dk.OracleEngine(Oracle())
+    for i in (0, n - 1):
+        kg = dk.keygen(level, seed[i].tobytes(), eng)
+        assert pk[i].cpu().numpy().tobytes() == kg["rho"] + kg["t1_packed"]
+        assert sk[i, 32:96].cpu().numpy().tobytes() == kg["key"] + kg["tr"]
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("shared", [False, True])
+def test_verify_sig_wire_kat(gpu, level, shared, kat_msgs):
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    k, pk, _, sig = kat_wire(level)
+    mu = mus(k, kat_msgs)
+    if shared:
+        # one key, many signatures: sign 24 messages under KAT key 0 on the host oracle path? -- use KAT 0 only, replicated
+        pkd = cu(gpu, pk[:1])
+        sg = np.repeat(sig[:1], 24, axis=0)
+        m = np.repeat(mu[:1], 24, axis=0)
+        sg[5, 40] ^= 1            # z bit
+        sg[6, 2] ^= 0x80          # c~ bit
+        m[7, 0] ^= 1              # other message
+        sg[8, -1] = p.omega + 1   # malformed hint
+        v = api.verify_sig(pkd, cu(gpu, sg), cu(gpu, m), level, shared_pk=True).cpu().numpy()
+        bad = {5, 6, 7, 8}
+        assert all((v[i] != 0) == (i in bad) for i in range(24))
+        assert v[8] & 4
+    else:
+        v = api.verify_sig(cu(gpu, pk), cu(gpu, sig), cu(gpu, mu), level).cpu().numpy()
+        assert (v == 0).all()
+        sg = sig.copy()
+        sg[3, 100] ^= 0x10
+        sg[4, 1] ^= 1
+        sg[9, -2] = p.omega + 9
+        pk2 = pk.copy()
+        pk2[11, 200] ^= 4
+        v = api.verify_sig(cu(gpu, pk2), cu(gpu, sg), cu(gpu, mu), level).cpu().numpy()
+        assert set(np.nonzero(v)[0]) == {3, 4, 9, 11}
+        assert v[9] & 4
