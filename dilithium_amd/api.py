@@ -355,3 +355,13 @@ def verify_sig(pk, sig, mu, level, shared_pk=False):
     _lib.check(_lib.load().dil_verify_sig_dev(_dev(verdict, torch.int32), _dev(pk, torch.uint8), _dev(sig, torch.uint8),
                                               _dev(mu, torch.uint8), level, B, int(shared_pk), _stream()), "dil_verify_sig_dev")
     return verdict
+
+
+def sign(sk, mu, level, shared_sk=False, max_attempts=512):
+    """wire-format deterministic signing: sk uint8 [B or 1, sk_bytes], mu uint8 [B,64] -> (sig uint8 [B,sig_bytes], attempts int32 [B])"""
+    B = mu.shape[0]
+    sig = torch.empty((B, sig_bytes(level)), dtype=torch.uint8, device=mu.device)
+    att = torch.empty((B,), dtype=torch.int32, device=mu.device)
+    _lib.check(_lib.load().dil_sign_dev(_dev(sig, torch.uint8), _dev(att, torch.int32), _dev(sk, torch.uint8), _dev(mu, torch.uint8),
+                                        level, B, int(shared_sk), max_attempts, _stream()), "dil_sign_dev")
+    return sig, att

@@ -214,7 +214,11 @@ int dil_device_count(int* count) { return (int)hipGetDeviceCount(count); }
 
 int dil_num_cus(void) { return g.ready ? g.t.num_cus : -1; }
 
-const char* dil_error_string(int code) { return hipGetErrorString((hipError_t)code); }
+const char* dil_error_string(int code)
+{
+    if (code == DIL_ERR_UNFINISHED) return "signing did not finish within max_attempts";
+    return hipGetErrorString((hipError_t)code);
+}
 
 int dil_init(int device)
 {
@@ -459,7 +463,7 @@ int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, vo
 namespace {
 struct StreamScratch {       // stream-ordered temporaries, freed on the same stream
     hipStream_t s;
-    void* p[8];
+    void* p[40];
     int n = 0;
     explicit StreamScratch(hipStream_t st) : s(st) {}
     int get(void** out, size_t bytes)
@@ -665,6 +669,90 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     if (rc) return rc;
     // verdict |= bad << 2   (tiny element-wise op done with the pointwise machinery would be overkill: reuse copy kernel? no --)
     return (int)dil::launch_or_flag(verdict, static_cast<int32_t*>(bad), 4, batch, g.t, s);
+}
+
+// ---- row N3: the whole signing rejection loop on the device ---------------------------------------
+// combined_top.v's sign FSMs (:1694-2229) retry one signature until it passes; a batch retries only
+// the still-pending signatures: after each round the accepted ones are scattered to their slots and
+// the rest are compacted (their attempt counter kappa advances by L, as the reference's does).
+int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                 int max_attempts, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    if (batch == 0) return 0;
+    if (batch > 0x7fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), sb = (size_t)32 * p.eta_bits, zb = (size_t)p.L * 32 * p.zbits;
+    const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
+    const size_t a_row = (size_t)p.K * p.L * 1024, l_row = (size_t)p.L * 1024, k_row = (size_t)p.K * 1024;
+    void *A, *s1h, *s2h, *t0h, *km, *rp, *idx0, *idx1, *cnt, *kap, *ct, *z, *h, *fl, *sigc, *mu_c, *rp_c;
+    if ((rc = ws.get(&A, nk * a_row)) || (rc = ws.get(&s1h, nk * l_row)) || (rc = ws.get(&s2h, nk * k_row)) ||
+        (rc = ws.get(&t0h, nk * k_row)) || (rc = ws.get(&km, batch * 96)) || (rc = ws.get(&rp, batch * 64)) ||
+        (rc = ws.get(&idx0, batch * 4)) || (rc = ws.get(&idx1, batch * 4)) || (rc = ws.get(&cnt, 4)) || (rc = ws.get(&kap, batch * 4)) ||
+        (rc = ws.get(&ct, batch * 32)) || (rc = ws.get(&z, batch * l_row)) || (rc = ws.get(&h, batch * p.K * 256)) ||
+        (rc = ws.get(&fl, batch * 4)) || (rc = ws.get(&sigc, batch * sgb)) || (rc = ws.get(&mu_c, batch * 64)) ||
+        (rc = ws.get(&rp_c, batch * 64)))
+        return rc;
+    // key material: A = ExpandA(rho), s1^ s2^ t0^ = NTT(unpack(sk))
+    DIL_TRY(dil::launch_expand_a(static_cast<int32_t*>(A), sk, skb, level, nk, s));
+    DIL_TRY(dil::launch_unpack(p.eta_bits, static_cast<int32_t*>(s1h), sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
+    DIL_TRY(dil::launch_unpack(p.eta_bits, static_cast<int32_t*>(s2h), sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
+    DIL_TRY(dil::launch_unpack(13, static_cast<int32_t*>(t0h), sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, g.t, s));
+    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, static_cast<int32_t*>(s1h), nk * p.L, g.t, s));
+    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, static_cast<int32_t*>(s2h), nk * p.K, g.t, s));
+    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, static_cast<int32_t*>(t0h), nk * p.K, g.t, s));
+    // rho' = SHAKE256(key || mu, 64)  (deterministic signing, as the reference's KATs)
+    DIL_TRY(dil::launch_copy_field(static_cast<uint8_t*>(km), 96, 0, sk, sk_stride, 32, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_copy_field(static_cast<uint8_t*>(km), 96, 32, mu, 64, 0, 64, batch, g.t, s));
+    DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(rp), 64, static_cast<uint64_t*>(km), 96, batch, s));
+    DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
+
+    void *A_c = nullptr, *s1h_c = nullptr, *s2h_c = nullptr, *t0h_c = nullptr;
+    int32_t *idx_cur = nullptr, *idx_next = static_cast<int32_t*>(idx0);
+    size_t n = batch;
+    for (int r = 0; r < max_attempts && n > 0; r++) {
+        const int32_t *Ar = static_cast<int32_t*>(A), *s1r = static_cast<int32_t*>(s1h), *s2r = static_cast<int32_t*>(s2h),
+                      *t0r = static_cast<int32_t*>(t0h);
+        const uint8_t *mur = mu, *rpr = static_cast<uint8_t*>(rp);
+        if (idx_cur) {
+            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, n, g.t, s));
+            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, n, g.t, s));
+            mur = static_cast<uint8_t*>(mu_c);
+            rpr = static_cast<uint8_t*>(rp_c);
+            if (!shared_sk) {
+                if (!A_c && ((rc = ws.get(&A_c, n * a_row)) || (rc = ws.get(&s1h_c, n * l_row)) || (rc = ws.get(&s2h_c, n * k_row)) ||
+                             (rc = ws.get(&t0h_c, n * k_row))))
+                    return rc;
+                DIL_TRY(dil::launch_gather_rows(A_c, A, idx_cur, a_row, n, g.t, s));
+                DIL_TRY(dil::launch_gather_rows(s1h_c, s1h, idx_cur, l_row, n, g.t, s));
+                DIL_TRY(dil::launch_gather_rows(s2h_c, s2h, idx_cur, k_row, n, g.t, s));
+                DIL_TRY(dil::launch_gather_rows(t0h_c, t0h, idx_cur, k_row, n, g.t, s));
+                Ar = static_cast<int32_t*>(A_c); s1r = static_cast<int32_t*>(s1h_c);
+                s2r = static_cast<int32_t*>(s2h_c); t0r = static_cast<int32_t*>(t0h_c);
+            }
+        }
+        DIL_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(kap), r * p.L, n, s));
+        rc = dil_sign_attempt_dev(static_cast<uint8_t*>(ct), static_cast<int32_t*>(z), static_cast<uint8_t*>(h), static_cast<int32_t*>(fl),
+                                  Ar, mur, rpr, static_cast<uint32_t*>(kap), s1r, s2r, t0r, level, n, shared_sk, stream);
+        if (rc) return rc;
+        uint8_t* sc = static_cast<uint8_t*>(sigc);
+        DIL_TRY(dil::launch_copy_field(sc, sgb, 0, static_cast<uint8_t*>(ct), 32, 0, 32, n, g.t, s));
+        DIL_TRY(dil::launch_pack(p.zbits, sc, sgb, 32, static_cast<int32_t*>(z), p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, g.t, s));
+        DIL_TRY(dil::launch_hint_pack(sc, sgb, 32 + zb, static_cast<uint8_t*>(h), p.K, p.omega, n, s));
+        DIL_TRY(hipMemsetAsync(cnt, 0, 4, s));
+        DIL_TRY(dil::launch_sign_collect(sig, sgb, attempts, idx_next, static_cast<int32_t*>(cnt), sc, static_cast<int32_t*>(fl), idx_cur,
+                                         r + 1, n, s));
+        int32_t pending = 0;
+        DIL_TRY(hipMemcpyAsync(&pending, cnt, 4, hipMemcpyDeviceToHost, s));
+        DIL_TRY(hipStreamSynchronize(s));
+        n = (size_t)pending;
+        idx_cur = idx_next;
+        idx_next = idx_cur == static_cast<int32_t*>(idx0) ? static_cast<int32_t*>(idx1) : static_cast<int32_t*>(idx0);
+    }
+    return n == 0 ? 0 : DIL_ERR_UNFINISHED;
 }
 
 // ---- events --------------------------------------------------------------------------------------

@@ -222,6 +222,40 @@ __global__ __launch_bounds__(256) void copy_field_kernel(uint8_t* __restrict__ d
     }
 }
 
+// dst[i] = src[idx[i]] for rows of `row_vec` VEC-sized words (rejection-loop compaction, row N3)
+template <typename VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(VEC* __restrict__ dst, const VEC* __restrict__ src,
+                                                          const int32_t* __restrict__ idx, size_t row_vec, size_t n)
+{
+    const size_t total = n * row_vec;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t i = g / row_vec, w = g % row_vec;
+        dst[g] = src[(size_t)idx[i] * row_vec + w];
+    }
+}
+
+// One wave per pending signature: accepted (flags == 0) -> copy the packed signature to its
+// final slot and record the attempt count; rejected -> append the item to the next pending list.
+__global__ __launch_bounds__(64) void sign_collect_kernel(uint8_t* __restrict__ sig, size_t sig_bytes, int32_t* __restrict__ attempts,
+                                                          int32_t* __restrict__ next_idx, int32_t* __restrict__ next_count,
+                                                          const uint8_t* __restrict__ sig_c, const int32_t* __restrict__ flags,
+                                                          const int32_t* __restrict__ idx, int attempt_no, size_t n)
+{
+    const size_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (i >= n) return;
+    const int32_t item = idx ? idx[i] : (int32_t)i;
+    if (flags[i] != 0) {
+        if (lane == 0) next_idx[atomicAdd(next_count, 1)] = item;
+        return;
+    }
+    const uint8_t* src = sig_c + i * sig_bytes;
+    uint8_t* dst = sig + (size_t)item * sig_bytes;
+    for (size_t t = lane; t < sig_bytes; t += 64) dst[t] = src[t];
+    if (lane == 0) attempts[item] = attempt_no;
+}
+
 // verdict[i] |= flag[i] ? bit : 0
 __global__ __launch_bounds__(256) void or_flag_kernel(int32_t* __restrict__ verdict, const int32_t* __restrict__ flag, int bit, size_t n)
 {
@@ -242,6 +276,34 @@ hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(or_flag_kernel, (int)((n + 255) / 256), 256, 0, s, verdict, flag, bit, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, const Tables& t, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const bool a16 = row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
+    if (a16) {
+        const size_t rv = row_bytes / 16;
+        hipLaunchKernelGGL(gather_rows_kernel<uint4>, grid1d(n * rv, t), 256, 0, s, static_cast<uint4*>(dst),
+                           static_cast<const uint4*>(src), idx, rv, n);
+    } else if (row_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 8 == 0) {
+        const size_t rv = row_bytes / 8;
+        hipLaunchKernelGGL(gather_rows_kernel<uint2>, grid1d(n * rv, t), 256, 0, s, static_cast<uint2*>(dst),
+                           static_cast<const uint2*>(src), idx, rv, n);
+    } else {
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid1d(n * row_bytes, t), 256, 0, s, static_cast<uint8_t*>(dst),
+                           static_cast<const uint8_t*>(src), idx, row_bytes, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sign_collect(uint8_t* sig, size_t sig_bytes, int32_t* attempts, int32_t* next_idx, int32_t* next_count,
+                               const uint8_t* sig_c, const int32_t* flags, const int32_t* idx, int attempt_no, size_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sign_collect_kernel, (int)n, 64, 0, s, sig, sig_bytes, attempts, next_idx, next_count, sig_c, flags, idx,
+                       attempt_no, n);
     return hipGetLastError();
 }
 

@@ -58,6 +58,9 @@ hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_str
                            hipStream_t s);
 hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const int32_t* s2, size_t n, const Tables& t, hipStream_t s);
 hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t n, const Tables& t, hipStream_t s);
+hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, const Tables& t, hipStream_t s);
+hipError_t launch_sign_collect(uint8_t* sig, size_t sig_bytes, int32_t* attempts, int32_t* next_idx, int32_t* next_count,
+                               const uint8_t* sig_c, const int32_t* flags, const int32_t* idx, int attempt_no, size_t n, hipStream_t s);
 hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,
                              int nbytes, size_t nitems, const Tables& t, hipStream_t s);
 

@@ -150,6 +150,14 @@ size_t dil_sig_bytes(int level);
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                        int shared_pk, void* stream);
 
+/* The whole deterministic signing loop (combined_top.v sign FSMs :1694-2229) for a batch: sk wire format
+ * ([batch][sk_bytes], or one key if shared_sk), mu [batch][64] -> sig [batch][sig_bytes], attempts[i] = number of
+ * rejection-loop rounds item i took (0 = not finished within max_attempts -> return DIL_ERR_UNFINISHED).
+ * Pending items are re-tried together, one round per attempt; synchronises `stream` once per round. */
+#define DIL_ERR_UNFINISHED (-2)
+int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                 int max_attempts, void* stream);
+
 /* ---- SURVEY 8(f) row N3 (first step): whole verify / sign-attempt sequences as ONE call --------
  * Everything between the wire-format codecs runs on the device, on `stream`, with no host round trip;
  * temporaries come from the stream-ordered allocator (hipMallocAsync) and are freed on the stream.

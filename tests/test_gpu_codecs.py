@@ -239,3 +239,47 @@ def test_verify_sig_wire_kat(gpu, level, shared, kat_msgs):
         v = api.verify_sig(cu(gpu, pk2), cu(gpu, sg), cu(gpu, mu), level).cpu().numpy()
         assert set(np.nonzero(v)[0]) == {3, 4, 9, 11}
         assert v[9] & 4
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_sign_wire_kat(gpu, level, kat_msgs):
+    """sk bytes + mu -> signature bytes identical to the KAT files, attempt counts as the host harness"""
+    from dilithium_amd import api
+    k, pk, sk, sig = kat_wire(level)
+    mu = mus(k, kat_msgs)
+    got, att = api.sign(cu(gpu, sk), cu(gpu, mu), level)
+    assert (att.cpu().numpy() == k["attempts"]).all()
+    assert (got.cpu().numpy() == sig).all()
+    # and they verify from bytes
+    assert (api.verify_sig(cu(gpu, pk), got, cu(gpu, mu), level).cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_sign_shared_key_many_messages(gpu, level, kat_msgs):
+    """one key, 2000 messages (the signing-server shape): every signature verifies; item 0 is the KAT signature;
+    the same messages signed as a distinct-key batch give identical bytes"""
+    from dilithium_amd import api
+    k, pk, sk, sig = kat_wire(level)
+    rng = np.random.default_rng(level)
+    n = 2000
+    mu = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    mu[0] = mus(k, kat_msgs[:1])[0]
+    skd, pkd, mud = cu(gpu, sk[:1]), cu(gpu, pk[:1]), cu(gpu, mu)
+    got, att = api.sign(skd, mud, level, shared_sk=True)
+    a = att.cpu().numpy()
+    assert a.min() >= 1 and a[0] == k["attempts"][0]
+    assert (got[0].cpu().numpy() == sig[0]).all()
+    assert (api.verify_sig(pkd, got, mud, level, shared_pk=True).cpu().numpy() == 0).all()
+    # expected number of attempts of the scheme: 4.25 / 5.1 / 3.85 (round-3 spec, table 2); loose statistical check
+    assert 3.0 < a.mean() < 6.5
+    m = 300
+    got2, att2 = api.sign(cu(gpu, np.repeat(sk[:1], m, axis=0)), mud[:m].contiguous(), level, shared_sk=False)
+    assert (got2 == got[:m]).all() and (att2 == att[:m]).all()
+
+
+def test_sign_unfinished(gpu, kat_msgs):
+    from dilithium_amd import api, lib
+    k, pk, sk, sig = kat_wire(3)
+    mu = mus(k, kat_msgs)
+    with pytest.raises(lib.DilError):
+        api.sign(cu(gpu, sk), cu(gpu, mu), 3, max_attempts=1)
