@@ -6,6 +6,7 @@
 #include "../../include/dil256.h"
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -97,6 +98,7 @@ struct State {
     dil::Tables t;
     void* scratch = nullptr;        // for *_host entry points
     size_t scratch_bytes = 0;
+    int sign_cap = 0;               // DIL_SIGN_CAP: entries in flight per signing round (0 = default)
 };
 State g;
 
@@ -252,7 +254,17 @@ int dil_init(int device)
     if (const char* e = getenv("DIL_NTT_BPC")) g.t.ntt_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.ntt_blocks_per_cu;
     if (const char* e = getenv("DIL_WPI_BPC")) g.t.wpi_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.wpi_blocks_per_cu;
     if (const char* e = getenv("DIL_FUSED_MODE")) g.t.fused_mode = atoi(e);
+    if (const char* e = getenv("DIL_SIGN_CAP")) g.sign_cap = atoi(e);
     if (const char* e = getenv("DIL_FUSED_WGPC")) g.t.fused_wgs_per_cu = atoi(e) > 0 ? atoi(e) : g.t.fused_wgs_per_cu;
+    {   // composite entry points take their temporaries from the stream-ordered pool: keep what it has
+        // grown to instead of handing it back to the driver at every synchronisation
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+            uint64_t keep = getenv("DIL_POOL_KEEP") ? strtoull(getenv("DIL_POOL_KEEP"), nullptr, 10) : (uint64_t)8 << 30;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
     g.device = device;
     g.ready = true;
     return 0;
@@ -508,6 +520,36 @@ int dil_verify_dev(int32_t* verdict, const int32_t* A, const uint8_t* ctilde, co
     return 0;
 }
 
+namespace {
+// temporaries of one signing attempt over `batch` entries
+struct AttemptScratch {
+    int32_t* y; uint8_t* w1; int32_t* w0; uint8_t* w1p; int32_t* c;
+    int alloc(StreamScratch& ws, int level, int K, int L, size_t batch)
+    {
+        void *py, *pw1, *pw0, *pw1p, *pc;
+        int rc;
+        if ((rc = ws.get(&py, batch * L * 1024)) || (rc = ws.get(&pw1, batch * K * 256)) || (rc = ws.get(&pw0, batch * K * 1024)) ||
+            (rc = ws.get(&pw1p, batch * K * (level == 2 ? 192 : 128))) || (rc = ws.get(&pc, batch * 1024)))
+            return rc;
+        y = static_cast<int32_t*>(py); w1 = static_cast<uint8_t*>(pw1); w0 = static_cast<int32_t*>(pw0);
+        w1p = static_cast<uint8_t*>(pw1p); c = static_cast<int32_t*>(pc);
+        return 0;
+    }
+};
+int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+                      const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s)
+{
+    DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, g.t, s));
+    DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, g.t, s));
+    DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s));
+    return 0;
+}
+}  // namespace
+
 int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
                          const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                          const int32_t* t0hat, int level, size_t batch, int shared_key, void* stream)
@@ -517,20 +559,9 @@ int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags
     if (batch == 0) return 0;
     hipStream_t s = S(stream);
     StreamScratch ws(s);
-    void *y, *w1, *w0, *w1p, *c;
-    const size_t wb = (size_t)K * (level == 2 ? 192 : 128);
-    if ((rc = ws.get(&y, batch * L * 1024)) || (rc = ws.get(&w1, batch * K * 256)) || (rc = ws.get(&w0, batch * K * 1024)) ||
-        (rc = ws.get(&w1p, batch * wb)) || (rc = ws.get(&c, batch * 1024)))
-        return rc;
-    DIL_TRY(dil::launch_expand_mask(static_cast<int32_t*>(y), rhoprime, kappa, level, batch, s));
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, static_cast<uint8_t*>(w1), static_cast<int32_t*>(w0), A,
-                               static_cast<int32_t*>(y), batch, shared_key, g.t, s));
-    DIL_TRY(dil::launch_pack_w1(static_cast<uint8_t*>(w1p), static_cast<uint8_t*>(w1), level, batch, g.t, s));
-    DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, static_cast<uint8_t*>(w1p), level, nullptr, batch, s));
-    DIL_TRY(dil::launch_sample_in_ball(static_cast<int32_t*>(c), ctilde, level, batch, s));
-    DIL_TRY(dil::launch_sign2(level, z, h, flags, static_cast<int32_t*>(c), static_cast<int32_t*>(y), static_cast<int32_t*>(w0),
-                              static_cast<uint8_t*>(w1), s1hat, s2hat, t0hat, batch, shared_key, g.t, s));
-    return 0;
+    AttemptScratch t;
+    if ((rc = t.alloc(ws, level, K, L, batch))) return rc;
+    return sign_attempt_impl(t, ctilde, z, h, flags, A, mu, rhoprime, kappa, s1hat, s2hat, t0hat, level, batch, shared_key, s);
 }
 
 // ---- rows N2 / N4: codecs, keygen, wire-format verify -------------------------------------------------
@@ -672,9 +703,12 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
 }
 
 // ---- row N3: the whole signing rejection loop on the device ---------------------------------------
-// combined_top.v's sign FSMs (:1694-2229) retry one signature until it passes; a batch retries only
-// the still-pending signatures: after each round the accepted ones are scattered to their slots and
-// the rest are compacted (their attempt counter kappa advances by L, as the reference's does).
+// combined_top.v's sign FSMs (:1694-2229) retry one signature until it passes.  A batch engine is
+// better used WIDE than deep: each round runs S speculative attempts (kappa = a0*L, (a0+1)*L, ...)
+// for every still-pending signature, S chosen so that a round keeps about `cap` entries in flight;
+// the first accepted attempt of an item wins, which is exactly the signature the sequential loop
+// produces.  The pending set shrinks geometrically while S grows, so the loop needs ~5 rounds
+// instead of the ~35 the unluckiest signature of a large batch takes.
 int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
                  int max_attempts, void* stream)
 {
@@ -682,19 +716,25 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     int rc = ensure_init();
     if (rc || (rc = level_par(level, &p))) return rc;
     if (batch == 0) return 0;
-    if (batch > 0x7fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
+    if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
+    if (batch == 1) shared_sk = 1;
     hipStream_t s = S(stream);
     StreamScratch ws(s);
     const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), sb = (size_t)32 * p.eta_bits, zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
     const size_t a_row = (size_t)p.K * p.L * 1024, l_row = (size_t)p.L * 1024, k_row = (size_t)p.K * 1024;
-    void *A, *s1h, *s2h, *t0h, *km, *rp, *idx0, *idx1, *cnt, *kap, *ct, *z, *h, *fl, *sigc, *mu_c, *rp_c;
+    // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
+    // speculate for free; distinct keys also replicate ~80 KiB of key material per entry, so stay lower there
+    const size_t cap = std::max<size_t>(batch, g.sign_cap ? (size_t)g.sign_cap : (shared_sk ? 16384 : 4096));
+    const int s_max = 64;
+    void *A, *s1h, *s2h, *t0h, *km, *rp, *idx0, *idx1, *cnt, *kap, *ct, *z, *h, *fl, *wine, *wini, *mu_c, *rp_c;
+    AttemptScratch att;
     if ((rc = ws.get(&A, nk * a_row)) || (rc = ws.get(&s1h, nk * l_row)) || (rc = ws.get(&s2h, nk * k_row)) ||
         (rc = ws.get(&t0h, nk * k_row)) || (rc = ws.get(&km, batch * 96)) || (rc = ws.get(&rp, batch * 64)) ||
-        (rc = ws.get(&idx0, batch * 4)) || (rc = ws.get(&idx1, batch * 4)) || (rc = ws.get(&cnt, 4)) || (rc = ws.get(&kap, batch * 4)) ||
-        (rc = ws.get(&ct, batch * 32)) || (rc = ws.get(&z, batch * l_row)) || (rc = ws.get(&h, batch * p.K * 256)) ||
-        (rc = ws.get(&fl, batch * 4)) || (rc = ws.get(&sigc, batch * sgb)) || (rc = ws.get(&mu_c, batch * 64)) ||
-        (rc = ws.get(&rp_c, batch * 64)))
+        (rc = ws.get(&idx0, batch * 4)) || (rc = ws.get(&idx1, batch * 4)) || (rc = ws.get(&cnt, 8)) || (rc = ws.get(&kap, cap * 4)) ||
+        (rc = ws.get(&ct, cap * 32)) || (rc = ws.get(&z, cap * l_row)) || (rc = ws.get(&h, cap * p.K * 256)) ||
+        (rc = ws.get(&fl, cap * 4)) || (rc = ws.get(&wine, batch * 4)) || (rc = ws.get(&wini, batch * 4)) ||
+        (rc = ws.get(&mu_c, cap * 64)) || (rc = ws.get(&rp_c, cap * 64)) || (rc = att.alloc(ws, level, p.K, p.L, cap)))
         return rc;
     // key material: A = ExpandA(rho), s1^ s2^ t0^ = NTT(unpack(sk))
     DIL_TRY(dil::launch_expand_a(static_cast<int32_t*>(A), sk, skb, level, nk, s));
@@ -713,42 +753,52 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     void *A_c = nullptr, *s1h_c = nullptr, *s2h_c = nullptr, *t0h_c = nullptr;
     int32_t *idx_cur = nullptr, *idx_next = static_cast<int32_t*>(idx0);
     size_t n = batch;
-    for (int r = 0; r < max_attempts && n > 0; r++) {
+    int a0 = 0;                                          // attempts every pending item has already failed
+    while (n > 0 && a0 < max_attempts) {
+        const int S_ = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
+        const size_t E = n * (size_t)S_;
+        const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
         const int32_t *Ar = static_cast<int32_t*>(A), *s1r = static_cast<int32_t*>(s1h), *s2r = static_cast<int32_t*>(s2h),
                       *t0r = static_cast<int32_t*>(t0h);
         const uint8_t *mur = mu, *rpr = static_cast<uint8_t*>(rp);
-        if (idx_cur) {
-            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, n, g.t, s));
-            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, n, g.t, s));
+        if (!direct) {
+            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, n, E, g.t, s));
+            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, n, E, g.t, s));
             mur = static_cast<uint8_t*>(mu_c);
             rpr = static_cast<uint8_t*>(rp_c);
             if (!shared_sk) {
-                if (!A_c && ((rc = ws.get(&A_c, n * a_row)) || (rc = ws.get(&s1h_c, n * l_row)) || (rc = ws.get(&s2h_c, n * k_row)) ||
-                             (rc = ws.get(&t0h_c, n * k_row))))
+                if (!A_c && ((rc = ws.get(&A_c, cap * a_row)) || (rc = ws.get(&s1h_c, cap * l_row)) ||
+                             (rc = ws.get(&s2h_c, cap * k_row)) || (rc = ws.get(&t0h_c, cap * k_row))))
                     return rc;
-                DIL_TRY(dil::launch_gather_rows(A_c, A, idx_cur, a_row, n, g.t, s));
-                DIL_TRY(dil::launch_gather_rows(s1h_c, s1h, idx_cur, l_row, n, g.t, s));
-                DIL_TRY(dil::launch_gather_rows(s2h_c, s2h, idx_cur, k_row, n, g.t, s));
-                DIL_TRY(dil::launch_gather_rows(t0h_c, t0h, idx_cur, k_row, n, g.t, s));
+                DIL_TRY(dil::launch_gather_rows(A_c, A, idx_cur, a_row, n, E, g.t, s));
+                DIL_TRY(dil::launch_gather_rows(s1h_c, s1h, idx_cur, l_row, n, E, g.t, s));
+                DIL_TRY(dil::launch_gather_rows(s2h_c, s2h, idx_cur, k_row, n, E, g.t, s));
+                DIL_TRY(dil::launch_gather_rows(t0h_c, t0h, idx_cur, k_row, n, E, g.t, s));
                 Ar = static_cast<int32_t*>(A_c); s1r = static_cast<int32_t*>(s1h_c);
                 s2r = static_cast<int32_t*>(s2h_c); t0r = static_cast<int32_t*>(t0h_c);
             }
         }
-        DIL_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(kap), r * p.L, n, s));
-        rc = dil_sign_attempt_dev(static_cast<uint8_t*>(ct), static_cast<int32_t*>(z), static_cast<uint8_t*>(h), static_cast<int32_t*>(fl),
-                                  Ar, mur, rpr, static_cast<uint32_t*>(kap), s1r, s2r, t0r, level, n, shared_sk, stream);
+        DIL_TRY(dil::launch_sign_kappa(static_cast<uint32_t*>(kap), (uint32_t)a0, (uint32_t)p.L, n, E, s));
+        rc = sign_attempt_impl(att, static_cast<uint8_t*>(ct), static_cast<int32_t*>(z), static_cast<uint8_t*>(h), static_cast<int32_t*>(fl),
+                               Ar, mur, rpr, static_cast<uint32_t*>(kap), s1r, s2r, t0r, level, E, shared_sk, s);
         if (rc) return rc;
-        uint8_t* sc = static_cast<uint8_t*>(sigc);
-        DIL_TRY(dil::launch_copy_field(sc, sgb, 0, static_cast<uint8_t*>(ct), 32, 0, 32, n, g.t, s));
-        DIL_TRY(dil::launch_pack(p.zbits, sc, sgb, 32, static_cast<int32_t*>(z), p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, g.t, s));
-        DIL_TRY(dil::launch_hint_pack(sc, sgb, 32 + zb, static_cast<uint8_t*>(h), p.K, p.omega, n, s));
-        DIL_TRY(hipMemsetAsync(cnt, 0, 4, s));
-        DIL_TRY(dil::launch_sign_collect(sig, sgb, attempts, idx_next, static_cast<int32_t*>(cnt), sc, static_cast<int32_t*>(fl), idx_cur,
-                                         r + 1, n, s));
+        // winners (first accepted attempt per item) -> packed straight into their signature slots
+        int32_t* counts = static_cast<int32_t*>(cnt);
+        DIL_TRY(hipMemsetAsync(cnt, 0, 8, s));
+        DIL_TRY(dil::launch_sign_collect(attempts, idx_next, static_cast<int32_t*>(wine), static_cast<int32_t*>(wini), counts,
+                                         static_cast<int32_t*>(fl), idx_cur, a0, S_, n, s));
+        dil::RowMap win;
+        win.src_row = static_cast<int32_t*>(wine);
+        win.dst_row = static_cast<int32_t*>(wini);
+        win.count = counts + 1;
+        DIL_TRY(dil::launch_copy_field(sig, sgb, 0, static_cast<uint8_t*>(ct), 32, 0, 32, n, g.t, s, win));
+        DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, static_cast<int32_t*>(z), p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, g.t, s, win));
+        DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, static_cast<uint8_t*>(h), p.K, p.omega, n, s, win));
         int32_t pending = 0;
         DIL_TRY(hipMemcpyAsync(&pending, cnt, 4, hipMemcpyDeviceToHost, s));
         DIL_TRY(hipStreamSynchronize(s));
         n = (size_t)pending;
+        a0 += S_;
         idx_cur = idx_next;
         idx_next = idx_cur == static_cast<int32_t*>(idx0) ? static_cast<int32_t*>(idx1) : static_cast<int32_t*>(idx0);
     }

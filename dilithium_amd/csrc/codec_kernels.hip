@@ -50,29 +50,37 @@ __global__ __launch_bounds__(256) void unpack_kernel(int32_t* __restrict__ out, 
 // ---------------------------------------------------------------------------------------
 // pack: one thread per OUTPUT byte; value_i = xf(centred(in[i])) as a BITS-bit field
 // ---------------------------------------------------------------------------------------
+// 8 coefficients make exactly BITS bytes: one thread per such group (32 per polynomial), two 16-B
+// loads, fields assembled at compile-time bit positions in a 160-bit accumulator.
 template <int BITS>
 __global__ __launch_bounds__(256) void pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
                                                    const int32_t* __restrict__ in, int polys, int xf, int32_t offset,
-                                                   size_t nitems)
+                                                   size_t nitems, RowMap map)
 {
-    constexpr int PB = 32 * BITS;                 // bytes per packed polynomial
-    const size_t total = nitems * (size_t)polys * PB;
+    if (map.count) nitems = min(nitems, (size_t)*map.count);
+    const size_t total = nitems * (size_t)polys * 32;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const size_t item = g / ((size_t)polys * PB);
-        const uint32_t r = (uint32_t)(g % ((size_t)polys * PB)), poly = r / PB, j = r % PB;
-        const int32_t* src = in + (item * polys + poly) * 256;
-        const uint32_t bit0 = 8 * j;
-        uint32_t acc = 0;
-        for (uint32_t i = bit0 / BITS; i * BITS < bit0 + 8 && i < 256; i++) {
-            int32_t v = src[i] % QC;                                   // any representative
+        const size_t item = g / ((size_t)polys * 32);
+        const uint32_t r = (uint32_t)(g % ((size_t)polys * 32)), poly = r >> 5, grp = r & 31;
+        const size_t irow = map.src_row ? (size_t)map.src_row[item] : item, orow = map.dst_row ? (size_t)map.dst_row[item] : item;
+        const int4* src = reinterpret_cast<const int4*>(in + (irow * polys + poly) * 256 + grp * 8);
+        const int4 lo = src[0], hi = src[1];
+        const int32_t c[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int32_t v = c[i] % QC;                                     // any representative
             v += (v >> 31) & QC;                                       // canonical
             v -= (((QC - 1) / 2 - v) >> 31) & QC;                      // centred
-            uint32_t f = (uint32_t)(xf == XF_OFFSET_MINUS ? offset - v : v) & ((1u << BITS) - 1);
-            const int rel = (int)(i * BITS) - (int)bit0;               // field start relative to this byte
-            acc |= rel >= 0 ? f << rel : f >> (-rel);
+            const uint32_t f = (uint32_t)(xf == XF_OFFSET_MINUS ? offset - v : v) & ((1u << BITS) - 1);
+            const int bit = i * BITS, wi = bit >> 5, sh = bit & 31;
+            w[wi] |= f << sh;
+            if (sh + BITS > 32) w[wi + 1] |= f >> (32 - sh);
         }
-        out[item * out_stride + out_offset + (size_t)poly * PB + j] = (uint8_t)acc;
+        uint8_t* dst = out + orow * out_stride + out_offset + (size_t)poly * (32 * BITS) + (size_t)grp * BITS;
+#pragma unroll
+        for (int bt = 0; bt < BITS; bt++) dst[bt] = (uint8_t)(w[bt >> 2] >> (8 * (bt & 3)));
     }
 }
 
@@ -122,13 +130,15 @@ __global__ __launch_bounds__(256) void hint_unpack_kernel(uint8_t* __restrict__ 
 
 // pack: h [K][256] bytes -> omega + K bytes (makehint.v:104-150).  One wave per item.
 __global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
-                                                        const uint8_t* __restrict__ h, int K, int omega, size_t nitems)
+                                                        const uint8_t* __restrict__ h, int K, int omega, size_t nitems, RowMap map)
 {
     const int lane = threadIdx.x & 63;
     const size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (map.count) nitems = min(nitems, (size_t)*map.count);
     if (it >= nitems) return;
-    uint8_t* dst = out + it * out_stride + out_offset;
-    const uint8_t* src = h + it * (size_t)K * 256;
+    const size_t irow = map.src_row ? (size_t)map.src_row[it] : it, orow = map.dst_row ? (size_t)map.dst_row[it] : it;
+    uint8_t* dst = out + orow * out_stride + out_offset;
+    const uint8_t* src = h + irow * (size_t)K * 256;
     for (int t = lane; t < omega + K; t += 64) dst[t] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     int count = 0;                                   // wave-uniform
@@ -212,48 +222,67 @@ __global__ __launch_bounds__(256) void power2round_kernel(int32_t* __restrict__ 
 // strided byte copy: dst[item][dst_off .. +n) = src[item][src_off .. +n)
 __global__ __launch_bounds__(256) void copy_field_kernel(uint8_t* __restrict__ dst, size_t dst_stride, size_t dst_off,
                                                          const uint8_t* __restrict__ src, size_t src_stride, size_t src_off,
-                                                         int nbytes, size_t nitems)
+                                                         int nbytes, size_t nitems, RowMap map)
 {
+    if (map.count) nitems = min(nitems, (size_t)*map.count);
     const size_t total = nitems * (size_t)nbytes;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
         const size_t item = g / (size_t)nbytes, b = g % (size_t)nbytes;
-        dst[item * dst_stride + dst_off + b] = src[item * src_stride + src_off + b];
+        const size_t irow = map.src_row ? (size_t)map.src_row[item] : item, orow = map.dst_row ? (size_t)map.dst_row[item] : item;
+        dst[orow * dst_stride + dst_off + b] = src[irow * src_stride + src_off + b];
     }
 }
 
-// dst[i] = src[idx[i]] for rows of `row_vec` VEC-sized words (rejection-loop compaction, row N3)
+// Rejection-loop bookkeeping (row N3).  A round works on E = n * S "entries": entry e is attempt
+// number a0 + e / n of pending item e % n (attempt-major, so one attempt's entries are contiguous).
+//
+// dst[e] = src[item(e % n)] for rows of `row_vec` VEC-sized words; item(i) = idx ? idx[i] : i
 template <typename VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(VEC* __restrict__ dst, const VEC* __restrict__ src,
-                                                          const int32_t* __restrict__ idx, size_t row_vec, size_t n)
+                                                          const int32_t* __restrict__ idx, size_t row_vec, size_t n, size_t entries)
 {
-    const size_t total = n * row_vec;
+    const size_t total = entries * row_vec;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const size_t i = g / row_vec, w = g % row_vec;
-        dst[g] = src[(size_t)idx[i] * row_vec + w];
+        const size_t e = g / row_vec, w = g % row_vec, i = e % n;
+        dst[g] = src[(size_t)(idx ? idx[i] : (int32_t)i) * row_vec + w];
     }
 }
 
-// One wave per pending signature: accepted (flags == 0) -> copy the packed signature to its
-// final slot and record the attempt count; rejected -> append the item to the next pending list.
-__global__ __launch_bounds__(64) void sign_collect_kernel(uint8_t* __restrict__ sig, size_t sig_bytes, int32_t* __restrict__ attempts,
-                                                          int32_t* __restrict__ next_idx, int32_t* __restrict__ next_count,
-                                                          const uint8_t* __restrict__ sig_c, const int32_t* __restrict__ flags,
-                                                          const int32_t* __restrict__ idx, int attempt_no, size_t n)
+// kappa[e] = (a0 + e / n) * L      (the reference's y-nonce counter advances by L per attempt)
+__global__ __launch_bounds__(256) void sign_kappa_kernel(uint32_t* __restrict__ kappa, uint32_t a0, uint32_t L, size_t n, size_t entries)
 {
-    const size_t i = blockIdx.x;
-    const int lane = threadIdx.x;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < entries) kappa[e] = (a0 + (uint32_t)(e / n)) * L;
+}
+
+// One thread per pending item: the FIRST accepted of its S speculative attempts wins -> the
+// (entry, item) pair goes on the winners list (packed into the item's signature slot by the
+// RowMap-driven codec launches that follow) and the attempt count is recorded; none accepted ->
+// the item goes on the next pending list.  counts[0] = pending, counts[1] = winners.
+__global__ __launch_bounds__(256) void sign_collect_kernel(int32_t* __restrict__ attempts, int32_t* __restrict__ next_idx,
+                                                           int32_t* __restrict__ win_entry, int32_t* __restrict__ win_item,
+                                                           int32_t* __restrict__ counts, const int32_t* __restrict__ flags,
+                                                           const int32_t* __restrict__ idx, int a0, int S, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t item = idx ? idx[i] : (int32_t)i;
-    if (flags[i] != 0) {
-        if (lane == 0) next_idx[atomicAdd(next_count, 1)] = item;
-        return;
+    int win = -1;
+    for (int j = 0; j < S; j++)
+        if (flags[(size_t)j * n + i] == 0) {
+            win = j;
+            break;
+        }
+    if (win < 0) {
+        next_idx[atomicAdd(&counts[0], 1)] = item;
+    } else {
+        const int w = atomicAdd(&counts[1], 1);
+        win_entry[w] = (int32_t)((size_t)win * n + i);
+        win_item[w] = item;
+        attempts[item] = a0 + win + 1;
     }
-    const uint8_t* src = sig_c + i * sig_bytes;
-    uint8_t* dst = sig + (size_t)item * sig_bytes;
-    for (size_t t = lane; t < sig_bytes; t += 64) dst[t] = src[t];
-    if (lane == 0) attempts[item] = attempt_no;
 }
 
 // verdict[i] |= flag[i] ? bit : 0
@@ -279,31 +308,39 @@ hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t
     return hipGetLastError();
 }
 
-hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, const Tables& t, hipStream_t s)
+hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, size_t entries,
+                              const Tables& t, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    const bool a16 = row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
-    if (a16) {
+    if (entries == 0) return hipSuccess;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | row_bytes;
+    if (al % 16 == 0) {
         const size_t rv = row_bytes / 16;
-        hipLaunchKernelGGL(gather_rows_kernel<uint4>, grid1d(n * rv, t), 256, 0, s, static_cast<uint4*>(dst),
-                           static_cast<const uint4*>(src), idx, rv, n);
-    } else if (row_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 8 == 0) {
+        hipLaunchKernelGGL(gather_rows_kernel<uint4>, grid1d(entries * rv, t), 256, 0, s, static_cast<uint4*>(dst),
+                           static_cast<const uint4*>(src), idx, rv, n, entries);
+    } else if (al % 8 == 0) {
         const size_t rv = row_bytes / 8;
-        hipLaunchKernelGGL(gather_rows_kernel<uint2>, grid1d(n * rv, t), 256, 0, s, static_cast<uint2*>(dst),
-                           static_cast<const uint2*>(src), idx, rv, n);
+        hipLaunchKernelGGL(gather_rows_kernel<uint2>, grid1d(entries * rv, t), 256, 0, s, static_cast<uint2*>(dst),
+                           static_cast<const uint2*>(src), idx, rv, n, entries);
     } else {
-        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid1d(n * row_bytes, t), 256, 0, s, static_cast<uint8_t*>(dst),
-                           static_cast<const uint8_t*>(src), idx, row_bytes, n);
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid1d(entries * row_bytes, t), 256, 0, s, static_cast<uint8_t*>(dst),
+                           static_cast<const uint8_t*>(src), idx, row_bytes, n, entries);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_sign_collect(uint8_t* sig, size_t sig_bytes, int32_t* attempts, int32_t* next_idx, int32_t* next_count,
-                               const uint8_t* sig_c, const int32_t* flags, const int32_t* idx, int attempt_no, size_t n, hipStream_t s)
+hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, size_t n, size_t entries, hipStream_t s)
+{
+    if (entries == 0) return hipSuccess;
+    hipLaunchKernelGGL(sign_kappa_kernel, (int)((entries + 255) / 256), 256, 0, s, kappa, a0, L, n, entries);
+    return hipGetLastError();
+}
+
+hipError_t launch_sign_collect(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
+                               const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(sign_collect_kernel, (int)n, 64, 0, s, sig, sig_bytes, attempts, next_idx, next_count, sig_c, flags, idx,
-                       attempt_no, n);
+    hipLaunchKernelGGL(sign_collect_kernel, (int)((n + 255) / 256), 256, 0, s, attempts, next_idx, win_entry, win_item, counts, flags,
+                       idx, a0, S, n);
     return hipGetLastError();
 }
 
@@ -322,11 +359,11 @@ hipError_t launch_unpack(int bits, int32_t* out, const uint8_t* in, size_t in_st
 }
 
 hipError_t launch_pack(int bits, uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int polys, int xf,
-                       int32_t offset, size_t nitems, const Tables& t, hipStream_t s)
+                       int32_t offset, size_t nitems, const Tables& t, hipStream_t s, RowMap map)
 {
     if (nitems == 0) return hipSuccess;
-    const int g = grid1d(nitems * (size_t)polys * 32 * bits, t);
-#define DIL_PK(B) case B: hipLaunchKernelGGL(pack_kernel<B>, g, 256, 0, s, out, out_stride, out_offset, in, polys, xf, offset, nitems); break
+    const int g = grid1d(nitems * (size_t)polys * 32, t);
+#define DIL_PK(B) case B: hipLaunchKernelGGL(pack_kernel<B>, g, 256, 0, s, out, out_stride, out_offset, in, polys, xf, offset, nitems, map); break
     switch (bits) {
         DIL_PK(3); DIL_PK(4); DIL_PK(6); DIL_PK(10); DIL_PK(13); DIL_PK(18); DIL_PK(20);
     default: return hipErrorInvalidValue;
@@ -344,10 +381,10 @@ hipError_t launch_hint_unpack(uint8_t* h, int32_t* bad, const uint8_t* in, size_
 }
 
 hipError_t launch_hint_pack(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int K, int omega, size_t nitems,
-                            hipStream_t s)
+                            hipStream_t s, RowMap map)
 {
     if (nitems == 0) return hipSuccess;
-    hipLaunchKernelGGL(hint_pack_kernel, (int)((nitems + 3) / 4), 256, 0, s, out, out_stride, out_offset, h, K, omega, nitems);
+    hipLaunchKernelGGL(hint_pack_kernel, (int)((nitems + 3) / 4), 256, 0, s, out, out_stride, out_offset, h, K, omega, nitems, map);
     return hipGetLastError();
 }
 
@@ -368,11 +405,11 @@ hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const 
 }
 
 hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,
-                             int nbytes, size_t nitems, const Tables& t, hipStream_t s)
+                             int nbytes, size_t nitems, const Tables& t, hipStream_t s, RowMap map)
 {
     if (nitems == 0 || nbytes == 0) return hipSuccess;
     hipLaunchKernelGGL(copy_field_kernel, grid1d(nitems * (size_t)nbytes, t), 256, 0, s, dst, dst_stride, dst_off, src, src_stride,
-                       src_off, nbytes, nitems);
+                       src_off, nbytes, nitems, map);
     return hipGetLastError();
 }
 

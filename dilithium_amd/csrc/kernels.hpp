@@ -46,22 +46,31 @@ hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t b
 
 // ---- rows N2 / N4: codecs, ExpandS, Power2Round (codec_kernels.hip) ----
 enum { XF_PLAIN = 0, XF_OFFSET_MINUS = 1 };
+// optional row indirection of the pack-side codecs (the signing loop packs only the accepted attempts):
+// work item w reads input row src_row[w], writes output row dst_row[w]; *count (device) bounds w
+struct RowMap {
+    const int32_t* src_row = nullptr;
+    const int32_t* dst_row = nullptr;
+    const int32_t* count = nullptr;
+};
 hipError_t launch_unpack(int bits, int32_t* out, const uint8_t* in, size_t in_stride, size_t in_offset, int polys, int xf,
                          int32_t offset, size_t nitems, const Tables& t, hipStream_t s);
 hipError_t launch_pack(int bits, uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int polys, int xf,
-                       int32_t offset, size_t nitems, const Tables& t, hipStream_t s);
+                       int32_t offset, size_t nitems, const Tables& t, hipStream_t s, RowMap map = RowMap());
 hipError_t launch_hint_unpack(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int K, int omega,
                               size_t nitems, hipStream_t s);
 hipError_t launch_hint_pack(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int K, int omega, size_t nitems,
-                            hipStream_t s);
+                            hipStream_t s, RowMap map = RowMap());
 hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_stride, int eta, int nonce0, int polys, size_t nitems,
                            hipStream_t s);
 hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const int32_t* s2, size_t n, const Tables& t, hipStream_t s);
 hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t n, const Tables& t, hipStream_t s);
-hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, const Tables& t, hipStream_t s);
-hipError_t launch_sign_collect(uint8_t* sig, size_t sig_bytes, int32_t* attempts, int32_t* next_idx, int32_t* next_count,
-                               const uint8_t* sig_c, const int32_t* flags, const int32_t* idx, int attempt_no, size_t n, hipStream_t s);
+hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, size_t entries,
+                              const Tables& t, hipStream_t s);
+hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, size_t n, size_t entries, hipStream_t s);
+hipError_t launch_sign_collect(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
+                               const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, hipStream_t s);
 hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,
-                             int nbytes, size_t nitems, const Tables& t, hipStream_t s);
+                             int nbytes, size_t nitems, const Tables& t, hipStream_t s, RowMap map = RowMap());
 
 }  // namespace dil

@@ -283,3 +283,16 @@ def test_sign_unfinished(gpu, kat_msgs):
     mu = mus(k, kat_msgs)
     with pytest.raises(lib.DilError):
         api.sign(cu(gpu, sk), cu(gpu, mu), 3, max_attempts=1)
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_sign_single_and_small_batches(gpu, level, kat_msgs):
+    """batch 1 / 3 / 17: the speculative (wide) rounds must pick the same first-accepted attempt as the sequential loop"""
+    from dilithium_amd import api
+    k, pk, sk, sig = kat_wire(level)
+    mu = mus(k, kat_msgs)
+    worst = int(np.argmax(k["attempts"]))
+    for lo, hi in ((0, 1), (worst, worst + 1), (5, 8), (20, 37)):
+        got, att = api.sign(cu(gpu, sk[lo:hi]), cu(gpu, mu[lo:hi]), level)
+        assert (att.cpu().numpy() == k["attempts"][lo:hi]).all()
+        assert (got.cpu().numpy() == sig[lo:hi]).all()
