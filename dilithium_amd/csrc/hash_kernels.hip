@@ -24,36 +24,9 @@ __global__ __launch_bounds__(64) void shake256_batch_kernel(uint64_t* __restrict
     if (i >= batch) return;
     Shake<17> sp;
     sp.init();
-    const uint64_t* src = in + i * in_words;
-    int w = 0;
-    for (int k = 0; k < in_words; k++) {
-        const uint64_t v = src[k];
-#pragma unroll
-        for (int t = 0; t < 17; t++)
-            if (t == w) sp.s[t] ^= v;
-        if (++w == 17) {
-            sp.next_block();
-            w = 0;
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 17; t++)
-        if (t == w) sp.s[t] ^= 0x1Full;
-    sp.s[16] ^= 0x8000000000000000ull;
-    keccak_f1600(sp.s);
-    uint64_t* dst = out + i * out_words;
-    int o = 0;
-    for (int k = 0; k < out_words; k++) {
-        uint64_t v = 0;
-#pragma unroll
-        for (int t = 0; t < 17; t++)
-            if (t == o) v = sp.s[t];
-        dst[k] = v;
-        if (++o == 17 && k + 1 < out_words) {
-            sp.next_block();
-            o = 0;
-        }
-    }
+    const int fill = sp.absorb<0>(in + i * (size_t)in_words, in_words);
+    sp.finish_words(fill);
+    sp.squeeze(out + i * (size_t)out_words, out_words);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -260,23 +233,8 @@ __global__ __launch_bounds__(64) void challenge_hash_kernel(uint64_t* __restrict
     sp.init();
 #pragma unroll
     for (int t = 0; t < 8; t++) sp.s[t] = mu[i * 8 + t];
-    int w = 8;
-    const uint64_t* src = w1p + i * (size_t)w1_words;
-    for (int k = 0; k < w1_words; k++) {
-        const uint64_t v = src[k];
-#pragma unroll
-        for (int t = 0; t < 17; t++)
-            if (t == w) sp.s[t] ^= v;
-        if (++w == 17) {
-            sp.next_block();
-            w = 0;
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 17; t++)
-        if (t == w) sp.s[t] ^= 0x1Full;
-    sp.s[16] ^= 0x8000000000000000ull;
-    keccak_f1600(sp.s);
+    const int fill = sp.absorb<8>(w1p + i * (size_t)w1_words, w1_words);
+    sp.finish_words(fill);
     if (expect) {
         const uint64_t d = (sp.s[0] ^ expect[i * 4]) | (sp.s[1] ^ expect[i * 4 + 1]) | (sp.s[2] ^ expect[i * 4 + 2]) |
                            (sp.s[3] ^ expect[i * 4 + 3]);

@@ -18,7 +18,22 @@ __device__ __constant__ uint64_t KECCAK_RC[24] = {
     0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
     0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// 64-bit rotate by a compile-time amount as two v_alignbit_b32 (the compiler's own lowering is a
+// pair of 64-bit shifts + or, which are slow multi-pass ops on CDNA)
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n)
+{
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (n == 32) return ((uint64_t)lo << 32) | hi;
+    uint32_t rl, rh;
+    if (n < 32) {
+        rh = __builtin_amdgcn_alignbit(hi, lo, 32 - n);
+        rl = __builtin_amdgcn_alignbit(lo, hi, 32 - n);
+    } else {
+        rh = __builtin_amdgcn_alignbit(lo, hi, 64 - n);
+        rl = __builtin_amdgcn_alignbit(hi, lo, 64 - n);
+    }
+    return ((uint64_t)rh << 32) | rl;
+}
 
 // 24 rounds; the round body is fully unrolled (static lane indices keep the state in registers),
 // the round loop is not (2 KB of code instead of 50 KB)
@@ -31,8 +46,10 @@ __device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25])
         uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
         uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
         uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
-        const uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1),
-                       d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1),
+                 d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+        // keep d materialised: LLVM otherwise re-associates a ^= (c ^ rot c') into two xors per lane word
+        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4));
 #pragma unroll
         for (int y = 0; y < 25; y += 5) {
             a[y] ^= d0; a[y + 1] ^= d1; a[y + 2] ^= d2; a[y + 3] ^= d3; a[y + 4] ^= d4;
@@ -87,6 +104,62 @@ struct Shake {
             if (w == (pos >> 3)) s[w] ^= v << (8 * (pos & 7));
     }
     __device__ __forceinline__ void next_block() { keccak_f1600(s); }
+
+    // Absorb `n` 64-bit words from src into a sponge whose current block already holds W0 words
+    // (compile time), permuting after each full block; returns the fill of the last, partial block.
+    // Whole blocks are absorbed with static state indices and all RATE_WORDS loads in flight at once
+    // (n is wave-uniform, so the partial tail is a run of scalar-predicated static accesses too).
+    template <int W0>
+    __device__ __forceinline__ int absorb(const uint64_t* __restrict__ src, int n)
+    {
+        int k = 0;
+        if (W0 != 0) {
+            if (n < RATE_WORDS - W0) {
+#pragma unroll
+                for (int t = W0; t < RATE_WORDS; t++)
+                    if (t - W0 < n) s[t] ^= src[t - W0];
+                return W0 + n;
+            }
+#pragma unroll
+            for (int t = W0; t < RATE_WORDS; t++) s[t] ^= src[t - W0];
+            keccak_f1600(s);
+            k = RATE_WORDS - W0;
+        }
+#pragma unroll 1
+        for (; k + RATE_WORDS <= n; k += RATE_WORDS) {
+            uint64_t v[RATE_WORDS];
+#pragma unroll
+            for (int t = 0; t < RATE_WORDS; t++) v[t] = src[k + t];
+#pragma unroll
+            for (int t = 0; t < RATE_WORDS; t++) s[t] ^= v[t];
+            keccak_f1600(s);
+        }
+        const int r = n - k;
+#pragma unroll
+        for (int t = 0; t < RATE_WORDS - 1; t++)
+            if (t < r) s[t] ^= src[k + t];
+        return r;
+    }
+    // pad (SHAKE suffix) after a message that left `fill` whole words in the current block, permute
+    __device__ __forceinline__ void finish_words(int fill)
+    {
+#pragma unroll
+        for (int t = 0; t < RATE_WORDS; t++)
+            if (t == fill) s[t] ^= 0x1Full;
+        s[RATE_WORDS - 1] ^= 0x8000000000000000ull;
+        keccak_f1600(s);
+    }
+    // squeeze n words to dst (n wave-uniform)
+    __device__ __forceinline__ void squeeze(uint64_t* __restrict__ dst, int n)
+    {
+#pragma unroll 1
+        for (int k = 0; k < n; k += RATE_WORDS) {
+            if (k) keccak_f1600(s);
+#pragma unroll
+            for (int t = 0; t < RATE_WORDS; t++)
+                if (k + t < n) dst[k + t] = s[t];
+        }
+    }
 };
 
 }  // namespace dil
