@@ -160,10 +160,10 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ ou
 // eta = 2: nibble < 15 -> 2 - (nibble mod 5);  eta = 4: nibble < 9 -> 4 - nibble.  Canonical out.
 // One lane per polynomial.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void expand_s_kernel(int32_t* __restrict__ s, const uint8_t* __restrict__ rhoprime,
+__global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__ s, const uint8_t* __restrict__ rhoprime,
                                                       size_t rp_stride, int eta, int nonce0, int polys, size_t nitems)
 {
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t p = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     const bool live = p < nitems * (size_t)polys;
     const size_t item = live ? p / (size_t)polys : 0;
     const uint32_t nonce = (uint32_t)(nonce0 + (int)(p % (size_t)polys));
@@ -393,7 +393,7 @@ hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_str
 {
     if (nitems == 0) return hipSuccess;
     const size_t total = nitems * (size_t)polys;
-    hipLaunchKernelGGL(expand_s_kernel, (int)((total + 63) / 64), 64, 0, s, sout, rhoprime, rp_stride, eta, nonce0, polys, nitems);
+    hipLaunchKernelGGL(expand_s_kernel, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, sout, rhoprime, rp_stride, eta, nonce0, polys, nitems);
     return hipGetLastError();
 }
 

@@ -17,10 +17,10 @@ constexpr uint32_t QU = 8380417u;
 // generic batched SHAKE256 with one input length for the whole batch:
 //   out[i][0..out_bytes) = SHAKE256(in[i][0..in_bytes)),  in_bytes, out_bytes multiples of 8
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void shake256_batch_kernel(uint64_t* __restrict__ out, int out_words,
+__global__ __launch_bounds__(HASH_BS) void shake256_batch_kernel(uint64_t* __restrict__ out, int out_words,
                                                             const uint64_t* __restrict__ in, int in_words, size_t batch)
 {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     if (i >= batch) return;
     Shake<17> sp;
     sp.init();
@@ -39,10 +39,10 @@ __device__ __forceinline__ void emit23(uint32_t v, int32_t* __restrict__ dst, in
     if (v < QU && cnt < 256) dst[cnt++] = (int32_t)v;
 }
 
-__global__ __launch_bounds__(64) void expand_a_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
+__global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
                                                       size_t rho_stride_words, int K, int L, size_t nitems)
 {
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t p = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     const size_t total = nitems * (size_t)(K * L);
     const bool live = p < total;
     const size_t item = live ? p / (size_t)(K * L) : 0;
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(64) void expand_a_kernel(int32_t* __restrict__ A, c
 // B = 18 (gamma1 = 2^17) or 20 (2^19) bits.  Output canonical in [0, q).  One lane per polynomial.
 // ---------------------------------------------------------------------------------------
 template <int B>
-__global__ __launch_bounds__(64) void expand_mask_kernel(int32_t* __restrict__ y, const uint64_t* __restrict__ rhoprime,
+__global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restrict__ y, const uint64_t* __restrict__ rhoprime,
                                                          const uint32_t* __restrict__ kappa, int L, size_t nitems)
 {
     constexpr int32_t GAMMA1 = 1 << (B - 1);
     constexpr uint64_t MASK = (1ull << B) - 1;
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t p = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     if (p >= nitems * (size_t)L) return;
     const size_t item = p / (size_t)L;
     const uint32_t nonce = (kappa[item] + (uint32_t)(p % (size_t)L)) & 0xFFFFu;
@@ -223,11 +223,11 @@ __global__ __launch_bounds__(256) void pack_w1_kernel(uint32_t* __restrict__ out
 // expect == nullptr : write the 32-byte digest to out32[i]
 // expect != nullptr : verdict[i] |= (digest != expect[i])        (VY_COMPARE, combined_top.v:1501)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void challenge_hash_kernel(uint64_t* __restrict__ out32, int32_t* __restrict__ verdict,
+__global__ __launch_bounds__(HASH_BS) void challenge_hash_kernel(uint64_t* __restrict__ out32, int32_t* __restrict__ verdict,
                                                             const uint64_t* __restrict__ mu, const uint64_t* __restrict__ w1p,
                                                             int w1_words, const uint64_t* __restrict__ expect, size_t batch)
 {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     if (i >= batch) return;
     Shake<17> sp;
     sp.init();
@@ -278,7 +278,7 @@ hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
     const int words = K * (level == 2 ? 192 : 128) / 8;
-    hipLaunchKernelGGL(challenge_hash_kernel, (int)((batch + 63) / 64), 64, 0, s, reinterpret_cast<uint64_t*>(out32), verdict,
+    hipLaunchKernelGGL(challenge_hash_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint64_t*>(out32), verdict,
                        reinterpret_cast<const uint64_t*>(mu), reinterpret_cast<const uint64_t*>(w1p), words,
                        reinterpret_cast<const uint64_t*>(expect), batch);
     return hipGetLastError();
@@ -298,7 +298,7 @@ hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int
 {
     if (batch == 0) return hipSuccess;
     if ((out_bytes & 7) || (in_bytes & 7) || out_bytes <= 0 || in_bytes < 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(shake256_batch_kernel, (int)((batch + 63) / 64), 64, 0, s, out, out_bytes / 8, in, in_bytes / 8, batch);
+    hipLaunchKernelGGL(shake256_batch_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, out, out_bytes / 8, in, in_bytes / 8, batch);
     return hipGetLastError();
 }
 
@@ -309,7 +309,7 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const size_t total = nitems * (size_t)(K * L);
-    hipLaunchKernelGGL(expand_a_kernel, (int)((total + 63) / 64), 64, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
+    hipLaunchKernelGGL(expand_a_kernel, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
     return hipGetLastError();
 }
 
@@ -319,9 +319,9 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t total = nitems * (size_t)L;
-    const int grid = (int)((total + 63) / 64);
-    if (level == 2) hipLaunchKernelGGL(expand_mask_kernel<18>, grid, 64, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
-    else hipLaunchKernelGGL(expand_mask_kernel<20>, grid, 64, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
+    const int grid = (int)((total + HASH_BS - 1) / HASH_BS);
+    if (level == 2) hipLaunchKernelGGL(expand_mask_kernel<18>, grid, HASH_BS, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
+    else hipLaunchKernelGGL(expand_mask_kernel<20>, grid, HASH_BS, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
     return hipGetLastError();
 }
 

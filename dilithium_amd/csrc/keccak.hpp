@@ -10,6 +10,9 @@
 
 namespace dil {
 
+// threads per workgroup of the lane-per-sponge kernels (one wave; 256 measured no better, profiles/r01_keccak_rates.txt)
+constexpr int HASH_BS = 64;
+
 __device__ __constant__ uint64_t KECCAK_RC[24] = {
     0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
     0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
