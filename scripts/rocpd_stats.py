@@ -11,7 +11,7 @@ def main():
     rows = cur.execute(
         "select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start), "
         "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) "
-        "from kernels group by name order by 6 desc").fetchall()
+        "from kernels group by name, grid_x order by 6 desc").fetchall()   # one row per (kernel, launch size)
     tot = sum(r[5] for r in rows) or 1
     lines = [f"{'kernel':72s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'total_ms':>9s} {'%':>6s} "
              f"{'vgpr':>5s} {'sgpr':>5s} {'lds':>6s} {'grid':>8s} {'wg':>5s}"]
