@@ -365,3 +365,37 @@ def sign(sk, mu, level, shared_sk=False, max_attempts=512):
     _lib.check(_lib.load().dil_sign_dev(_dev(sig, torch.uint8), _dev(att, torch.int32), _dev(sk, torch.uint8), _dev(mu, torch.uint8),
                                         level, B, int(shared_sk), max_attempts, _stream()), "dil_sign_dev")
     return sig, att
+
+
+# ---- host-buffer forms (numpy uint8 arrays in, numpy out) ---------------------------------------------
+def _np8(a, cols=None):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags.c_contiguous and a.ndim == 2):
+        raise ValueError("expected a C-contiguous 2-D numpy uint8 array")
+    if cols is not None and a.shape[1] != cols:
+        raise ValueError(f"expected rows of {cols} bytes, got {a.shape[1]}")
+    return C.c_void_p(a.ctypes.data)
+
+
+def keygen_host(seed, level):
+    B = seed.shape[0]
+    pk = np.empty((B, pk_bytes(level)), dtype=np.uint8)
+    sk = np.empty((B, sk_bytes(level)), dtype=np.uint8)
+    _lib.check(_lib.load().dil_keygen_host(_np8(pk), _np8(sk), _np8(seed, 32), level, B), "dil_keygen_host")
+    return pk, sk
+
+
+def sign_host(sk, mu, level, shared_sk=False, max_attempts=512):
+    B = mu.shape[0]
+    sig = np.empty((B, sig_bytes(level)), dtype=np.uint8)
+    att = np.empty((B,), dtype=np.int32)
+    _lib.check(_lib.load().dil_sign_host(_np8(sig), C.c_void_p(att.ctypes.data), _np8(sk, sk_bytes(level)), _np8(mu, 64), level, B,
+                                         int(shared_sk), max_attempts), "dil_sign_host")
+    return sig, att
+
+
+def verify_sig_host(pk, sig, mu, level, shared_pk=False):
+    B = sig.shape[0]
+    verdict = np.empty((B,), dtype=np.int32)
+    _lib.check(_lib.load().dil_verify_sig_host(C.c_void_p(verdict.ctypes.data), _np8(pk, pk_bytes(level)), _np8(sig, sig_bytes(level)),
+                                               _np8(mu, 64), level, B, int(shared_pk)), "dil_verify_sig_host")
+    return verdict

@@ -805,6 +805,77 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     return n == 0 ? 0 : DIL_ERR_UNFINISHED;
 }
 
+// ---- host-buffer forms of the whole operations (H2D -> device call -> D2H on the null stream) --------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    int alloc(size_t bytes) { return (int)hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+int dil_keygen_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch)
+{
+    const size_t pkb = dil_pk_bytes(level), skb = dil_sk_bytes(level);
+    if (!pkb) return (int)hipErrorInvalidValue;
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevBuf dpk, dsk, dseed;
+    if ((rc = dpk.alloc(batch * pkb)) || (rc = dsk.alloc(batch * skb)) || (rc = dseed.alloc(batch * 32))) return rc;
+    DIL_TRY(hipMemcpy(dseed.p, seed, batch * 32, hipMemcpyHostToDevice));
+    rc = dil_keygen_dev(static_cast<uint8_t*>(dpk.p), static_cast<uint8_t*>(dsk.p), static_cast<uint8_t*>(dseed.p), level, batch, nullptr);
+    if (rc) return rc;
+    DIL_TRY(hipMemcpy(pk, dpk.p, batch * pkb, hipMemcpyDeviceToHost));
+    DIL_TRY(hipMemcpy(sk, dsk.p, batch * skb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                  int max_attempts)
+{
+    const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level);
+    if (!skb) return (int)hipErrorInvalidValue;
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t nk = shared_sk ? 1 : batch;
+    DevBuf dsig, datt, dsk, dmu;
+    if ((rc = dsig.alloc(batch * sgb)) || (rc = datt.alloc(batch * 4)) || (rc = dsk.alloc(nk * skb)) || (rc = dmu.alloc(batch * 64)))
+        return rc;
+    DIL_TRY(hipMemcpy(dsk.p, sk, nk * skb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dmu.p, mu, batch * 64, hipMemcpyHostToDevice));
+    const int src = dil_sign_dev(static_cast<uint8_t*>(dsig.p), static_cast<int32_t*>(datt.p), static_cast<uint8_t*>(dsk.p),
+                                 static_cast<uint8_t*>(dmu.p), level, batch, shared_sk, max_attempts, nullptr);
+    if (src && src != DIL_ERR_UNFINISHED) return src;
+    DIL_TRY(hipDeviceSynchronize());
+    DIL_TRY(hipMemcpy(sig, dsig.p, batch * sgb, hipMemcpyDeviceToHost));
+    if (attempts) DIL_TRY(hipMemcpy(attempts, datt.p, batch * 4, hipMemcpyDeviceToHost));
+    return src;
+}
+
+int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                        int shared_pk)
+{
+    const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
+    if (!pkb) return (int)hipErrorInvalidValue;
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t nk = shared_pk ? 1 : batch;
+    DevBuf dv, dpk, dsig, dmu;
+    if ((rc = dv.alloc(batch * 4)) || (rc = dpk.alloc(nk * pkb)) || (rc = dsig.alloc(batch * sgb)) || (rc = dmu.alloc(batch * 64)))
+        return rc;
+    DIL_TRY(hipMemcpy(dpk.p, pk, nk * pkb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dsig.p, sig, batch * sgb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dmu.p, mu, batch * 64, hipMemcpyHostToDevice));
+    rc = dil_verify_sig_dev(static_cast<int32_t*>(dv.p), static_cast<uint8_t*>(dpk.p), static_cast<uint8_t*>(dsig.p),
+                            static_cast<uint8_t*>(dmu.p), level, batch, shared_pk, nullptr);
+    if (rc) return rc;
+    DIL_TRY(hipMemcpy(verdict, dv.p, batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // ---- events --------------------------------------------------------------------------------------
 int dil_event_create(void** ev)
 {

@@ -456,9 +456,7 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     }
 }
 
-#ifndef DIL_SHARED_TWREG
-#define DIL_SHARED_TWREG 0
-#endif
+// (twiddles in registers instead of LDS were tried in the shared-key kernels: no gain, the verify variant spilled)
 // ---------------------------------------------------------------------------------------
 // Shared-key wave-per-item kernels.  When one key serves the whole batch (one signer, or many
 // signatures under one public key) its NTT-domain material -- A [K][L] (+ t1^ for verify; s1^,
@@ -498,13 +496,7 @@ __global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
     stage_tables(lds, fwd_tab, inv_tab);
     uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
     stage_polys(Al, A, K * L);
-#if DIL_SHARED_TWREG
-    TwRegs twf, twi;
-    twf.load(fwd_tab, lane);
-    twi.load(inv_tab, lane);
-#else
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-#endif
     const LaneMasks lm(lane);
     uint32_t* yl = Al + K * L * 256 + wv * (L * 256);
     uint32_t* sc = Al + (K * L + NW * L) * 256 + wv * 64;   // byte-plane scratch
@@ -549,13 +541,7 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
     uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
     uint32_t* Tl = Al + K * L * 256;
     stage_polys(Al, A, K * L);
-#if DIL_SHARED_TWREG
-    TwRegs twf, twi;
-    twf.load(fwd_tab, lane);
-    twi.load(inv_tab, lane);
-#else
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-#endif
     const LaneMasks lm(lane);
     uint32_t* zl = Tl + K * 256 + wv * (L * 256);
     uint32_t* sc = Tl + (K + NW * L) * 256 + wv * 64;        // byte-plane scratch

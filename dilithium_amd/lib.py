@@ -60,6 +60,9 @@ SIGNATURES = {
     "dil_sig_bytes": [C.c_int],
     "dil_verify_sig_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
+    "dil_keygen_host": [_vp, _vp, _vp, C.c_int, _sz],
+    "dil_sign_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int],
+    "dil_verify_sig_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int],
     "dil_verify_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_attempt_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_event_create": [C.POINTER(_vp)],

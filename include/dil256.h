@@ -158,6 +158,14 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
 int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
                  int max_attempts, void* stream);
 
+/* host-buffer forms of the three whole operations (what the reference's test benches tb_keygen_top.v / tb_sign_top.v /
+ * tb_verify_top.v stream through the 64-bit port): H2D, the device call, D2H; synchronous */
+int dil_keygen_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch);
+int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                  int max_attempts);
+int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                        int shared_pk);
+
 /* ---- SURVEY 8(f) row N3 (first step): whole verify / sign-attempt sequences as ONE call --------
  * Everything between the wire-format codecs runs on the device, on `stream`, with no host round trip;
  * temporaries come from the stream-ordered allocator (hipMallocAsync) and are freed on the stream.

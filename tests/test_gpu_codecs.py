@@ -296,3 +296,24 @@ def test_sign_single_and_small_batches(gpu, level, kat_msgs):
         got, att = api.sign(cu(gpu, sk[lo:hi]), cu(gpu, mu[lo:hi]), level)
         assert (att.cpu().numpy() == k["attempts"][lo:hi]).all()
         assert (got.cpu().numpy() == sig[lo:hi]).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_host_buffer_scheme_kat(gpu, level, kat_msgs):
+    """the host-pointer forms (numpy in, numpy out): the three operations of the reference's test benches on KAT bytes"""
+    from dilithium_amd import api
+    k, pk, sk, sig = kat_wire(level)
+    mu = mus(k, kat_msgs)
+    gpk, gsk = api.keygen_host(np.ascontiguousarray(k["seed"]), level)
+    assert (gpk == pk).all() and (gsk == sk).all()
+    gsig, att = api.sign_host(np.ascontiguousarray(sk), mu, level)
+    assert (gsig == sig).all() and (att == k["attempts"]).all()
+    v = api.verify_sig_host(np.ascontiguousarray(pk), gsig, mu, level)
+    assert (v == 0).all()
+    bad = gsig.copy()
+    bad[17, 50] ^= 2
+    assert list(np.nonzero(api.verify_sig_host(np.ascontiguousarray(pk), bad, mu, level))[0]) == [17]
+    # one key, several messages
+    s1, a1 = api.sign_host(np.ascontiguousarray(sk[:1]), mu[:9], level, shared_sk=True)
+    assert (api.verify_sig_host(np.ascontiguousarray(pk[:1]), s1, mu[:9], level, shared_pk=True) == 0).all()
+    assert (s1[0] == sig[0]).all()
