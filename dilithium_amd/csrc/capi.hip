@@ -538,14 +538,14 @@ struct AttemptScratch {
 };
 int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
-                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s)
+                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap())
 {
     DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, g.t, s));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, g.t, s, km));
     DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, g.t, s));
     DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
     DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
-    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s));
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s, km));
     return 0;
 }
 }  // namespace
@@ -724,8 +724,8 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
     const size_t a_row = (size_t)p.K * p.L * 1024, l_row = (size_t)p.L * 1024, k_row = (size_t)p.K * 1024;
     // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
-    // speculate for free; distinct keys also replicate ~80 KiB of key material per entry, so stay lower there
-    const size_t cap = std::max<size_t>(batch, g.sign_cap ? (size_t)g.sign_cap : (shared_sk ? 16384 : 4096));
+    // speculate for free
+    const size_t cap = std::max<size_t>(batch, g.sign_cap ? (size_t)g.sign_cap : 16384);
     const int s_max = 64;
     void *A, *s1h, *s2h, *t0h, *km, *rp, *idx0, *idx1, *cnt, *kap, *ct, *z, *h, *fl, *wine, *wini, *mu_c, *rp_c;
     AttemptScratch att;
@@ -750,7 +750,6 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(rp), 64, static_cast<uint64_t*>(km), 96, batch, s));
     DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
 
-    void *A_c = nullptr, *s1h_c = nullptr, *s2h_c = nullptr, *t0h_c = nullptr;
     int32_t *idx_cur = nullptr, *idx_next = static_cast<int32_t*>(idx0);
     size_t n = batch;
     int a0 = 0;                                          // attempts every pending item has already failed
@@ -758,29 +757,20 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         const int S_ = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
         const size_t E = n * (size_t)S_;
         const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
-        const int32_t *Ar = static_cast<int32_t*>(A), *s1r = static_cast<int32_t*>(s1h), *s2r = static_cast<int32_t*>(s2h),
-                      *t0r = static_cast<int32_t*>(t0h);
         const uint8_t *mur = mu, *rpr = static_cast<uint8_t*>(rp);
         if (!direct) {
-            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, n, E, g.t, s));
-            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, n, E, g.t, s));
+            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, g.t, s));
+            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, g.t, s));
             mur = static_cast<uint8_t*>(mu_c);
             rpr = static_cast<uint8_t*>(rp_c);
-            if (!shared_sk) {
-                if (!A_c && ((rc = ws.get(&A_c, cap * a_row)) || (rc = ws.get(&s1h_c, cap * l_row)) ||
-                             (rc = ws.get(&s2h_c, cap * k_row)) || (rc = ws.get(&t0h_c, cap * k_row))))
-                    return rc;
-                DIL_TRY(dil::launch_gather_rows(A_c, A, idx_cur, a_row, n, E, g.t, s));
-                DIL_TRY(dil::launch_gather_rows(s1h_c, s1h, idx_cur, l_row, n, E, g.t, s));
-                DIL_TRY(dil::launch_gather_rows(s2h_c, s2h, idx_cur, k_row, n, E, g.t, s));
-                DIL_TRY(dil::launch_gather_rows(t0h_c, t0h, idx_cur, k_row, n, E, g.t, s));
-                Ar = static_cast<int32_t*>(A_c); s1r = static_cast<int32_t*>(s1h_c);
-                s2r = static_cast<int32_t*>(s2h_c); t0r = static_cast<int32_t*>(t0h_c);
-            }
         }
-        DIL_TRY(dil::launch_sign_kappa(static_cast<uint32_t*>(kap), (uint32_t)a0, (uint32_t)p.L, n, E, s));
+        dil::KeyMap keys;                                // per-item keys are read in place through the pending list
+        keys.idx = idx_cur;
+        keys.S = (uint32_t)S_;
+        DIL_TRY(dil::launch_sign_kappa(static_cast<uint32_t*>(kap), (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
         rc = sign_attempt_impl(att, static_cast<uint8_t*>(ct), static_cast<int32_t*>(z), static_cast<uint8_t*>(h), static_cast<int32_t*>(fl),
-                               Ar, mur, rpr, static_cast<uint32_t*>(kap), s1r, s2r, t0r, level, E, shared_sk, s);
+                               static_cast<int32_t*>(A), mur, rpr, static_cast<uint32_t*>(kap), static_cast<int32_t*>(s1h),
+                               static_cast<int32_t*>(s2h), static_cast<int32_t*>(t0h), level, E, shared_sk, s, keys);
         if (rc) return rc;
         // winners (first accepted attempt per item) -> packed straight into their signature slots
         int32_t* counts = static_cast<int32_t*>(cnt);

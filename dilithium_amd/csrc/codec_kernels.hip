@@ -235,26 +235,27 @@ __global__ __launch_bounds__(256) void copy_field_kernel(uint8_t* __restrict__ d
 }
 
 // Rejection-loop bookkeeping (row N3).  A round works on E = n * S "entries": entry e is attempt
-// number a0 + e / n of pending item e % n (attempt-major, so one attempt's entries are contiguous).
+// number a0 + e % S of pending item e / S (item-major: the S attempts of one item are adjacent, so
+// their reads of the item's key material hit L2).
 //
-// dst[e] = src[item(e % n)] for rows of `row_vec` VEC-sized words; item(i) = idx ? idx[i] : i
+// dst[e] = src[item(e / S)] for rows of `row_vec` VEC-sized words; item(i) = idx ? idx[i] : i
 template <typename VEC>
 __global__ __launch_bounds__(256) void gather_rows_kernel(VEC* __restrict__ dst, const VEC* __restrict__ src,
-                                                          const int32_t* __restrict__ idx, size_t row_vec, size_t n, size_t entries)
+                                                          const int32_t* __restrict__ idx, size_t row_vec, uint32_t S, size_t entries)
 {
     const size_t total = entries * row_vec;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const size_t e = g / row_vec, w = g % row_vec, i = e % n;
+        const size_t e = g / row_vec, w = g % row_vec, i = e / S;
         dst[g] = src[(size_t)(idx ? idx[i] : (int32_t)i) * row_vec + w];
     }
 }
 
-// kappa[e] = (a0 + e / n) * L      (the reference's y-nonce counter advances by L per attempt)
-__global__ __launch_bounds__(256) void sign_kappa_kernel(uint32_t* __restrict__ kappa, uint32_t a0, uint32_t L, size_t n, size_t entries)
+// kappa[e] = (a0 + e % S) * L      (the reference's y-nonce counter advances by L per attempt)
+__global__ __launch_bounds__(256) void sign_kappa_kernel(uint32_t* __restrict__ kappa, uint32_t a0, uint32_t L, uint32_t S, size_t entries)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < entries) kappa[e] = (a0 + (uint32_t)(e / n)) * L;
+    if (e < entries) kappa[e] = (a0 + (uint32_t)(e % S)) * L;
 }
 
 // One thread per pending item: the FIRST accepted of its S speculative attempts wins -> the
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void sign_collect_kernel(int32_t* __restrict__
     const int32_t item = idx ? idx[i] : (int32_t)i;
     int win = -1;
     for (int j = 0; j < S; j++)
-        if (flags[(size_t)j * n + i] == 0) {
+        if (flags[i * (size_t)S + j] == 0) {
             win = j;
             break;
         }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void sign_collect_kernel(int32_t* __restrict__
         next_idx[atomicAdd(&counts[0], 1)] = item;
     } else {
         const int w = atomicAdd(&counts[1], 1);
-        win_entry[w] = (int32_t)((size_t)win * n + i);
+        win_entry[w] = (int32_t)(i * (size_t)S + win);
         win_item[w] = item;
         attempts[item] = a0 + win + 1;
     }
@@ -308,7 +309,7 @@ hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t
     return hipGetLastError();
 }
 
-hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, size_t entries,
+hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, uint32_t S, size_t entries,
                               const Tables& t, hipStream_t s)
 {
     if (entries == 0) return hipSuccess;
@@ -316,22 +317,22 @@ hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, si
     if (al % 16 == 0) {
         const size_t rv = row_bytes / 16;
         hipLaunchKernelGGL(gather_rows_kernel<uint4>, grid1d(entries * rv, t), 256, 0, s, static_cast<uint4*>(dst),
-                           static_cast<const uint4*>(src), idx, rv, n, entries);
+                           static_cast<const uint4*>(src), idx, rv, S, entries);
     } else if (al % 8 == 0) {
         const size_t rv = row_bytes / 8;
         hipLaunchKernelGGL(gather_rows_kernel<uint2>, grid1d(entries * rv, t), 256, 0, s, static_cast<uint2*>(dst),
-                           static_cast<const uint2*>(src), idx, rv, n, entries);
+                           static_cast<const uint2*>(src), idx, rv, S, entries);
     } else {
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid1d(entries * row_bytes, t), 256, 0, s, static_cast<uint8_t*>(dst),
-                           static_cast<const uint8_t*>(src), idx, row_bytes, n, entries);
+                           static_cast<const uint8_t*>(src), idx, row_bytes, S, entries);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, size_t n, size_t entries, hipStream_t s)
+hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, uint32_t S, size_t entries, hipStream_t s)
 {
     if (entries == 0) return hipSuccess;
-    hipLaunchKernelGGL(sign_kappa_kernel, (int)((entries + 255) / 256), 256, 0, s, kappa, a0, L, n, entries);
+    hipLaunchKernelGGL(sign_kappa_kernel, (int)((entries + 255) / 256), 256, 0, s, kappa, a0, L, S, entries);
     return hipGetLastError();
 }
 

@@ -26,13 +26,24 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
 hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t* b, const int32_t* acc, size_t batch,
                             const Tables& t, hipStream_t s);
 hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);
+// Optional key indirection of the per-item-key pipelines (the signing loop's speculative entries): entry `it` uses the
+// key material of row idx[it / S] (idx == nullptr: row it / S).  Default = identity.
+struct KeyMap {
+    const int32_t* idx = nullptr;
+    uint32_t S = 1;
+    __host__ __device__ size_t key(size_t it) const
+    {
+        const uint32_t i = (uint32_t)it / S;
+        return idx ? (size_t)idx[i] : (size_t)i;
+    }
+};
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
-                         size_t batch, int shared_A, const Tables& t, hipStream_t s);
+                         size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km = KeyMap());
 hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
                          const uint8_t* h, size_t batch, int shared_pk, const Tables& t, hipStream_t s);
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
-                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s);
+                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km = KeyMap());
 
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
@@ -65,9 +76,9 @@ hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_str
                            hipStream_t s);
 hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const int32_t* s2, size_t n, const Tables& t, hipStream_t s);
 hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t n, const Tables& t, hipStream_t s);
-hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, size_t n, size_t entries,
+hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, uint32_t S, size_t entries,
                               const Tables& t, hipStream_t s);
-hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, size_t n, size_t entries, hipStream_t s);
+hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, uint32_t S, size_t entries, hipStream_t s);
 hipError_t launch_sign_collect(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
                                const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, hipStream_t s);
 hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,

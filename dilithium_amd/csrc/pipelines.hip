@@ -12,7 +12,7 @@ template <int K, int L, int LEVEL, int OUT>
 __global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
-    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+    KeyMap km, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DWORDS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
     uint32_t* vec = lds + LDS_VEC;
     for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
         ARow<L> Ar;
-        if (wv < K) Ar.load(A + ((shared_A ? 0 : it * K) + wv) * (size_t)L * 256, lane, !shared_A);
+        if (wv < K) Ar.load(A + ((shared_A ? 0 : km.key(it) * K) + wv) * (size_t)L * 256, lane, !shared_A && km.S == 1);
         if (wv < L) {
             int32_t r[4];
             load_strided(r, y + (it * L + wv) * 256, lane);
@@ -121,7 +121,7 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
                   const int32_t* __restrict__ w0, const uint8_t* __restrict__ w1,
                   const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
                   const int32_t* __restrict__ t0hat, size_t batch, int shared_key,
-                  const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+                  KeyMap km, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_DWORDS];
@@ -145,7 +145,7 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
         const int4 ch = *reinterpret_cast<const int4*>(chat + 4 * lane);
         uint32_t bits = 0, nh = 0;
         if (wv < L) {
-            const int4 s = *reinterpret_cast<const int4*>(s1hat + ((shared_key ? 0 : it * L) + wv) * 256 + 4 * lane);
+            const int4 s = *reinterpret_cast<const int4*>(s1hat + ((shared_key ? 0 : km.key(it) * L) + wv) * 256 + 4 * lane);
             int32_t r[4] = {mont_mul(ch.x, s.x), mont_mul(ch.y, s.y), mont_mul(ch.z, s.z), mont_mul(ch.w, s.w)};
             ntt_inv_core(r, twi, lm);
             const size_t o = (it * L + wv) * 256;
@@ -159,7 +159,7 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
             if (__ballot(rej)) bits |= 1;
         }
         if (wv < K) {
-            const size_t ko = ((shared_key ? 0 : it * K) + wv) * 256 + 4 * lane;
+            const size_t ko = ((shared_key ? 0 : km.key(it) * K) + wv) * 256 + 4 * lane;
             const int4 s2 = *reinterpret_cast<const int4*>(s2hat + ko);
             const int4 t0 = *reinterpret_cast<const int4*>(t0hat + ko);
             int32_t a[4] = {mont_mul(ch.x, s2.x), mont_mul(ch.y, s2.y), mont_mul(ch.z, s2.z), mont_mul(ch.w, s2.w)};
@@ -262,7 +262,7 @@ template <int K, int L, int LEVEL, int OUT>
 __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
-    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+    KeyMap km, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64];
     const int lane = threadIdx.x & 63;
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     if (it < batch) yr.load(y + it * L * 256, lane);
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
-        const int32_t* Ait = A + (shared_A ? 0 : it * K) * (size_t)L * 256;
+        const int32_t* Ait = A + (shared_A ? 0 : km.key(it) * K) * (size_t)L * 256;
         ARow<L> Ar;
-        Ar.load(Ait, lane, !shared_A);
+        Ar.load(Ait, lane, !shared_A && km.S == 1);
 #pragma unroll
         for (int l = 0; l < L; l++) {
             ntt_fwd_core(yr.v[l], twf, lm);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, yl, lane);
-            if (k + 1 < K) Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_A);
+            if (k + 1 < K) Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_A && km.S == 1);
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
             ntt_inv_core(r, twi, lm);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
     const int32_t* __restrict__ c, const int32_t* __restrict__ y, const int32_t* __restrict__ w0,
     const uint8_t* __restrict__ w1, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
-    const int32_t* __restrict__ t0hat, size_t batch, int shared_key, const uint32_t* __restrict__ fwd_tab,
+    const int32_t* __restrict__ t0hat, size_t batch, int shared_key, KeyMap km, const uint32_t* __restrict__ fwd_tab,
     const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
@@ -399,9 +399,9 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * 64;   // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * 4;
     for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
-        const int32_t* s1 = s1hat + (shared_key ? 0 : it * L) * 256;
-        const int32_t* s2 = s2hat + (shared_key ? 0 : it * K) * 256;
-        const int32_t* t0 = t0hat + (shared_key ? 0 : it * K) * 256;
+        const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
+        const int32_t* s2 = s2hat + (shared_key ? 0 : km.key(it) * K) * 256;
+        const int32_t* t0 = t0hat + (shared_key ? 0 : km.key(it) * K) * 256;
         int32_t ch[4];
         load_strided(ch, c + it * 256, lane);
         int4 sn = *reinterpret_cast<const int4*>(s1 + 4 * lane);
@@ -622,7 +622,7 @@ static inline bool use_wpi(size_t batch, const Tables& t)
 
 template <int LEVEL, int OUT>
 static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
-                                      size_t batch, int shared_A, const Tables& t, hipStream_t s)
+                                      size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     if (use_wpi(batch, t) && shared_A) {
@@ -635,23 +635,23 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
     if (use_wpi(batch, t)) {
         const int g = grid_for((batch + 3) / 4,
                                t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT>, 256, t.wpi_blocks_per_cu));
-        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, t.fwd,
+        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, km, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
     }
     const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
     hipLaunchKernelGGL((matvec_kernel<K, L, LEVEL, OUT>), grid, 64 * (K > L ? K : L), 0, s, w, w1, w0, A, y, batch,
-                       shared_A, t.fwd, t.inv_pipe);
+                       shared_A, km, t.fwd, t.inv_pipe);
     return hipGetLastError();
 }
 
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A,
-                         const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s)
+                         const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km)
 {
     if (batch == 0) return hipSuccess;
-#define DIL_MV(LV)                                                                                   \
-    return out_mode == OUT_W ? launch_matvec_level<LV, OUT_W>(w, w1, w0, A, y, batch, shared_A, t, s) \
-                             : launch_matvec_level<LV, OUT_W1W0>(w, w1, w0, A, y, batch, shared_A, t, s)
+#define DIL_MV(LV)                                                                                       \
+    return out_mode == OUT_W ? launch_matvec_level<LV, OUT_W>(w, w1, w0, A, y, batch, shared_A, t, s, km) \
+                             : launch_matvec_level<LV, OUT_W1W0>(w, w1, w0, A, y, batch, shared_A, t, s, km)
     switch (level) {
     case 2: DIL_MV(2);
     case 3: DIL_MV(3);
@@ -707,14 +707,14 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
 
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
-                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s)
+                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km)
 {
     if (batch == 0) return hipSuccess;
     if (use_wpi(batch, t)) {
         switch (level) {
-        case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
-        case 3: hipLaunchKernelGGL(sign2_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<3>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
-        case 5: hipLaunchKernelGGL(sign2_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<5>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe); break;
+        case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
+        case 3: hipLaunchKernelGGL(sign2_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<3>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
+        case 5: hipLaunchKernelGGL(sign2_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<5>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
@@ -723,7 +723,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
 #define DIL_S2(LV)                                                                                             \
     hipLaunchKernelGGL(sign2_kernel<LV>, grid,                                                                 \
                        64 * (Par<LV>::K > Par<LV>::L + 1 ? Par<LV>::K : Par<LV>::L + 1), 0, s, z, h, flags, c, \
-                       y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, t.fwd, t.inv_pipe);                       \
+                       y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe);                   \
     break
     switch (level) {
     case 2: DIL_S2(2);
