@@ -99,6 +99,7 @@ struct State {
     void* scratch = nullptr;        // for *_host entry points
     size_t scratch_bytes = 0;
     int sign_cap = 0;               // DIL_SIGN_CAP: entries in flight per signing round (0 = default)
+    int sign_streams = 1;           // DIL_SIGN_STREAMS: 2 = split each signing round over the caller stream and a helper (measured: no gain)
 };
 State g;
 
@@ -255,6 +256,7 @@ int dil_init(int device)
     if (const char* e = getenv("DIL_WPI_BPC")) g.t.wpi_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.wpi_blocks_per_cu;
     if (const char* e = getenv("DIL_FUSED_MODE")) g.t.fused_mode = atoi(e);
     if (const char* e = getenv("DIL_SIGN_CAP")) g.sign_cap = atoi(e);
+    if (const char* e = getenv("DIL_SIGN_STREAMS")) g.sign_streams = atoi(e);
     if (const char* e = getenv("DIL_FUSED_WGPC")) g.t.fused_wgs_per_cu = atoi(e) > 0 ? atoi(e) : g.t.fused_wgs_per_cu;
     {   // composite entry points take their temporaries from the stream-ordered pool: keep what it has
         // grown to instead of handing it back to the driver at every synchronisation
@@ -538,9 +540,11 @@ struct AttemptScratch {
 };
 int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
-                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap())
+                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
+                      int phases = 3)
 {
-    DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
+    if (phases & 1) DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
+    if (!(phases & 2)) return 0;
     DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, g.t, s, km));
     DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, g.t, s));
     DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
@@ -548,6 +552,38 @@ int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint
     DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s, km));
     return 0;
 }
+
+// The same attempt over entries [off, off + cnt) of the per-entry arrays (per-key arrays are addressed through km)
+int sign_attempt_range(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                       const int32_t* t0hat, int level, int K, int L, size_t off, size_t cnt, int shared_key, hipStream_t s, dil::KeyMap km,
+                       int phases = 3)
+{
+    AttemptScratch u = t;
+    u.y += off * L * 256; u.w1 += off * K * 256; u.w0 += off * K * 256; u.w1p += off * K * (level == 2 ? 192 : 128); u.c += off * 256;
+    km.base += (uint32_t)off;
+    return sign_attempt_impl(u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
+                             rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases);
+}
+
+// A second stream for the signing loop: the hash kernels of a round are latency-bound (one sponge per lane, a few
+// hundred waves), the polynomial kernels throughput-bound; two half-rounds in flight overlap the two kinds.
+struct AuxStream {
+    std::mutex mu;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;   // fork: the aux half may start; join: it is done
+    int device = -1;
+    bool ensure(int dev)
+    {
+        if (s && device == dev) return true;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        device = dev;
+        return true;
+    }
+};
+AuxStream g_aux;
 }  // namespace
 
 int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
@@ -750,6 +786,8 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(rp), 64, static_cast<uint64_t*>(km), 96, batch, s));
     DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
 
+    std::unique_lock<std::mutex> aux_lock(g_aux.mu, std::try_to_lock);   // one signing loop at a time uses the aux stream
+    const bool two_streams = g.sign_streams > 1 && aux_lock.owns_lock() && g_aux.ensure(g.device);
     int32_t *idx_cur = nullptr, *idx_next = static_cast<int32_t*>(idx0);
     size_t n = batch;
     int a0 = 0;                                          // attempts every pending item has already failed
@@ -768,10 +806,26 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         keys.idx = idx_cur;
         keys.S = (uint32_t)S_;
         DIL_TRY(dil::launch_sign_kappa(static_cast<uint32_t*>(kap), (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
-        rc = sign_attempt_impl(att, static_cast<uint8_t*>(ct), static_cast<int32_t*>(z), static_cast<uint8_t*>(h), static_cast<int32_t*>(fl),
-                               static_cast<int32_t*>(A), mur, rpr, static_cast<uint32_t*>(kap), static_cast<int32_t*>(s1h),
-                               static_cast<int32_t*>(s2h), static_cast<int32_t*>(t0h), level, E, shared_sk, s, keys);
-        if (rc) return rc;
+        // Two half-rounds, staggered by one kernel: the aux half starts when the main half's ExpandMask is done, so its
+        // throughput-bound kernels run under the main half's latency-bound hashing and vice versa.
+        const size_t half = two_streams && E >= 4096 ? (E / 2) : 0;      // entries [half, E) on the aux stream
+        auto part = [&](size_t off, size_t cnt, hipStream_t st, int phases) {
+            return sign_attempt_range(att, static_cast<uint8_t*>(ct), static_cast<int32_t*>(z), static_cast<uint8_t*>(h),
+                                      static_cast<int32_t*>(fl), static_cast<int32_t*>(A), mur, rpr, static_cast<uint32_t*>(kap),
+                                      static_cast<int32_t*>(s1h), static_cast<int32_t*>(s2h), static_cast<int32_t*>(t0h), level, p.K, p.L,
+                                      off, cnt, shared_sk, st, keys, phases);
+        };
+        if (half) {
+            if ((rc = part(0, half, s, 1))) return rc;                   // main: ExpandMask
+            DIL_TRY(hipEventRecord(g_aux.fork, s));
+            DIL_TRY(hipStreamWaitEvent(g_aux.s, g_aux.fork, 0));
+            if ((rc = part(half, E - half, g_aux.s, 3))) return rc;      // aux: the whole chain
+            if ((rc = part(0, half, s, 2))) return rc;                   // main: the rest
+            DIL_TRY(hipEventRecord(g_aux.join, g_aux.s));
+            DIL_TRY(hipStreamWaitEvent(s, g_aux.join, 0));
+        } else if ((rc = part(0, E, s, 3))) {
+            return rc;
+        }
         // winners (first accepted attempt per item) -> packed straight into their signature slots
         int32_t* counts = static_cast<int32_t*>(cnt);
         DIL_TRY(hipMemsetAsync(cnt, 0, 8, s));

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__
     }
     sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
     sp.s[16] ^= 0x8000000000000000ull;
-    int32_t* dst = s + p * 256;
+    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, s + p * 256, live);
     int cnt = live ? 0 : 256;
     while (__any(cnt < 256)) {
         keccak_f1600(sp.s);
@@ -198,8 +199,9 @@ __global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__
                     ok = nib < 9;
                     v = 4 - nib;
                 }
-                if (ok && cnt < 256) dst[cnt++] = v + ((v >> 31) & QC);
+                if (ok && cnt < 256) sink.put(cnt++, v + ((v >> 31) & QC));
             }
+            sink.flush_if_ready(cnt);          // <= 16 coefficients per 64-bit word
         }
     }
 }

@@ -33,10 +33,10 @@ __global__ __launch_bounds__(HASH_BS) void shake256_batch_kernel(uint64_t* __res
 // ExpandA: A[item][i][j] = RejUniform(SHAKE128(rho || byte j || byte i)), 3-byte little-endian
 // candidates masked to 23 bits, accepted when < q.  One lane per polynomial.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void emit23(uint32_t v, int32_t* __restrict__ dst, int& cnt)
+__device__ __forceinline__ void emit23(uint32_t v, CoeffSink& sink, int& cnt)
 {
     v &= 0x7FFFFFu;
-    if (v < QU && cnt < 256) dst[cnt++] = (int32_t)v;
+    if (v < QU && cnt < 256) sink.put(cnt++, (int32_t)v);
 }
 
 __global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
@@ -53,21 +53,23 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__
     for (int w = 0; w < 4; w++) sp.s[w] = rho[item * rho_stride_words + w];
     sp.s[4] = (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16);
     sp.s[20] ^= 0x8000000000000000ull;
-    int32_t* dst = A + p * 256;
+    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, A + p * 256, live);
     int cnt = live ? 0 : 256;
     while (__any(cnt < 256)) {
         keccak_f1600(sp.s);
 #pragma unroll
         for (int g = 0; g < 7; g++) {
             const uint64_t w0 = sp.s[3 * g], w1 = sp.s[3 * g + 1], w2 = sp.s[3 * g + 2];
-            emit23((uint32_t)w0, dst, cnt);
-            emit23((uint32_t)(w0 >> 24), dst, cnt);
-            emit23((uint32_t)((w0 >> 48) | (w1 << 16)), dst, cnt);
-            emit23((uint32_t)(w1 >> 8), dst, cnt);
-            emit23((uint32_t)(w1 >> 32), dst, cnt);
-            emit23((uint32_t)((w1 >> 56) | (w2 << 8)), dst, cnt);
-            emit23((uint32_t)(w2 >> 16), dst, cnt);
-            emit23((uint32_t)(w2 >> 40), dst, cnt);
+            emit23((uint32_t)w0, sink, cnt);
+            emit23((uint32_t)(w0 >> 24), sink, cnt);
+            emit23((uint32_t)((w0 >> 48) | (w1 << 16)), sink, cnt);
+            emit23((uint32_t)(w1 >> 8), sink, cnt);
+            emit23((uint32_t)(w1 >> 32), sink, cnt);
+            emit23((uint32_t)((w1 >> 56) | (w2 << 8)), sink, cnt);
+            emit23((uint32_t)(w2 >> 16), sink, cnt);
+            emit23((uint32_t)(w2 >> 40), sink, cnt);
+            sink.flush_if_ready(cnt);
         }
     }
 }
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
     for (int w = 0; w < 8; w++) sp.s[w] = rhoprime[item * 8 + w];
     sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
     sp.s[16] ^= 0x8000000000000000ull;
-    int32_t* dst = y + p * 256;
+    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, y + p * 256);
     uint64_t buf = 0;
     int nbits = 0, cnt = 0;          // wave-uniform
     while (cnt < 256) {
@@ -106,18 +109,19 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
                 const int need = B - nbits;
                 const uint32_t t = (uint32_t)((buf | (word << nbits)) & MASK);
                 const int32_t v = GAMMA1 - (int32_t)t;
-                dst[cnt++] = v + ((v >> 31) & (int32_t)QU);
+                sink.put(cnt++, v + ((v >> 31) & (int32_t)QU));
                 avail -= need;
             }
             uint64_t rest = (avail == 64) ? word : (word >> (64 - avail));
             while (avail >= B && cnt < 256) {
                 const int32_t v = GAMMA1 - (int32_t)(rest & MASK);
-                dst[cnt++] = v + ((v >> 31) & (int32_t)QU);
+                sink.put(cnt++, v + ((v >> 31) & (int32_t)QU));
                 rest >>= B;
                 avail -= B;
             }
             buf = rest;
             nbits = avail;
+            sink.flush_if_ready(cnt);          // <= 4 coefficients per 64-bit word
         }
     }
 }

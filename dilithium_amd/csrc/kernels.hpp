@@ -27,13 +27,14 @@ hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t*
                             const Tables& t, hipStream_t s);
 hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);
 // Optional key indirection of the per-item-key pipelines (the signing loop's speculative entries): entry `it` uses the
-// key material of row idx[it / S] (idx == nullptr: row it / S).  Default = identity.
+// key material of row idx[(base + it) / S] (idx == nullptr: that row number itself).  Default = identity.
 struct KeyMap {
     const int32_t* idx = nullptr;
     uint32_t S = 1;
+    uint32_t base = 0;          // entry number of this launch's item 0 (a round may be split over two streams)
     __host__ __device__ size_t key(size_t it) const
     {
-        const uint32_t i = (uint32_t)it / S;
+        const uint32_t i = (base + (uint32_t)it) / S;
         return idx ? (size_t)idx[i] : (size_t)i;
     }
 };

@@ -13,14 +13,17 @@ g = torch.Generator(device="cuda").manual_seed(0)
 u8 = lambda *s: torch.randint(0, 256, s, dtype=torch.uint8, device="cuda", generator=g)
 
 
-def wall(fn, reps=3):
+def wall(fn, reps=9):
+    """median wall time of a (synchronising) call"""
     fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
 
 
 for level in (2, 3, 5):
