@@ -99,6 +99,7 @@ struct State {
     void* scratch = nullptr;        // for *_host entry points
     size_t scratch_bytes = 0;
     int sign_cap = 0;               // DIL_SIGN_CAP: entries in flight per signing round (0 = default)
+    int aux_overlap = 1;            // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream
     int sign_streams = 1;           // DIL_SIGN_STREAMS: 2 = split each signing round over the caller stream and a helper (measured: no gain)
 };
 State g;
@@ -257,6 +258,7 @@ int dil_init(int device)
     if (const char* e = getenv("DIL_FUSED_MODE")) g.t.fused_mode = atoi(e);
     if (const char* e = getenv("DIL_SIGN_CAP")) g.sign_cap = atoi(e);
     if (const char* e = getenv("DIL_SIGN_STREAMS")) g.sign_streams = atoi(e);
+    if (const char* e = getenv("DIL_AUX_OVERLAP")) g.aux_overlap = atoi(e);
     if (const char* e = getenv("DIL_FUSED_WGPC")) g.t.fused_wgs_per_cu = atoi(e) > 0 ? atoi(e) : g.t.fused_wgs_per_cu;
     {   // composite entry points take their temporaries from the stream-ordered pool: keep what it has
         // grown to instead of handing it back to the driver at every synchronisation
@@ -584,6 +586,40 @@ struct AuxStream {
     }
 };
 AuxStream g_aux;
+
+// Run an independent part of a composite call on the helper stream (if nobody else is using it): fork() returns the
+// stream to launch that part on -- the helper, ordered after everything already on `main`, or `main` itself -- and
+// join() makes `main` wait for it.
+struct AuxFork {
+    std::unique_lock<std::mutex> lk;
+    hipStream_t main;
+    bool on, forked = false;
+    explicit AuxFork(hipStream_t m) : lk(g_aux.mu, std::try_to_lock), main(m)
+    {
+        on = g.aux_overlap && lk.owns_lock() && g_aux.ensure(g.device);
+    }
+    // `sponges`: lanes of the lane-per-sponge work going to the helper.  Only latency-bound work (less than about one
+    // wave per SIMD) gains from running beside the main stream; throughput-bound work just pays the fork/join.
+    hipStream_t fork(size_t sponges)
+    {
+        if (!on || sponges >= (size_t)g.t.num_cus * 256) return main;
+        if (hipEventRecord(g_aux.fork, main) != hipSuccess || hipStreamWaitEvent(g_aux.s, g_aux.fork, 0) != hipSuccess) {
+            on = false;
+            return main;
+        }
+        forked = true;
+        return g_aux.s;
+    }
+    int join()
+    {
+        if (!forked) return 0;
+        forked = false;
+        DIL_TRY(hipEventRecord(g_aux.join, g_aux.s));
+        DIL_TRY(hipStreamWaitEvent(main, g_aux.join, 0));
+        return 0;
+    }
+    ~AuxFork() { (void)join(); }
+};
 }  // namespace
 
 int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
@@ -669,8 +705,7 @@ int dil_expand_s_dev(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t s
     LevelPar p;
     int rc = ensure_init();
     if (rc || (rc = level_par(level, &p))) return rc;
-    DIL_TRY(dil::launch_expand_s(s1, rhoprime, stride, p.eta, 0, p.L, batch, S(stream)));
-    return (int)dil::launch_expand_s(s2, rhoprime, stride, p.eta, p.L, p.K, batch, S(stream));
+    return (int)dil::launch_expand_s(s1, s2, rhoprime, stride, p.eta, p.L, p.K, batch, S(stream));
 }
 
 int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch, void* stream)
@@ -688,27 +723,33 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
         (rc = ws.get(&t0, batch * p.K * 1024)) || (rc = ws.get(&tr, batch * 32)))
         return rc;
     uint8_t* e = static_cast<uint8_t*>(exp);                       // rho(32) | rho'(64) | key(32)  (KG_*)
+    int32_t *s1p = static_cast<int32_t*>(s1), *s2p = static_cast<int32_t*>(s2);
+    AuxFork ax(s);
     DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(exp), 128, reinterpret_cast<const uint64_t*>(seed), 32, batch, s));
+    // ExpandS (helper stream) runs beside ExpandA: both are Keccak-bound and independent
+    DIL_TRY(dil::launch_expand_s(s1p, s2p, e + 32, 128, p.eta, p.L, p.K, batch, ax.fork(batch * p.K * p.L)));
     DIL_TRY(dil::launch_expand_a(static_cast<int32_t*>(A), e, 128, level, batch, s));
-    DIL_TRY(dil::launch_expand_s(static_cast<int32_t*>(s1), e + 32, 128, p.eta, 0, p.L, batch, s));
-    DIL_TRY(dil::launch_expand_s(static_cast<int32_t*>(s2), e + 32, 128, p.eta, p.L, p.K, batch, s));
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, static_cast<int32_t*>(w), nullptr, nullptr, static_cast<int32_t*>(A),
-                               static_cast<int32_t*>(s1), batch, 0, g.t, s));
-    DIL_TRY(dil::launch_power2round(static_cast<int32_t*>(t1), static_cast<int32_t*>(t0), static_cast<int32_t*>(w),
-                                    static_cast<int32_t*>(s2), batch * p.K * 256, g.t, s));
+    if ((rc = ax.join())) return rc;
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, static_cast<int32_t*>(w), nullptr, nullptr, static_cast<int32_t*>(A), s1p, batch, 0, g.t, s));
+    DIL_TRY(dil::launch_power2round(static_cast<int32_t*>(t1), static_cast<int32_t*>(t0), static_cast<int32_t*>(w), s2p,
+                                    batch * p.K * 256, g.t, s));
     // pk = rho | t1
     DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, g.t, s));
     DIL_TRY(dil::launch_pack(10, pk, pkb, 32, static_cast<int32_t*>(t1), p.K, dil::XF_PLAIN, 0, batch, g.t, s));
-    // tr = SHAKE256(pk, 32)   (pk length is a multiple of 8 at every level)
-    DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, batch, s));
+    // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level): one long sponge per key, latency-bound --
+    // on the helper stream, under the packing of the rest of sk
+    {
+        hipStream_t a = ax.fork(batch);
+        DIL_TRY(dil::launch_shake256(static_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, batch, a));
+        DIL_TRY(dil::launch_copy_field(sk, skb, 64, static_cast<uint8_t*>(tr), 32, 0, 32, batch, g.t, a));
+    }
     // sk = rho | key | tr | s1 | s2 | t0
     DIL_TRY(dil::launch_copy_field(sk, skb, 0, e, 128, 0, 32, batch, g.t, s));
     DIL_TRY(dil::launch_copy_field(sk, skb, 32, e, 128, 96, 32, batch, g.t, s));
-    DIL_TRY(dil::launch_copy_field(sk, skb, 64, static_cast<uint8_t*>(tr), 32, 0, 32, batch, g.t, s));
-    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, static_cast<int32_t*>(s1), p.L, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
-    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, static_cast<int32_t*>(s2), p.K, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, s1p, p.L, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, s2p, p.K, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
     DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, static_cast<int32_t*>(t0), p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, g.t, s));
-    return 0;
+    return ax.join();
 }
 
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
@@ -718,23 +759,33 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     int rc = ensure_init();
     if (rc || (rc = level_par(level, &p))) return rc;
     if (batch == 0) return 0;
+    if (reinterpret_cast<uintptr_t>(pk) & 7) return (int)hipErrorInvalidValue;      // rho is read as 64-bit words
     hipStream_t s = S(stream);
     StreamScratch ws(s);
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
-    const size_t nk = shared_pk ? 1 : batch;
-    void *A, *t1, *z, *h, *bad, *ct;
+    const size_t nk = shared_pk ? 1 : batch, wb = (size_t)p.K * (level == 2 ? 192 : 128);
+    void *A, *t1, *z, *h, *bad, *ct, *c, *w1, *w1p;
     if ((rc = ws.get(&A, nk * p.K * p.L * 1024)) || (rc = ws.get(&t1, nk * p.K * 1024)) || (rc = ws.get(&z, batch * p.L * 1024)) ||
-        (rc = ws.get(&h, batch * p.K * 256)) || (rc = ws.get(&bad, batch * 4)) || (rc = ws.get(&ct, batch * 32)))
+        (rc = ws.get(&h, batch * p.K * 256)) || (rc = ws.get(&bad, batch * 4)) || (rc = ws.get(&ct, batch * 32)) ||
+        (rc = ws.get(&c, batch * 1024)) || (rc = ws.get(&w1, batch * p.K * 256)) || (rc = ws.get(&w1p, batch * wb)))
         return rc;
-    DIL_TRY(dil::launch_expand_a(static_cast<int32_t*>(A), pk, pkb, level, nk, s));
-    DIL_TRY(dil::launch_unpack(10, static_cast<int32_t*>(t1), pk, pkb, 32, p.K, dil::XF_PLAIN, 0, nk, g.t, s));
+    AuxFork ax(s);
+    {   // public-key side (helper stream): A = ExpandA(rho), t1
+        hipStream_t a = ax.fork(nk * p.K * p.L);
+        DIL_TRY(dil::launch_expand_a(static_cast<int32_t*>(A), pk, pkb, level, nk, a));
+        DIL_TRY(dil::launch_unpack(10, static_cast<int32_t*>(t1), pk, pkb, 32, p.K, dil::XF_PLAIN, 0, nk, g.t, a));
+    }
+    // signature side: c~, z, hints, ||z|| check, c = SampleInBall(c~)
     DIL_TRY(dil::launch_copy_field(static_cast<uint8_t*>(ct), 32, 0, sig, sgb, 0, 32, batch, g.t, s));
     DIL_TRY(dil::launch_unpack(p.zbits, static_cast<int32_t*>(z), sig, sgb, 32, p.L, dil::XF_OFFSET_MINUS, p.gamma1, batch, g.t, s));
     DIL_TRY(dil::launch_hint_unpack(static_cast<uint8_t*>(h), static_cast<int32_t*>(bad), sig, sgb, 32 + zb, p.K, p.omega, batch, s));
-    rc = dil_verify_dev(verdict, static_cast<int32_t*>(A), static_cast<uint8_t*>(ct), static_cast<int32_t*>(z),
-                        static_cast<int32_t*>(t1), static_cast<uint8_t*>(h), mu, level, batch, shared_pk, stream);
-    if (rc) return rc;
-    // verdict |= bad << 2   (tiny element-wise op done with the pointwise machinery would be overkill: reuse copy kernel? no --)
+    DIL_TRY(dil::launch_z_norm(verdict, static_cast<int32_t*>(z), level, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(static_cast<int32_t*>(c), static_cast<uint8_t*>(ct), level, batch, s));
+    if ((rc = ax.join())) return rc;
+    DIL_TRY(dil::launch_verify(level, static_cast<uint8_t*>(w1), static_cast<int32_t*>(A), static_cast<int32_t*>(z),
+                               static_cast<int32_t*>(c), static_cast<int32_t*>(t1), static_cast<uint8_t*>(h), batch, shared_pk, g.t, s));
+    DIL_TRY(dil::launch_pack_w1(static_cast<uint8_t*>(w1p), static_cast<uint8_t*>(w1), level, batch, g.t, s));
+    DIL_TRY(dil::launch_challenge_hash(nullptr, verdict, mu, static_cast<uint8_t*>(w1p), level, static_cast<uint8_t*>(ct), batch, s));
     return (int)dil::launch_or_flag(verdict, static_cast<int32_t*>(bad), 4, batch, g.t, s);
 }
 

@@ -160,13 +160,17 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ ou
 // eta = 2: nibble < 15 -> 2 - (nibble mod 5);  eta = 4: nibble < 9 -> 4 - nibble.  Canonical out.
 // One lane per polynomial.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__ s, const uint8_t* __restrict__ rhoprime,
-                                                      size_t rp_stride, int eta, int nonce0, int polys, size_t nitems)
+__global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__ s, int32_t* __restrict__ s_tail, int split,
+                                                      const uint8_t* __restrict__ rhoprime, size_t rp_stride, int eta, int nonce0,
+                                                      int polys, size_t nitems)
 {
     const size_t p = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     const bool live = p < nitems * (size_t)polys;
     const size_t item = live ? p / (size_t)polys : 0;
-    const uint32_t nonce = (uint32_t)(nonce0 + (int)(p % (size_t)polys));
+    const int j = (int)(p % (size_t)polys);
+    const uint32_t nonce = (uint32_t)(nonce0 + j);
+    // polynomials [0, split) of an item go to s [item][split][256], the rest to s_tail [item][polys - split][256]
+    int32_t* out = j < split ? s + (item * split + j) * 256 : s_tail + (item * (size_t)(polys - split) + (j - split)) * 256;
     Shake<17> sp;
     sp.init();
     const uint8_t* rp = rhoprime + item * rp_stride;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__
     sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
     sp.s[16] ^= 0x8000000000000000ull;
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, s + p * 256, live);
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, out, live);
     int cnt = live ? 0 : 256;
     while (__any(cnt < 256)) {
         keccak_f1600(sp.s);
@@ -391,12 +395,13 @@ hipError_t launch_hint_pack(uint8_t* out, size_t out_stride, size_t out_offset, 
     return hipGetLastError();
 }
 
-hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_stride, int eta, int nonce0, int polys, size_t nitems,
+hipError_t launch_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t rp_stride, int eta, int L, int K, size_t nitems,
                            hipStream_t s)
 {
     if (nitems == 0) return hipSuccess;
-    const size_t total = nitems * (size_t)polys;
-    hipLaunchKernelGGL(expand_s_kernel, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, sout, rhoprime, rp_stride, eta, nonce0, polys, nitems);
+    const size_t total = nitems * (size_t)(L + K);
+    hipLaunchKernelGGL(expand_s_kernel, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime, rp_stride, eta, 0,
+                       L + K, nitems);
     return hipGetLastError();
 }
 

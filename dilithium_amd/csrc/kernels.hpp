@@ -73,7 +73,7 @@ hipError_t launch_hint_unpack(uint8_t* h, int32_t* bad, const uint8_t* in, size_
                               size_t nitems, hipStream_t s);
 hipError_t launch_hint_pack(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int K, int omega, size_t nitems,
                             hipStream_t s, RowMap map = RowMap());
-hipError_t launch_expand_s(int32_t* sout, const uint8_t* rhoprime, size_t rp_stride, int eta, int nonce0, int polys, size_t nitems,
+hipError_t launch_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t rp_stride, int eta, int L, int K, size_t nitems,
                            hipStream_t s);
 hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const int32_t* s2, size_t n, const Tables& t, hipStream_t s);
 hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t n, const Tables& t, hipStream_t s);

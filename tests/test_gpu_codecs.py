@@ -317,3 +317,62 @@ def test_host_buffer_scheme_kat(gpu, level, kat_msgs):
     s1, a1 = api.sign_host(np.ascontiguousarray(sk[:1]), mu[:9], level, shared_sk=True)
     assert (api.verify_sig_host(np.ascontiguousarray(pk[:1]), s1, mu[:9], level, shared_pk=True) == 0).all()
     assert (s1[0] == sig[0]).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_random_keys_and_messages_vs_host_harness(gpu, level):
+    """beyond the KAT files: 24 fresh seeds / messages, device keygen + sign byte-identical to the host KAT harness
+    (hashlib SHAKE + oracle polynomial arithmetic), and the signatures verify"""
+    from dilithium_amd import api
+    from oracle.oracle import Oracle
+    p = dk.PARAMS[level]
+    eng = dk.OracleEngine(Oracle())
+    rng = np.random.default_rng(1000 + level)
+    n = 24
+    seeds = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msgs = [rng.integers(0, 256, int(rng.integers(1, 200)), dtype=np.uint8).tobytes() for _ in range(n)]
+    pk, sk = api.keygen(cu(gpu, seeds), level)
+    pkh, skh = pk.cpu().numpy(), sk.cpu().numpy()
+    items, mu = [], []
+    for i in range(n):
+        kg = dk.keygen(level, seeds[i].tobytes(), eng)
+        s1p, s2p, t0p = dk.pack_eta(p, kg["s1"]), dk.pack_eta(p, kg["s2"]), dk.pack_t0(p, kg["t0"])
+        assert pkh[i].tobytes() == kg["rho"] + kg["t1_packed"]
+        assert skh[i].tobytes() == kg["rho"] + kg["key"] + kg["tr"] + s1p + s2p + t0p
+        items.append(dict(rho=kg["rho"], key=kg["key"], tr=kg["tr"], s1_packed=s1p, s2_packed=s2p, t0_packed=t0p, msg=msgs[i]))
+        mu.append(np.frombuffer(hashlib.shake_256(kg["tr"] + msgs[i]).digest(64), dtype=np.uint8))
+    mu = np.stack(mu)
+    want = dk.sign_batch(level, items, eng)
+    sig, att = api.sign(sk, cu(gpu, mu), level)
+    sigh, atth = sig.cpu().numpy(), att.cpu().numpy()
+    for i in range(n):
+        assert sigh[i].tobytes() == want[i][0] + want[i][1] + want[i][2], i
+        assert atth[i] == want[i][3]
+    assert (api.verify_sig(pk, sig, cu(gpu, mu), level).cpu().numpy() == 0).all()
+
+
+def test_scheme_entry_points_edge_cases(gpu):
+    from dilithium_amd import api, lib
+    L = lib.load()
+    # empty batches are no-ops
+    e8 = lambda c: gpu.empty((0, c), dtype=gpu.uint8, device="cuda")   # noqa: E731
+    pk, sk = api.keygen(e8(32), 3)
+    assert pk.shape == (0, 1952) and sk.shape == (0, 4000)
+    sig, att = api.sign(e8(4000), e8(64), 3)
+    assert sig.shape == (0, 3293)
+    assert api.verify_sig(e8(1952), e8(3293), e8(64), 3).numel() == 0
+    # unknown level -> error code, not a crash
+    seed = gpu.zeros((2, 32), dtype=gpu.uint8, device="cuda")
+    assert L.dil_pk_bytes(4) == 0 and L.dil_sk_bytes(1) == 0 and L.dil_sig_bytes(7) == 0
+    out = gpu.zeros((2, 8000), dtype=gpu.uint8, device="cuda")
+    assert L.dil_keygen_dev(out.data_ptr(), out.data_ptr(), seed.data_ptr(), 4, 2, None) != 0
+    assert L.dil_unpack_dev(out.data_ptr(), out.data_ptr(), 100, 0, 9, 3, 1, None) != 0      # unknown codec kind
+    # a public key that is not 8-byte aligned is refused (rho is read as 64-bit words)
+    k = load_kat(3)
+    pkb = np.concatenate([k["rho"], k["t1"]], axis=1)[:1]
+    buf = gpu.zeros(pkb.shape[1] + 8, dtype=gpu.uint8, device="cuda")
+    buf[1:1 + pkb.shape[1]] = cu(gpu, pkb[0])
+    sg = cu(gpu, np.concatenate([k["ctilde"], k["z"], k["h"]], axis=1)[:1])
+    mu0 = gpu.zeros((1, 64), dtype=gpu.uint8, device="cuda")
+    verdict = gpu.zeros(1, dtype=gpu.int32, device="cuda")
+    assert L.dil_verify_sig_dev(verdict.data_ptr(), buf.data_ptr() + 1, sg.data_ptr(), mu0.data_ptr(), 3, 1, 0, None) != 0

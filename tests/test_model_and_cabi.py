@@ -93,3 +93,23 @@ def test_no_cpu_fallback_without_gpu(lib):
     assert (a == before).all()
     with pytest.raises(DilError):
         api.init(0)
+
+
+def test_wire_sizes_and_scheme_entry_points_without_gpu(lib):
+    """size queries are pure host arithmetic (round-3 v3.1 wire formats); the whole-operation entry points fail
+    loudly -- never produce bytes -- when there is no GPU"""
+    sizes = {2: (1312, 2528, 2420), 3: (1952, 4000, 3293), 5: (2592, 4864, 4595)}
+    for level, want in sizes.items():
+        assert (lib.dil_pk_bytes(level), lib.dil_sk_bytes(level), lib.dil_sig_bytes(level)) == want
+    assert lib.dil_pk_bytes(4) == 0
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dilithium_amd import api, DilError
+    seed = np.zeros((1, 32), dtype=np.uint8)
+    with pytest.raises(DilError):
+        api.keygen_host(seed, 3)
+    with pytest.raises(DilError):
+        api.sign_host(np.zeros((1, 4000), dtype=np.uint8), np.zeros((1, 64), dtype=np.uint8), 3)
+    with pytest.raises(DilError):
+        api.verify_sig_host(np.zeros((1, 1952), dtype=np.uint8), np.zeros((1, 3293), dtype=np.uint8), np.zeros((1, 64), dtype=np.uint8), 3)
