@@ -275,6 +275,50 @@ __global__ __launch_bounds__(256) void z_norm_kernel(int32_t* __restrict__ verdi
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+// Two-lane-per-sponge forms of the two long-sponge kernels (keccak.hpp, Shake2): chosen by the launchers when one
+// sponge per lane would leave the SIMDs under-occupied.  Thread t = sponge t/2, half t&1; a dead sponge in a live wave
+// still runs (both lanes of a pair must execute the DPP exchanges) but neither loads nor stores.
+__global__ __launch_bounds__(HASH_BS) void shake256_batch2_kernel(uint32_t* __restrict__ out, int out_words,
+                                                             const uint32_t* __restrict__ in, int in_words, size_t batch)
+{
+    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const size_t i = t >> 1;
+    if (i >= batch) return;                                   // whole pairs leave together
+    Shake2<17> sp;
+    sp.init(t & 1);
+    const int fill = sp.absorb<0>(in + i * (size_t)in_words * 2, in_words);
+    sp.finish_words(fill);
+    sp.squeeze(out + i * (size_t)out_words * 2, out_words);
+}
+
+__global__ __launch_bounds__(HASH_BS) void challenge_hash2_kernel(uint32_t* __restrict__ out32, int32_t* __restrict__ verdict,
+                                                             const uint32_t* __restrict__ mu, const uint32_t* __restrict__ w1p,
+                                                             int w1_words, const uint32_t* __restrict__ expect, size_t batch)
+{
+    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const size_t i = t >> 1;
+    if (i >= batch) return;
+    const int hi = (int)(t & 1);
+    Shake2<17> sp;
+    sp.init(hi);
+#pragma unroll
+    for (int w = 0; w < 8; w++) sp.s[w] = mu[i * 16 + 2 * w + hi];
+    const int fill = sp.absorb<8>(w1p + i * (size_t)w1_words * 2, w1_words);
+    sp.finish_words(fill);
+    if (expect) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) d |= sp.s[w] ^ expect[i * 8 + 2 * w + hi];
+        if (d) atomicOr(&verdict[i], 1);                      // both halves may flag the same item
+    } else {
+#pragma unroll
+        for (int w = 0; w < 4; w++) out32[i * 8 + 2 * w + hi] = sp.s[w];
+    }
+}
+
+// one sponge per lane fills the chip from about one wave per SIMD; below that the two-lane form is faster
+static inline bool few_sponges(size_t batch) { return batch < 65536; }
+
 hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,
                                  const uint8_t* expect, size_t batch, hipStream_t s)
 {
@@ -282,6 +326,12 @@ hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
     const int words = K * (level == 2 ? 192 : 128) / 8;
+    if (few_sponges(batch)) {
+        hipLaunchKernelGGL(challenge_hash2_kernel, (int)((2 * batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint32_t*>(out32),
+                           verdict, reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words,
+                           reinterpret_cast<const uint32_t*>(expect), batch);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(challenge_hash_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint64_t*>(out32), verdict,
                        reinterpret_cast<const uint64_t*>(mu), reinterpret_cast<const uint64_t*>(w1p), words,
                        reinterpret_cast<const uint64_t*>(expect), batch);
@@ -302,6 +352,11 @@ hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int
 {
     if (batch == 0) return hipSuccess;
     if ((out_bytes & 7) || (in_bytes & 7) || out_bytes <= 0 || in_bytes < 0) return hipErrorInvalidValue;
+    if (few_sponges(batch)) {
+        hipLaunchKernelGGL(shake256_batch2_kernel, (int)((2 * batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint32_t*>(out),
+                           out_bytes / 8, reinterpret_cast<const uint32_t*>(in), in_bytes / 8, batch);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(shake256_batch_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, out, out_bytes / 8, in, in_bytes / 8, batch);
     return hipGetLastError();
 }

@@ -2,6 +2,7 @@
 // sponges per wavefront, the whole 1600-bit state in 50 VGPRs).  Row N1 of SURVEY 8(f): what the
 // reference does with three VHDL Keccak cores (keccak_*.vhd, sha3_*.vhd; control word
 // {final, mode, outbits, inbits}, keccak_datapath.vhd:97,116-117) feeding its samplers.
+// Round = 182 instructions (lane per sponge) / ~120 (two lanes per sponge) thanks to v_bitop3_b32 and v_alignbit_b32.
 // Written from FIPS 202; checked against hashlib (tests/test_gpu_hash.py) and, through the
 // samplers, against the reference's KAT vectors.
 #pragma once
@@ -23,6 +24,21 @@ __device__ __constant__ uint64_t KECCAK_RC[24] = {
 
 // 64-bit rotate by a compile-time amount as two v_alignbit_b32 (the compiler's own lowering is a
 // pair of 64-bit shifts + or, which are slow multi-pass ops on CDNA)
+// gfx950 has a 3-input bitwise op with an 8-bit truth table (index = a<<2 | b<<1 | c): one instruction for the
+// 3-way xors of theta and for chi's  a ^ (~b & c)
+__device__ __forceinline__ uint32_t xor3_32(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t chi_32(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xD2); }
+__device__ __forceinline__ uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c)
+{
+    return ((uint64_t)xor3_32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)) << 32) |
+           xor3_32((uint32_t)a, (uint32_t)b, (uint32_t)c);
+}
+__device__ __forceinline__ uint64_t chi_64(uint64_t a, uint64_t b, uint64_t c)
+{
+    return ((uint64_t)chi_32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)) << 32) |
+           chi_32((uint32_t)a, (uint32_t)b, (uint32_t)c);
+}
+
 __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n)
 {
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
@@ -44,18 +60,20 @@ __device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25])
 {
 #pragma unroll 1
     for (int round = 0; round < 24; round++) {
-        uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
-        uint64_t c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
-        uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
-        uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
-        uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
-        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1),
-                 d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
-        // keep d materialised: LLVM otherwise re-associates a ^= (c ^ rot c') into two xors per lane word
-        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4));
+        const uint64_t c0 = xor3_64(xor3_64(a[0], a[5], a[10]), a[15], a[20]);
+        const uint64_t c1 = xor3_64(xor3_64(a[1], a[6], a[11]), a[16], a[21]);
+        const uint64_t c2 = xor3_64(xor3_64(a[2], a[7], a[12]), a[17], a[22]);
+        const uint64_t c3 = xor3_64(xor3_64(a[3], a[8], a[13]), a[18], a[23]);
+        const uint64_t c4 = xor3_64(xor3_64(a[4], a[9], a[14]), a[19], a[24]);
+        // theta: a[x][y] ^= c[x-1] ^ rot(c[x+1], 1) as ONE 3-input xor per word
+        const uint64_t r0 = rotl64(c1, 1), r1 = rotl64(c2, 1), r2 = rotl64(c3, 1), r3 = rotl64(c4, 1), r4 = rotl64(c0, 1);
 #pragma unroll
         for (int y = 0; y < 25; y += 5) {
-            a[y] ^= d0; a[y + 1] ^= d1; a[y + 2] ^= d2; a[y + 3] ^= d3; a[y + 4] ^= d4;
+            a[y] = xor3_64(a[y], c4, r0);
+            a[y + 1] = xor3_64(a[y + 1], c0, r1);
+            a[y + 2] = xor3_64(a[y + 2], c1, r2);
+            a[y + 3] = xor3_64(a[y + 3], c2, r3);
+            a[y + 4] = xor3_64(a[y + 4], c3, r4);
         }
         // rho + pi
         uint64_t b[25];
@@ -69,11 +87,11 @@ __device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25])
         // chi
 #pragma unroll
         for (int y = 0; y < 25; y += 5) {
-            a[y] = b[y] ^ (~b[y + 1] & b[y + 2]);
-            a[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]);
-            a[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]);
-            a[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]);
-            a[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]);
+            a[y] = chi_64(b[y], b[y + 1], b[y + 2]);
+            a[y + 1] = chi_64(b[y + 1], b[y + 2], b[y + 3]);
+            a[y + 2] = chi_64(b[y + 2], b[y + 3], b[y + 4]);
+            a[y + 3] = chi_64(b[y + 3], b[y + 4], b[y]);
+            a[y + 4] = chi_64(b[y + 4], b[y], b[y + 1]);
         }
         a[0] ^= KECCAK_RC[round];
     }
@@ -161,6 +179,131 @@ struct Shake {
 #pragma unroll
             for (int t = 0; t < RATE_WORDS; t++)
                 if (k + t < n) dst[k + t] = s[t];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two lanes per sponge, for latency-bound hashing (few, long sponges: H(mu || w1), tr = H(pk), small batches).
+// Lane 2i holds the LOW 32 bits of the 25 state words of sponge i, lane 2i+1 the HIGH 32 bits.  theta's parities,
+// chi and iota are lane-local 32-bit work; a 64-bit rotation by n is, in both lanes,
+//     own' = alignbit(own, partner, 32 - n)   (n < 32)      own' = alignbit(partner, own, 64 - n)   (n > 32)
+// with the partner's half fetched by one DPP quad_perm[1,0,3,2] move.  160 instructions per round per lane instead of
+// 270, i.e. 1.7x shorter latency per permutation at 1.2x the issue slots per sponge -- so it is used only where one
+// sponge per lane leaves the SIMDs under-occupied.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t k2_partner(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+}
+template <int N>
+__device__ __forceinline__ uint32_t k2_rot(uint32_t own)
+{
+    static_assert(N > 0 && N < 64 && N != 32, "rotation amount");
+    const uint32_t par = k2_partner(own);
+    return N < 32 ? __builtin_amdgcn_alignbit(own, par, 32 - N) : __builtin_amdgcn_alignbit(par, own, 64 - N);
+}
+
+__device__ __forceinline__ void keccak2_f1600(uint32_t (&a)[25], bool hi)
+{
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        const uint32_t c0 = xor3_32(xor3_32(a[0], a[5], a[10]), a[15], a[20]);
+        const uint32_t c1 = xor3_32(xor3_32(a[1], a[6], a[11]), a[16], a[21]);
+        const uint32_t c2 = xor3_32(xor3_32(a[2], a[7], a[12]), a[17], a[22]);
+        const uint32_t c3 = xor3_32(xor3_32(a[3], a[8], a[13]), a[18], a[23]);
+        const uint32_t c4 = xor3_32(xor3_32(a[4], a[9], a[14]), a[19], a[24]);
+        const uint32_t r0 = k2_rot<1>(c1), r1 = k2_rot<1>(c2), r2 = k2_rot<1>(c3), r3 = k2_rot<1>(c4), r4 = k2_rot<1>(c0);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            a[y] = xor3_32(a[y], c4, r0);
+            a[y + 1] = xor3_32(a[y + 1], c0, r1);
+            a[y + 2] = xor3_32(a[y + 2], c1, r2);
+            a[y + 3] = xor3_32(a[y + 3], c2, r3);
+            a[y + 4] = xor3_32(a[y + 4], c3, r4);
+        }
+        uint32_t b[25];
+        b[0] = a[0];
+        b[10] = k2_rot<1>(a[1]);   b[20] = k2_rot<62>(a[2]);  b[5] = k2_rot<28>(a[3]);   b[15] = k2_rot<27>(a[4]);
+        b[16] = k2_rot<36>(a[5]);  b[1] = k2_rot<44>(a[6]);   b[11] = k2_rot<6>(a[7]);   b[21] = k2_rot<55>(a[8]);
+        b[6] = k2_rot<20>(a[9]);   b[7] = k2_rot<3>(a[10]);   b[17] = k2_rot<10>(a[11]); b[2] = k2_rot<43>(a[12]);
+        b[12] = k2_rot<25>(a[13]); b[22] = k2_rot<39>(a[14]); b[23] = k2_rot<41>(a[15]); b[8] = k2_rot<45>(a[16]);
+        b[18] = k2_rot<15>(a[17]); b[3] = k2_rot<21>(a[18]);  b[13] = k2_rot<8>(a[19]);  b[14] = k2_rot<18>(a[20]);
+        b[24] = k2_rot<2>(a[21]);  b[9] = k2_rot<61>(a[22]);  b[19] = k2_rot<56>(a[23]); b[4] = k2_rot<14>(a[24]);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+            a[y] = chi_32(b[y], b[y + 1], b[y + 2]);
+            a[y + 1] = chi_32(b[y + 1], b[y + 2], b[y + 3]);
+            a[y + 2] = chi_32(b[y + 2], b[y + 3], b[y + 4]);
+            a[y + 3] = chi_32(b[y + 3], b[y + 4], b[y]);
+            a[y + 4] = chi_32(b[y + 4], b[y], b[y + 1]);
+        }
+        const uint64_t rc = KECCAK_RC[round];
+        a[0] ^= hi ? (uint32_t)(rc >> 32) : (uint32_t)rc;
+    }
+}
+
+// The two-lane sponge: same interface as Shake<>, message/digest addressed as 32-bit halves (src32 = the 64-bit-word
+// stream viewed as dwords; this lane takes dword 2w + hi of word w).
+template <int RATE_WORDS>
+struct Shake2 {
+    uint32_t s[25];
+    bool hi;
+    __device__ __forceinline__ void init(bool high_half)
+    {
+        hi = high_half;
+#pragma unroll
+        for (int i = 0; i < 25; i++) s[i] = 0;
+    }
+    template <int W0>
+    __device__ __forceinline__ int absorb(const uint32_t* __restrict__ src32, int n)
+    {
+        const uint32_t* src = src32 + (hi ? 1 : 0);
+        int k = 0;
+        if (W0 != 0) {
+            if (n < RATE_WORDS - W0) {
+#pragma unroll
+                for (int t = W0; t < RATE_WORDS; t++)
+                    if (t - W0 < n) s[t] ^= src[2 * (t - W0)];
+                return W0 + n;
+            }
+#pragma unroll
+            for (int t = W0; t < RATE_WORDS; t++) s[t] ^= src[2 * (t - W0)];
+            keccak2_f1600(s, hi);
+            k = RATE_WORDS - W0;
+        }
+#pragma unroll 1
+        for (; k + RATE_WORDS <= n; k += RATE_WORDS) {
+            uint32_t v[RATE_WORDS];
+#pragma unroll
+            for (int t = 0; t < RATE_WORDS; t++) v[t] = src[2 * (k + t)];
+#pragma unroll
+            for (int t = 0; t < RATE_WORDS; t++) s[t] ^= v[t];
+            keccak2_f1600(s, hi);
+        }
+        const int r = n - k;
+#pragma unroll
+        for (int t = 0; t < RATE_WORDS - 1; t++)
+            if (t < r) s[t] ^= src[2 * (k + t)];
+        return r;
+    }
+    __device__ __forceinline__ void finish_words(int fill)
+    {
+#pragma unroll
+        for (int t = 0; t < RATE_WORDS; t++)
+            if (t == fill) s[t] ^= hi ? 0u : 0x1Fu;
+        s[RATE_WORDS - 1] ^= hi ? 0x80000000u : 0u;
+        keccak2_f1600(s, hi);
+    }
+    __device__ __forceinline__ void squeeze(uint32_t* __restrict__ dst32, int n)
+    {
+        uint32_t* dst = dst32 + (hi ? 1 : 0);
+#pragma unroll 1
+        for (int k = 0; k < n; k += RATE_WORDS) {
+            if (k) keccak2_f1600(s, hi);
+#pragma unroll
+            for (int t = 0; t < RATE_WORDS; t++)
+                if (k + t < n) dst[2 * (k + t)] = s[t];
         }
     }
 };
