@@ -65,6 +65,38 @@ def cpu_baseline(sample_polys=4096, target_s=10.0):
                       f"1 thread of {os.cpu_count()} host CPUs"}
 
 
+def cpu_baseline_all_threads(per_poly_s, target_s=5.0, sample_polys=1024):
+    """the same reference ntt()+invntt() on every host hardware thread at once (the reference itself is single-threaded;
+    SURVEY 8(d) asks for both figures).  ctypes drops the GIL during the foreign call, so plain threads run in parallel."""
+    import threading
+    from oracle.oracle import Oracle, Reference, splitmix64_polys
+    o = Oracle()
+    if Reference.available():
+        r = Reference()
+        f_ntt, f_inv = r.addr("ntt"), r.addr("invntt")
+    else:
+        f_ntt, f_inv = o.fn_addr("orc_ntt"), o.fn_addr("orc_invntt")
+    nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    reps = max(1, int(target_s / max(2 * per_poly_s * sample_polys, 1e-6)))
+    bufs = [splitmix64_polys(sample_polys, seed=100 + i) for i in range(nthreads)]
+
+    def work(buf):
+        for _ in range(reps):
+            o.time_poly_fn(f_ntt, buf, 1)
+            o.time_poly_fn(f_inv, buf, 1)
+
+    ths = [threading.Thread(target=work, args=(b,)) for b in bufs]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    n = 2 * reps * sample_polys * nthreads
+    return {"value": n / dt, "unit": "NTT/s", "cores": nthreads,
+            "sample": f"{nthreads} threads x {reps} x (ntt + invntt) over {sample_polys} polynomials = {n} transforms in {dt:.1f} s"}
+
+
 def cpu_baseline_verify(target_s=5.0):
     from oracle.oracle import Oracle
     o = Oracle()
@@ -332,6 +364,10 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"]["all_threads"] = cpu_baseline_all_threads(1.0 / out["cpu_baseline"]["value"])
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"]["all_threads"] = {"error": repr(e)}
             if not args.no_secondary:
                 out["secondary"]["cpu_baseline"] = cpu_baseline_verify()
         print(json.dumps(out))

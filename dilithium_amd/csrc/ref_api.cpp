@@ -59,6 +59,17 @@ constexpr ZetaTable ZT{};
 #define Z64(i) Z8(i), Z8(i + 8), Z8(i + 16), Z8(i + 24), Z8(i + 32), Z8(i + 40), Z8(i + 48), Z8(i + 56)
 extern const data_t zetas_barrett[DILITHIUM_N] = {Z64(0), Z64(64), Z64(128), Z64(192)};
 
+// consts_hw.cpp:2-91: the twiddle ROM of the radix-2x2 butterfly unit, row t = (z[k], z[2k], z[2k+1]) for
+// k = 1; 4..7; 16..31; 64..127 (one row per butterfly group of passes 0..3).  Our kernels do not read it -- it is
+// exported because it is part of the reference's data surface (consts_hw.h:7).
+#define H(k) {Z(k), Z(2 * (k)), Z(2 * (k) + 1)}
+#define H4(k) H(k), H(k + 1), H(k + 2), H(k + 3)
+#define H16(k) H4(k), H4(k + 4), H4(k + 8), H4(k + 12)
+extern const data_t zetas_barrett_hw[85][3] = {H(1), H4(4), H16(16), H16(64), H16(80), H16(96), H16(112)};
+#undef H16
+#undef H4
+#undef H
+
 void ntt(data_t a[DILITHIUM_N]) { ok("ntt", dil_ntt_host(a, 1)); }
 void invntt(data_t a[DILITHIUM_N]) { ok("invntt", dil_invntt_host(a, 1)); }
 void pointwise_barrett(data_t c[DILITHIUM_N], const data_t a[DILITHIUM_N], const data_t b[DILITHIUM_N])

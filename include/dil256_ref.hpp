@@ -38,6 +38,7 @@ enum OPERATION { FORWARD_NTT_MODE, INVERSE_NTT_MODE, MUL_MODE };
 enum MAPPING { NATURAL, AFTER_NTT, AFTER_INVNTT };
 
 extern const data_t zetas_barrett[DILITHIUM_N];
+extern const data_t zetas_barrett_hw[85][3];   // consts_hw.h:7
 
 void ntt(data_t a[DILITHIUM_N]);
 void invntt(data_t a[DILITHIUM_N]);

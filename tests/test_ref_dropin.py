@@ -33,6 +33,15 @@ def test_ref_library_exports_reference_symbols(oracle):
         assert hasattr(lib, name), name
     z = np.ctypeslib.as_array((C.c_int32 * 256).in_dll(lib, "zetas_barrett"))
     assert (z == oracle.zetas()).all()
+    # consts_hw.h:7 -- the butterfly unit's twiddle ROM: (z[k], z[2k], z[2k+1]) for k = 1; 4..7; 16..31; 64..127
+    hw = np.ctypeslib.as_array((C.c_int32 * (85 * 3)).in_dll(lib, "zetas_barrett_hw")).reshape(85, 3)
+    ks = [1] + list(range(4, 8)) + list(range(16, 32)) + list(range(64, 128))
+    assert (hw == np.array([[z[k], z[2 * k], z[2 * k + 1]] for k in ks])).all()
+    from oracle import oracle as orc
+    ref_so = os.path.join(os.path.dirname(orc.__file__), "_ref", "libref.so")
+    if os.path.exists(ref_so):     # the compiled reference's own table, when it has been built
+        ref_hw = np.ctypeslib.as_array((C.c_int32 * (85 * 3)).in_dll(C.CDLL(ref_so), "zetas_barrett_hw")).reshape(85, 3)
+        assert (hw == ref_hw).all()
     ra = lib._Z15resolve_address7MAPPINGj
     ra.restype = C.c_uint
     for m in range(3):
