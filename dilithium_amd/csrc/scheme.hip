@@ -1,0 +1,613 @@
+// scheme.hip -- SURVEY 8(f) rows N1-N4 behind include/dil256.h: the composite entry points that run whole Dilithium
+// operations on the device (single-call verify / sign attempt, wire-format codecs, key generation, verification and
+// the signing rejection loop from bytes, and their host-buffer forms).  The kernels are in hash_kernels.hip,
+// codec_kernels.hip and pipelines.hip; this file only sequences them on streams.
+#include "capi_internal.hpp"
+
+#include <algorithm>
+#include <stdlib.h>
+
+using dil::rt::g;
+using dil::rt::ensure_init;
+using dil::rt::S;
+
+// (every dil_* function below is declared extern "C" in include/dil256.h and inherits that linkage)
+
+// ---- row N3 (first step): composite sequences, device-resident end to end -----------------------
+namespace {
+// Temporaries of a composite call.  Each stream that makes composite calls gets a grow-only device arena (plus two
+// pinned host words) that is reused from call to call: calls on one stream are ordered, so the next call may overwrite
+// what the previous one used.  A call carves its buffers out of the arena; whatever does not fit (first call, or a
+// bigger batch than ever before) comes from the stream-ordered pool for this call only, and the arena is regrown to
+// the new high-water mark afterwards.  Steady state: no allocation and no free per call (25 hipFreeAsync calls were
+// costing a signing call 1 ms of host time).
+struct Arena {
+    hipStream_t stream = nullptr;
+    char* base = nullptr;
+    size_t size = 0;
+    int32_t* pinned = nullptr;      // two host words for small read-backs
+    bool in_use = false;
+};
+struct ArenaPool {
+    std::mutex mu;
+    Arena slots[8];
+    Arena* acquire(hipStream_t s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        Arena* free_slot = nullptr;
+        for (Arena& a : slots) {
+            if (a.base && a.stream == s) return a.in_use ? nullptr : (a.in_use = true, &a);
+            if (!a.base && !a.in_use && !free_slot) free_slot = &a;
+        }
+        if (!free_slot) return nullptr;
+        free_slot->stream = s;
+        free_slot->in_use = true;
+        return free_slot;
+    }
+    void release(Arena* a, size_t wanted)
+    {
+        if (wanted > a->size) {       // grow for next time; hipFree waits for the work that still uses the old block
+            if (a->base) (void)hipFree(a->base);
+            a->base = nullptr;
+            a->size = 0;
+            const size_t sz = wanted + wanted / 8;
+            if (hipMalloc(reinterpret_cast<void**>(&a->base), sz) == hipSuccess) a->size = sz;
+            else (void)hipGetLastError();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        a->in_use = false;
+    }
+    void clear()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (Arena& a : slots) {
+            if (a.in_use) continue;
+            if (a.base) (void)hipFree(a.base);
+            if (a.pinned) (void)hipHostFree(a.pinned);
+            a = Arena();
+        }
+    }
+};
+ArenaPool g_arenas;
+}  // namespace
+void dil::rt::release_scratch() { g_arenas.clear(); }
+namespace {
+
+struct StreamScratch {
+    hipStream_t s;
+    Arena* arena;
+    size_t used = 0;             // bytes carved or wanted so far (256-byte granules)
+    void* spill[40];             // buffers that did not fit: stream-ordered pool, this call only
+    int nspill = 0;
+    int rc = 0;                  // first allocation failure; check once after the last take()
+    explicit StreamScratch(hipStream_t st) : s(st), arena(g_arenas.acquire(st)) {}
+    template <class T>
+    T* take(size_t count)
+    {
+        const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        const size_t off = used;
+        used += bytes ? bytes : 256;
+        if (arena && off + bytes <= arena->size) return reinterpret_cast<T*>(arena->base + off);
+        void* q = nullptr;
+        if (rc == 0 && nspill < 40) {
+            hipError_t e = hipMallocAsync(&q, bytes ? bytes : 256, s);
+            if (e != hipSuccess) rc = (int)e;
+            else spill[nspill++] = q;
+        } else if (rc == 0) {
+            rc = (int)hipErrorOutOfMemory;
+        }
+        return static_cast<T*>(q);
+    }
+    // two pinned host words (per arena; a private allocation when the call has no arena)
+    int32_t* own_pinned = nullptr;
+    int32_t* pinned_words()
+    {
+        int32_t** slot = arena ? &arena->pinned : &own_pinned;
+        if (!*slot && hipHostMalloc(reinterpret_cast<void**>(slot), 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            *slot = nullptr;
+            rc = rc ? rc : (int)hipErrorOutOfMemory;
+        }
+        return *slot;
+    }
+    ~StreamScratch()
+    {
+        for (int i = 0; i < nspill; i++) (void)hipFreeAsync(spill[i], s);
+        if (own_pinned) (void)hipHostFree(own_pinned);
+        if (arena) g_arenas.release(arena, used);
+    }
+};
+int level_kl(int level, int* K, int* L)
+{
+    switch (level) {
+    case 2: *K = 4; *L = 4; return 0;
+    case 3: *K = 6; *L = 5; return 0;
+    case 5: *K = 8; *L = 7; return 0;
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+}  // namespace
+
+int dil_verify_dev(int32_t* verdict, const int32_t* A, const uint8_t* ctilde, const int32_t* z, const int32_t* t1,
+                   const uint8_t* h, const uint8_t* mu, int level, size_t batch, int shared_pk, void* stream)
+{
+    int rc = ensure_init(), K, L;
+    if (rc || (rc = level_kl(level, &K, &L))) return rc;
+    if (batch == 0) return 0;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    int32_t* c = ws.take<int32_t>(batch * 256);
+    uint8_t* w1 = ws.take<uint8_t>(batch * K * 256);
+    uint8_t* w1p = ws.take<uint8_t>(batch * K * (level == 2 ? 192 : 128));
+    if (ws.rc) return ws.rc;
+    DIL_TRY(dil::launch_z_norm(verdict, z, level, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(c, ctilde, level, batch, s));
+    DIL_TRY(dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, g.t, s));
+    DIL_TRY(dil::launch_pack_w1(w1p, w1, level, batch, g.t, s));
+    DIL_TRY(dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, ctilde, batch, s));
+    return 0;
+}
+
+namespace {
+// temporaries of one signing attempt over `batch` entries
+struct AttemptScratch {
+    int32_t* y; uint8_t* w1; int32_t* w0; uint8_t* w1p; int32_t* c;
+    int alloc(StreamScratch& ws, int level, int K, int L, size_t batch)
+    {
+        y = ws.take<int32_t>(batch * L * 256);
+        w1 = ws.take<uint8_t>(batch * K * 256);
+        w0 = ws.take<int32_t>(batch * K * 256);
+        w1p = ws.take<uint8_t>(batch * K * (level == 2 ? 192 : 128));
+        c = ws.take<int32_t>(batch * 256);
+        return ws.rc;
+    }
+};
+int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+                      const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
+                      int phases = 3)
+{
+    if (phases & 1) DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
+    if (!(phases & 2)) return 0;
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, g.t, s, km));
+    DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, g.t, s));
+    DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s, km));
+    return 0;
+}
+
+// The same attempt over entries [off, off + cnt) of the per-entry arrays (per-key arrays are addressed through km)
+int sign_attempt_range(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                       const int32_t* t0hat, int level, int K, int L, size_t off, size_t cnt, int shared_key, hipStream_t s, dil::KeyMap km,
+                       int phases = 3)
+{
+    AttemptScratch u = t;
+    u.y += off * L * 256; u.w1 += off * K * 256; u.w0 += off * K * 256; u.w1p += off * K * (level == 2 ? 192 : 128); u.c += off * 256;
+    km.base += (uint32_t)off;
+    return sign_attempt_impl(u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
+                             rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases);
+}
+
+// A second stream for the signing loop: the hash kernels of a round are latency-bound (one sponge per lane, a few
+// hundred waves), the polynomial kernels throughput-bound; two half-rounds in flight overlap the two kinds.
+struct AuxStream {
+    std::mutex mu;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;   // fork: the aux half may start; join: it is done
+    int device = -1;
+    bool ensure(int dev)
+    {
+        if (s && device == dev) return true;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
+        device = dev;
+        return true;
+    }
+};
+AuxStream g_aux;
+
+// Run an independent part of a composite call on the helper stream (if nobody else is using it): fork() returns the
+// stream to launch that part on -- the helper, ordered after everything already on `main`, or `main` itself -- and
+// join() makes `main` wait for it.
+struct AuxFork {
+    std::unique_lock<std::mutex> lk;
+    hipStream_t main;
+    bool on, forked = false;
+    explicit AuxFork(hipStream_t m) : lk(g_aux.mu, std::try_to_lock), main(m)
+    {
+        on = g.aux_overlap && lk.owns_lock() && g_aux.ensure(g.device);
+    }
+    // `sponges`: lanes of the lane-per-sponge work going to the helper.  Only latency-bound work (less than about one
+    // wave per SIMD) gains from running beside the main stream; throughput-bound work just pays the fork/join.
+    hipStream_t fork(size_t sponges)
+    {
+        if (!on || sponges >= (size_t)g.t.num_cus * 256) return main;
+        if (hipEventRecord(g_aux.fork, main) != hipSuccess || hipStreamWaitEvent(g_aux.s, g_aux.fork, 0) != hipSuccess) {
+            on = false;
+            return main;
+        }
+        forked = true;
+        return g_aux.s;
+    }
+    int join()
+    {
+        if (!forked) return 0;
+        forked = false;
+        DIL_TRY(hipEventRecord(g_aux.join, g_aux.s));
+        DIL_TRY(hipStreamWaitEvent(main, g_aux.join, 0));
+        return 0;
+    }
+    ~AuxFork() { (void)join(); }
+};
+}  // namespace
+
+int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
+                         const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                         const int32_t* t0hat, int level, size_t batch, int shared_key, void* stream)
+{
+    int rc = ensure_init(), K, L;
+    if (rc || (rc = level_kl(level, &K, &L))) return rc;
+    if (batch == 0) return 0;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    AttemptScratch t;
+    if ((rc = t.alloc(ws, level, K, L, batch))) return rc;
+    return sign_attempt_impl(t, ctilde, z, h, flags, A, mu, rhoprime, kappa, s1hat, s2hat, t0hat, level, batch, shared_key, s);
+}
+
+// ---- rows N2 / N4: codecs, keygen, wire-format verify -------------------------------------------------
+namespace {
+struct LevelPar { int K, L, eta, omega, zbits, eta_bits; int32_t gamma1; };
+int level_par(int level, LevelPar* p)
+{
+    switch (level) {
+    case 2: *p = {4, 4, 2, 80, 18, 3, 1 << 17}; return 0;
+    case 3: *p = {6, 5, 4, 55, 20, 4, 1 << 19}; return 0;
+    case 5: *p = {8, 7, 2, 75, 20, 3, 1 << 19}; return 0;
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+struct CodecDesc { int bits, polys, xf; int32_t offset; };
+int codec_desc(int kind, const LevelPar& p, CodecDesc* d)
+{
+    switch (kind) {
+    case DIL_CODEC_T1: *d = {10, p.K, dil::XF_PLAIN, 0}; return 0;
+    case DIL_CODEC_T0: *d = {13, p.K, dil::XF_OFFSET_MINUS, 1 << 12}; return 0;
+    case DIL_CODEC_S1: *d = {p.eta_bits, p.L, dil::XF_OFFSET_MINUS, p.eta}; return 0;
+    case DIL_CODEC_S2: *d = {p.eta_bits, p.K, dil::XF_OFFSET_MINUS, p.eta}; return 0;
+    case DIL_CODEC_Z: *d = {p.zbits, p.L, dil::XF_OFFSET_MINUS, p.gamma1}; return 0;
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+}  // namespace
+
+size_t dil_pk_bytes(int level) { LevelPar p; return level_par(level, &p) ? 0 : 32 + (size_t)p.K * 320; }
+size_t dil_sk_bytes(int level)
+{
+    LevelPar p;
+    return level_par(level, &p) ? 0 : 96 + (size_t)(p.L + p.K) * 32 * p.eta_bits + (size_t)p.K * 416;
+}
+size_t dil_sig_bytes(int level) { LevelPar p; return level_par(level, &p) ? 0 : 32 + (size_t)p.L * 32 * p.zbits + p.omega + p.K; }
+
+int dil_unpack_dev(int32_t* out, const uint8_t* in, size_t in_stride, size_t in_offset, int kind, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    CodecDesc d;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
+    return (int)dil::launch_unpack(d.bits, out, in, in_stride, in_offset, d.polys, d.xf, d.offset, batch, g.t, S(stream));
+}
+int dil_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int kind, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    CodecDesc d;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
+    return (int)dil::launch_pack(d.bits, out, out_stride, out_offset, in, d.polys, d.xf, d.offset, batch, g.t, S(stream));
+}
+int dil_hint_unpack_dev(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    return (int)dil::launch_hint_unpack(h, bad, in, in_stride, in_offset, p.K, p.omega, batch, S(stream));
+}
+int dil_hint_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    return (int)dil::launch_hint_pack(out, out_stride, out_offset, h, p.K, p.omega, batch, S(stream));
+}
+int dil_expand_s_dev(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t stride, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    return (int)dil::launch_expand_s(s1, s2, rhoprime, stride, p.eta, p.L, p.K, batch, S(stream));
+}
+
+int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    if (batch == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(seed)) & 7) return (int)hipErrorInvalidValue;   // hashed as 64-bit words
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    const size_t pkb = dil_pk_bytes(level), skb = dil_sk_bytes(level), sb = (size_t)32 * p.eta_bits;
+    uint8_t* e = ws.take<uint8_t>(batch * 128);                    // rho(32) | rho'(64) | key(32)  (KG_*)
+    int32_t* A = ws.take<int32_t>(batch * p.K * p.L * 256);
+    int32_t* s1 = ws.take<int32_t>(batch * p.L * 256);
+    int32_t* s2 = ws.take<int32_t>(batch * p.K * 256);
+    int32_t* w = ws.take<int32_t>(batch * p.K * 256);
+    int32_t* t1 = ws.take<int32_t>(batch * p.K * 256);
+    int32_t* t0 = ws.take<int32_t>(batch * p.K * 256);
+    uint8_t* tr = ws.take<uint8_t>(batch * 32);
+    if (ws.rc) return ws.rc;
+    AuxFork ax(s);
+    DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(e), 128, reinterpret_cast<const uint64_t*>(seed), 32, batch, s));
+    // ExpandS (helper stream, when it is latency-bound) runs beside ExpandA: independent, both Keccak-bound
+    DIL_TRY(dil::launch_expand_s(s1, s2, e + 32, 128, p.eta, p.L, p.K, batch, ax.fork(batch * p.K * p.L)));
+    DIL_TRY(dil::launch_expand_a(A, e, 128, level, batch, s));
+    if ((rc = ax.join())) return rc;
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, s1, batch, 0, g.t, s));
+    DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, g.t, s));
+    // pk = rho | t1
+    DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(10, pk, pkb, 32, t1, p.K, dil::XF_PLAIN, 0, batch, g.t, s));
+    // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level): one long sponge per key, latency-bound --
+    // on the helper stream, under the packing of the rest of sk
+    {
+        hipStream_t a = ax.fork(batch);
+        DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, batch, a));
+        DIL_TRY(dil::launch_copy_field(sk, skb, 64, tr, 32, 0, 32, batch, g.t, a));
+    }
+    // sk = rho | key | tr | s1 | s2 | t0
+    DIL_TRY(dil::launch_copy_field(sk, skb, 0, e, 128, 0, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_copy_field(sk, skb, 32, e, 128, 96, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, s1, p.L, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, s2, p.K, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
+    DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, g.t, s));
+    return ax.join();
+}
+
+int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                       int shared_pk, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    if (batch == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // read as 64-bit words
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
+    const size_t nk = shared_pk ? 1 : batch;
+    int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
+    int32_t* t1 = ws.take<int32_t>(nk * p.K * 256);
+    int32_t* z = ws.take<int32_t>(batch * p.L * 256);
+    uint8_t* h = ws.take<uint8_t>(batch * p.K * 256);
+    int32_t* bad = ws.take<int32_t>(batch);
+    uint8_t* ct = ws.take<uint8_t>(batch * 32);
+    int32_t* c = ws.take<int32_t>(batch * 256);
+    uint8_t* w1 = ws.take<uint8_t>(batch * p.K * 256);
+    uint8_t* w1p = ws.take<uint8_t>(batch * p.K * (level == 2 ? 192 : 128));
+    if (ws.rc) return ws.rc;
+    AuxFork ax(s);
+    {   // public-key side (helper stream when it is latency-bound): A = ExpandA(rho), t1
+        hipStream_t a = ax.fork(nk * p.K * p.L);
+        DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, a));
+        DIL_TRY(dil::launch_unpack(10, t1, pk, pkb, 32, p.K, dil::XF_PLAIN, 0, nk, g.t, a));
+    }
+    // signature side: c~, z, hints, ||z|| check, c = SampleInBall(c~)
+    DIL_TRY(dil::launch_copy_field(ct, 32, 0, sig, sgb, 0, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_unpack(p.zbits, z, sig, sgb, 32, p.L, dil::XF_OFFSET_MINUS, p.gamma1, batch, g.t, s));
+    DIL_TRY(dil::launch_hint_unpack(h, bad, sig, sgb, 32 + zb, p.K, p.omega, batch, s));
+    DIL_TRY(dil::launch_z_norm(verdict, z, level, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(c, ct, level, batch, s));
+    if ((rc = ax.join())) return rc;
+    DIL_TRY(dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, g.t, s));
+    DIL_TRY(dil::launch_pack_w1(w1p, w1, level, batch, g.t, s));
+    DIL_TRY(dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, ct, batch, s));
+    return (int)dil::launch_or_flag(verdict, bad, 4, batch, g.t, s);
+}
+
+// ---- row N3: the whole signing rejection loop on the device ---------------------------------------
+// combined_top.v's sign FSMs (:1694-2229) retry one signature until it passes.  A batch engine is
+// better used WIDE than deep: each round runs S speculative attempts (kappa = a0*L, (a0+1)*L, ...)
+// for every still-pending signature, S chosen so that a round keeps about `cap` entries in flight;
+// the first accepted attempt of an item wins, which is exactly the signature the sequential loop
+// produces.  The pending set shrinks geometrically while S grows, so the loop needs ~5 rounds
+// instead of the ~35 the unluckiest signature of a large batch takes.
+int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                 int max_attempts, void* stream)
+{
+    LevelPar p;
+    int rc = ensure_init();
+    if (rc || (rc = level_par(level, &p))) return rc;
+    if (batch == 0) return 0;
+    if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
+    if (reinterpret_cast<uintptr_t>(sk) & 7) return (int)hipErrorInvalidValue;       // rho is read as 64-bit words
+    if (batch == 1) shared_sk = 1;
+    hipStream_t s = S(stream);
+    StreamScratch ws(s);
+    const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), sb = (size_t)32 * p.eta_bits, zb = (size_t)p.L * 32 * p.zbits;
+    const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
+    // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
+    // speculate for free
+    const size_t cap = std::max<size_t>(batch, g.sign_cap ? (size_t)g.sign_cap : 16384);
+    const int s_max = 64;
+    // per key
+    int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
+    int32_t* s1h = ws.take<int32_t>(nk * p.L * 256);
+    int32_t* s2h = ws.take<int32_t>(nk * p.K * 256);
+    int32_t* t0h = ws.take<int32_t>(nk * p.K * 256);
+    // per item
+    uint8_t* km = ws.take<uint8_t>(batch * 96);          // key || mu
+    uint8_t* rp = ws.take<uint8_t>(batch * 64);          // rho'
+    int32_t* idx0 = ws.take<int32_t>(batch);             // pending lists (ping-pong)
+    int32_t* idx1 = ws.take<int32_t>(batch);
+    int32_t* wine = ws.take<int32_t>(batch);             // winners of a round: entry, item
+    int32_t* wini = ws.take<int32_t>(batch);
+    int32_t* own_attempts = attempts ? nullptr : ws.take<int32_t>(batch);
+    int32_t* counts = ws.take<int32_t>(2);               // [0] pending, [1] winners
+    // per entry
+    uint32_t* kap = ws.take<uint32_t>(cap);
+    uint8_t* ct = ws.take<uint8_t>(cap * 32);
+    int32_t* z = ws.take<int32_t>(cap * p.L * 256);
+    uint8_t* h = ws.take<uint8_t>(cap * p.K * 256);
+    int32_t* fl = ws.take<int32_t>(cap);
+    uint8_t* mu_c = ws.take<uint8_t>(cap * 64);
+    uint8_t* rp_c = ws.take<uint8_t>(cap * 64);
+    AttemptScratch att;
+    if ((rc = att.alloc(ws, level, p.K, p.L, cap))) return rc;
+    if (!attempts) attempts = own_attempts;
+    int32_t* host_counts = ws.pinned_words();            // pageable memory would make the read-back a blocking staged copy
+    if (ws.rc) return ws.rc;
+
+    // key material: A = ExpandA(rho), s1^ s2^ t0^ = NTT(unpack(sk))
+    DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s));
+    DIL_TRY(dil::launch_unpack(p.eta_bits, s1h, sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
+    DIL_TRY(dil::launch_unpack(p.eta_bits, s2h, sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
+    DIL_TRY(dil::launch_unpack(13, t0h, sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, g.t, s));
+    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s1h, nk * p.L, g.t, s));
+    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s2h, nk * p.K, g.t, s));
+    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, t0h, nk * p.K, g.t, s));
+    // rho' = SHAKE256(key || mu, 64)  (deterministic signing, as the reference's KATs)
+    DIL_TRY(dil::launch_copy_field(km, 96, 0, sk, sk_stride, 32, 32, batch, g.t, s));
+    DIL_TRY(dil::launch_copy_field(km, 96, 32, mu, 64, 0, 64, batch, g.t, s));
+    DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(rp), 64, reinterpret_cast<uint64_t*>(km), 96, batch, s));
+    DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
+
+    std::unique_lock<std::mutex> aux_lock(g_aux.mu, std::defer_lock);    // one signing loop at a time may use the helper stream
+    const bool two_streams = g.sign_streams > 1 && aux_lock.try_lock() && g_aux.ensure(g.device);
+    int32_t *idx_cur = nullptr, *idx_next = idx0;
+    size_t n = batch;
+    int a0 = 0;                                          // attempts every pending item has already failed
+    while (n > 0 && a0 < max_attempts) {
+        const int S_ = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
+        const size_t E = n * (size_t)S_;
+        const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
+        const uint8_t *mur = mu, *rpr = rp;
+        if (!direct) {
+            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, g.t, s));
+            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, g.t, s));
+            mur = mu_c;
+            rpr = rp_c;
+        }
+        dil::KeyMap keys;                                // per-item keys are read in place through the pending list
+        keys.idx = idx_cur;
+        keys.S = (uint32_t)S_;
+        DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
+        auto part = [&](size_t off, size_t cnt, hipStream_t st, int phases) {
+            return sign_attempt_range(att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, off, cnt, shared_sk, st,
+                                      keys, phases);
+        };
+        // Optional (DIL_SIGN_STREAMS=2; measured: no gain): two half-rounds staggered by one kernel, the helper half
+        // starting when the main half's ExpandMask is done.
+        const size_t half = two_streams && E >= 4096 ? (E / 2) : 0;      // entries [half, E) on the helper stream
+        if (half) {
+            if ((rc = part(0, half, s, 1))) return rc;                   // main: ExpandMask
+            DIL_TRY(hipEventRecord(g_aux.fork, s));
+            DIL_TRY(hipStreamWaitEvent(g_aux.s, g_aux.fork, 0));
+            if ((rc = part(half, E - half, g_aux.s, 3))) return rc;      // helper: the whole chain
+            if ((rc = part(0, half, s, 2))) return rc;                   // main: the rest
+            DIL_TRY(hipEventRecord(g_aux.join, g_aux.s));
+            DIL_TRY(hipStreamWaitEvent(s, g_aux.join, 0));
+        } else if ((rc = part(0, E, s, 3))) {
+            return rc;
+        }
+        // winners (first accepted attempt per item) -> packed straight into their signature slots
+        DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
+        DIL_TRY(dil::launch_sign_collect(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, s));
+        dil::RowMap win;
+        win.src_row = wine;
+        win.dst_row = wini;
+        win.count = counts + 1;
+        DIL_TRY(dil::launch_copy_field(sig, sgb, 0, ct, 32, 0, 32, n, g.t, s, win));
+        DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, g.t, s, win));
+        DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n, s, win));
+        DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
+        DIL_TRY(hipStreamSynchronize(s));
+        n = (size_t)host_counts[0];
+        a0 += S_;
+        idx_cur = idx_next;
+        idx_next = idx_cur == idx0 ? idx1 : idx0;
+    }
+    return n == 0 ? 0 : DIL_ERR_UNFINISHED;
+}
+
+// ---- host-buffer forms of the whole operations (H2D -> device call -> D2H on the null stream) --------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    int alloc(size_t bytes) { return (int)hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+int dil_keygen_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch)
+{
+    const size_t pkb = dil_pk_bytes(level), skb = dil_sk_bytes(level);
+    if (!pkb) return (int)hipErrorInvalidValue;
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    DevBuf dpk, dsk, dseed;
+    if ((rc = dpk.alloc(batch * pkb)) || (rc = dsk.alloc(batch * skb)) || (rc = dseed.alloc(batch * 32))) return rc;
+    DIL_TRY(hipMemcpy(dseed.p, seed, batch * 32, hipMemcpyHostToDevice));
+    rc = dil_keygen_dev(static_cast<uint8_t*>(dpk.p), static_cast<uint8_t*>(dsk.p), static_cast<uint8_t*>(dseed.p), level, batch, nullptr);
+    if (rc) return rc;
+    DIL_TRY(hipMemcpy(pk, dpk.p, batch * pkb, hipMemcpyDeviceToHost));
+    DIL_TRY(hipMemcpy(sk, dsk.p, batch * skb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                  int max_attempts)
+{
+    const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level);
+    if (!skb) return (int)hipErrorInvalidValue;
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t nk = shared_sk ? 1 : batch;
+    DevBuf dsig, datt, dsk, dmu;
+    if ((rc = dsig.alloc(batch * sgb)) || (rc = datt.alloc(batch * 4)) || (rc = dsk.alloc(nk * skb)) || (rc = dmu.alloc(batch * 64)))
+        return rc;
+    DIL_TRY(hipMemcpy(dsk.p, sk, nk * skb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dmu.p, mu, batch * 64, hipMemcpyHostToDevice));
+    const int src = dil_sign_dev(static_cast<uint8_t*>(dsig.p), static_cast<int32_t*>(datt.p), static_cast<uint8_t*>(dsk.p),
+                                 static_cast<uint8_t*>(dmu.p), level, batch, shared_sk, max_attempts, nullptr);
+    if (src && src != DIL_ERR_UNFINISHED) return src;
+    DIL_TRY(hipDeviceSynchronize());
+    DIL_TRY(hipMemcpy(sig, dsig.p, batch * sgb, hipMemcpyDeviceToHost));
+    if (attempts) DIL_TRY(hipMemcpy(attempts, datt.p, batch * 4, hipMemcpyDeviceToHost));
+    return src;
+}
+
+int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                        int shared_pk)
+{
+    const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
+    if (!pkb) return (int)hipErrorInvalidValue;
+    if (batch == 0) return 0;
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t nk = shared_pk ? 1 : batch;
+    DevBuf dv, dpk, dsig, dmu;
+    if ((rc = dv.alloc(batch * 4)) || (rc = dpk.alloc(nk * pkb)) || (rc = dsig.alloc(batch * sgb)) || (rc = dmu.alloc(batch * 64)))
+        return rc;
+    DIL_TRY(hipMemcpy(dpk.p, pk, nk * pkb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dsig.p, sig, batch * sgb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dmu.p, mu, batch * 64, hipMemcpyHostToDevice));
+    rc = dil_verify_sig_dev(static_cast<int32_t*>(dv.p), static_cast<uint8_t*>(dpk.p), static_cast<uint8_t*>(dsig.p),
+                            static_cast<uint8_t*>(dmu.p), level, batch, shared_pk, nullptr);
+    if (rc) return rc;
+    DIL_TRY(hipMemcpy(verdict, dv.p, batch * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
