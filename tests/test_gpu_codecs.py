@@ -376,3 +376,38 @@ def test_scheme_entry_points_edge_cases(gpu):
     mu0 = gpu.zeros((1, 64), dtype=gpu.uint8, device="cuda")
     verdict = gpu.zeros(1, dtype=gpu.int32, device="cuda")
     assert L.dil_verify_sig_dev(verdict.data_ptr(), buf.data_ptr() + 1, sg.data_ptr(), mu0.data_ptr(), 3, 1, 0, None) != 0
+
+
+def test_concurrent_calls_on_two_streams(gpu, kat_msgs):
+    """two host threads, each on its own stream, sign and verify at the same time: per-stream scratch arenas and the
+    shared helper stream must not let the calls disturb each other"""
+    import threading
+    from dilithium_amd import api
+    level = 3
+    k, pk, sk, sig = kat_wire(level)
+    mu = mus(k, kat_msgs)
+    skd, pkd, mud = cu(gpu, sk), cu(gpu, pk), cu(gpu, mu)
+    gpu.cuda.synchronize()
+    results, errors = {}, []
+
+    def worker(name, lo, hi):
+        try:
+            st = gpu.cuda.Stream()
+            with gpu.cuda.stream(st):
+                for _ in range(6):
+                    s, a = api.sign(skd[lo:hi].contiguous(), mud[lo:hi].contiguous(), level)
+                    v = api.verify_sig(pkd[lo:hi].contiguous(), s, mud[lo:hi].contiguous(), level)
+                    st.synchronize()
+                    assert (s.cpu().numpy() == sig[lo:hi]).all() and int(v.abs().sum()) == 0
+                results[name] = True
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=("a", 0, 50)), threading.Thread(target=worker, args=("b", 50, 100)),
+           threading.Thread(target=worker, args=("c", 20, 80))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    assert results == {"a": True, "b": True, "c": True}
