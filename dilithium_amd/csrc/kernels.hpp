@@ -44,7 +44,8 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
                          const uint8_t* h, size_t batch, int shared_pk, const Tables& t, hipStream_t s);
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
-                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km = KeyMap());
+                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km = KeyMap(),
+                        int32_t* w0_scratch = nullptr);   // == w0: rejected attempts stop at their first failed check
 
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);

@@ -456,6 +456,120 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     }
 }
 
+// Sign phase 2 for the signing LOOP (dil_sign_dev): same arithmetic, but an attempt is abandoned at its first failed
+// check, and the checks run in the order that rejects most per transform spent: (A) r0 = w0 - c s2 row by row
+// (fails 61 % of level-5 attempts), (B) z = y + c s1 (34 %), (C) c t0 and the hints.  flags reports only that first
+// failure (2 / 1 / 4, | 8 for too many hints); z and h are complete only when flags == 0, which is all the loop
+// reads.  r0 is parked in the attempt's own w0 scratch between (A) and (C).  Expected inverse transforms per level-5
+// attempt: ~10 instead of 23.
+template <int LEVEL>
+__global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
+    int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
+    const int32_t* __restrict__ c, const int32_t* __restrict__ y, int32_t* __restrict__ w0,
+    const uint8_t* __restrict__ w1, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
+    const int32_t* __restrict__ t0hat, size_t batch, int shared_key, KeyMap km, const uint32_t* __restrict__ fwd_tab,
+    const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64];
+    const int lane = threadIdx.x & 63;
+    stage_tables(lds, fwd_tab, inv_tab);
+    __syncthreads();
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * 64;   // byte-plane scratch
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+        const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
+        const int32_t* s2 = s2hat + (shared_key ? 0 : km.key(it) * K) * 256;
+        const int32_t* t0 = t0hat + (shared_key ? 0 : km.key(it) * K) * 256;
+        int32_t ch[4];
+        load_strided(ch, c + it * 256, lane);
+        int4 kn = *reinterpret_cast<const int4*>(s2 + 4 * lane);
+        ntt_fwd_core(ch, twf, lm);
+        uint32_t bits = 0, nh = 0;
+        // (A) r0 rows
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            const int4 a2 = kn;
+            const size_t o = (it * K + k) * 256;
+            int32_t wv0[4];
+            load_strided(wv0, w0 + o, lane);
+            if (k + 1 < K) kn = *reinterpret_cast<const int4*>(s2 + (k + 1) * 256 + 4 * lane);
+            int32_t a[4] = {mont_mul(ch[0], a2.x), mont_mul(ch[1], a2.y), mont_mul(ch[2], a2.z), mont_mul(ch[3], a2.w)};
+            ntt_inv_core(a, twi, lm);
+            bool rej = false;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t r0 = canon_any(wv0[m] - a[m]);
+                rej |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
+                w0[o + lane + 64 * m] = (int32_t)r0;
+            }
+            if (__ballot(rej)) {
+                bits = 2;
+                break;
+            }
+        }
+        // (B) z rows
+        if (!bits) {
+            kn = *reinterpret_cast<const int4*>(s1 + 4 * lane);
+#pragma unroll 1
+            for (int l = 0; l < L; l++) {
+                const int4 sv = kn;
+                const size_t o = (it * L + l) * 256;
+                int32_t yv[4];
+                load_strided(yv, y + o, lane);
+                if (l + 1 < L) kn = *reinterpret_cast<const int4*>(s1 + (l + 1) * 256 + 4 * lane);
+                int32_t r[4] = {mont_mul(ch[0], sv.x), mont_mul(ch[1], sv.y), mont_mul(ch[2], sv.z), mont_mul(ch[3], sv.w)};
+                ntt_inv_core(r, twi, lm);
+                bool rej = false;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t v = canon_any(r[m] + yv[m]);
+                    rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
+                    z_out[o + lane + 64 * m] = (int32_t)v;
+                }
+                if (__ballot(rej)) {
+                    bits = 1;
+                    break;
+                }
+            }
+        }
+        // (C) c t0 rows and the hints
+        if (!bits) {
+            kn = *reinterpret_cast<const int4*>(t0 + 4 * lane);
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int4 b0 = kn;
+                const size_t o = (it * K + k) * 256;
+                int32_t r0v[4];
+                uint32_t wv1[4], hv[4];
+                load_strided(r0v, w0 + o, lane);          // this lane's own stores of stage (A)
+                const uint32_t w1p = load_row_u8(w1 + o, lane);
+                if (k + 1 < K) kn = *reinterpret_cast<const int4*>(t0 + (k + 1) * 256 + 4 * lane);
+                int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
+                ntt_inv_core(b, twi, lm);
+                bool rej = false;
+                unpack_row_u8(wv1, w1p, sc, lane);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t ct0 = canon_small(b[m]);
+                    rej |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
+                    const uint32_t sm = canon_small((int32_t)((uint32_t)r0v[m] + ct0) - Q);
+                    hv[m] = make_hint<LEVEL>(sm, wv1[m]);
+                    nh += __popcll(__ballot(hv[m]));
+                }
+                store_row_u8(h_out + o, hv, sc, lane);
+                if (__ballot(rej)) {
+                    bits = 4;
+                    break;
+                }
+            }
+        }
+        if (lane == 0) flags_out[it] = (int32_t)(bits | (nh > (uint32_t)Par<LEVEL>::OMEGA ? 8u : 0u));
+    }
+}
+
 // (twiddles in registers instead of LDS were tried in the shared-key kernels: no gain, the verify variant spilled)
 // ---------------------------------------------------------------------------------------
 // Shared-key wave-per-item kernels.  When one key serves the whole batch (one signer, or many
@@ -707,9 +821,26 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
 
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
-                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km)
+                        const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km,
+                        int32_t* w0_scratch)
 {
     if (batch == 0) return hipSuccess;
+    if (use_wpi(batch, t) && w0_scratch) {      // the signing loop's early-exit form (w0 is its own scratch, reused for r0)
+        if (w0_scratch != w0) return hipErrorInvalidValue;
+#define DIL_S2E(LV)                                                                                                              \
+    hipLaunchKernelGGL(sign2_early_wpi_kernel<LV>,                                                                               \
+                       grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu)), \
+                       256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe);          \
+    break
+        switch (level) {
+        case 2: DIL_S2E(2);
+        case 3: DIL_S2E(3);
+        case 5: DIL_S2E(5);
+        default: return hipErrorInvalidValue;
+        }
+#undef DIL_S2E
+        return hipGetLastError();
+    }
     if (use_wpi(batch, t)) {
         switch (level) {
         case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;

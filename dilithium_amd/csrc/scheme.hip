@@ -164,7 +164,7 @@ struct AttemptScratch {
 int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                       const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
-                      int phases = 3)
+                      int phases = 3, bool early_exit = false)
 {
     if (phases & 1) DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
     if (!(phases & 2)) return 0;
@@ -172,7 +172,8 @@ int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint
     DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, g.t, s));
     DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
     DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
-    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s, km));
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s, km,
+                              early_exit ? t.w0 : nullptr));
     return 0;
 }
 
@@ -180,13 +181,13 @@ int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint
 int sign_attempt_range(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                        const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                        const int32_t* t0hat, int level, int K, int L, size_t off, size_t cnt, int shared_key, hipStream_t s, dil::KeyMap km,
-                       int phases = 3)
+                       int phases = 3, bool early_exit = false)
 {
     AttemptScratch u = t;
     u.y += off * L * 256; u.w1 += off * K * 256; u.w0 += off * K * 256; u.w1p += off * K * (level == 2 ? 192 : 128); u.c += off * 256;
     km.base += (uint32_t)off;
     return sign_attempt_impl(u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
-                             rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases);
+                             rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases, early_exit);
 }
 
 // A second stream for the signing loop: the hash kernels of a round are latency-bound (one sponge per lane, a few
@@ -505,7 +506,7 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
         auto part = [&](size_t off, size_t cnt, hipStream_t st, int phases) {
             return sign_attempt_range(att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, off, cnt, shared_sk, st,
-                                      keys, phases);
+                                      keys, phases, g.sign_early != 0);
         };
         // Optional (DIL_SIGN_STREAMS=2; measured: no gain): two half-rounds staggered by one kernel, the helper half
         // starting when the main half's ExpandMask is done.
