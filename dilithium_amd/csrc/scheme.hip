@@ -432,7 +432,7 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     if (rc || (rc = level_par(level, &p))) return rc;
     if (batch == 0) return 0;
     if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
-    if (reinterpret_cast<uintptr_t>(sk) & 7) return (int)hipErrorInvalidValue;       // rho is read as 64-bit words
+    if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // hashed as 64-bit words
     if (batch == 1) shared_sk = 1;
     hipStream_t s = S(stream);
     StreamScratch ws(s);
