@@ -13,10 +13,12 @@ L3-resident one (the L3-resident rate is reported beside it as `llc_resident_val
 metric value = transforms / second over all GPUs (weak scaling: per-GPU work fixed).
 
 Also reported on the same JSON line:
-  roofline      dominant kernel (forward NTT): algorithmic bytes (2048 B x 65536 per launch) /
-                its average duration, measured with HIP events on the launch stream inside the
-                timed region; peak 8 TB/s (MI355X_MICROARCH.md); traffic from the committed
-                rocprofv3 PMC pass (profiles/), or null.
+  roofline      dominant kernels (forward / inverse NTT, alternating, same bytes): algorithmic bytes
+                (2048 B x 65536 per launch) / the average launch duration over the timed region, from
+                two HIP events on the launch stream around the region (no events inside it: an event
+                record between launches costs microseconds of GPU idle time); a separate untimed
+                instrumented pass splits forward from inverse.  peak 8 TB/s (MI355X_MICROARCH.md);
+                traffic from the committed rocprofv3 PMC pass (profiles/), or null.
   cpu_baseline  the reference's own ntt()+invntt() (oracle/_ref, kind "reference") -- or our C
                 restatement (kind "port") -- on one host core, bounded sample.
   secondary     Dilithium-3 verify cores / s (configs[3], batch 8192, distinct pk) with its own
@@ -77,24 +79,31 @@ def cpu_baseline_all_threads(per_poly_s, target_s=5.0, sample_polys=1024):
     else:
         f_ntt, f_inv = o.fn_addr("orc_ntt"), o.fn_addr("orc_invntt")
     nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    reps = max(1, int(target_s / max(2 * per_poly_s * sample_polys, 1e-6)))
+    chunk = max(1, int(0.05 / max(per_poly_s * sample_polys, 1e-6)))      # ~50 ms per foreign call
     bufs = [splitmix64_polys(sample_polys, seed=100 + i) for i in range(nthreads)]
+    done = [0] * nthreads
+    deadline = [0.0]
 
-    def work(buf):     # two long foreign calls per thread (the GIL is only held between them)
-        o.time_poly_fn(f_ntt, buf, reps)
-        o.time_poly_fn(f_inv, buf, reps)
+    def work(i):       # time-bounded: a cgroup CPU quota below the visible CPU count must not stretch the run
+        buf, n = bufs[i], 0
+        while time.perf_counter() < deadline[0]:
+            o.time_poly_fn(f_ntt, buf, chunk)
+            o.time_poly_fn(f_inv, buf, chunk)
+            n += 2 * chunk * sample_polys
+        done[i] = n
 
-    ths = [threading.Thread(target=work, args=(b,)) for b in bufs]
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
     t0 = time.perf_counter()
+    deadline[0] = t0 + target_s
     for t in ths:
         t.start()
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    n = 2 * reps * sample_polys * nthreads
+    n = sum(done)
     return {"value": n / dt, "unit": "NTT/s", "cores": nthreads,
-            "sample": f"{nthreads} threads x ({reps} x ntt, then {reps} x invntt) over {sample_polys} polynomials each = {n} "
-                      f"transforms in {dt:.1f} s"}
+            "sample": f"{nthreads} threads, each alternating {chunk} x ntt / {chunk} x invntt over {sample_polys} polynomials "
+                      f"until {target_s:.0f} s had passed = {n} transforms in {dt:.1f} s"}
 
 
 def cpu_baseline_verify(target_s=5.0):
@@ -137,8 +146,11 @@ def pmc_traffic(kernel_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--prewarm-ms", type=float, default=200.0,
+                    help="untimed: keep launching steps for this long before the W warm-up steps, so that the GPU has "
+                         "left its idle power state (short runs measured 10 %% low without it)")
     ap.add_argument("--rotate", type=int, default=8, help="distinct resident batches the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -179,37 +191,51 @@ def main():
         dlib.check(L.dil_ntt_dev(p, BATCH, stream))
         dlib.check(L.dil_invntt_dev(p, BATCH, stream))
 
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:      # untimed clock/power warm-up
+        for i in range(32):
+            step(i)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
     K = args.steps
-    EV_EVERY = 4                      # bracket the kernels of every 4th step with HIP events (less perturbation)
-    evs = {i: (ev(), ev(), ev()) for i in range(0, K, EV_EVERY)}
+    # Timed region: EXACTLY K steps, bracketed by two HIP events on the launch stream (and by barrier + synchronize for
+    # the wall clock).  No events inside: an event record between two launches costs several microseconds of GPU
+    # idle time (the marker packet drains the pipeline), which at 26 us per kernel is a 10 % perturbation.
+    e_start, e_end = ev(), ev()
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rc = 0
+    rc = L.dil_event_record(e_start, stream)
     for i in range(K):
         p = ptrs[i % R]
-        if i in evs:
-            e0, e1, e2 = evs[i]
-            L.dil_event_record(e0, stream)
-            rc |= L.dil_ntt_dev(p, BATCH, stream)
-            L.dil_event_record(e1, stream)
-            rc |= L.dil_invntt_dev(p, BATCH, stream)
-            L.dil_event_record(e2, stream)
-        else:
-            rc |= L.dil_ntt_dev(p, BATCH, stream)
-            rc |= L.dil_invntt_dev(p, BATCH, stream)
+        rc |= L.dil_ntt_dev(p, BATCH, stream)
+        rc |= L.dil_invntt_dev(p, BATCH, stream)
+    rc |= L.dil_event_record(e_end, stream)
     torch.cuda.synchronize()
     sharding.barrier()
     dt = time.perf_counter() - t0
     dlib.check(rc, "timed NTT launches")
     dt = sharding.max_over_ranks(dt)
-    fwd_ms = float(np.mean([elapsed(e0, e1) for e0, e1, _ in evs.values()]))
-    inv_ms = float(np.mean([elapsed(e1, e2) for _, e1, e2 in evs.values()]))
+    launch_ms = elapsed(e_start, e_end) / (2 * K)        # average over the 2K launches of the timed region
     assert torch.equal(bufs[0][:64], check), "fwd+inv round trip is not the identity"
     value = world * K * 2 * BATCH / dt
+
+    # instrumented pass (NOT timed for `value`): events around single launches split forward from inverse; each figure
+    # includes the event/dispatch overhead the timed region does not pay
+    ni = max(8, min(40, K // 4))
+    evs = [(ev(), ev(), ev()) for _ in range(ni)]
+    for i, (e0, e1, e2) in enumerate(evs):
+        p = ptrs[i % R]
+        L.dil_event_record(e0, stream)
+        L.dil_ntt_dev(p, BATCH, stream)
+        L.dil_event_record(e1, stream)
+        L.dil_invntt_dev(p, BATCH, stream)
+        L.dil_event_record(e2, stream)
+    torch.cuda.synchronize()
+    fwd_ms = float(np.mean([elapsed(e0, e1) for e0, e1, _ in evs]))
+    inv_ms = float(np.mean([elapsed(e1, e2) for _, e1, e2 in evs]))
 
     # LLC-resident variant (same 64 MiB batch every step) for context
     for i in range(5):
@@ -222,7 +248,7 @@ def main():
     torch.cuda.synchronize()
     llc_value = world * K * 2 * BATCH / sharding.max_over_ranks(time.perf_counter() - t1)
 
-    fwd_gbs = NTT_BYTES * BATCH / (fwd_ms * 1e-3) / 1e9
+    ntt_gbs = NTT_BYTES * BATCH / (launch_ms * 1e-3) / 1e9
     out = {
         "metric": "ntt256_transforms_per_sec", "value": value, "unit": "NTT/s", "n_gpus": world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -231,12 +257,18 @@ def main():
                                "batch=65536 polynomials per GPU; step = 1 fwd launch + 1 inv launch",
                    "batch_per_gpu": BATCH, "rotating_resident_batches": R, "parallelism": f"shard x{world}",
                    "bytes_per_transform": NTT_BYTES},
-        "roofline": {"bound": "hbm", "kernel": "ntt_fwd_kernel<LAYOUT_POLY>", "achieved": fwd_gbs,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fwd_gbs / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("ntt_fwd_kernel"), "avg_launch_ms": fwd_ms,
+        "roofline": {"bound": "hbm",
+                     "kernel": "ntt_fwd_kernel<LAYOUT_POLY> / ntt_inv_kernel<LAYOUT_POLY> (alternating launches of the "
+                               "timed region, identical algorithmic bytes)",
+                     "achieved": ntt_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("ntt_fwd_kernel"), "avg_launch_ms": launch_ms,
                      "algorithmic_bytes_per_launch": NTT_BYTES * BATCH,
-                     "inverse_kernel": {"avg_launch_ms": inv_ms,
-                                        "achieved": NTT_BYTES * BATCH / (inv_ms * 1e-3) / 1e9}},
+                     "timing": "two HIP events on the launch stream around the whole timed region / (2 x steps) launches",
+                     "per_kernel_instrumented": {
+                         "note": "separate untimed pass, events around single launches (adds event/dispatch overhead)",
+                         "ntt_fwd_kernel_ms": fwd_ms, "ntt_inv_kernel_ms": inv_ms,
+                         "ntt_fwd_kernel_GBps": NTT_BYTES * BATCH / (fwd_ms * 1e-3) / 1e9,
+                         "ntt_inv_kernel_GBps": NTT_BYTES * BATCH / (inv_ms * 1e-3) / 1e9}},
         "llc_resident_value": llc_value,
     }
 
