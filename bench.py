@@ -152,6 +152,10 @@ def main():
                     help="untimed: keep launching steps for this long before the W warm-up steps, so that the GPU has "
                          "left its idle power state (short runs measured 10 %% low without it)")
     ap.add_argument("--rotate", type=int, default=8, help="distinct resident batches the steps rotate over")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps alternate over (step i runs on stream i %% S; a batch always stays on one "
+                         "stream).  2 keeps a second launch in flight, which fills the dispatch gap and the ramp/tail of "
+                         "every kernel: +15 %% over one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -180,16 +184,41 @@ def main():
 
     # ---- inputs, resident in HBM ------------------------------------------------------------
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    NS = max(1, args.streams)
     R = max(1, args.rotate)
+    R += (-R) % NS                                        # a batch must always meet the same stream
     bufs = [torch.randint(0, 8380417, (BATCH, 256), dtype=torch.int32, device="cuda", generator=g) for _ in range(R)]
     check = bufs[0][:64].clone()
+    torch.cuda.synchronize()
 
     ptrs = [C.c_void_p(b.data_ptr()) for b in bufs]      # direct C-ABI calls: minimal host overhead
+    tstreams = [torch.cuda.Stream() for _ in range(NS)] if NS > 1 else [torch.cuda.current_stream()]
+    hstreams = [C.c_void_p(ts.cuda_stream) for ts in tstreams]
 
-    def step(i):
-        p = ptrs[i % R]
-        dlib.check(L.dil_ntt_dev(p, BATCH, stream))
-        dlib.check(L.dil_invntt_dev(p, BATCH, stream))
+    def step(i, fixed=None):
+        p = ptrs[(i % R) if fixed is None else (fixed + i % NS)]
+        st = hstreams[i % NS]
+        return L.dil_ntt_dev(p, BATCH, st) | L.dil_invntt_dev(p, BATCH, st)
+
+    def region(k, fixed=None):
+        """EXACTLY k steps, bracketed by one HIP event pair per stream; returns (wall seconds, per-stream event ms)"""
+        e0 = [ev() for _ in range(NS)]
+        e1 = [ev() for _ in range(NS)]
+        sharding.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = 0
+        for j in range(NS):
+            rc |= L.dil_event_record(e0[j], hstreams[j])
+        for i in range(k):
+            rc |= step(i, fixed)
+        for j in range(NS):
+            rc |= L.dil_event_record(e1[j], hstreams[j])
+        torch.cuda.synchronize()
+        sharding.barrier()
+        wall = time.perf_counter() - t0
+        dlib.check(rc, "timed NTT launches")
+        return sharding.max_over_ranks(wall), [elapsed(a, b) for a, b in zip(e0, e1)]
 
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:      # untimed clock/power warm-up
@@ -200,107 +229,127 @@ def main():
         step(i)
     torch.cuda.synchronize()
     K = args.steps
-    # Timed region: EXACTLY K steps, bracketed by two HIP events on the launch stream (and by barrier + synchronize for
-    # the wall clock).  No events inside: an event record between two launches costs several microseconds of GPU
-    # idle time (the marker packet drains the pipeline), which at 26 us per kernel is a 10 % perturbation.
-    e_start, e_end = ev(), ev()
-    sharding.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rc = L.dil_event_record(e_start, stream)
-    for i in range(K):
-        p = ptrs[i % R]
-        rc |= L.dil_ntt_dev(p, BATCH, stream)
-        rc |= L.dil_invntt_dev(p, BATCH, stream)
-    rc |= L.dil_event_record(e_end, stream)
-    torch.cuda.synchronize()
-    sharding.barrier()
-    dt = time.perf_counter() - t0
-    dlib.check(rc, "timed NTT launches")
-    dt = sharding.max_over_ranks(dt)
-    launch_ms = elapsed(e_start, e_end) / (2 * K)        # average over the 2K launches of the timed region
+    # Timed region: no events inside (an event record between two launches costs several microseconds of GPU idle
+    # time -- the marker packet drains the pipeline -- which at 26 us per kernel is a 10 % perturbation).
+    dt, ev_ms = region(K)
     assert torch.equal(bufs[0][:64], check), "fwd+inv round trip is not the identity"
     value = world * K * 2 * BATCH / dt
+    launches = [2 * len(range(j, K, NS)) for j in range(NS)]            # per stream
+    # average duration of one launch as the stream (and rocprof) sees it: with NS streams NS launches overlap
+    launch_ms = float(np.mean([m / n for m, n in zip(ev_ms, launches) if n]))
+    region_ms = max(ev_ms)
+    ntt_gbs = NTT_BYTES * BATCH * 2 * K / (region_ms * 1e-3) / 1e9      # aggregate over the timed region
 
-    # instrumented pass (NOT timed for `value`): events around single launches split forward from inverse; each figure
-    # includes the event/dispatch overhead the timed region does not pay
+    # instrumented pass (NOT timed for `value`): one stream, events around single launches split forward from inverse;
+    # each figure includes the event/dispatch overhead the timed region does not pay
+    s_one = hstreams[0]
     ni = max(8, min(40, K // 4))
     evs = [(ev(), ev(), ev()) for _ in range(ni)]
     for i, (e0, e1, e2) in enumerate(evs):
-        p = ptrs[i % R]
-        L.dil_event_record(e0, stream)
-        L.dil_ntt_dev(p, BATCH, stream)
-        L.dil_event_record(e1, stream)
-        L.dil_invntt_dev(p, BATCH, stream)
-        L.dil_event_record(e2, stream)
+        p = ptrs[(i * NS) % R]
+        L.dil_event_record(e0, s_one)
+        L.dil_ntt_dev(p, BATCH, s_one)
+        L.dil_event_record(e1, s_one)
+        L.dil_invntt_dev(p, BATCH, s_one)
+        L.dil_event_record(e2, s_one)
     torch.cuda.synchronize()
     fwd_ms = float(np.mean([elapsed(e0, e1) for e0, e1, _ in evs]))
     inv_ms = float(np.mean([elapsed(e1, e2) for _, e1, e2 in evs]))
+    # the same K steps on ONE stream, for reference
+    one_stream_value = None
+    if NS > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(K):
+            p = ptrs[i % R]
+            L.dil_ntt_dev(p, BATCH, s_one)
+            L.dil_invntt_dev(p, BATCH, s_one)
+        torch.cuda.synchronize()
+        one_stream_value = world * K * 2 * BATCH / sharding.max_over_ranks(time.perf_counter() - t1)
 
-    # LLC-resident variant (same 64 MiB batch every step) for context
-    for i in range(5):
-        step(0)
+    # LLC-resident variant (the same NS batches every step: 64 MiB each, inside the 256 MiB Infinity Cache) for context
+    for i in range(8):
+        step(i, fixed=0)
     torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(K):
-        L.dil_ntt_dev(ptrs[0], BATCH, stream)
-        L.dil_invntt_dev(ptrs[0], BATCH, stream)
-    torch.cuda.synchronize()
-    llc_value = world * K * 2 * BATCH / sharding.max_over_ranks(time.perf_counter() - t1)
+    llc_dt, _ = region(K, fixed=0)
+    llc_value = world * K * 2 * BATCH / llc_dt
 
-    ntt_gbs = NTT_BYTES * BATCH / (launch_ms * 1e-3) / 1e9
     out = {
         "metric": "ntt256_transforms_per_sec", "value": value, "unit": "NTT/s", "n_gpus": world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batched forward+inverse NTT, n=256, q=8380417, "
                                "batch=65536 polynomials per GPU; step = 1 fwd launch + 1 inv launch",
-                   "batch_per_gpu": BATCH, "rotating_resident_batches": R, "parallelism": f"shard x{world}",
-                   "bytes_per_transform": NTT_BYTES},
+                   "batch_per_gpu": BATCH, "rotating_resident_batches": R, "streams": NS,
+                   "parallelism": f"shard x{world}", "bytes_per_transform": NTT_BYTES},
         "roofline": {"bound": "hbm",
                      "kernel": "ntt_fwd_kernel<LAYOUT_POLY> / ntt_inv_kernel<LAYOUT_POLY> (alternating launches of the "
                                "timed region, identical algorithmic bytes)",
                      "achieved": ntt_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS,
                      "traffic": pmc_traffic("ntt_fwd_kernel"), "avg_launch_ms": launch_ms,
+                     "concurrent_launches": NS,
                      "algorithmic_bytes_per_launch": NTT_BYTES * BATCH,
-                     "timing": "two HIP events on the launch stream around the whole timed region / (2 x steps) launches",
+                     "timing": "one HIP event pair per launch stream around the whole timed region; avg_launch_ms = that "
+                               "stream's elapsed time / its launches (the per-kernel duration rocprofv3 reports); "
+                               "achieved = all launches' algorithmic bytes / the region's elapsed time "
+                               "(= concurrent_launches x bytes per launch / avg_launch_ms)",
                      "per_kernel_instrumented": {
                          "note": "separate untimed pass, events around single launches (adds event/dispatch overhead)",
                          "ntt_fwd_kernel_ms": fwd_ms, "ntt_inv_kernel_ms": inv_ms,
                          "ntt_fwd_kernel_GBps": NTT_BYTES * BATCH / (fwd_ms * 1e-3) / 1e9,
                          "ntt_inv_kernel_GBps": NTT_BYTES * BATCH / (inv_ms * 1e-3) / 1e9}},
         "llc_resident_value": llc_value,
+        "one_stream_value": one_stream_value,
     }
 
     # ---- secondary: Dilithium-3 verify core, configs[3] ----------------------------------------
     if not args.no_secondary:
-        A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank)
         cu = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
-        dA, dz, dc, dt1, dh = cu(A), cu(z), cu(c), cu(t1_), cu(h)
-        w1 = torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")
+        # The fused kernel holds its items' vectors in LDS and sizes its persistent grid to fill every CU, so a second
+        # launch in flight cannot become resident beside it: measured 108 M/s on two streams vs 119 M/s on one -> one stream.
+        VNS = 1
+        vsets = []
+        for j in range(VNS):
+            A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank + 100 * j)
+            vsets.append((cu(A), cu(z), cu(c), cu(t1_), cu(h), torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
+        dA, dz, dc, dt1, dh, w1 = vsets[0]
+        vptr = [[C.c_void_p(t.data_ptr()) for t in vs_] for vs_ in vsets]
+        torch.cuda.synchronize()
+
+        def vstep(i):
+            pA, pz, pc, pt1, ph, pw1 = vptr[i % VNS]
+            return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, hstreams[i % VNS])
+
         vs = max(10, K // 4)
-        for _ in range(3):
-            api.verify_core(dA, dz, dc, dt1, dh, 3, out=w1)
+        for i in range(2 * VNS + 2):
+            vstep(i)
         torch.cuda.synchronize()
         sharding.barrier()
-        e0, e1 = ev(), ev()
+        ve0 = [ev() for _ in range(VNS)]
+        ve1 = [ev() for _ in range(VNS)]
         tv = time.perf_counter()
-        L.dil_event_record(e0, stream)
-        for _ in range(vs):
-            api.verify_core(dA, dz, dc, dt1, dh, 3, out=w1)
-        L.dil_event_record(e1, stream)
+        rcv = 0
+        for j in range(VNS):
+            rcv |= L.dil_event_record(ve0[j], hstreams[j])
+        for i in range(vs):
+            rcv |= vstep(i)
+        for j in range(VNS):
+            rcv |= L.dil_event_record(ve1[j], hstreams[j])
         torch.cuda.synchronize()
         sharding.barrier()
         tv = sharding.max_over_ranks(time.perf_counter() - tv)
-        v_ms = elapsed(e0, e1) / vs
-        v_gbs = VERIFY3_BYTES * VBATCH / (v_ms * 1e-3) / 1e9
+        dlib.check(rcv, "timed verify launches")
+        v_ev = [elapsed(a_, b_) for a_, b_ in zip(ve0, ve1)]
+        v_launches = [len(range(j, vs, VNS)) for j in range(VNS)]
+        v_ms = float(np.mean([m / n for m, n in zip(v_ev, v_launches) if n]))     # per-kernel duration (NS overlap)
+        v_gbs = VERIFY3_BYTES * VBATCH * vs / (max(v_ev) * 1e-3) / 1e9            # aggregate over the region
         sec = {"metric": "dilithium3_verify_cores_per_sec", "value": world * vs * VBATCH / tv, "unit": "verify/s",
                "config": {"workload": "BASELINE configs[3]: level-3 verify core (NTT z, A.z - c.t1.2^d, INTT, "
                                       "UseHint -> w1), batch=8192 per GPU, distinct pk (A, t1 per item)",
-                          "bytes_per_verify": VERIFY3_BYTES},
+                          "bytes_per_verify": VERIFY3_BYTES, "streams": VNS},
                "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("verify_kernel"),
-                            "avg_launch_ms": v_ms}}
+                            "avg_launch_ms": v_ms, "concurrent_launches": VNS}}
         # same pipeline with ONE public key for the whole batch (A, t1 staged in LDS): VALU-bound, reported beside it
         torch.cuda.synchronize()
         e2, e3 = ev(), ev()

@@ -43,3 +43,17 @@ with torch.cuda.stream(s):
 torch.cuda.synchronize()
 t_graph = timed(graph.replay)
 print(f"graph      : {t_graph / K * 1e6:7.2f} us per step  ({2 * B * K / t_graph / 1e9:.3f} G NTT/s)")
+
+# several streams: step i on stream i % S (fwd then inv of one batch stay ordered on their stream); the other
+# streams' kernels fill the dispatch gap and the ramp/tail of each launch
+for S in (2, 3, 4):
+    ss = [torch.cuda.Stream() for _ in range(S)]
+
+    def stepsS(k):
+        for i in range(k):
+            with torch.cuda.stream(ss[i % S]):
+                api.ntt(bufs[i % R])
+                api.invntt(bufs[i % R])
+
+    t = timed(lambda: stepsS(K))
+    print(f"{S} streams  : {t / K * 1e6:7.2f} us per step  ({2 * B * K / t / 1e9:.3f} G NTT/s, {2 * B * K * 2048 / t / 1e12:.2f} TB/s)")
