@@ -156,6 +156,7 @@ def main():
                     help="HIP streams the steps alternate over (step i runs on stream i %% S; a batch always stays on one "
                          "stream).  2 keeps a second launch in flight, which fills the dispatch gap and the ramp/tail of "
                          "every kernel: +15 %% over one stream")
+    ap.add_argument("--verify-streams", type=int, default=1, help="streams of the secondary (fused verify) metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -307,7 +308,7 @@ def main():
         cu = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
         # The fused kernel holds its items' vectors in LDS and sizes its persistent grid to fill every CU, so a second
         # launch in flight cannot become resident beside it: measured 108 M/s on two streams vs 119 M/s on one -> one stream.
-        VNS = 1
+        VNS = max(1, min(NS, args.verify_streams))
         vsets = []
         for j in range(VNS):
             A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank + 100 * j)
