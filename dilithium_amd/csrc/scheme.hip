@@ -81,6 +81,8 @@ struct StreamScratch {
     int nspill = 0;
     int rc = 0;                  // first allocation failure; check once after the last take()
     explicit StreamScratch(hipStream_t st) : s(st), arena(g_arenas.acquire(st)) {}
+    // arena looked up under `key` (any unique handle), spills allocated on `st`
+    StreamScratch(hipStream_t key, hipStream_t st) : s(st), arena(g_arenas.acquire(key)) {}
     template <class T>
     T* take(size_t count)
     {
@@ -544,11 +546,8 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
 
 // ---- host-buffer forms of the whole operations (H2D -> device call -> D2H on the null stream) --------
 namespace {
-struct DevBuf {
-    void* p = nullptr;
-    int alloc(size_t bytes) { return (int)hipMalloc(&p, bytes ? bytes : 1); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
+// staging buffers of the host-buffer forms: their own arena (the device call they wrap owns the null stream's)
+const hipStream_t HOST_STAGE_KEY = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(1));
 }  // namespace
 
 int dil_keygen_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch)
@@ -558,13 +557,16 @@ int dil_keygen_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, si
     if (batch == 0) return 0;
     int rc = ensure_init();
     if (rc) return rc;
-    DevBuf dpk, dsk, dseed;
-    if ((rc = dpk.alloc(batch * pkb)) || (rc = dsk.alloc(batch * skb)) || (rc = dseed.alloc(batch * 32))) return rc;
-    DIL_TRY(hipMemcpy(dseed.p, seed, batch * 32, hipMemcpyHostToDevice));
-    rc = dil_keygen_dev(static_cast<uint8_t*>(dpk.p), static_cast<uint8_t*>(dsk.p), static_cast<uint8_t*>(dseed.p), level, batch, nullptr);
+    StreamScratch ws(HOST_STAGE_KEY, nullptr);
+    uint8_t* dpk = ws.take<uint8_t>(batch * pkb);
+    uint8_t* dsk = ws.take<uint8_t>(batch * skb);
+    uint8_t* dseed = ws.take<uint8_t>(batch * 32);
+    if (ws.rc) return ws.rc;
+    DIL_TRY(hipMemcpy(dseed, seed, batch * 32, hipMemcpyHostToDevice));
+    rc = dil_keygen_dev(dpk, dsk, dseed, level, batch, nullptr);
     if (rc) return rc;
-    DIL_TRY(hipMemcpy(pk, dpk.p, batch * pkb, hipMemcpyDeviceToHost));
-    DIL_TRY(hipMemcpy(sk, dsk.p, batch * skb, hipMemcpyDeviceToHost));
+    DIL_TRY(hipMemcpy(pk, dpk, batch * pkb, hipMemcpyDeviceToHost));
+    DIL_TRY(hipMemcpy(sk, dsk, batch * skb, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -577,17 +579,19 @@ int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint
     int rc = ensure_init();
     if (rc) return rc;
     const size_t nk = shared_sk ? 1 : batch;
-    DevBuf dsig, datt, dsk, dmu;
-    if ((rc = dsig.alloc(batch * sgb)) || (rc = datt.alloc(batch * 4)) || (rc = dsk.alloc(nk * skb)) || (rc = dmu.alloc(batch * 64)))
-        return rc;
-    DIL_TRY(hipMemcpy(dsk.p, sk, nk * skb, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(dmu.p, mu, batch * 64, hipMemcpyHostToDevice));
-    const int src = dil_sign_dev(static_cast<uint8_t*>(dsig.p), static_cast<int32_t*>(datt.p), static_cast<uint8_t*>(dsk.p),
-                                 static_cast<uint8_t*>(dmu.p), level, batch, shared_sk, max_attempts, nullptr);
+    StreamScratch ws(HOST_STAGE_KEY, nullptr);
+    uint8_t* dsig = ws.take<uint8_t>(batch * sgb);
+    int32_t* datt = ws.take<int32_t>(batch);
+    uint8_t* dsk = ws.take<uint8_t>(nk * skb);
+    uint8_t* dmu = ws.take<uint8_t>(batch * 64);
+    if (ws.rc) return ws.rc;
+    DIL_TRY(hipMemcpy(dsk, sk, nk * skb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dmu, mu, batch * 64, hipMemcpyHostToDevice));
+    const int src = dil_sign_dev(dsig, datt, dsk, dmu, level, batch, shared_sk, max_attempts, nullptr);
     if (src && src != DIL_ERR_UNFINISHED) return src;
     DIL_TRY(hipDeviceSynchronize());
-    DIL_TRY(hipMemcpy(sig, dsig.p, batch * sgb, hipMemcpyDeviceToHost));
-    if (attempts) DIL_TRY(hipMemcpy(attempts, datt.p, batch * 4, hipMemcpyDeviceToHost));
+    DIL_TRY(hipMemcpy(sig, dsig, batch * sgb, hipMemcpyDeviceToHost));
+    if (attempts) DIL_TRY(hipMemcpy(attempts, datt, batch * 4, hipMemcpyDeviceToHost));
     return src;
 }
 
@@ -600,15 +604,17 @@ int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig,
     int rc = ensure_init();
     if (rc) return rc;
     const size_t nk = shared_pk ? 1 : batch;
-    DevBuf dv, dpk, dsig, dmu;
-    if ((rc = dv.alloc(batch * 4)) || (rc = dpk.alloc(nk * pkb)) || (rc = dsig.alloc(batch * sgb)) || (rc = dmu.alloc(batch * 64)))
-        return rc;
-    DIL_TRY(hipMemcpy(dpk.p, pk, nk * pkb, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(dsig.p, sig, batch * sgb, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(dmu.p, mu, batch * 64, hipMemcpyHostToDevice));
-    rc = dil_verify_sig_dev(static_cast<int32_t*>(dv.p), static_cast<uint8_t*>(dpk.p), static_cast<uint8_t*>(dsig.p),
-                            static_cast<uint8_t*>(dmu.p), level, batch, shared_pk, nullptr);
+    StreamScratch ws(HOST_STAGE_KEY, nullptr);
+    int32_t* dv = ws.take<int32_t>(batch);
+    uint8_t* dpk = ws.take<uint8_t>(nk * pkb);
+    uint8_t* dsig = ws.take<uint8_t>(batch * sgb);
+    uint8_t* dmu = ws.take<uint8_t>(batch * 64);
+    if (ws.rc) return ws.rc;
+    DIL_TRY(hipMemcpy(dpk, pk, nk * pkb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dsig, sig, batch * sgb, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(dmu, mu, batch * 64, hipMemcpyHostToDevice));
+    rc = dil_verify_sig_dev(dv, dpk, dsig, dmu, level, batch, shared_pk, nullptr);
     if (rc) return rc;
-    DIL_TRY(hipMemcpy(verdict, dv.p, batch * 4, hipMemcpyDeviceToHost));
+    DIL_TRY(hipMemcpy(verdict, dv, batch * 4, hipMemcpyDeviceToHost));
     return 0;
 }
