@@ -249,6 +249,7 @@ int dil_init(int device)
     if (const char* e = getenv("DIL_FUSED_MODE")) g.t.fused_mode = atoi(e);
     if (const char* e = getenv("DIL_SIGN_CAP")) g.sign_cap = atoi(e);
     if (const char* e = getenv("DIL_SIGN_EARLY")) g.sign_early = atoi(e);
+    if (const char* e = getenv("DIL_SIGN_WASTE")) g.sign_waste = atoi(e);
     if (const char* e = getenv("DIL_SIGN_STREAMS")) g.sign_streams = atoi(e);
     if (const char* e = getenv("DIL_AUX_OVERLAP")) g.aux_overlap = atoi(e);
     if (const char* e = getenv("DIL_FUSED_WGPC")) g.t.fused_wgs_per_cu = atoi(e) > 0 ? atoi(e) : g.t.fused_wgs_per_cu;

@@ -18,6 +18,7 @@ struct State {
     void* scratch = nullptr;        // for *_host entry points
     size_t scratch_bytes = 0;
     int sign_early = 1;             // DIL_SIGN_EARLY: 0 = the signing loop evaluates every check of every attempt
+    int sign_waste = 6144;          // DIL_SIGN_WASTE: speculative entries a round may expect to waste (see dil_sign_dev)
     int sign_cap = 0;               // DIL_SIGN_CAP: entries in flight per signing round (0 = default)
     int aux_overlap = 1;            // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream
     int sign_streams = 1;           // DIL_SIGN_STREAMS: 2 = split each signing round over the caller stream and a helper (measured: no gain)

@@ -492,7 +492,19 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     size_t n = batch;
     int a0 = 0;                                          // attempts every pending item has already failed
     while (n > 0 && a0 < max_attempts) {
-        const int S_ = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
+        // Attempts per pending item this round: as many as fit in `cap` entries, but only while the work expected to be
+        // wasted on attempts after an item's first success, n * (1 - (1-p)^(S-1)) entries with p ~ 0.2, stays below the
+        // work a saved round's fixed latency is worth (g.sign_waste entries; matters for batches >> 16384).
+        int S_ = 1;
+        {
+            const int s_lim = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
+            double keep = 1.0;                       // (1-p)^(S-1)
+            while (S_ < s_lim) {
+                keep *= 0.8;
+                if ((double)n * (1.0 - keep) > (double)g.sign_waste) break;
+                S_++;
+            }
+        }
         const size_t E = n * (size_t)S_;
         const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
         const uint8_t *mur = mu, *rpr = rp;
