@@ -27,21 +27,37 @@ struct Arena {
     size_t size = 0;
     int32_t* pinned = nullptr;      // two host words for small read-backs
     bool in_use = false;
+    uint64_t last_use = 0;
 };
 struct ArenaPool {
     std::mutex mu;
     Arena slots[8];
+    uint64_t tick = 0;
     Arena* acquire(hipStream_t s)
     {
         std::lock_guard<std::mutex> lk(mu);
-        Arena* free_slot = nullptr;
+        Arena *free_slot = nullptr, *lru = nullptr;
         for (Arena& a : slots) {
-            if (a.base && a.stream == s) return a.in_use ? nullptr : (a.in_use = true, &a);
-            if (!a.base && !a.in_use && !free_slot) free_slot = &a;
+            if (a.base && a.stream == s) {
+                if (a.in_use) return nullptr;
+                a.in_use = true;
+                a.last_use = ++tick;
+                return &a;
+            }
+            if (a.in_use) continue;
+            if (!a.base && !free_slot) free_slot = &a;
+            if (a.base && (!lru || a.last_use < lru->last_use)) lru = &a;
+        }
+        if (!free_slot && lru) {      // every slot belongs to some other (possibly long gone) stream: evict the stalest
+            (void)hipFree(lru->base);
+            if (lru->pinned) (void)hipHostFree(lru->pinned);
+            *lru = Arena();
+            free_slot = lru;
         }
         if (!free_slot) return nullptr;
         free_slot->stream = s;
         free_slot->in_use = true;
+        free_slot->last_use = ++tick;
         return free_slot;
     }
     void release(Arena* a, size_t wanted)
