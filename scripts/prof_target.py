@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small fixed workloads for rocprofv3 (kernel trace or --pmc passes):
-   prof_target.py ntt | verify | verify_shared | sign | all   [reps]"""
+   prof_target.py ntt | verify | verify_shared | sign | hash | scheme | all   [reps]"""
 import os
 import sys
 
@@ -49,6 +49,20 @@ def main():
         for _ in range(reps):
             w1, w0 = api.sign_phase1(A, y, 5, shared_key=True)
             api.sign_phase2(c, y, w0, w1, s1h, s2h, t0h, 5, shared_key=True)
+    if what in ("hash", "scheme"):
+        n = 8192
+        u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g)  # noqa: E731
+        seed, mu = u8(n, 32), u8(n, 64)
+        kap = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for _ in range(reps):
+            if what == "hash":
+                api.expand_a(u8(n, 32), 3)
+                api.expand_mask(mu, kap, 5)
+                api.shake256(u8(n, 1088), 32)
+            else:
+                pk, sk = api.keygen(seed, 3)
+                sig, _ = api.sign(sk[:1], mu, 3, shared_sk=True)
+                api.verify_sig(pk[:1], sig, mu, 3, shared_pk=True)
     torch.cuda.synchronize()
 
 

@@ -27,7 +27,7 @@ def main():
             lines.append("")
             lines.append("PMC (summed over SEs/XCCs, average per dispatch)")
             for name, cn, v, n in pm:
-                if name.startswith("void dil::") or "--all" in sys.argv:
+                if "dil::" in name or "--all" in sys.argv:
                     lines.append(f"{name:60s} {cn:28s} {v:18.1f}  (dispatches={n})")
     except Exception as e:  # noqa: BLE001
         lines.append(f"(no PMC table: {e})")
