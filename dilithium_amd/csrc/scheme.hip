@@ -488,19 +488,24 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     int32_t* host_counts = ws.pinned_words();            // pageable memory would make the read-back a blocking staged copy
     if (ws.rc) return ws.rc;
 
-    // key material: A = ExpandA(rho), s1^ s2^ t0^ = NTT(unpack(sk))
-    DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s));
-    DIL_TRY(dil::launch_unpack(p.eta_bits, s1h, sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
-    DIL_TRY(dil::launch_unpack(p.eta_bits, s2h, sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
-    DIL_TRY(dil::launch_unpack(13, t0h, sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, g.t, s));
-    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s1h, nk * p.L, g.t, s));
-    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s2h, nk * p.K, g.t, s));
-    DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, t0h, nk * p.K, g.t, s));
-    // rho' = SHAKE256(key || mu, 64)  (deterministic signing, as the reference's KATs)
-    DIL_TRY(dil::launch_copy_field(km, 96, 0, sk, sk_stride, 32, 32, batch, g.t, s));
-    DIL_TRY(dil::launch_copy_field(km, 96, 32, mu, 64, 0, 64, batch, g.t, s));
-    DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(rp), 64, reinterpret_cast<uint64_t*>(km), 96, batch, s));
-    DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
+    {
+        // key material: A = ExpandA(rho) -- on the helper stream when it is latency-bound (one or few keys), beside the
+        // rest of the set-up -- and s1^ s2^ t0^ = NTT(unpack(sk))
+        AuxFork ax(s);
+        DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, ax.fork(nk * p.K * p.L)));
+        DIL_TRY(dil::launch_unpack(p.eta_bits, s1h, sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
+        DIL_TRY(dil::launch_unpack(p.eta_bits, s2h, sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
+        DIL_TRY(dil::launch_unpack(13, t0h, sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, g.t, s));
+        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s1h, nk * p.L, g.t, s));
+        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s2h, nk * p.K, g.t, s));
+        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, t0h, nk * p.K, g.t, s));
+        // rho' = SHAKE256(key || mu, 64)  (deterministic signing, as the reference's KATs)
+        DIL_TRY(dil::launch_copy_field(km, 96, 0, sk, sk_stride, 32, 32, batch, g.t, s));
+        DIL_TRY(dil::launch_copy_field(km, 96, 32, mu, 64, 0, 64, batch, g.t, s));
+        DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(rp), 64, reinterpret_cast<uint64_t*>(km), 96, batch, s));
+        DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
+        if ((rc = ax.join())) return rc;
+    }
 
     std::unique_lock<std::mutex> aux_lock(g_aux.mu, std::defer_lock);    // one signing loop at a time may use the helper stream
     const bool two_streams = g.sign_streams > 1 && aux_lock.try_lock() && g_aux.ensure(g.device);
