@@ -301,6 +301,9 @@ def main():
                          "ntt_inv_kernel_GBps": NTT_BYTES * BATCH / (inv_ms * 1e-3) / 1e9}},
         "llc_resident_value": llc_value,
         "one_stream_value": one_stream_value,
+        # context: the same kernel without its loads/stores, i.e. the integer-ALU ceiling of this arithmetic
+        "valu_ceiling": {"value": 3.74e9, "unit": "NTT/s per GPU", "source": "profiles/r01_tune_ntt.txt, compute-only variant "
+                                                                             "(not measured in this run)"},
     }
 
     # ---- secondary: Dilithium-3 verify core, configs[3] ----------------------------------------
