@@ -80,12 +80,27 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
 #pragma unroll
     for (int m = 0; m < 4; m++) off[m] = fwd_in_off<LAYOUT>(lane + 64 * m, mapping);
     const int out_off = fwd_out_row_off<LAYOUT>(lane, mapping);
+    TwRegs tw;
+    const LaneMasks lm(lane);
+    if (LAYOUT == LAYOUT_BRAM && mapping == MAP_AFTER_INVNTT) {
+        // this mapping puts the lane's 4 inputs at 16 (lane>>2) + 4 m + (lane&3): 16-byte pieces 64 B apart for every
+        // load instruction.  Read the wave's 1 KiB with one dwordx4 per lane instead and transpose inside each quad.
+        int4 nx = ld_nt4(polys + wave * 256 + 4 * lane);
+        tw.load(tw_tab, lane);
+        for (size_t p = wave; p < batch; p += nwaves) {
+            int32_t r[4] = {nx.x, nx.y, nx.z, nx.w};
+            const size_t pn = p + nwaves;
+            if (pn < batch) nx = ld_nt4(polys + pn * 256 + 4 * lane);
+            xchg_10(r, lm);
+            ntt_fwd_core(r, tw, lm);
+            st_nt4(polys + p * 256 + out_off, canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
+        }
+        return;
+    }
     int32_t nxt[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) nxt[m] = ld_nt(polys + wave * 256 + off[m]);
-    TwRegs tw;
     tw.load(tw_tab, lane);
-    const LaneMasks lm(lane);
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
         const size_t pn = p + nwaves;
@@ -120,6 +135,14 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ poly
         const size_t pn = p + nwaves;
         if (pn < batch) nxt = ld_nt4(polys + pn * 256 + in_off);
         ntt_inv_core(r, tw, lm);
+        if (LAYOUT == LAYOUT_BRAM && mapping == MAP_NATURAL) {
+            // outputs of this (op, mapping) land at 16 (lane>>2) + 4 m + (lane&3): transpose inside each quad and
+            // write the wave's 1 KiB as one dwordx4 per lane instead of four 16-byte-granular scatters
+            xchg_10(r, lm);
+            st_nt4(polys + p * 256 + 4 * lane, (int32_t)canon_small(r[0]), (int32_t)canon_small(r[1]), (int32_t)canon_small(r[2]),
+                   (int32_t)canon_small(r[3]));
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < 4; m++) st_nt(polys + p * 256 + off[m], (int32_t)canon_small(r[m]));
     }
