@@ -312,8 +312,9 @@ def main():
         # The fused kernel holds its items' vectors in LDS and sizes its persistent grid to fill every CU, so a second
         # launch in flight cannot become resident beside it: measured 108 M/s on two streams vs 119 M/s on one -> one stream.
         VNS = max(1, min(NS, args.verify_streams))
+        VSETS = max(2, VNS)          # rotate over >= 2 input sets (2 x 360 MiB > the 256 MiB Infinity Cache): HBM-streaming
         vsets = []
-        for j in range(VNS):
+        for j in range(VSETS):
             A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank + 100 * j)
             vsets.append((cu(A), cu(z), cu(c), cu(t1_), cu(h), torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
         dA, dz, dc, dt1, dh, w1 = vsets[0]
@@ -321,7 +322,7 @@ def main():
         torch.cuda.synchronize()
 
         def vstep(i):
-            pA, pz, pc, pt1, ph, pw1 = vptr[i % VNS]
+            pA, pz, pc, pt1, ph, pw1 = vptr[i % VSETS]
             return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, hstreams[i % VNS])
 
         vs = max(10, K // 4)
@@ -350,10 +351,20 @@ def main():
         sec = {"metric": "dilithium3_verify_cores_per_sec", "value": world * vs * VBATCH / tv, "unit": "verify/s",
                "config": {"workload": "BASELINE configs[3]: level-3 verify core (NTT z, A.z - c.t1.2^d, INTT, "
                                       "UseHint -> w1), batch=8192 per GPU, distinct pk (A, t1 per item)",
-                          "bytes_per_verify": VERIFY3_BYTES, "streams": VNS},
+                          "bytes_per_verify": VERIFY3_BYTES, "streams": VNS, "rotating_input_sets": VSETS},
                "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("verify_kernel"),
                             "avg_launch_ms": v_ms, "concurrent_launches": VNS}}
+        # the same launches over ONE input set (360 MiB, partly served by the 256 MiB Infinity Cache), for context
+        torch.cuda.synchronize()
+        ea, eb = ev(), ev()
+        L.dil_event_record(ea, hstreams[0])
+        for i in range(vs):
+            pA, pz, pc, pt1, ph, pw1 = vptr[0]
+            L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, hstreams[0])
+        L.dil_event_record(eb, hstreams[0])
+        torch.cuda.synchronize()
+        sec["llc_assisted_value"] = world * VBATCH / (elapsed(ea, eb) / vs * 1e-3)
         # same pipeline with ONE public key for the whole batch (A, t1 staged in LDS): VALU-bound, reported beside it
         torch.cuda.synchronize()
         e2, e3 = ev(), ev()
