@@ -201,47 +201,13 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
 
 // ---------------------------------------------------------------------------------------
 // Wave-per-item variants of the fused pipelines (large batches).
-// One wavefront carries one whole item through every stage: the L NTT-domain vectors stay in
-// its registers (4L VGPRs), the matrix rows stream through, no LDS data exchange and no
-// barrier after the one-time twiddle staging.  Rows are software-prefetched: the loads of row
+// One wavefront carries one whole item through every stage: the L NTT-domain vectors sit in a
+// private LDS slice of the wave (keeping them in 4L VGPRs was tried first and cost occupancy), the
+// matrix rows stream through registers, and there is no barrier after the one-time twiddle staging.  Rows are software-prefetched: the loads of row
 // k+1 are issued as soon as the MACs of row k have consumed the row registers, and fly under
 // NTT(t1_k) + INTT(row k).  With batch >= 8 items per SIMD this keeps the VALUs busier than
 // the workgroup-per-item kernels above (which remain the low-latency path for small batches).
 // ---------------------------------------------------------------------------------------
-template <int L>
-__device__ __forceinline__ void mac_row_regs(int64_t (&acc)[4], const ARow<L>& A, const int32_t (&vh)[L][4])
-{
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-        acc[0] += (int64_t)A.v[l].x * vh[l][0];
-        acc[1] += (int64_t)A.v[l].y * vh[l][1];
-        acc[2] += (int64_t)A.v[l].z * vh[l][2];
-        acc[3] += (int64_t)A.v[l].w * vh[l][3];
-    }
-}
-
-// forward-transform L consecutive polynomials (+ optionally one extra from `tail`) into
-// registers, loading polynomial l+1 while l is being transformed
-template <int L, bool TAIL, class TW>
-__device__ __forceinline__ void fwd_vector(int32_t (&vh)[L][4], int32_t (&th)[4], const int32_t* __restrict__ v,
-                                           const int32_t* __restrict__ tail, const TW& twf, const LaneMasks& lm, int lane)
-{
-    int32_t cur[4], nxt[4] = {0, 0, 0, 0};
-    load_strided(cur, v, lane);
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-        if (l + 1 < L) load_strided(nxt, v + (l + 1) * 256, lane);
-        else if (TAIL) load_strided(nxt, tail, lane);
-        ntt_fwd_core(cur, twf, lm);
-#pragma unroll
-        for (int m = 0; m < 4; m++) { vh[l][m] = cur[m]; cur[m] = nxt[m]; }
-    }
-    if (TAIL) {
-#pragma unroll
-        for (int m = 0; m < 4; m++) th[m] = cur[m];     // loaded, NOT yet transformed
-    }
-}
-
 // raw (time-domain) inputs of one item, prefetched a whole row phase ahead
 template <int NP>
 struct RawPolys {
