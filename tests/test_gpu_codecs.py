@@ -411,3 +411,26 @@ def test_concurrent_calls_on_two_streams(gpu, kat_msgs):
         t.join()
     assert not errors, errors
     assert results == {"a": True, "b": True, "c": True}
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_full_size_roundtrip_keygen_sign_verify(gpu, level):
+    """BASELINE config sizes (8192 per GPU), size-independent property: fresh keys -> signatures -> all verify; a
+    signature never verifies under its neighbour's key; signing is deterministic"""
+    from dilithium_amd import api
+    n = 8192
+    g = gpu.Generator(device="cuda").manual_seed(7 + level)
+    seed = gpu.randint(0, 256, (n, 32), dtype=gpu.uint8, device="cuda", generator=g)
+    mu = gpu.randint(0, 256, (n, 64), dtype=gpu.uint8, device="cuda", generator=g)
+    pk, sk = api.keygen(seed, level)
+    sig, att = api.sign(sk, mu, level)
+    assert int(att.min()) >= 1
+    assert int(api.verify_sig(pk, sig, mu, level).abs().sum()) == 0
+    wrong = api.verify_sig(pk.roll(1, 0).contiguous(), sig, mu, level)
+    assert int((wrong == 0).sum()) == 0
+    sig2, att2 = api.sign(sk, mu, level)
+    assert gpu.equal(sig, sig2) and gpu.equal(att, att2)
+    # the shared-key path gives the same bytes for the items signed under key 0
+    sig0, _ = api.sign(sk[:1], mu[:64].contiguous(), level, shared_sk=True)
+    sigd, _ = api.sign(sk[:1].repeat(64, 1), mu[:64].contiguous(), level)
+    assert gpu.equal(sig0, sigd)
