@@ -160,36 +160,39 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ ou
 // eta = 2: nibble < 15 -> 2 - (nibble mod 5);  eta = 4: nibble < 9 -> 4 - nibble.  Canonical out.
 // One lane per polynomial.
 // ---------------------------------------------------------------------------------------
+template <bool TWO>            // TWO: two lanes per sponge (few keys: latency-bound)
 __global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__ s, int32_t* __restrict__ s_tail, int split,
                                                       const uint8_t* __restrict__ rhoprime, size_t rp_stride, int eta, int nonce0,
                                                       int polys, size_t nitems)
 {
-    const size_t p = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const size_t p = TWO ? t >> 1 : t;
     const bool live = p < nitems * (size_t)polys;
     const size_t item = live ? p / (size_t)polys : 0;
     const int j = (int)(p % (size_t)polys);
     const uint32_t nonce = (uint32_t)(nonce0 + j);
     // polynomials [0, split) of an item go to s [item][split][256], the rest to s_tail [item][polys - split][256]
     int32_t* out = j < split ? s + (item * split + j) * 256 : s_tail + (item * (size_t)(polys - split) + (j - split)) * 256;
-    Shake<17> sp;
-    sp.init();
+    LaneSponge<17, TWO> sp;
+    sp.init(TWO && (t & 1));
     const uint8_t* rp = rhoprime + item * rp_stride;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
         uint64_t v = 0;
         for (int b = 0; b < 8; b++) v |= (uint64_t)rp[8 * w + b] << (8 * b);
-        sp.s[w] = v;
+        sp.set(w, v);
     }
-    sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
-    sp.s[16] ^= 0x8000000000000000ull;
+    sp.set(8, (uint64_t)nonce | (0x1Full << 16));
+    sp.pad_end();
+    const bool wr = live && sp.writer();
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, out, live);
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, out, wr);
     int cnt = live ? 0 : 256;
     while (__any(cnt < 256)) {
-        keccak_f1600(sp.s);
+        sp.permute();
 #pragma unroll
         for (int w = 0; w < 17; w++) {
-            uint64_t word = sp.s[w];
+            uint64_t word = sp.word(w);
 #pragma unroll
             for (int n = 0; n < 16; n++) {
                 const int nib = (int)(word & 15);
@@ -203,9 +206,12 @@ __global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__
                     ok = nib < 9;
                     v = 4 - nib;
                 }
-                if (ok && cnt < 256) sink.put(cnt++, v + ((v >> 31) & QC));
+                if (ok && cnt < 256) {
+                    if (wr) sink.put(cnt, v + ((v >> 31) & QC));
+                    cnt++;
+                }
             }
-            sink.flush_if_ready(cnt);          // <= 16 coefficients per 64-bit word
+            if (wr) sink.flush_if_ready(cnt);  // <= 16 coefficients per 64-bit word
         }
     }
 }
@@ -400,8 +406,12 @@ hipError_t launch_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, si
 {
     if (nitems == 0) return hipSuccess;
     const size_t total = nitems * (size_t)(L + K);
-    hipLaunchKernelGGL(expand_s_kernel, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime, rp_stride, eta, 0,
-                       L + K, nitems);
+    if (total <= 16384)
+        hipLaunchKernelGGL(expand_s_kernel<true>, (int)((2 * total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime,
+                           rp_stride, eta, 0, L + K, nitems);
+    else
+        hipLaunchKernelGGL(expand_s_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime,
+                           rp_stride, eta, 0, L + K, nitems);
     return hipGetLastError();
 }
 

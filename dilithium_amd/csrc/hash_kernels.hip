@@ -87,50 +87,54 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__
 // ExpandMask: y[item][l] = gamma1 - Unpack_B(SHAKE256(rho' || LE16(kappa[item] + l))),
 // B = 18 (gamma1 = 2^17) or 20 (2^19) bits.  Output canonical in [0, q).  One lane per polynomial.
 // ---------------------------------------------------------------------------------------
-template <int B>
+template <int B, bool TWO>     // TWO: two lanes per sponge (few items: latency-bound)
 __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restrict__ y, const uint64_t* __restrict__ rhoprime,
                                                          const uint32_t* __restrict__ kappa, int L, size_t nitems)
 {
     constexpr int32_t GAMMA1 = 1 << (B - 1);
     constexpr uint64_t MASK = (1ull << B) - 1;
-    const size_t p = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
-    if (p >= nitems * (size_t)L) return;
+    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const size_t p = TWO ? t >> 1 : t;
+    if (p >= nitems * (size_t)L) return;               // (two-lane: whole pairs leave together)
     const size_t item = p / (size_t)L;
     const uint32_t nonce = (kappa[item] + (uint32_t)(p % (size_t)L)) & 0xFFFFu;
-    Shake<17> sp;
-    sp.init();
+    LaneSponge<17, TWO> sp;
+    sp.init(TWO && (t & 1));
 #pragma unroll
-    for (int w = 0; w < 8; w++) sp.s[w] = rhoprime[item * 8 + w];
-    sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
-    sp.s[16] ^= 0x8000000000000000ull;
+    for (int w = 0; w < 8; w++) sp.set(w, rhoprime[item * 8 + w]);
+    sp.set(8, (uint64_t)nonce | (0x1Full << 16));
+    sp.pad_end();
+    const bool wr = sp.writer();
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, y + p * 256);
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, y + p * 256, wr);
     uint64_t buf = 0;
     int nbits = 0, cnt = 0;          // wave-uniform
     while (cnt < 256) {
-        keccak_f1600(sp.s);
+        sp.permute();
 #pragma unroll
         for (int w = 0; w < 17; w++) {
-            const uint64_t word = sp.s[w];
+            const uint64_t word = sp.word(w);
             // consume `word` (64 fresh bits) behind the nbits (< B) left in buf
             int avail = 64;
             if (nbits > 0 && cnt < 256) {
                 const int need = B - nbits;
-                const uint32_t t = (uint32_t)((buf | (word << nbits)) & MASK);
-                const int32_t v = GAMMA1 - (int32_t)t;
-                sink.put(cnt++, v + ((v >> 31) & (int32_t)QU));
+                const uint32_t f = (uint32_t)((buf | (word << nbits)) & MASK);
+                const int32_t v = GAMMA1 - (int32_t)f;
+                if (wr) sink.put(cnt, v + ((v >> 31) & (int32_t)QU));
+                cnt++;
                 avail -= need;
             }
             uint64_t rest = (avail == 64) ? word : (word >> (64 - avail));
             while (avail >= B && cnt < 256) {
                 const int32_t v = GAMMA1 - (int32_t)(rest & MASK);
-                sink.put(cnt++, v + ((v >> 31) & (int32_t)QU));
+                if (wr) sink.put(cnt, v + ((v >> 31) & (int32_t)QU));
+                cnt++;
                 rest >>= B;
                 avail -= B;
             }
             buf = rest;
             nbits = avail;
-            sink.flush_if_ready(cnt);          // <= 4 coefficients per 64-bit word
+            if (wr) sink.flush_if_ready(cnt);  // <= 4 coefficients per 64-bit word
         }
     }
 }
@@ -439,9 +443,16 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t total = nitems * (size_t)L;
+    const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
+    if (total <= 16384) {        // latency-bound: two lanes per sponge
+        const int grid = (int)((2 * total + HASH_BS - 1) / HASH_BS);
+        if (level == 2) hipLaunchKernelGGL((expand_mask_kernel<18, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
+        else hipLaunchKernelGGL((expand_mask_kernel<20, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
+        return hipGetLastError();
+    }
     const int grid = (int)((total + HASH_BS - 1) / HASH_BS);
-    if (level == 2) hipLaunchKernelGGL(expand_mask_kernel<18>, grid, HASH_BS, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
-    else hipLaunchKernelGGL(expand_mask_kernel<20>, grid, HASH_BS, 0, s, y, reinterpret_cast<const uint64_t*>(rhoprime), kappa, L, nitems);
+    if (level == 2) hipLaunchKernelGGL((expand_mask_kernel<18, false>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
+    else hipLaunchKernelGGL((expand_mask_kernel<20, false>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
     return hipGetLastError();
 }
 

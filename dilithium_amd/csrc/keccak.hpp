@@ -308,6 +308,36 @@ struct Shake2 {
     }
 };
 
+// One interface over both sponge forms for the samplers: state words are set and read as 64-bit values; in the two-lane
+// form each lane keeps its half and word() rebuilds the 64-bit value with one DPP exchange (both lanes of a pair then
+// run the same sampling logic and agree on every counter; only writer() lanes store).
+template <int RATE_WORDS, bool TWO>
+struct LaneSponge;
+template <int RATE_WORDS>
+struct LaneSponge<RATE_WORDS, false> {
+    Shake<RATE_WORDS> sp;
+    __device__ __forceinline__ void init(bool) { sp.init(); }
+    __device__ __forceinline__ bool writer() const { return true; }
+    __device__ __forceinline__ void set(int w, uint64_t v) { sp.s[w] = v; }
+    __device__ __forceinline__ void pad_end() { sp.s[RATE_WORDS - 1] ^= 0x8000000000000000ull; }
+    __device__ __forceinline__ void permute() { keccak_f1600(sp.s); }
+    __device__ __forceinline__ uint64_t word(int w) const { return sp.s[w]; }
+};
+template <int RATE_WORDS>
+struct LaneSponge<RATE_WORDS, true> {
+    Shake2<RATE_WORDS> sp;
+    __device__ __forceinline__ void init(bool hi) { sp.init(hi); }
+    __device__ __forceinline__ bool writer() const { return !sp.hi; }
+    __device__ __forceinline__ void set(int w, uint64_t v) { sp.s[w] = sp.hi ? (uint32_t)(v >> 32) : (uint32_t)v; }
+    __device__ __forceinline__ void pad_end() { sp.s[RATE_WORDS - 1] ^= sp.hi ? 0x80000000u : 0u; }
+    __device__ __forceinline__ void permute() { keccak2_f1600(sp.s, sp.hi); }
+    __device__ __forceinline__ uint64_t word(int w) const
+    {
+        const uint32_t own = sp.s[w], par = k2_partner(own);
+        return sp.hi ? (((uint64_t)own << 32) | par) : (((uint64_t)par << 32) | own);
+    }
+};
+
 // Output staging of the lane-per-sponge samplers.  Each lane emits the coefficients of its own polynomial one at a
 // time; written straight to global memory that is a 4-byte store per lane per coefficient, 64 different cache lines
 // per store instruction (measured: a third of ExpandA's time).  Instead each lane keeps a ring of 32 coefficients in
