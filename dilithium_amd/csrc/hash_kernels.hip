@@ -33,13 +33,8 @@ __global__ __launch_bounds__(HASH_BS) void shake256_batch_kernel(uint64_t* __res
 // ExpandA: A[item][i][j] = RejUniform(SHAKE128(rho || byte j || byte i)), 3-byte little-endian
 // candidates masked to 23 bits, accepted when < q.  One lane per polynomial.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void emit23(uint32_t v, CoeffSink& sink, int& cnt)
-{
-    v &= 0x7FFFFFu;
-    if (v < QU && cnt < 256) sink.put(cnt++, (int32_t)v);
-}
-// the same for the two-lane kernel: every lane counts, only `writer` lanes store
-__device__ __forceinline__ void emit23_2(uint32_t v, CoeffSink& sink, int& cnt, bool writer)
+// every lane counts, only `writer` lanes store (two-lane sponges: both lanes of a pair run this with the same words)
+__device__ __forceinline__ void emit23(uint32_t v, CoeffSink& sink, int& cnt, bool writer)
 {
     v &= 0x7FFFFFu;
     if (v < QU && cnt < 256) {
@@ -48,37 +43,40 @@ __device__ __forceinline__ void emit23_2(uint32_t v, CoeffSink& sink, int& cnt, 
     }
 }
 
+template <bool TWO>            // TWO: two lanes per sponge (one or a few keys: the five permutations per polynomial are pure latency)
 __global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
                                                       size_t rho_stride_words, int K, int L, size_t nitems)
 {
-    const size_t p = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const size_t p = TWO ? t >> 1 : t;
     const size_t total = nitems * (size_t)(K * L);
-    const bool live = p < total;
+    const bool live = p < total;                       // (two-lane: whole pairs are live or dead together)
     const size_t item = live ? p / (size_t)(K * L) : 0;
     const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
-    Shake<21> sp;
-    sp.init();
+    LaneSponge<21, TWO> sp;
+    sp.init(TWO && (t & 1));
 #pragma unroll
-    for (int w = 0; w < 4; w++) sp.s[w] = rho[item * rho_stride_words + w];
-    sp.s[4] = (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16);
-    sp.s[20] ^= 0x8000000000000000ull;
+    for (int w = 0; w < 4; w++) sp.set(w, rho[item * rho_stride_words + w]);
+    sp.set(4, (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16));
+    sp.pad_end();
+    const bool wr = live && sp.writer();
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, A + p * 256, live);
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, A + p * 256, wr);
     int cnt = live ? 0 : 256;
     while (__any(cnt < 256)) {
-        keccak_f1600(sp.s);
+        sp.permute();
 #pragma unroll
         for (int g = 0; g < 7; g++) {
-            const uint64_t w0 = sp.s[3 * g], w1 = sp.s[3 * g + 1], w2 = sp.s[3 * g + 2];
-            emit23((uint32_t)w0, sink, cnt);
-            emit23((uint32_t)(w0 >> 24), sink, cnt);
-            emit23((uint32_t)((w0 >> 48) | (w1 << 16)), sink, cnt);
-            emit23((uint32_t)(w1 >> 8), sink, cnt);
-            emit23((uint32_t)(w1 >> 32), sink, cnt);
-            emit23((uint32_t)((w1 >> 56) | (w2 << 8)), sink, cnt);
-            emit23((uint32_t)(w2 >> 16), sink, cnt);
-            emit23((uint32_t)(w2 >> 40), sink, cnt);
-            sink.flush_if_ready(cnt);
+            const uint64_t w0 = sp.word(3 * g), w1 = sp.word(3 * g + 1), w2 = sp.word(3 * g + 2);
+            emit23((uint32_t)w0, sink, cnt, wr);
+            emit23((uint32_t)(w0 >> 24), sink, cnt, wr);
+            emit23((uint32_t)((w0 >> 48) | (w1 << 16)), sink, cnt, wr);
+            emit23((uint32_t)(w1 >> 8), sink, cnt, wr);
+            emit23((uint32_t)(w1 >> 32), sink, cnt, wr);
+            emit23((uint32_t)((w1 >> 56) | (w2 << 8)), sink, cnt, wr);
+            emit23((uint32_t)(w2 >> 16), sink, cnt, wr);
+            emit23((uint32_t)(w2 >> 40), sink, cnt, wr);
+            if (wr) sink.flush_if_ready(cnt);
         }
     }
 }
@@ -374,53 +372,6 @@ hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int
     return hipGetLastError();
 }
 
-// ExpandA, two lanes per sponge (keccak.hpp Shake2): for one or a few keys the K*L sponges do not fill a wave per
-// SIMD and the five permutations per polynomial are pure latency; halving the state per lane shortens them 1.45x.
-// Both lanes of a pair rebuild the squeezed 64-bit words (one DPP exchange per word) and run the same candidate
-// logic, so their counters agree; only the even lane stores.
-__global__ __launch_bounds__(HASH_BS) void expand_a2_kernel(int32_t* __restrict__ A, const uint32_t* __restrict__ rho32,
-                                                       size_t rho_stride_dwords, int K, int L, size_t nitems)
-{
-    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
-    const size_t p = t >> 1;
-    const bool hi = t & 1;
-    const size_t total = nitems * (size_t)(K * L);
-    const bool live = p < total;                       // whole pairs are live or dead together
-    const size_t item = live ? p / (size_t)(K * L) : 0;
-    const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
-    Shake2<21> sp;
-    sp.init(hi);
-#pragma unroll
-    for (int w = 0; w < 4; w++) sp.s[w] = rho32[item * rho_stride_dwords + 2 * w + (hi ? 1 : 0)];
-    sp.s[4] = hi ? 0u : ((uint32_t)j | ((uint32_t)i << 8) | (0x1Fu << 16));
-    sp.s[20] ^= hi ? 0x80000000u : 0u;
-    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, A + p * 256, live && !hi);
-    int cnt = live ? 0 : 256;
-    while (__any(cnt < 256)) {
-        keccak2_f1600(sp.s, hi);
-#pragma unroll
-        for (int g = 0; g < 7; g++) {
-            uint64_t w[3];
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const uint32_t own = sp.s[3 * g + q], par = k2_partner(own);
-                w[q] = hi ? (((uint64_t)own << 32) | par) : (((uint64_t)par << 32) | own);
-            }
-            const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
-            emit23_2((uint32_t)w0, sink, cnt, !hi);
-            emit23_2((uint32_t)(w0 >> 24), sink, cnt, !hi);
-            emit23_2((uint32_t)((w0 >> 48) | (w1 << 16)), sink, cnt, !hi);
-            emit23_2((uint32_t)(w1 >> 8), sink, cnt, !hi);
-            emit23_2((uint32_t)(w1 >> 32), sink, cnt, !hi);
-            emit23_2((uint32_t)((w1 >> 56) | (w2 << 8)), sink, cnt, !hi);
-            emit23_2((uint32_t)(w2 >> 16), sink, cnt, !hi);
-            emit23_2((uint32_t)(w2 >> 40), sink, cnt, !hi);
-            if (!hi) sink.flush_if_ready(cnt);
-        }
-    }
-}
-
 hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s)
 {
     if (rho_stride_bytes & 7) return hipErrorInvalidValue;
@@ -429,11 +380,11 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const size_t total = nitems * (size_t)(K * L);
     if (total <= 16384) {        // latency-bound: two lanes per sponge
-        hipLaunchKernelGGL(expand_a2_kernel, (int)((2 * total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A,
-                           reinterpret_cast<const uint32_t*>(rho), rho_stride_bytes / 4, K, L, nitems);
+        hipLaunchKernelGGL(expand_a_kernel<true>, (int)((2 * total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A,
+                           reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(expand_a_kernel, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
+    hipLaunchKernelGGL(expand_a_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
     return hipGetLastError();
 }
 
