@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small fixed workloads for rocprofv3 (kernel trace or --pmc passes):
-   prof_target.py ntt | verify | verify_shared | sign | hash | scheme | all   [reps]"""
+   prof_target.py ntt | verify | verify_rot | verify_shared | sign | hash | scheme | all   [reps]"""
 import os
 import sys
 
@@ -36,6 +36,17 @@ def main():
                 api.verify_core(A, z, c, t1, h, 3, out=w1)
             if what not in ("verify", "ntt+verify"):
                 api.verify_core(A[:1], z, c, t1[:1], h, 3, shared_pk=True, out=w1)
+    if what == "verify_rot":        # two input sets alternating: HBM-streaming like bench.py's secondary metric
+        n, K, L = 8192, 6, 5
+        sets = []
+        for _ in range(2):
+            t1 = torch.randint(0, 1024, (n, K, 256), dtype=torch.int32, device="cuda", generator=g)
+            h = (torch.rand((n, K, 256), device="cuda", generator=g) < 0.03).to(torch.uint8)
+            sets.append((rnd(n, K, L, 256), rnd(n, L, 256), rnd(n, 256), t1, h))
+        w1 = torch.empty((n, K, 256), dtype=torch.uint8, device="cuda")
+        for i in range(2 * reps + 2):
+            A, z, c, t1, h = sets[i % 2]
+            api.verify_core(A, z, c, t1, h, 3, out=w1)
     if what in ("matvec_shared", "matvec"):
         n, K, L = 8192, 6, 5
         A, y = rnd(n if what == "matvec" else 1, K, L, 256), rnd(n, L, 256)
