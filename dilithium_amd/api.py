@@ -58,6 +58,17 @@ def init(device: int = -1) -> None:
     _lib.check(_lib.load().dil_init(device), "dil_init")
 
 
+def set_option(name: str, value: int) -> None:
+    """process-wide option of the library (include/dil256.h): "fused_mode", "fuse_wire", "zeroize", ..."""
+    _lib.check(_lib.load().dil_set_option(name.encode(), int(value)), f"dil_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int()
+    _lib.check(_lib.load().dil_get_option(name.encode(), C.byref(v)), f"dil_get_option({name})")
+    return int(v.value)
+
+
 # ---- H2/H3/H5 -----------------------------------------------------------------------------------
 def ntt(a):
     """in-place forward NTT of every polynomial of `a` (ref_ntt.cpp:28-47)"""

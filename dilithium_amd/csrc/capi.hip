@@ -10,23 +10,169 @@
 #include <stdlib.h>
 #include <string.h>
 
+namespace {
+constexpr int64_t Q = DIL_Q;
+void build_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe);
+}  // namespace
+
 namespace dil {
 namespace rt {
-State g;
-int ensure_init()
+Config cfg;
+namespace {
+Device g_dev[MAX_DEVICES];
+std::once_flag g_env_once;
+
+struct OptName { const char* name; const char* env; std::atomic<int>* slot; };
+const OptName* option_table(int* n)
 {
-    if (g.ready) return 0;
-    return dil_init(-1);
+    static const OptName tab[] = {
+        {"fused_mode", "DIL_FUSED_MODE", &cfg.fused_mode},
+        {"ntt_blocks_per_cu", "DIL_NTT_BPC", &cfg.ntt_blocks_per_cu},
+        {"wpi_blocks_per_cu", "DIL_WPI_BPC", &cfg.wpi_blocks_per_cu},
+        {"fused_wgs_per_cu", "DIL_FUSED_WGPC", &cfg.fused_wgs_per_cu},
+        {"sign_early", "DIL_SIGN_EARLY", &cfg.sign_early},
+        {"sign_waste", "DIL_SIGN_WASTE", &cfg.sign_waste},
+        {"sign_cap", "DIL_SIGN_CAP", &cfg.sign_cap},
+        {"aux_overlap", "DIL_AUX_OVERLAP", &cfg.aux_overlap},
+        {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
+        {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
+    };
+    *n = (int)(sizeof(tab) / sizeof(tab[0]));
+    return tab;
+}
+void read_env()
+{
+    int n;
+    const OptName* tab = option_table(&n);
+    for (int i = 0; i < n; i++)
+        if (const char* e = getenv(tab[i].env)) tab[i].slot->store(atoi(e));
+}
+
+// bring one device up: twiddle tables, CU count, private spill pool.  Caller holds d.mu and has `id` current.
+int init_device(Device& d, int id)
+{
+    hipDeviceProp_t prop;
+    DIL_TRY(hipGetDeviceProperties(&prop, id));
+    static uint32_t h_tab[3 * 2048];
+    static std::once_flag tab_once;
+    std::call_once(tab_once, [] { build_tables(h_tab, h_tab + 2048, h_tab + 4096); });
+    DIL_TRY(hipMalloc(reinterpret_cast<void**>(&d.d_tables), sizeof(h_tab)));
+    DIL_TRY(hipMemcpy(d.d_tables, h_tab, sizeof(h_tab), hipMemcpyHostToDevice));
+    d.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    d.id = id;
+    {   // Spills of the composite calls come from a PRIVATE stream-ordered pool that keeps what it has grown to
+        // (the application's default pool and its release threshold are not touched).
+        hipMemPoolProps pp = {};
+        pp.allocType = hipMemAllocationTypePinned;
+        pp.location.type = hipMemLocationTypeDevice;
+        pp.location.id = id;
+        if (hipMemPoolCreate(&d.pool, &pp) == hipSuccess) {
+            uint64_t keep = getenv("DIL_POOL_KEEP") ? strtoull(getenv("DIL_POOL_KEEP"), nullptr, 10) : (uint64_t)8 << 30;
+            (void)hipMemPoolSetAttribute(d.pool, hipMemPoolAttrReleaseThreshold, &keep);
+        } else {
+            d.pool = nullptr;        // fall back to the default pool, attributes untouched
+        }
+        (void)hipGetLastError();
+    }
+    return 0;
+}
+
+// tear one device down (caller holds d.mu; `d.id` is made current for the frees and restored by the caller)
+void destroy_device(Device& d)
+{
+    d.arenas.clear();
+    d.aux.destroy();
+    if (d.hp.ready) {
+        for (int i = 0; i < HOST_STREAMS; i++) {
+            (void)hipFree(d.hp.dev[i]);
+            (void)hipStreamDestroy(d.hp.stream[i]);
+        }
+        d.hp = HostPipe{};
+    }
+    if (d.d_tables) (void)hipFree(d.d_tables);
+    if (d.scratch) (void)hipFree(d.scratch);
+    if (d.pool) (void)hipMemPoolDestroy(d.pool);
+    d.d_tables = nullptr;
+    d.scratch = nullptr;
+    d.scratch_bytes = 0;
+    d.pool = nullptr;
+}
+}  // namespace
+
+std::atomic<int>* option_slot(const char* name)
+{
+    int n;
+    const OptName* tab = option_table(&n);
+    for (int i = 0; i < n; i++)
+        if (name && strcmp(name, tab[i].name) == 0) return tab[i].slot;
+    return nullptr;
+}
+
+int current(Device** out)
+{
+    int id = 0;
+    DIL_TRY(hipGetDevice(&id));
+    if (id < 0 || id >= MAX_DEVICES) return (int)hipErrorInvalidDevice;
+    Device& d = g_dev[id];
+    if (!d.ready.load(std::memory_order_acquire)) {
+        std::call_once(g_env_once, read_env);
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (!d.ready.load(std::memory_order_relaxed)) {
+            const int rc = init_device(d, id);
+            if (rc) {
+                destroy_device(d);
+                return rc;
+            }
+            d.ready.store(true, std::memory_order_release);
+        }
+    }
+    *out = &d;
+    return 0;
+}
+
+dil::Tables Device::tables() const
+{
+    dil::Tables t;
+    t.fwd = d_tables;
+    t.inv = d_tables + 2048;
+    t.inv_pipe = d_tables + 4096;
+    t.device = id;
+    t.num_cus = num_cus;
+    auto pos = [](int v, int dflt) { return v > 0 ? v : dflt; };
+    t.ntt_blocks_per_cu = pos(cfg.ntt_blocks_per_cu.load(std::memory_order_relaxed), 8);
+    t.wpi_blocks_per_cu = pos(cfg.wpi_blocks_per_cu.load(std::memory_order_relaxed), 8);
+    t.fused_wgs_per_cu = pos(cfg.fused_wgs_per_cu.load(std::memory_order_relaxed), 4);
+    t.fused_mode = cfg.fused_mode.load(std::memory_order_relaxed);
+    return t;
+}
+
+bool AuxStream::ensure()
+{
+    if (s) return true;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; return false; }
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+        destroy();
+        return false;
+    }
+    return true;
+}
+void AuxStream::destroy()
+{
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (s) (void)hipStreamDestroy(s);
+    s = nullptr;
+    fork = join = nullptr;
 }
 }  // namespace rt
 }  // namespace dil
 
 namespace {
-using dil::rt::g;
-using dil::rt::ensure_init;
 using dil::rt::S;
+using dil::rt::Device;
+using dil::rt::HOST_STREAMS;
 
-constexpr int64_t Q = DIL_Q;
 
 // ---- twiddles: zeta^brv8(k), zeta = 1753 (consts.cpp:64-97; zetas.txt holds them mod q) ----
 unsigned brv8(unsigned x)
@@ -107,19 +253,18 @@ void build_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe)
 
 
 
-int ensure_scratch(size_t bytes)
+int ensure_scratch(Device& d, size_t bytes)
 {
-    if (bytes <= g.scratch_bytes) return 0;
-    if (g.scratch) {
-        DIL_TRY(hipFree(g.scratch));
-        g.scratch = nullptr;
-        g.scratch_bytes = 0;
+    if (bytes <= d.scratch_bytes) return 0;
+    if (d.scratch) {
+        DIL_TRY(hipFree(d.scratch));
+        d.scratch = nullptr;
+        d.scratch_bytes = 0;
     }
-    DIL_TRY(hipMalloc(&g.scratch, bytes));
-    g.scratch_bytes = bytes;
+    DIL_TRY(hipMalloc(&d.scratch, bytes));
+    d.scratch_bytes = bytes;
     return 0;
 }
-
 
 // host wrapper: the reference's callers hold HOST buffers.  Small batches: copy in, run, copy
 // out on the default stream.  Large batches: chunks of HOST_CHUNK polynomials round-robin over
@@ -127,19 +272,13 @@ int ensure_scratch(size_t bytes)
 // one chunk overlap the kernel and the opposite-direction transfer of its neighbours.  With
 // DIL_HOST_PIN=1 the caller's buffer is page-locked (hipHostRegister) for the duration of the call
 // so that the copies are true asynchronous DMA.
+// Locking: these entry points share the device's staging buffers, so they are serialised by the device's
+// `host_mu` -- a lock of their own; initialisation (Device::mu) and every *_dev entry point are never blocked by it.
 constexpr size_t HOST_CHUNK = 16384;     // polynomials per chunk (16 MiB)
-constexpr int HOST_STREAMS = 3;
 
-struct HostPipe {
-    hipStream_t stream[HOST_STREAMS] = {nullptr, nullptr, nullptr};
-    int32_t* dev[HOST_STREAMS] = {nullptr, nullptr, nullptr};
-    bool ready = false;
-    int pin = -1;
-};
-HostPipe hp;
-
-int ensure_pipe()
+int ensure_pipe(Device& d)
 {
+    dil::rt::HostPipe& hp = d.hp;
     if (hp.ready) return 0;
     for (int i = 0; i < HOST_STREAMS; i++) {
         DIL_TRY(hipStreamCreateWithFlags(&hp.stream[i], hipStreamNonBlocking));
@@ -152,25 +291,26 @@ int ensure_pipe()
 }
 
 template <class F>
-int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, stream) -> int
+int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, tables, stream) -> int
 {
     if (batch == 0) return 0;
-    int rc = ensure_init();
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g.mu);
+    DIL_ENTER(d, T);
+    std::lock_guard<std::mutex> lk(d.host_mu);
+    int rc;
     if (batch <= HOST_CHUNK) {
         const size_t bytes = batch * 1024;
-        rc = ensure_scratch(bytes);
+        rc = ensure_scratch(d, bytes);
         if (rc) return rc;
-        DIL_TRY(hipMemcpy(g.scratch, h, bytes, hipMemcpyHostToDevice));
-        rc = fn(static_cast<int32_t*>(g.scratch), batch, (hipStream_t)0);
+        DIL_TRY(hipMemcpy(d.scratch, h, bytes, hipMemcpyHostToDevice));
+        rc = fn(static_cast<int32_t*>(d.scratch), batch, T, (hipStream_t)0);
         if (rc) return rc;
-        DIL_TRY(hipDeviceSynchronize());
-        DIL_TRY(hipMemcpy(h, g.scratch, bytes, hipMemcpyDeviceToHost));
+        DIL_TRY(hipStreamSynchronize(nullptr));
+        DIL_TRY(hipMemcpy(h, d.scratch, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
-    rc = ensure_pipe();
+    rc = ensure_pipe(d);
     if (rc) return rc;
+    dil::rt::HostPipe& hp = d.hp;
     bool pinned = false;
     if (hp.pin) pinned = hipHostRegister(h, batch * 1024, hipHostRegisterDefault) == hipSuccess;
     int err = 0;
@@ -180,7 +320,7 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
         const size_t n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
         int32_t* hc = h + off * 256;
         err = (int)hipMemcpyAsync(hp.dev[s], hc, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
-        if (!err) err = fn(hp.dev[s], n, hp.stream[s]);
+        if (!err) err = fn(hp.dev[s], n, T, hp.stream[s]);
         if (!err) err = (int)hipMemcpyAsync(hc, hp.dev[s], n * 1024, hipMemcpyDeviceToHost, hp.stream[s]);
     }
     for (int i = 0; i < HOST_STREAMS; i++) {
@@ -189,6 +329,26 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     }
     if (pinned) (void)hipHostUnregister(h);
     return err;
+}
+
+// two-operand host form (pointwise / bram mul): c <- op(a, b), one staging buffer of 2 x batch polynomials
+template <class F>
+int host_binary(int32_t* out, const int32_t* a, const int32_t* b, size_t batch, F&& fn)
+{
+    if (batch == 0) return 0;
+    DIL_ENTER(d, T);
+    std::lock_guard<std::mutex> lk(d.host_mu);
+    const size_t bytes = batch * 1024;
+    const int rc = ensure_scratch(d, 2 * bytes);
+    if (rc) return rc;
+    int32_t* da = static_cast<int32_t*>(d.scratch);
+    int32_t* db = da + batch * 256;
+    DIL_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    DIL_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    DIL_TRY(fn(da, db, T));
+    DIL_TRY(hipStreamSynchronize(nullptr));
+    DIL_TRY(hipMemcpy(out, da, bytes, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 }  // namespace
@@ -206,7 +366,11 @@ void dil_host_zetas(int32_t* zetas)
 
 int dil_device_count(int* count) { return (int)hipGetDeviceCount(count); }
 
-int dil_num_cus(void) { return g.ready ? g.t.num_cus : -1; }
+int dil_num_cus(void)
+{
+    Device* d = nullptr;
+    return dil::rt::current(&d) ? -1 : d->num_cus;
+}
 
 const char* dil_error_string(int code)
 {
@@ -216,142 +380,95 @@ const char* dil_error_string(int code)
 
 int dil_init(int device)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    int cur = 0;
-    if (device < 0) {
-        DIL_TRY(hipGetDevice(&cur));
-        device = cur;
-    }
-    if (g.ready && g.device == device) return 0;
-    if (g.ready) dil::rt::release_scratch();        // arenas belong to the previous device
-    DIL_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    DIL_TRY(hipGetDeviceProperties(&prop, device));
-    if (g.d_tables) {
-        (void)hipFree(g.d_tables);
-        g.d_tables = nullptr;
-    }
-    if (g.scratch) {
-        (void)hipFree(g.scratch);
-        g.scratch = nullptr;
-        g.scratch_bytes = 0;
-    }
-    static uint32_t h_tab[3 * 2048];
-    build_tables(h_tab, h_tab + 2048, h_tab + 4096);
-    DIL_TRY(hipMalloc(reinterpret_cast<void**>(&g.d_tables), sizeof(h_tab)));
-    DIL_TRY(hipMemcpy(g.d_tables, h_tab, sizeof(h_tab), hipMemcpyHostToDevice));
-    g.t.fwd = g.d_tables;
-    g.t.inv = g.d_tables + 2048;
-    g.t.inv_pipe = g.d_tables + 4096;
-    g.t.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = getenv("DIL_NTT_BPC")) g.t.ntt_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.ntt_blocks_per_cu;
-    if (const char* e = getenv("DIL_WPI_BPC")) g.t.wpi_blocks_per_cu = atoi(e) > 0 ? atoi(e) : g.t.wpi_blocks_per_cu;
-    if (const char* e = getenv("DIL_FUSED_MODE")) g.t.fused_mode = atoi(e);
-    if (const char* e = getenv("DIL_SIGN_CAP")) g.sign_cap = atoi(e);
-    if (const char* e = getenv("DIL_SIGN_EARLY")) g.sign_early = atoi(e);
-    if (const char* e = getenv("DIL_SIGN_WASTE")) g.sign_waste = atoi(e);
-    if (const char* e = getenv("DIL_SIGN_STREAMS")) g.sign_streams = atoi(e);
-    if (const char* e = getenv("DIL_AUX_OVERLAP")) g.aux_overlap = atoi(e);
-    if (const char* e = getenv("DIL_FUSED_WGPC")) g.t.fused_wgs_per_cu = atoi(e) > 0 ? atoi(e) : g.t.fused_wgs_per_cu;
-    {   // composite entry points take their temporaries from the stream-ordered pool: keep what it has
-        // grown to instead of handing it back to the driver at every synchronisation
-        hipMemPool_t pool;
-        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-            uint64_t keep = getenv("DIL_POOL_KEEP") ? strtoull(getenv("DIL_POOL_KEEP"), nullptr, 10) : (uint64_t)8 << 30;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        }
-        (void)hipGetLastError();
-    }
-    g.device = device;
-    g.ready = true;
-    return 0;
+    if (device >= 0) DIL_TRY(hipSetDevice(device));
+    Device* d = nullptr;
+    return dil::rt::current(&d);
 }
 
 int dil_shutdown(void)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (!g.ready) return 0;
-    dil::rt::release_scratch();
-    if (g.d_tables) (void)hipFree(g.d_tables);
-    if (g.scratch) (void)hipFree(g.scratch);
-    if (hp.ready) {
-        for (int i = 0; i < HOST_STREAMS; i++) {
-            (void)hipFree(hp.dev[i]);
-            (void)hipStreamDestroy(hp.stream[i]);
-        }
-        hp = HostPipe{};
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int i = 0; i < dil::rt::MAX_DEVICES; i++) {
+        Device& d = dil::rt::g_dev[i];
+        std::lock_guard<std::mutex> lk(d.mu);
+        if (!d.ready.load()) continue;
+        if (hipSetDevice(i) == hipSuccess) dil::rt::destroy_device(d);
+        d.ready.store(false);
     }
-    g.d_tables = nullptr;
-    g.scratch = nullptr;
-    g.scratch_bytes = 0;
-    g.ready = false;
+    if (have_cur) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+    return 0;
+}
+
+int dil_set_option(const char* name, int value)
+{
+    std::atomic<int>* slot = dil::rt::option_slot(name);
+    if (!slot) return (int)hipErrorInvalidValue;
+    std::call_once(dil::rt::g_env_once, dil::rt::read_env);     // an explicit setting wins over the environment
+    slot->store(value);
+    return 0;
+}
+
+int dil_get_option(const char* name, int* value)
+{
+    std::atomic<int>* slot = dil::rt::option_slot(name);
+    if (!slot || !value) return (int)hipErrorInvalidValue;
+    std::call_once(dil::rt::g_env_once, dil::rt::read_env);
+    *value = slot->load();
     return 0;
 }
 
 // ---- transforms ---------------------------------------------------------------------------
 int dil_ntt_dev(int32_t* polys, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, polys, batch, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, polys, batch, T, S(stream));
 }
 int dil_invntt_dev(int32_t* polys, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, polys, batch, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, polys, batch, T, S(stream));
 }
 int dil_ntt_host(int32_t* polys, size_t batch)
 {
-    return host_inplace(polys, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, d, n, g.t, st); });
+    return host_inplace(polys, batch, [](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
+        return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, p, n, t, st);
+    });
 }
 int dil_invntt_host(int32_t* polys, size_t batch)
 {
-    return host_inplace(polys, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, d, n, g.t, st); });
+    return host_inplace(polys, batch, [](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
+        return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, p, n, t, st);
+    });
 }
 
 // ---- element-wise ---------------------------------------------------------------------------
 int dil_pointwise_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_pointwise(dil::OP_MUL, c, a, b, nullptr, batch, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_pointwise(dil::OP_MUL, c, a, b, nullptr, batch, T, S(stream));
 }
 int dil_pointwise_acc_dev(int32_t* c, const int32_t* acc, const int32_t* a, const int32_t* b, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_pointwise(dil::OP_MAC, c, a, b, acc, batch, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_pointwise(dil::OP_MAC, c, a, b, acc, batch, T, S(stream));
 }
 int dil_poly_add_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_pointwise(dil::OP_ADD, c, a, b, nullptr, batch, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_pointwise(dil::OP_ADD, c, a, b, nullptr, batch, T, S(stream));
 }
 int dil_poly_sub_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_pointwise(dil::OP_SUB, c, a, b, nullptr, batch, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_pointwise(dil::OP_SUB, c, a, b, nullptr, batch, T, S(stream));
 }
 int dil_pointwise_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
 {
-    if (batch == 0) return 0;
-    int rc = ensure_init();
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lk(g.mu);
-    const size_t bytes = batch * 1024;
-    rc = ensure_scratch(2 * bytes);
-    if (rc) return rc;
-    int32_t* da = static_cast<int32_t*>(g.scratch);
-    int32_t* db = da + batch * 256;
-    DIL_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
-    DIL_TRY(dil::launch_pointwise(dil::OP_MUL, da, da, db, nullptr, batch, g.t, 0));
-    DIL_TRY(hipDeviceSynchronize());
-    DIL_TRY(hipMemcpy(c, da, bytes, hipMemcpyDeviceToHost));
-    return 0;
+    return host_binary(c, a, b, batch, [batch](int32_t* da, int32_t* db, const dil::Tables& t) {
+        return dil::launch_pointwise(dil::OP_MUL, da, da, db, nullptr, batch, t, 0);
+    });
 }
 
 // ---- bram (hardware-model API) -----------------------------------------------------------------
@@ -359,114 +476,97 @@ static int check_mapping(int m) { return (m < 0 || m > 2) ? (int)hipErrorInvalid
 
 int dil_bram_fwdntt_dev(int32_t* ram, size_t batch, int mapping, void* stream)
 {
-    int rc = ensure_init();
-    if (rc || (rc = check_mapping(mapping))) return rc;
-    return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, ram, batch, g.t, S(stream));
+    if (int rc = check_mapping(mapping)) return rc;
+    DIL_ENTER(d, T);
+    return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, ram, batch, T, S(stream));
 }
 int dil_bram_invntt_dev(int32_t* ram, size_t batch, int mapping, void* stream)
 {
-    int rc = ensure_init();
-    if (rc || (rc = check_mapping(mapping))) return rc;
-    return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, ram, batch, g.t, S(stream));
+    if (int rc = check_mapping(mapping)) return rc;
+    DIL_ENTER(d, T);
+    return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, ram, batch, T, S(stream));
 }
 int dil_bram_mul_dev(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, void* stream)
 {
-    int rc = ensure_init();
-    if (rc || (rc = check_mapping(mapping))) return rc;
-    return (int)dil::launch_bram_mul(ram, mul_ram, batch, mapping, g.t, S(stream));
+    if (int rc = check_mapping(mapping)) return rc;
+    DIL_ENTER(d, T);
+    return (int)dil::launch_bram_mul(ram, mul_ram, batch, mapping, T, S(stream));
 }
 int dil_bram_fwdntt_host(int32_t* ram, size_t batch, int mapping)
 {
-    int rc = check_mapping(mapping);
-    if (rc) return rc;
-    return host_inplace(ram, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, d, n, g.t, st); });
+    if (int rc = check_mapping(mapping)) return rc;
+    return host_inplace(ram, batch, [mapping](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
+        return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, p, n, t, st);
+    });
 }
 int dil_bram_invntt_host(int32_t* ram, size_t batch, int mapping)
 {
-    int rc = check_mapping(mapping);
-    if (rc) return rc;
-    return host_inplace(ram, batch, [&](int32_t* d, size_t n, hipStream_t st) { return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, d, n, g.t, st); });
+    if (int rc = check_mapping(mapping)) return rc;
+    return host_inplace(ram, batch, [mapping](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
+        return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, p, n, t, st);
+    });
 }
 int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping)
 {
-    if (batch == 0) return 0;
-    int rc = check_mapping(mapping);
-    if (rc || (rc = ensure_init())) return rc;
-    std::lock_guard<std::mutex> lk(g.mu);
-    const size_t bytes = batch * 1024;
-    rc = ensure_scratch(2 * bytes);
-    if (rc) return rc;
-    int32_t* da = static_cast<int32_t*>(g.scratch);
-    int32_t* db = da + batch * 256;
-    DIL_TRY(hipMemcpy(da, ram, bytes, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(db, mul_ram, bytes, hipMemcpyHostToDevice));
-    DIL_TRY(dil::launch_bram_mul(da, db, batch, mapping, g.t, 0));
-    DIL_TRY(hipDeviceSynchronize());
-    DIL_TRY(hipMemcpy(ram, da, bytes, hipMemcpyDeviceToHost));
-    return 0;
+    if (int rc = check_mapping(mapping)) return rc;
+    return host_binary(ram, ram, mul_ram, batch, [batch, mapping](int32_t* da, int32_t* db, const dil::Tables& t) {
+        return dil::launch_bram_mul(da, db, batch, mapping, t, 0);
+    });
 }
 
 // ---- fused pipelines ---------------------------------------------------------------------------
 int dil_matvec_dev(int32_t* w, const int32_t* A, const int32_t* y, int level, size_t batch, int shared_A, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, y, batch, shared_A, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, y, batch, shared_A, T, S(stream));
 }
 int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
                         const uint8_t* h, int level, size_t batch, int shared_pk, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, T, S(stream));
 }
 int dil_sign_phase1_dev(uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y, int level, size_t batch,
                         int shared_key, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_matvec(level, dil::OUT_W1W0, nullptr, w1, w0, A, y, batch, shared_key, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_matvec(level, dil::OUT_W1W0, nullptr, w1, w0, A, y, batch, shared_key, T, S(stream));
 }
 int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, const int32_t* w0,
                         const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
                         size_t batch, int shared_key, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, T, S(stream));
 }
 
 // ---- row N1: samplers ---------------------------------------------------------------------------
 int dil_shake256_dev(uint8_t* out, size_t out_bytes, const uint8_t* in, size_t in_bytes, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
+    DIL_ENTER(d, T);
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) & 7) return (int)hipErrorInvalidValue;
     return (int)dil::launch_shake256(reinterpret_cast<uint64_t*>(out), (int)out_bytes, reinterpret_cast<const uint64_t*>(in),
                                      (int)in_bytes, batch, S(stream));
 }
 int dil_expand_a_dev(int32_t* A, const uint8_t* rho, int level, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
+    DIL_ENTER(d, T);
     return (int)dil::launch_expand_a(A, rho, 32, level, batch, S(stream));
 }
 int dil_expand_mask_dev(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
+    DIL_ENTER(d, T);
     return (int)dil::launch_expand_mask(y, rhoprime, kappa, level, batch, S(stream));
 }
 int dil_sample_in_ball_dev(int32_t* c, const uint8_t* ctilde, int level, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
+    DIL_ENTER(d, T);
     return (int)dil::launch_sample_in_ball(c, ctilde, level, batch, S(stream));
 }
 int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, void* stream)
 {
-    int rc = ensure_init();
-    if (rc) return rc;
-    return (int)dil::launch_pack_w1(out, w1, level, batch, g.t, S(stream));
+    DIL_ENTER(d, T);
+    return (int)dil::launch_pack_w1(out, w1, level, batch, T, S(stream));
 }
 
 // ---- events --------------------------------------------------------------------------------------

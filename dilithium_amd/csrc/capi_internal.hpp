@@ -1,39 +1,110 @@
-// capi_internal.hpp -- what the translation units behind include/dil256.h share: the per-process runtime state,
-// lazy initialisation, error propagation.
+// capi_internal.hpp -- what the translation units behind include/dil256.h share: the process-wide options, the
+// PER-DEVICE runtime state (one `Device` per HIP device, created on first use by whichever thread has that device
+// current), lazy initialisation and error propagation.  There is no single "the" device: a C++ host that drives
+// eight GPUs from one process (one thread per GPU, or one thread switching with hipSetDevice) gets eight independent
+// Device records -- twiddle tables, scratch, arenas, helper stream -- and never shares a lock between them.
 #pragma once
 #include "../../include/dil256.h"
 #include "kernels.hpp"
 
+#include <atomic>
 #include <mutex>
-
-namespace dil {
-namespace rt {
-
-struct State {
-    std::mutex mu;
-    bool ready = false;
-    int device = -1;
-    uint32_t* d_tables = nullptr;   // fwd | inv | inv_pipe
-    dil::Tables t;
-    void* scratch = nullptr;        // for *_host entry points
-    size_t scratch_bytes = 0;
-    int sign_early = 1;             // DIL_SIGN_EARLY: 0 = the signing loop evaluates every check of every attempt
-    int sign_waste = 6144;          // DIL_SIGN_WASTE: speculative entries a round may expect to waste (see dil_sign_dev)
-    int sign_cap = 0;               // DIL_SIGN_CAP: entries in flight per signing round (0 = default)
-    int aux_overlap = 1;            // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream
-    int sign_streams = 1;           // DIL_SIGN_STREAMS: 2 = split each signing round over the caller stream and a helper (measured: no gain)
-};
-extern State g;
-
-int ensure_init();
-void release_scratch();        // frees the composite calls' per-stream arenas (scheme.hip)
-inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-}  // namespace rt
-}  // namespace dil
 
 #define DIL_TRY(expr)                          \
     do {                                       \
         hipError_t e__ = (expr);               \
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
+
+namespace dil {
+namespace rt {
+
+constexpr int MAX_DEVICES = 32;
+
+// Process-wide tunables (dil_set_option / environment at first use); read at call time, never cached in a launch.
+struct Config {
+    std::atomic<int> fused_mode{0};        // DIL_FUSED_MODE: 0 auto (by batch), 1 workgroup-per-item, 2 wave-per-item
+    std::atomic<int> ntt_blocks_per_cu{8}; // DIL_NTT_BPC
+    std::atomic<int> wpi_blocks_per_cu{8}; // DIL_WPI_BPC
+    std::atomic<int> fused_wgs_per_cu{4};  // DIL_FUSED_WGPC
+    std::atomic<int> sign_early{1};        // DIL_SIGN_EARLY: 0 = the signing loop evaluates every check of every attempt
+    std::atomic<int> sign_waste{6144};     // DIL_SIGN_WASTE: speculative entries a round may expect to waste
+    std::atomic<int> sign_cap{0};          // DIL_SIGN_CAP: entries in flight per signing round (0 = default 16384)
+    std::atomic<int> aux_overlap{1};       // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream
+    std::atomic<int> zeroize{0};           // DIL_ZEROIZE: 1 = signing / keygen clear their device scratch before returning
+    std::atomic<int> fuse_wire{1};         // DIL_FUSE_WIRE: 0 = wire-format verify runs the unfused (codec + core) sequence
+};
+extern Config cfg;
+std::atomic<int>* option_slot(const char* name);     // nullptr: unknown option
+
+// ---- per-stream scratch arenas of the composite calls (scheme.hip) ------------------------------------------
+struct Arena {
+    hipStream_t stream = nullptr;
+    char* base = nullptr;
+    size_t size = 0;
+    int32_t* pinned = nullptr;      // two host words for small read-backs
+    bool in_use = false;
+    uint64_t last_use = 0;
+};
+struct ArenaPool {
+    std::mutex mu;
+    Arena slots[8];
+    uint64_t tick = 0;
+    Arena* acquire(hipStream_t s);
+    int release(Arena* a, size_t wanted);        // regrows to `wanted` if needed; returns the hipError_t of a failed regrow
+    void clear();
+};
+
+// helper stream of the composite calls: latency-bound independent parts run beside the caller's stream
+struct AuxStream {
+    std::mutex mu;
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ensure();
+    void destroy();
+};
+
+// staging of the *_host transform entry points (capi.hip)
+constexpr int HOST_STREAMS = 3;
+struct HostPipe {
+    hipStream_t stream[HOST_STREAMS] = {nullptr, nullptr, nullptr};
+    int32_t* dev[HOST_STREAMS] = {nullptr, nullptr, nullptr};
+    bool ready = false;
+    int pin = -1;
+};
+
+struct Device {
+    std::mutex mu;                  // guards (re)initialisation and teardown only
+    std::atomic<bool> ready{false};
+    int id = -1;
+    uint32_t* d_tables = nullptr;   // fwd | inv | inv_pipe
+    int num_cus = 256;
+    hipMemPool_t pool = nullptr;    // private stream-ordered pool for spills (the application's default pool is left alone)
+    std::mutex host_mu;             // serialises the *_host transform entry points of THIS device (they share `scratch`, `hp`)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    HostPipe hp;
+    ArenaPool arenas;
+    AuxStream aux;
+    // launch configuration for a call made now: device constants + the current options
+    dil::Tables tables() const;
+};
+
+// The Device record of the calling thread's CURRENT HIP device, initialised on first use.  Every entry point starts
+// here, so buffers, stream and tables always belong to one device: the one HIP itself would launch on.
+int current(Device** out);
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace rt
+}  // namespace dil
+
+// boilerplate of an entry point: `DIL_ENTER(dv, T)` declares `dil::rt::Device& dv` and `const dil::Tables T`
+#define DIL_ENTER(dv, T)                               \
+    dil::rt::Device* dv##_ptr = nullptr;               \
+    {                                                  \
+        const int rc__ = dil::rt::current(&dv##_ptr);  \
+        if (rc__) return rc__;                         \
+    }                                                  \
+    dil::rt::Device& dv = *dv##_ptr;                   \
+    const dil::Tables T = dv.tables();                 \
+    (void)T

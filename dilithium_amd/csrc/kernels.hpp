@@ -15,11 +15,12 @@ struct Tables {
     const uint32_t* fwd = nullptr;   // device, [4][64][8]
     const uint32_t* inv = nullptr;   // device, [4][64][8]  standalone inverse (f = 1/256)
     const uint32_t* inv_pipe = nullptr;   // same, f = 2^32/256: cancels the 2^-32 of the fused pointwise stage
+    int device = 0;               // HIP device these tables live on (key of the occupancy cache)
     int num_cus = 256;
-    int ntt_blocks_per_cu = 8;    // persistent 256-thread blocks per CU for the NTT kernels   (env DIL_NTT_BPC)
-    int fused_wgs_per_cu = 4;     // persistent workgroups per CU, workgroup-per-item pipelines (env DIL_FUSED_WGPC)
-    int wpi_blocks_per_cu = 8;    // cap on persistent 256-thread blocks per CU (actual = occupancy), wave-per-item (env DIL_WPI_BPC)
-    int fused_mode = 0;           // 0 auto (by batch size), 1 workgroup-per-item, 2 wave-per-item (env DIL_FUSED_MODE)
+    int ntt_blocks_per_cu = 8;    // persistent 256-thread blocks per CU for the NTT kernels   (option ntt_blocks_per_cu)
+    int fused_wgs_per_cu = 4;     // persistent workgroups per CU, workgroup-per-item pipelines (option fused_wgs_per_cu)
+    int wpi_blocks_per_cu = 8;    // cap on persistent 256-thread blocks per CU (actual = occupancy), wave-per-item (option wpi_blocks_per_cu)
+    int fused_mode = 0;           // 0 auto (by batch size), 1 workgroup-per-item, 2 wave-per-item (option fused_mode)
 };
 
 hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, size_t batch, const Tables& t, hipStream_t s);

@@ -714,7 +714,7 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
     }
     if (use_wpi(batch, t)) {
         const int g = grid_for((batch + 3) / 4,
-                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT>, 256, t.wpi_blocks_per_cu));
+                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT>, 256, t.wpi_blocks_per_cu, t.device));
         hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, km, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
@@ -750,7 +750,7 @@ static void launch_verify_wpi(uint8_t* w1, const int32_t* A, const int32_t* z, c
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
         hipLaunchKernelGGL((verify_shared_kernel<LEVEL, NW>), g, 64 * NW, 0, s, w1, A, z, c, t1, h, batch, t.fwd, t.inv_pipe);
     } else {
-        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<LEVEL>, 256, t.wpi_blocks_per_cu));
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<LEVEL>, 256, t.wpi_blocks_per_cu, t.device));
         hipLaunchKernelGGL((verify_wpi_kernel<LEVEL>), g, 256, 0, s, w1, A, z, c, t1, h, batch, shared_pk, t.fwd, t.inv_pipe);
     }
 }
@@ -795,7 +795,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
         if (w0_scratch != w0) return hipErrorInvalidValue;
 #define DIL_S2E(LV)                                                                                                              \
     hipLaunchKernelGGL(sign2_early_wpi_kernel<LV>,                                                                               \
-                       grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu)), \
+                       grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu, t.device)), \
                        256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe);          \
     break
         switch (level) {
@@ -809,9 +809,9 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
     }
     if (use_wpi(batch, t)) {
         switch (level) {
-        case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
-        case 3: hipLaunchKernelGGL(sign2_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<3>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
-        case 5: hipLaunchKernelGGL(sign2_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<5>, 256, t.wpi_blocks_per_cu)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
+        case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu, t.device)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
+        case 3: hipLaunchKernelGGL(sign2_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<3>, 256, t.wpi_blocks_per_cu, t.device)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
+        case 5: hipLaunchKernelGGL(sign2_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<5>, 256, t.wpi_blocks_per_cu, t.device)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();

@@ -7,6 +7,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -107,4 +108,81 @@ void reshape(bram* ram, const data_t in[DILITHIUM_N])           // util.cpp:61-7
 {
     for (int i = 0; i < BRAM_DEPT; i++)
         for (int j = 0; j < 4; j++) ram->coeffs[i][j] = in[4 * i + j];
+}
+
+// ---- the rest of the hardware model's helper surface, so that the reference's own
+// ntt2x2_test.cpp links against this library with nothing else on the link line ---------------------------
+// ram_util.h:29-31: one `bram` row = 4 coefficients
+void read_ram(data_t data_out[4], const bram* ram, const unsigned ram_i) { memcpy(data_out, ram->coeffs[ram_i], 4 * sizeof(data_t)); }
+void write_ram(bram* ram, const unsigned ram_i, const data_t data_in[4]) { memcpy(ram->coeffs[ram_i], data_in, 4 * sizeof(data_t)); }
+
+// ram_util.h:33 -- the twiddle ROM address generator of the butterfly unit (ram_util.cpp:45-94 ==
+// twiddle_resolver.v:87-130): group `i` of pass `level` (0, 2, 4, 6) reads ROM row base(level') + (i' mod 4^(level'/2))
+// with base = 0, 1, 5, 21; forward: level' = level, i' = i, outputs (z[k], z[k], z[2k], z[2k+1]);
+// inverse: level' = 6 - level, i' = 63 - i, outputs (z[2k+1], z[2k], z[k], z[k]).
+void get_twiddle_factors(data_t data_out[4], int i, int level, OPERATION mode)
+{
+    static const unsigned row_base[4] = {0, 1, 5, 21};
+    if (mode != FORWARD_NTT_MODE && mode != INVERSE_NTT_MODE) {      // the reference reads row 0, column 0 four times
+        data_out[0] = data_out[1] = data_out[2] = data_out[3] = zetas_barrett_hw[0][0];
+        return;
+    }
+    const bool fwd = mode == FORWARD_NTT_MODE;
+    const int lv = fwd ? level : DILITHIUM_LOGN - 2 - level;
+    const unsigned grp = (unsigned)(fwd ? i : BRAM_DEPT - 1 - i) & ((1u << lv) - 1u);
+    const data_t* row = zetas_barrett_hw[row_base[lv >> 1] + grp];
+    if (fwd) {
+        data_out[0] = data_out[1] = row[0];
+        data_out[2] = row[1];
+        data_out[3] = row[2];
+    } else {
+        data_out[0] = row[2];
+        data_out[1] = row[1];
+        data_out[2] = data_out[3] = row[0];
+    }
+}
+
+// util.h:46: 0 = equal (exact comparison, as the reference's)
+int compare_array(data_t* a, data_t* b, int bound) { return memcmp(a, b, (size_t)bound * sizeof(data_t)) != 0; }
+
+// util.h:48-50: `array` (reference order) against `ram` behind `mapping`, both reduced to [0, q) first; prints the
+// first mismatching row in the reference's format and returns 1, else 0
+int compare_bram_array(bram* ram, data_t array[DILITHIUM_N], const char* string, enum MAPPING mapping, int print_out)
+{
+    auto canon = [](data_t v) { return (data_t)(((int64_t)v % Qc + Qc) % Qc); };
+    for (int r = 0; r < BRAM_DEPT; r++) {
+        const unsigned addr = resolve_address(mapping, (unsigned)r);
+        data_t gold[4], got[4];
+        bool same = true;
+        for (int j = 0; j < 4; j++) {
+            gold[j] = canon(array[4 * r + j]);
+            got[j] = canon(ram->coeffs[addr][j]);
+            same = same && gold[j] == got[j];
+        }
+        if (print_out) {
+            printf("%d: %d, %d, %d, %d\n", r, gold[0], gold[1], gold[2], gold[3]);
+            printf("[%d]: |%d, %d, %d, %d|\n--------------\n", 4 * r, got[0], got[1], got[2], got[3]);
+        }
+        if (!same) {
+            printf("%s Error at index: %d => %u\n", string, 4 * r, addr);
+            printf("gold: %12u | %12u | %12u | %12u [*]\n", gold[0], gold[1], gold[2], gold[3]);
+            printf("test: %12u | %12u | %12u | %12u\n", got[0], got[1], got[2], got[3]);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+void print_reshaped_array(bram* ram, int bound, const char* string)    // util.h:40
+{
+    printf("%s :\n", string);
+    for (int i = 0; i < bound; i++)
+        for (int j = 0; j < 4; j++) printf("%u, ", ram->coeffs[i][j]);
+    printf("\n");
+}
+void print_index_reshaped_array(bram* ram, int index)                  // util.h:42
+{
+    printf("[%d]: ", index);
+    for (int j = 0; j < 4; j++) printf("%u, ", ram->coeffs[index][j]);
+    printf("\n");
 }

@@ -7,98 +7,95 @@
 #include <algorithm>
 #include <stdlib.h>
 
-using dil::rt::g;
-using dil::rt::ensure_init;
 using dil::rt::S;
+using dil::rt::Arena;
+using dil::rt::ArenaPool;
+using dil::rt::Device;
 
 // (every dil_* function below is declared extern "C" in include/dil256.h and inherits that linkage)
 
 // ---- row N3 (first step): composite sequences, device-resident end to end -----------------------
-namespace {
 // Temporaries of a composite call.  Each stream that makes composite calls gets a grow-only device arena (plus two
 // pinned host words) that is reused from call to call: calls on one stream are ordered, so the next call may overwrite
 // what the previous one used.  A call carves its buffers out of the arena; whatever does not fit (first call, or a
-// bigger batch than ever before) comes from the stream-ordered pool for this call only, and the arena is regrown to
-// the new high-water mark afterwards.  Steady state: no allocation and no free per call (25 hipFreeAsync calls were
-// costing a signing call 1 ms of host time).
-struct Arena {
-    hipStream_t stream = nullptr;
-    char* base = nullptr;
-    size_t size = 0;
-    int32_t* pinned = nullptr;      // two host words for small read-backs
-    bool in_use = false;
-    uint64_t last_use = 0;
-};
-struct ArenaPool {
-    std::mutex mu;
-    Arena slots[8];
-    uint64_t tick = 0;
-    Arena* acquire(hipStream_t s)
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        Arena *free_slot = nullptr, *lru = nullptr;
-        for (Arena& a : slots) {
-            if (a.base && a.stream == s) {
-                if (a.in_use) return nullptr;
-                a.in_use = true;
-                a.last_use = ++tick;
-                return &a;
-            }
-            if (a.in_use) continue;
-            if (!a.base && !free_slot) free_slot = &a;
-            if (a.base && (!lru || a.last_use < lru->last_use)) lru = &a;
+// bigger batch than ever before) comes from the device's private stream-ordered pool for this call only, and the arena
+// is regrown to the new high-water mark afterwards.  Steady state: no allocation and no free per call (25 hipFreeAsync
+// calls were costing a signing call 1 ms of host time).  Arenas are per DEVICE (capi_internal.hpp).
+Arena* ArenaPool::acquire(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(mu);
+    Arena *free_slot = nullptr, *lru = nullptr;
+    for (Arena& a : slots) {
+        if (a.base && a.stream == s) {
+            if (a.in_use) return nullptr;
+            a.in_use = true;
+            a.last_use = ++tick;
+            return &a;
         }
-        if (!free_slot && lru) {      // every slot belongs to some other (possibly long gone) stream: evict the stalest
-            (void)hipFree(lru->base);
-            if (lru->pinned) (void)hipHostFree(lru->pinned);
-            *lru = Arena();
-            free_slot = lru;
-        }
-        if (!free_slot) return nullptr;
-        free_slot->stream = s;
-        free_slot->in_use = true;
-        free_slot->last_use = ++tick;
-        return free_slot;
+        if (a.in_use) continue;
+        if (!a.base && !free_slot) free_slot = &a;
+        if (a.base && (!lru || a.last_use < lru->last_use)) lru = &a;
     }
-    void release(Arena* a, size_t wanted)
-    {
-        if (wanted > a->size) {       // grow for next time; hipFree waits for the work that still uses the old block
-            if (a->base) (void)hipFree(a->base);
+    if (!free_slot && lru) {      // every slot belongs to some other (possibly long gone) stream: evict the stalest
+        (void)hipFree(lru->base);
+        if (lru->pinned) (void)hipHostFree(lru->pinned);
+        *lru = Arena();
+        free_slot = lru;
+    }
+    if (!free_slot) return nullptr;
+    free_slot->stream = s;
+    free_slot->in_use = true;
+    free_slot->last_use = ++tick;
+    return free_slot;
+}
+int ArenaPool::release(Arena* a, size_t wanted)
+{
+    int rc = 0;
+    if (wanted > a->size) {       // grow for next time; hipFree waits for the work that still uses the old block
+        if (a->base) (void)hipFree(a->base);
+        a->base = nullptr;
+        a->size = 0;
+        const size_t sz = wanted + wanted / 8;
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&a->base), sz);
+        if (e == hipSuccess) {
+            a->size = sz;
+        } else {                  // reported to the caller (StreamScratch::close): the next call would spill everything
+            (void)hipGetLastError();
             a->base = nullptr;
-            a->size = 0;
-            const size_t sz = wanted + wanted / 8;
-            if (hipMalloc(reinterpret_cast<void**>(&a->base), sz) == hipSuccess) a->size = sz;
-            else (void)hipGetLastError();
-        }
-        std::lock_guard<std::mutex> lk(mu);
-        a->in_use = false;
-    }
-    void clear()
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        for (Arena& a : slots) {
-            if (a.in_use) continue;
-            if (a.base) (void)hipFree(a.base);
-            if (a.pinned) (void)hipHostFree(a.pinned);
-            a = Arena();
+            rc = (int)e;
         }
     }
-};
-ArenaPool g_arenas;
-}  // namespace
-void dil::rt::release_scratch() { g_arenas.clear(); }
+    std::lock_guard<std::mutex> lk(mu);
+    a->in_use = false;
+    return rc;
+}
+void ArenaPool::clear()
+{
+    std::lock_guard<std::mutex> lk(mu);
+    for (Arena& a : slots) {
+        if (a.in_use) continue;
+        if (a.base) (void)hipFree(a.base);
+        if (a.pinned) (void)hipHostFree(a.pinned);
+        a = Arena();
+    }
+}
+
 namespace {
 
 struct StreamScratch {
+    Device& dv;
     hipStream_t s;
     Arena* arena;
     size_t used = 0;             // bytes carved or wanted so far (256-byte granules)
     void* spill[40];             // buffers that did not fit: stream-ordered pool, this call only
+    size_t spill_bytes[40];
     int nspill = 0;
     int rc = 0;                  // first allocation failure; check once after the last take()
-    explicit StreamScratch(hipStream_t st) : s(st), arena(g_arenas.acquire(st)) {}
+    bool closed = false;
+    bool secret = false;         // the call puts key-dependent data here: wiped on close when option `zeroize` is set
+    StreamScratch(Device& d, hipStream_t st) : dv(d), s(st), arena(d.arenas.acquire(st)) {}
     // arena looked up under `key` (any unique handle), spills allocated on `st`
-    StreamScratch(hipStream_t key, hipStream_t st) : s(st), arena(g_arenas.acquire(key)) {}
+    StreamScratch(Device& d, hipStream_t key, hipStream_t st) : dv(d), s(st), arena(d.arenas.acquire(key)) {}
     template <class T>
     T* take(size_t count)
     {
@@ -108,9 +105,14 @@ struct StreamScratch {
         if (arena && off + bytes <= arena->size) return reinterpret_cast<T*>(arena->base + off);
         void* q = nullptr;
         if (rc == 0 && nspill < 40) {
-            hipError_t e = hipMallocAsync(&q, bytes ? bytes : 256, s);
-            if (e != hipSuccess) rc = (int)e;
-            else spill[nspill++] = q;
+            const size_t nb = bytes ? bytes : 256;
+            hipError_t e = dv.pool ? hipMallocFromPoolAsync(&q, nb, dv.pool, s) : hipMallocAsync(&q, nb, s);
+            if (e != hipSuccess) {
+                rc = (int)e;
+            } else {
+                spill_bytes[nspill] = nb;
+                spill[nspill++] = q;
+            }
         } else if (rc == 0) {
             rc = (int)hipErrorOutOfMemory;
         }
@@ -127,12 +129,33 @@ struct StreamScratch {
         }
         return *slot;
     }
-    ~StreamScratch()
+    // End of the call: wipe (option `zeroize`, secret-bearing calls only), hand spills back, regrow the arena to the
+    // high-water mark.  Returns `status`, or -- when that is 0 -- the error of a failed wipe / regrow, so an arena
+    // that could not be regrown is reported instead of silently degrading to per-call spills.
+    int close(int status)
     {
+        if (closed) return status;
+        closed = true;
+        int err = 0;
+        if (secret && dil::rt::cfg.zeroize.load(std::memory_order_relaxed)) {
+            if (arena && arena->base && used) {
+                const hipError_t e = hipMemsetAsync(arena->base, 0, used < arena->size ? used : arena->size, s);
+                if (e != hipSuccess && !err) err = (int)e;
+            }
+            for (int i = 0; i < nspill; i++) {
+                const hipError_t e = hipMemsetAsync(spill[i], 0, spill_bytes[i], s);
+                if (e != hipSuccess && !err) err = (int)e;
+            }
+        }
         for (int i = 0; i < nspill; i++) (void)hipFreeAsync(spill[i], s);
         if (own_pinned) (void)hipHostFree(own_pinned);
-        if (arena) g_arenas.release(arena, used);
+        if (arena) {
+            const int e = dv.arenas.release(arena, used);
+            if (e && !err) err = e;
+        }
+        return status ? status : err;
     }
+    ~StreamScratch() { (void)close(0); }
 };
 int level_kl(int level, int* K, int* L)
 {
@@ -148,21 +171,22 @@ int level_kl(int level, int* K, int* L)
 int dil_verify_dev(int32_t* verdict, const int32_t* A, const uint8_t* ctilde, const int32_t* z, const int32_t* t1,
                    const uint8_t* h, const uint8_t* mu, int level, size_t batch, int shared_pk, void* stream)
 {
-    int rc = ensure_init(), K, L;
-    if (rc || (rc = level_kl(level, &K, &L))) return rc;
+    int rc, K, L;
+    if ((rc = level_kl(level, &K, &L))) return rc;
+    DIL_ENTER(dv, T);
     if (batch == 0) return 0;
     hipStream_t s = S(stream);
-    StreamScratch ws(s);
+    StreamScratch ws(dv, s);
     int32_t* c = ws.take<int32_t>(batch * 256);
     uint8_t* w1 = ws.take<uint8_t>(batch * K * 256);
     uint8_t* w1p = ws.take<uint8_t>(batch * K * (level == 2 ? 192 : 128));
     if (ws.rc) return ws.rc;
     DIL_TRY(dil::launch_z_norm(verdict, z, level, batch, s));
     DIL_TRY(dil::launch_sample_in_ball(c, ctilde, level, batch, s));
-    DIL_TRY(dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, g.t, s));
-    DIL_TRY(dil::launch_pack_w1(w1p, w1, level, batch, g.t, s));
+    DIL_TRY(dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, T, s));
+    DIL_TRY(dil::launch_pack_w1(w1p, w1, level, batch, T, s));
     DIL_TRY(dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, ctilde, batch, s));
-    return 0;
+    return ws.close(0);
 }
 
 namespace {
@@ -179,24 +203,24 @@ struct AttemptScratch {
         return ws.rc;
     }
 };
-int sign_attempt_impl(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                       const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
                       int phases = 3, bool early_exit = false)
 {
     if (phases & 1) DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
     if (!(phases & 2)) return 0;
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, g.t, s, km));
-    DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, g.t, s));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km));
+    DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, T, s));
     DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
     DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
-    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, g.t, s, km,
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
                               early_exit ? t.w0 : nullptr));
     return 0;
 }
 
 // The same attempt over entries [off, off + cnt) of the per-entry arrays (per-key arrays are addressed through km)
-int sign_attempt_range(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+int sign_attempt_range(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                        const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                        const int32_t* t0hat, int level, int K, int L, size_t off, size_t cnt, int shared_key, hipStream_t s, dil::KeyMap km,
                        int phases = 3, bool early_exit = false)
@@ -204,58 +228,40 @@ int sign_attempt_range(const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uin
     AttemptScratch u = t;
     u.y += off * L * 256; u.w1 += off * K * 256; u.w0 += off * K * 256; u.w1p += off * K * (level == 2 ? 192 : 128); u.c += off * 256;
     km.base += (uint32_t)off;
-    return sign_attempt_impl(u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
+    return sign_attempt_impl(T, u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
                              rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases, early_exit);
 }
-
-// A second stream for the signing loop: the hash kernels of a round are latency-bound (one sponge per lane, a few
-// hundred waves), the polynomial kernels throughput-bound; two half-rounds in flight overlap the two kinds.
-struct AuxStream {
-    std::mutex mu;
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;   // fork: the aux half may start; join: it is done
-    int device = -1;
-    bool ensure(int dev)
-    {
-        if (s && device == dev) return true;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) return false;
-        device = dev;
-        return true;
-    }
-};
-AuxStream g_aux;
 
 // Run an independent part of a composite call on the helper stream (if nobody else is using it): fork() returns the
 // stream to launch that part on -- the helper, ordered after everything already on `main`, or `main` itself -- and
 // join() makes `main` wait for it.
 struct AuxFork {
+    Device& dv;
     std::unique_lock<std::mutex> lk;
     hipStream_t main;
     bool on, forked = false;
-    explicit AuxFork(hipStream_t m) : lk(g_aux.mu, std::try_to_lock), main(m)
+    AuxFork(Device& d, hipStream_t m) : dv(d), lk(d.aux.mu, std::try_to_lock), main(m)
     {
-        on = g.aux_overlap && lk.owns_lock() && g_aux.ensure(g.device);
+        on = dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed) && lk.owns_lock() && dv.aux.ensure();
     }
     // `sponges`: lanes of the lane-per-sponge work going to the helper.  Only latency-bound work (less than about one
     // wave per SIMD) gains from running beside the main stream; throughput-bound work just pays the fork/join.
     hipStream_t fork(size_t sponges)
     {
-        if (!on || sponges >= (size_t)g.t.num_cus * 256) return main;
-        if (hipEventRecord(g_aux.fork, main) != hipSuccess || hipStreamWaitEvent(g_aux.s, g_aux.fork, 0) != hipSuccess) {
+        if (!on || sponges >= (size_t)dv.num_cus * 256) return main;
+        if (hipEventRecord(dv.aux.fork, main) != hipSuccess || hipStreamWaitEvent(dv.aux.s, dv.aux.fork, 0) != hipSuccess) {
             on = false;
             return main;
         }
         forked = true;
-        return g_aux.s;
+        return dv.aux.s;
     }
     int join()
     {
         if (!forked) return 0;
         forked = false;
-        DIL_TRY(hipEventRecord(g_aux.join, g_aux.s));
-        DIL_TRY(hipStreamWaitEvent(main, g_aux.join, 0));
+        DIL_TRY(hipEventRecord(dv.aux.join, dv.aux.s));
+        DIL_TRY(hipStreamWaitEvent(main, dv.aux.join, 0));
         return 0;
     }
     ~AuxFork() { (void)join(); }
@@ -266,14 +272,15 @@ int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags
                          const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                          const int32_t* t0hat, int level, size_t batch, int shared_key, void* stream)
 {
-    int rc = ensure_init(), K, L;
-    if (rc || (rc = level_kl(level, &K, &L))) return rc;
+    int rc, K, L;
+    if ((rc = level_kl(level, &K, &L))) return rc;
+    DIL_ENTER(dv, T);
     if (batch == 0) return 0;
     hipStream_t s = S(stream);
-    StreamScratch ws(s);
+    StreamScratch ws(dv, s);
     AttemptScratch t;
     if ((rc = t.alloc(ws, level, K, L, batch))) return rc;
-    return sign_attempt_impl(t, ctilde, z, h, flags, A, mu, rhoprime, kappa, s1hat, s2hat, t0hat, level, batch, shared_key, s);
+    return ws.close(sign_attempt_impl(T, t, ctilde, z, h, flags, A, mu, rhoprime, kappa, s1hat, s2hat, t0hat, level, batch, shared_key, s));
 }
 
 // ---- rows N2 / N4: codecs, keygen, wire-format verify -------------------------------------------------
@@ -314,49 +321,55 @@ int dil_unpack_dev(int32_t* out, const uint8_t* in, size_t in_stride, size_t in_
 {
     LevelPar p;
     CodecDesc d;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
-    return (int)dil::launch_unpack(d.bits, out, in, in_stride, in_offset, d.polys, d.xf, d.offset, batch, g.t, S(stream));
+    int rc;
+    if ((rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
+    DIL_ENTER(dv, T);
+    return (int)dil::launch_unpack(d.bits, out, in, in_stride, in_offset, d.polys, d.xf, d.offset, batch, T, S(stream));
 }
 int dil_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int kind, int level, size_t batch, void* stream)
 {
     LevelPar p;
     CodecDesc d;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
-    return (int)dil::launch_pack(d.bits, out, out_stride, out_offset, in, d.polys, d.xf, d.offset, batch, g.t, S(stream));
+    int rc;
+    if ((rc = level_par(level, &p)) || (rc = codec_desc(kind, p, &d))) return rc;
+    DIL_ENTER(dv, T);
+    return (int)dil::launch_pack(d.bits, out, out_stride, out_offset, in, d.polys, d.xf, d.offset, batch, T, S(stream));
 }
 int dil_hint_unpack_dev(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int level, size_t batch, void* stream)
 {
     LevelPar p;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p))) return rc;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
     return (int)dil::launch_hint_unpack(h, bad, in, in_stride, in_offset, p.K, p.omega, batch, S(stream));
 }
 int dil_hint_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int level, size_t batch, void* stream)
 {
     LevelPar p;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p))) return rc;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
     return (int)dil::launch_hint_pack(out, out_stride, out_offset, h, p.K, p.omega, batch, S(stream));
 }
 int dil_expand_s_dev(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t stride, int level, size_t batch, void* stream)
 {
     LevelPar p;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p))) return rc;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
     return (int)dil::launch_expand_s(s1, s2, rhoprime, stride, p.eta, p.L, p.K, batch, S(stream));
 }
 
 int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch, void* stream)
 {
     LevelPar p;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p))) return rc;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
     if (batch == 0) return 0;
     if ((reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(seed)) & 7) return (int)hipErrorInvalidValue;   // hashed as 64-bit words
     hipStream_t s = S(stream);
-    StreamScratch ws(s);
+    StreamScratch ws(dv, s);
     const size_t pkb = dil_pk_bytes(level), skb = dil_sk_bytes(level), sb = (size_t)32 * p.eta_bits;
     uint8_t* e = ws.take<uint8_t>(batch * 128);                    // rho(32) | rho'(64) | key(32)  (KG_*)
     int32_t* A = ws.take<int32_t>(batch * p.K * p.L * 256);
@@ -367,43 +380,45 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     int32_t* t0 = ws.take<int32_t>(batch * p.K * 256);
     uint8_t* tr = ws.take<uint8_t>(batch * 32);
     if (ws.rc) return ws.rc;
-    AuxFork ax(s);
+    ws.secret = true;            // rho', key, s1, s2, t0
+    AuxFork ax(dv, s);
     DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(e), 128, reinterpret_cast<const uint64_t*>(seed), 32, batch, s));
     // ExpandS (helper stream, when it is latency-bound) runs beside ExpandA: independent, both Keccak-bound
     DIL_TRY(dil::launch_expand_s(s1, s2, e + 32, 128, p.eta, p.L, p.K, batch, ax.fork(batch * p.K * p.L)));
     DIL_TRY(dil::launch_expand_a(A, e, 128, level, batch, s));
     if ((rc = ax.join())) return rc;
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, s1, batch, 0, g.t, s));
-    DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, g.t, s));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, s1, batch, 0, T, s));
+    DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, T, s));
     // pk = rho | t1
-    DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, g.t, s));
-    DIL_TRY(dil::launch_pack(10, pk, pkb, 32, t1, p.K, dil::XF_PLAIN, 0, batch, g.t, s));
+    DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, T, s));
+    DIL_TRY(dil::launch_pack(10, pk, pkb, 32, t1, p.K, dil::XF_PLAIN, 0, batch, T, s));
     // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level): one long sponge per key, latency-bound --
     // on the helper stream, under the packing of the rest of sk
     {
         hipStream_t a = ax.fork(batch);
         DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, batch, a));
-        DIL_TRY(dil::launch_copy_field(sk, skb, 64, tr, 32, 0, 32, batch, g.t, a));
+        DIL_TRY(dil::launch_copy_field(sk, skb, 64, tr, 32, 0, 32, batch, T, a));
     }
     // sk = rho | key | tr | s1 | s2 | t0
-    DIL_TRY(dil::launch_copy_field(sk, skb, 0, e, 128, 0, 32, batch, g.t, s));
-    DIL_TRY(dil::launch_copy_field(sk, skb, 32, e, 128, 96, 32, batch, g.t, s));
-    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, s1, p.L, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
-    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, s2, p.K, dil::XF_OFFSET_MINUS, p.eta, batch, g.t, s));
-    DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, g.t, s));
-    return ax.join();
+    DIL_TRY(dil::launch_copy_field(sk, skb, 0, e, 128, 0, 32, batch, T, s));
+    DIL_TRY(dil::launch_copy_field(sk, skb, 32, e, 128, 96, 32, batch, T, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, s1, p.L, dil::XF_OFFSET_MINUS, p.eta, batch, T, s));
+    DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, s2, p.K, dil::XF_OFFSET_MINUS, p.eta, batch, T, s));
+    DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, T, s));
+    return ws.close(ax.join());
 }
 
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                        int shared_pk, void* stream)
 {
     LevelPar p;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p))) return rc;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
     if (batch == 0) return 0;
     if ((reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // read as 64-bit words
     hipStream_t s = S(stream);
-    StreamScratch ws(s);
+    StreamScratch ws(dv, s);
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_pk ? 1 : batch;
     int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
@@ -416,23 +431,23 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     uint8_t* w1 = ws.take<uint8_t>(batch * p.K * 256);
     uint8_t* w1p = ws.take<uint8_t>(batch * p.K * (level == 2 ? 192 : 128));
     if (ws.rc) return ws.rc;
-    AuxFork ax(s);
+    AuxFork ax(dv, s);
     {   // public-key side (helper stream when it is latency-bound): A = ExpandA(rho), t1
         hipStream_t a = ax.fork(nk * p.K * p.L);
         DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, a));
-        DIL_TRY(dil::launch_unpack(10, t1, pk, pkb, 32, p.K, dil::XF_PLAIN, 0, nk, g.t, a));
+        DIL_TRY(dil::launch_unpack(10, t1, pk, pkb, 32, p.K, dil::XF_PLAIN, 0, nk, T, a));
     }
     // signature side: c~, z, hints, ||z|| check, c = SampleInBall(c~)
-    DIL_TRY(dil::launch_copy_field(ct, 32, 0, sig, sgb, 0, 32, batch, g.t, s));
-    DIL_TRY(dil::launch_unpack(p.zbits, z, sig, sgb, 32, p.L, dil::XF_OFFSET_MINUS, p.gamma1, batch, g.t, s));
+    DIL_TRY(dil::launch_copy_field(ct, 32, 0, sig, sgb, 0, 32, batch, T, s));
+    DIL_TRY(dil::launch_unpack(p.zbits, z, sig, sgb, 32, p.L, dil::XF_OFFSET_MINUS, p.gamma1, batch, T, s));
     DIL_TRY(dil::launch_hint_unpack(h, bad, sig, sgb, 32 + zb, p.K, p.omega, batch, s));
     DIL_TRY(dil::launch_z_norm(verdict, z, level, batch, s));
     DIL_TRY(dil::launch_sample_in_ball(c, ct, level, batch, s));
     if ((rc = ax.join())) return rc;
-    DIL_TRY(dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, g.t, s));
-    DIL_TRY(dil::launch_pack_w1(w1p, w1, level, batch, g.t, s));
+    DIL_TRY(dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, T, s));
+    DIL_TRY(dil::launch_pack_w1(w1p, w1, level, batch, T, s));
     DIL_TRY(dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, ct, batch, s));
-    return (int)dil::launch_or_flag(verdict, bad, 4, batch, g.t, s);
+    return ws.close((int)dil::launch_or_flag(verdict, bad, 4, batch, T, s));
 }
 
 // ---- row N3: the whole signing rejection loop on the device ---------------------------------------
@@ -446,20 +461,26 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
                  int max_attempts, void* stream)
 {
     LevelPar p;
-    int rc = ensure_init();
-    if (rc || (rc = level_par(level, &p))) return rc;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
     if (batch == 0) return 0;
     if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // hashed as 64-bit words
     if (batch == 1) shared_sk = 1;
     hipStream_t s = S(stream);
-    StreamScratch ws(s);
+    StreamScratch ws(dv, s);
     const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), sb = (size_t)32 * p.eta_bits, zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
     // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
     // speculate for free
-    const size_t cap = std::max<size_t>(batch, g.sign_cap ? (size_t)g.sign_cap : 16384);
     const int s_max = 64;
+    const int opt_cap = dil::rt::cfg.sign_cap.load(std::memory_order_relaxed);
+    const int sign_waste = dil::rt::cfg.sign_waste.load(std::memory_order_relaxed);
+    const bool sign_early = dil::rt::cfg.sign_early.load(std::memory_order_relaxed) != 0;
+    // (a round never uses more than batch * s_max entries: a single signature gets 64 entries, not 16384)
+    const size_t cap = std::min<size_t>(std::max<size_t>(batch, opt_cap > 0 ? (size_t)opt_cap : 16384), batch * (size_t)s_max);
+    ws.secret = true;            // s1^ s2^ t0^, key, rho', y, rejected z: wiped on close when option `zeroize` is set
     // per key
     int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
     int32_t* s1h = ws.take<int32_t>(nk * p.L * 256);
@@ -491,38 +512,36 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
     {
         // key material: A = ExpandA(rho) -- on the helper stream when it is latency-bound (one or few keys), beside the
         // rest of the set-up -- and s1^ s2^ t0^ = NTT(unpack(sk))
-        AuxFork ax(s);
+        AuxFork ax(dv, s);
         DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, ax.fork(nk * p.K * p.L)));
-        DIL_TRY(dil::launch_unpack(p.eta_bits, s1h, sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
-        DIL_TRY(dil::launch_unpack(p.eta_bits, s2h, sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, g.t, s));
-        DIL_TRY(dil::launch_unpack(13, t0h, sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, g.t, s));
-        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s1h, nk * p.L, g.t, s));
-        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s2h, nk * p.K, g.t, s));
-        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, t0h, nk * p.K, g.t, s));
+        DIL_TRY(dil::launch_unpack(p.eta_bits, s1h, sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, T, s));
+        DIL_TRY(dil::launch_unpack(p.eta_bits, s2h, sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, T, s));
+        DIL_TRY(dil::launch_unpack(13, t0h, sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, T, s));
+        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s1h, nk * p.L, T, s));
+        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s2h, nk * p.K, T, s));
+        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, t0h, nk * p.K, T, s));
         // rho' = SHAKE256(key || mu, 64)  (deterministic signing, as the reference's KATs)
-        DIL_TRY(dil::launch_copy_field(km, 96, 0, sk, sk_stride, 32, 32, batch, g.t, s));
-        DIL_TRY(dil::launch_copy_field(km, 96, 32, mu, 64, 0, 64, batch, g.t, s));
+        DIL_TRY(dil::launch_copy_field(km, 96, 0, sk, sk_stride, 32, 32, batch, T, s));
+        DIL_TRY(dil::launch_copy_field(km, 96, 32, mu, 64, 0, 64, batch, T, s));
         DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(rp), 64, reinterpret_cast<uint64_t*>(km), 96, batch, s));
         DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
         if ((rc = ax.join())) return rc;
     }
 
-    std::unique_lock<std::mutex> aux_lock(g_aux.mu, std::defer_lock);    // one signing loop at a time may use the helper stream
-    const bool two_streams = g.sign_streams > 1 && aux_lock.try_lock() && g_aux.ensure(g.device);
     int32_t *idx_cur = nullptr, *idx_next = idx0;
     size_t n = batch;
     int a0 = 0;                                          // attempts every pending item has already failed
     while (n > 0 && a0 < max_attempts) {
         // Attempts per pending item this round: as many as fit in `cap` entries, but only while the work expected to be
         // wasted on attempts after an item's first success, n * (1 - (1-p)^(S-1)) entries with p ~ 0.2, stays below the
-        // work a saved round's fixed latency is worth (g.sign_waste entries; matters for batches >> 16384).
+        // work a saved round's fixed latency is worth (option sign_waste entries; matters for batches >> 16384).
         int S_ = 1;
         {
             const int s_lim = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
             double keep = 1.0;                       // (1-p)^(S-1)
             while (S_ < s_lim) {
                 keep *= 0.8;
-                if ((double)n * (1.0 - keep) > (double)g.sign_waste) break;
+                if ((double)n * (1.0 - keep) > (double)sign_waste) break;
                 S_++;
             }
         }
@@ -530,8 +549,8 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
         const uint8_t *mur = mu, *rpr = rp;
         if (!direct) {
-            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, g.t, s));
-            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, g.t, s));
+            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, T, s));
+            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, T, s));
             mur = mu_c;
             rpr = rp_c;
         }
@@ -539,24 +558,9 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         keys.idx = idx_cur;
         keys.S = (uint32_t)S_;
         DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
-        auto part = [&](size_t off, size_t cnt, hipStream_t st, int phases) {
-            return sign_attempt_range(att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, off, cnt, shared_sk, st,
-                                      keys, phases, g.sign_early != 0);
-        };
-        // Optional (DIL_SIGN_STREAMS=2; measured: no gain): two half-rounds staggered by one kernel, the helper half
-        // starting when the main half's ExpandMask is done.
-        const size_t half = two_streams && E >= 4096 ? (E / 2) : 0;      // entries [half, E) on the helper stream
-        if (half) {
-            if ((rc = part(0, half, s, 1))) return rc;                   // main: ExpandMask
-            DIL_TRY(hipEventRecord(g_aux.fork, s));
-            DIL_TRY(hipStreamWaitEvent(g_aux.s, g_aux.fork, 0));
-            if ((rc = part(half, E - half, g_aux.s, 3))) return rc;      // helper: the whole chain
-            if ((rc = part(0, half, s, 2))) return rc;                   // main: the rest
-            DIL_TRY(hipEventRecord(g_aux.join, g_aux.s));
-            DIL_TRY(hipStreamWaitEvent(s, g_aux.join, 0));
-        } else if ((rc = part(0, E, s, 3))) {
+        if ((rc = sign_attempt_range(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, 0, E, shared_sk, s, keys, 3,
+                                     sign_early)))
             return rc;
-        }
         // winners (first accepted attempt per item) -> packed straight into their signature slots
         DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
         DIL_TRY(dil::launch_sign_collect(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, s));
@@ -564,8 +568,8 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         win.src_row = wine;
         win.dst_row = wini;
         win.count = counts + 1;
-        DIL_TRY(dil::launch_copy_field(sig, sgb, 0, ct, 32, 0, 32, n, g.t, s, win));
-        DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, g.t, s, win));
+        DIL_TRY(dil::launch_copy_field(sig, sgb, 0, ct, 32, 0, 32, n, T, s, win));
+        DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, T, s, win));
         DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n, s, win));
         DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
         DIL_TRY(hipStreamSynchronize(s));
@@ -574,7 +578,7 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         idx_cur = idx_next;
         idx_next = idx_cur == idx0 ? idx1 : idx0;
     }
-    return n == 0 ? 0 : DIL_ERR_UNFINISHED;
+    return ws.close(n == 0 ? 0 : DIL_ERR_UNFINISHED);
 }
 
 // ---- host-buffer forms of the whole operations (H2D -> device call -> D2H on the null stream) --------
@@ -588,19 +592,20 @@ int dil_keygen_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, si
     const size_t pkb = dil_pk_bytes(level), skb = dil_sk_bytes(level);
     if (!pkb) return (int)hipErrorInvalidValue;
     if (batch == 0) return 0;
-    int rc = ensure_init();
-    if (rc) return rc;
-    StreamScratch ws(HOST_STAGE_KEY, nullptr);
+    int rc;
+    DIL_ENTER(dv, T);
+    StreamScratch ws(dv, HOST_STAGE_KEY, nullptr);
     uint8_t* dpk = ws.take<uint8_t>(batch * pkb);
     uint8_t* dsk = ws.take<uint8_t>(batch * skb);
     uint8_t* dseed = ws.take<uint8_t>(batch * 32);
     if (ws.rc) return ws.rc;
+    ws.secret = true;            // seed and the staged secret keys
     DIL_TRY(hipMemcpy(dseed, seed, batch * 32, hipMemcpyHostToDevice));
     rc = dil_keygen_dev(dpk, dsk, dseed, level, batch, nullptr);
     if (rc) return rc;
     DIL_TRY(hipMemcpy(pk, dpk, batch * pkb, hipMemcpyDeviceToHost));
     DIL_TRY(hipMemcpy(sk, dsk, batch * skb, hipMemcpyDeviceToHost));
-    return 0;
+    return ws.close(0);
 }
 
 int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
@@ -609,23 +614,23 @@ int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint
     const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level);
     if (!skb) return (int)hipErrorInvalidValue;
     if (batch == 0) return 0;
-    int rc = ensure_init();
-    if (rc) return rc;
+    DIL_ENTER(dv, T);
     const size_t nk = shared_sk ? 1 : batch;
-    StreamScratch ws(HOST_STAGE_KEY, nullptr);
+    StreamScratch ws(dv, HOST_STAGE_KEY, nullptr);
     uint8_t* dsig = ws.take<uint8_t>(batch * sgb);
     int32_t* datt = ws.take<int32_t>(batch);
     uint8_t* dsk = ws.take<uint8_t>(nk * skb);
     uint8_t* dmu = ws.take<uint8_t>(batch * 64);
     if (ws.rc) return ws.rc;
+    ws.secret = true;            // the staged secret key
     DIL_TRY(hipMemcpy(dsk, sk, nk * skb, hipMemcpyHostToDevice));
     DIL_TRY(hipMemcpy(dmu, mu, batch * 64, hipMemcpyHostToDevice));
     const int src = dil_sign_dev(dsig, datt, dsk, dmu, level, batch, shared_sk, max_attempts, nullptr);
     if (src && src != DIL_ERR_UNFINISHED) return src;
-    DIL_TRY(hipDeviceSynchronize());
+    DIL_TRY(hipStreamSynchronize(nullptr));
     DIL_TRY(hipMemcpy(sig, dsig, batch * sgb, hipMemcpyDeviceToHost));
     if (attempts) DIL_TRY(hipMemcpy(attempts, datt, batch * 4, hipMemcpyDeviceToHost));
-    return src;
+    return ws.close(src);
 }
 
 int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
@@ -634,11 +639,11 @@ int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig,
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
     if (!pkb) return (int)hipErrorInvalidValue;
     if (batch == 0) return 0;
-    int rc = ensure_init();
-    if (rc) return rc;
+    int rc;
+    DIL_ENTER(dv, T);
     const size_t nk = shared_pk ? 1 : batch;
-    StreamScratch ws(HOST_STAGE_KEY, nullptr);
-    int32_t* dv = ws.take<int32_t>(batch);
+    StreamScratch ws(dv, HOST_STAGE_KEY, nullptr);
+    int32_t* dverd = ws.take<int32_t>(batch);
     uint8_t* dpk = ws.take<uint8_t>(nk * pkb);
     uint8_t* dsig = ws.take<uint8_t>(batch * sgb);
     uint8_t* dmu = ws.take<uint8_t>(batch * 64);
@@ -646,8 +651,8 @@ int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig,
     DIL_TRY(hipMemcpy(dpk, pk, nk * pkb, hipMemcpyHostToDevice));
     DIL_TRY(hipMemcpy(dsig, sig, batch * sgb, hipMemcpyHostToDevice));
     DIL_TRY(hipMemcpy(dmu, mu, batch * 64, hipMemcpyHostToDevice));
-    rc = dil_verify_sig_dev(dv, dpk, dsig, dmu, level, batch, shared_pk, nullptr);
+    rc = dil_verify_sig_dev(dverd, dpk, dsig, dmu, level, batch, shared_pk, nullptr);
     if (rc) return rc;
-    DIL_TRY(hipMemcpy(verdict, dv, batch * 4, hipMemcpyDeviceToHost));
+    DIL_TRY(hipMemcpy(verdict, dverd, batch * 4, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -22,6 +22,8 @@ SIGNATURES = {
     "dil_shutdown": [],
     "dil_device_count": [C.POINTER(C.c_int)],
     "dil_num_cus": [],
+    "dil_set_option": [C.c_char_p, C.c_int],
+    "dil_get_option": [C.c_char_p, C.POINTER(C.c_int)],
     "dil_error_string": [C.c_int],
     "dil_host_twiddle_tables": [_u32p, _u32p, _u32p],
     "dil_host_zetas": [_i32p],

@@ -15,11 +15,22 @@
  *   and are asynchronous; *_host entry points take host pointers and are synchronous
  *   (H2D copy, kernel, D2H copy).
  * Value domain
- *   time-domain inputs (a, y, z, c, w0): any int32 in [-q, 2^31); NTT-domain inputs
- *   (A, s1hat, s2hat, t0hat, b of pointwise ops) in (-q, q) for the pointwise ops and canonical
- *   [0, q) for the fused pipelines.  ALL outputs are canonical residues in [0, q) -- the RTL's
- *   convention (butterfly.v:194-195); the reference C++ returns (-q, q) and its own tests
+ *   forward transforms (dil_ntt_*, dil_bram_fwdntt_*): any int32 with |x| < 2^31 - 7q (the lazy butterflies
+ *   widen a value by < 6q in total and the final reduction needs 2^22 of headroom; tests/test_gpu_ntt.py probes the edge);
+ *   inverse transforms and the time-domain inputs of the fused pipelines (y, z, c, w0, t1): |x| < q (canonical
+ *   [0, q) or centred); NTT-domain inputs (A, s1hat, s2hat, t0hat, b of pointwise ops) in (-q, q) for the
+ *   pointwise ops and canonical [0, q) for the fused pipelines.  ALL outputs are canonical residues in [0, q)
+ *   -- the RTL's convention (butterfly.v:194-195); the reference C++ returns (-q, q) and its own tests
  *   compare canonically (util.cpp:98-112, ref_test_ntt_ntt2x2.cpp:31-42).
+ * Devices and threads
+ *   State is kept PER HIP DEVICE and created on first use by whichever thread has that device current: every
+ *   entry point works on the calling thread's current device (hipGetDevice), which must be the device that owns
+ *   the buffers and the stream passed in -- HIP's own rule for a kernel launch.  One process can therefore drive
+ *   all GPUs of a node: one host thread per GPU (hipSetDevice / dil_init(device) once per thread), or one thread
+ *   switching devices between calls.  Calls are thread-safe; concurrent composite calls (dil_keygen / dil_sign /
+ *   dil_verify_sig ...) on ONE stream are not ordered against each other's scratch -- use a stream per thread,
+ *   as with any stream-ordered API.  The *_host transform entry points of one device serialise on a lock of
+ *   their own (they share staging buffers); dil_*_multi_host (below) spreads a host batch over every GPU.
  */
 #ifndef DIL256_H
 #define DIL256_H
@@ -40,10 +51,26 @@ extern "C" {
 #define DIL_MAP_AFTER_INVNTT 2
 
 /* ---- life cycle --------------------------------------------------------------------- */
-/* Select `device`, build + upload the twiddle tables (derived from zeta = 1753; identical
- * to consts.cpp:64-97 / zetas.txt mod q).  Idempotent; -1 = keep the current device. */
+/* dil_init: make `device` the calling thread's current HIP device (-1 = keep the current one) and bring its
+ * state up: twiddle tables (derived from zeta = 1753; identical to consts.cpp:64-97 / zetas.txt mod q), a
+ * private memory pool.  Optional and idempotent -- every entry point initialises its device on first use.
+ * dil_shutdown: free the state of every device this process has used (no call may be in flight). */
 int dil_init(int device);
 int dil_shutdown(void);
+/* Process-wide options (also read once from the environment, names in parentheses):
+ *   "fused_mode"  (DIL_FUSED_MODE)  0 = pick the fused-pipeline kernel shape by batch size (default),
+ *                                   1 = workgroup-per-item kernels, 2 = wave-per-item / shared-key kernels.
+ *                                   Both shapes compute identical results; tests run both on the same input.
+ *   "fuse_wire"   (DIL_FUSE_WIRE)   1 = wire-format verification reads packed z / t1 / hints in the fused kernel
+ *                                   (default), 0 = separate codec kernels + int32 verify core
+ *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
+ *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
+ *                                   in the per-stream arena until the next call on that stream overwrites it
+ *   "sign_early", "sign_cap", "sign_waste", "aux_overlap", "ntt_blocks_per_cu", "wpi_blocks_per_cu",
+ *   "fused_wgs_per_cu"              tuning knobs
+ * Unknown name -> hipErrorInvalidValue. */
+int dil_set_option(const char* name, int value);
+int dil_get_option(const char* name, int* value);
 int dil_device_count(int* count);
 int dil_num_cus(void);
 const char* dil_error_string(int code);
@@ -152,8 +179,10 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
 
 /* The whole deterministic signing loop (combined_top.v sign FSMs :1694-2229) for a batch: sk wire format
  * ([batch][sk_bytes], or one key if shared_sk), mu [batch][64] -> sig [batch][sig_bytes], attempts[i] = number of
- * rejection-loop rounds item i took (0 = not finished within max_attempts -> return DIL_ERR_UNFINISHED).
- * Pending items are re-tried together, one round per attempt; synchronises `stream` once per round. */
+ * ATTEMPTS (values of kappa / L tried, the accepted one included) item i took -- the count the sequential reference
+ * loop would report; 0 = not finished within max_attempts -> return DIL_ERR_UNFINISHED.
+ * Pending items are re-tried together in wide speculative rounds (several attempts per item per round, the first
+ * accepted one wins); synchronises `stream` once per ROUND (about 5 rounds for a large batch). */
 #define DIL_ERR_UNFINISHED (-2)
 int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
                  int max_attempts, void* stream);

@@ -8,7 +8,8 @@
 //     config.h:29-51        BRAM<T>, bram, enum OPERATION, enum MAPPING
 //     ntt2x2.h:30-34        ntt2x2_fwdntt, ntt2x2_mul, ntt2x2_invntt
 //     address_encoder_decoder.h   resolve_address
-//     util.h                reshape
+//     util.h:40-50          reshape, compare_array, compare_bram_array, print_reshaped_array, print_index_reshaped_array
+//     ram_util.h:29-33      read_ram, write_ram, get_twiddle_factors
 // compiles against this header and links against libdil256_ref.so + libdil256.so instead:
 // same names, same C++ linkage, same in-place / caller-owns-buffers contract.  Every call runs
 // on the GPU (batch = 1 through the host-pointer C-ABI of include/dil256.h); results are the
@@ -53,5 +54,13 @@ void ntt2x2_invntt(bram* ram, enum OPERATION mode, enum MAPPING mapping);
 
 unsigned resolve_address(enum MAPPING mapping, unsigned addr);
 void reshape(bram* ram, const data_t in[DILITHIUM_N]);
+int compare_array(data_t* a, data_t* b, int bound);
+int compare_bram_array(bram* ram, data_t array[DILITHIUM_N], const char* string, enum MAPPING mapping, int print_out);
+void print_reshaped_array(bram* ram, int bound, const char* string);
+void print_index_reshaped_array(bram* ram, int index);
+
+void read_ram(data_t data_out[4], const bram* ram, const unsigned ram_i);
+void write_ram(bram* ram, const unsigned ram_i, const data_t data_in[4]);
+void get_twiddle_factors(data_t data_out[4], int i, int level, OPERATION mode);
 
 #endif

@@ -33,6 +33,18 @@ def build(force: bool = False) -> None:
     ref = os.path.join(HERE, "_ref", "libref.so")
     if os.path.isdir("/root/reference/dilithium-256") and (force or not os.path.exists(ref)):
         subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+    build_dropin_mains(force)
+
+
+def build_dropin_mains(force: bool = False) -> bool:
+    """Link the reference's UNCHANGED test mains (from /root/reference) against the GPU drop-in into _ref/.
+    Returns True if both binaries exist afterwards."""
+    outs = [os.path.join(HERE, "_ref", n) for n in ("ref_test_ntt_ntt2x2_dropin", "ntt2x2_test_dropin")]
+    dropin = os.path.join(os.path.dirname(HERE), "dilithium_amd", "libdil256_ref.so")
+    if os.path.isdir("/root/reference/dilithium-256") and os.path.exists(dropin) and \
+            (force or not all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(dropin) for o in outs)):
+        subprocess.check_call(["make", "-C", HERE, "dropin_mains"], stdout=subprocess.DEVNULL)
+    return all(os.path.exists(o) for o in outs)
 
 
 class Oracle:

@@ -62,6 +62,28 @@ def test_edge_values(gpu, oracle):
     assert (host(i) == oracle.invntt(a)).all()
 
 
+def test_forward_value_domain_edge(gpu, oracle):
+    """include/dil256.h: the forward transforms accept any int32 with |x| < 2^31 - 7q (lazy butterflies widen a value
+    by < 6q in total, the final reduction needs 2^22 of headroom).  Probe the edge itself, both signs, all-equal /
+    alternating / random-near-the-edge rows; expected = the oracle on the canonical residues (the map is linear mod q)."""
+    from dilithium_amd import api
+    edge = (1 << 31) - 7 * Q
+    rng = np.random.default_rng(3)
+    rows = [np.full(N, edge - 1), np.full(N, -(edge - 1)), np.tile([edge - 1, -(edge - 1)], 128),
+            np.tile([-(edge - 1), edge - 1, edge - 1, -(edge - 1)], 64)]
+    rows += [(edge - 1 - rng.integers(0, 1 << 20, N)) * rng.choice([-1, 1], N) for _ in range(28)]
+    a = np.array(rows, dtype=np.int64)
+    assert np.abs(a).max() < edge
+    f = dev(gpu, a.astype(np.int32))
+    api.ntt(f)
+    want = oracle.ntt(np.mod(a, Q).astype(np.int32))
+    assert (host(f) == want).all()
+    b = dev(gpu, a.astype(np.int32))
+    api.ntt2x2_fwdntt(b.view(-1, 64, 4), 0)       # the bram flavour shares the butterfly core: same domain
+    from oracle.oracle import canon
+    assert (host(b).reshape(len(rows), -1) == canon(oracle.bram_fwdntt(np.mod(a, Q).astype(np.int32), 0))).all()
+
+
 def test_signed_inputs(gpu, oracle):
     """the reference is correct for any |x| < q (SURVEY 8b value domain)"""
     from dilithium_amd import api

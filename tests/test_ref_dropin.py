@@ -13,7 +13,11 @@ CPP = os.path.join(ROOT, "tests", "cpp")
 # Itanium-mangled names of the reference's functions (what a TU built against its headers imports)
 MANGLED = ["_Z3nttPi", "_Z6invnttPi", "_Z17pointwise_barrettPiPKiS1_", "_Z10ntt2x2_refPi", "_Z13invntt2x2_refPi",
            "_Z13ntt2x2_fwdnttP4BRAMIiE9OPERATION7MAPPING", "_Z13ntt2x2_invnttP4BRAMIiE9OPERATION7MAPPING",
-           "_Z10ntt2x2_mulP4BRAMIiEPKS0_7MAPPING", "_Z15resolve_address7MAPPINGj", "_Z7reshapeP4BRAMIiEPKi"]
+           "_Z10ntt2x2_mulP4BRAMIiEPKS0_7MAPPING", "_Z15resolve_address7MAPPINGj", "_Z7reshapeP4BRAMIiEPKi",
+           # the rest of the H6 helper surface (ram_util.h:29-33, util.h:40-50)
+           "_Z8read_ramPiPK4BRAMIiEj", "_Z9write_ramP4BRAMIiEjPKi", "_Z19get_twiddle_factorsPiii9OPERATION",
+           "_Z13compare_arrayPiS_i", "_Z18compare_bram_arrayP4BRAMIiEPiPKc7MAPPINGi",
+           "_Z20print_reshaped_arrayP4BRAMIiEiPKc", "_Z26print_index_reshaped_arrayP4BRAMIiEi"]
 
 
 def _build():
@@ -47,6 +51,105 @@ def test_ref_library_exports_reference_symbols(oracle):
     for m in range(3):
         for a in range(64):
             assert ra(m, a) == oracle.lib.orc_resolve_address(m, a)
+
+
+def _ref_lib():
+    from oracle import oracle as orc
+    p = os.path.join(os.path.dirname(orc.__file__), "_ref", "libref.so")
+    return C.CDLL(p) if os.path.exists(p) else None
+
+
+def test_h6_helpers_match_compiled_reference():
+    """read_ram / write_ram / get_twiddle_factors / compare_array / compare_bram_array of the drop-in == the
+    reference's own (hardware_code/ram_util.cpp:28-94, util.cpp:85-140) on every argument combination"""
+    _build()
+    ref = _ref_lib()
+    if ref is None:
+        pytest.skip("compiled reference (oracle/_ref/libref.so) not present")
+    from dilithium_amd import _build as b
+    ours = C.CDLL(b.REF_LIB)
+    rng = np.random.default_rng(5)
+    # get_twiddle_factors: every (i, level, mode), incl. MUL_MODE (the reference's default branch)
+    for mode in (0, 1, 2):
+        for level in (0, 2, 4, 6):
+            for i in range(64):
+                a, r = (C.c_int32 * 4)(), (C.c_int32 * 4)()
+                ours._Z19get_twiddle_factorsPiii9OPERATION(a, i, level, mode)
+                ref._Z19get_twiddle_factorsPiii9OPERATION(r, i, level, mode)
+                assert list(a) == list(r), (mode, level, i)
+    # read_ram / write_ram
+    ram = rng.integers(0, 8380417, (64, 4)).astype(np.int32)
+    for lib in (ours, ref):
+        out = (C.c_int32 * 4)()
+        lib._Z8read_ramPiPK4BRAMIiEj(out, ram.ctypes.data_as(C.c_void_p), 37)
+        assert list(out) == ram[37].tolist()
+        w = ram.copy()
+        row = (C.c_int32 * 4)(1, 2, 3, 4)
+        lib._Z9write_ramP4BRAMIiEjPKi(w.ctypes.data_as(C.c_void_p), 11, row)
+        assert w[11].tolist() == [1, 2, 3, 4] and (np.delete(w, 11, 0) == np.delete(ram, 11, 0)).all()
+    # compare_array / compare_bram_array: equal, congruent-but-different representatives, and one corrupted coefficient,
+    # under each mapping (stdout of the mismatch report is not compared, only the verdict)
+    ra = ours._Z15resolve_address7MAPPINGj
+    ra.restype = C.c_uint
+    poly = rng.integers(0, 8380417, 256).astype(np.int32)
+    for mapping in range(3):
+        bram = np.zeros((64, 4), np.int32)
+        for r_ in range(64):
+            bram[ra(mapping, r_)] = poly[4 * r_:4 * r_ + 4]
+        shifted = poly.copy()
+        shifted[::3] -= 8380417                      # same residues, negative representatives
+        bad = poly.copy()
+        bad[129] ^= 1
+        for lib in (ours, ref):
+            f = lib._Z18compare_bram_arrayP4BRAMIiEPiPKc7MAPPINGi
+            p_ = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+            assert f(p_(bram), p_(poly.copy()), b"t", mapping, 0) == 0
+            assert f(p_(bram), p_(shifted.copy()), b"t", mapping, 0) == 0
+            assert f(p_(bram), p_(bad.copy()), b"t", mapping, 0) == 1
+    for lib in (ours, ref):
+        f = lib._Z13compare_arrayPiS_i
+        x, y = poly.copy(), poly.copy()
+        assert f(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), 256) == 0
+        y[255] += 1
+        assert f(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), 256) == 1
+        assert f(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), 255) == 0
+
+
+def test_reference_unchanged_mains_link_against_dropin():
+    """ref_test_ntt_ntt2x2.cpp and ntt2x2_test.cpp, UNCHANGED and from /root/reference, link against libdil256_ref.so
+    with no reference source on the link line (oracle/Makefile `dropin_mains`).  Build container only."""
+    if not os.path.isdir("/root/reference/dilithium-256"):
+        pytest.skip("reference tree not present (GPU box)")
+    _build()
+    from oracle import oracle as orc
+    assert orc.build_dropin_mains(force=True)
+    out = subprocess.run(["nm", "-u", os.path.join(os.path.dirname(orc.__file__), "_ref", "ntt2x2_test_dropin")],
+                         capture_output=True, text=True).stdout
+    for sym in ("_Z18compare_bram_arrayP4BRAMIiEPiPKc7MAPPINGi", "_Z13ntt2x2_fwdnttP4BRAMIiE9OPERATION7MAPPING", "_Z3nttPi"):
+        assert sym in out, sym        # resolved at run time by the drop-in, not by reference objects
+
+
+@pytest.mark.gpu
+def test_reference_unchanged_main_runs_on_gpu(gpu):
+    """the reference's own ref_test_ntt_ntt2x2 main (100 000 + 100 000 iterations, every call a batch of one on the
+    GPU) prints OK twice.  The binary is built in the build container (it needs /root/reference) and travels."""
+    from oracle import oracle as orc
+    exe = os.path.join(os.path.dirname(orc.__file__), "_ref", "ref_test_ntt_ntt2x2_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_test_ntt_ntt2x2_dropin not built (needs /root/reference)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("OK") == 2
+
+
+@pytest.mark.gpu
+def test_batched_differential_at_reference_iteration_counts(gpu):
+    """10^5 + 10^5 (ref_test_ntt_ntt2x2.cpp:29) and 10^6 x {MUL, NTT, INVNTT, polymul} (ntt2x2_test.cpp:139) through the
+    batched host-pointer C-ABI vs the CPU oracle"""
+    _build()
+    out = subprocess.run([os.path.join(CPP, "test_batched_differential")], capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("OK") == 3 and "ERROR" not in out.stdout
 
 
 @pytest.mark.gpu
