@@ -368,6 +368,18 @@ def verify_sig(pk, sig, mu, level, shared_pk=False):
     return verdict
 
 
+def verify_wire_core(A, pk, sig, level, shared_pk=False):
+    """the fused wire-format verify kernel: (w1 packed uint8 [B, K*128|192], verdict int32 [B] with bits 2 | 4)"""
+    K, _ = _kl(level)
+    B = sig.shape[0]
+    w1p = torch.empty((B, K * (192 if level == 2 else 128)), dtype=torch.uint8, device=sig.device)
+    verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
+    _lib.check(_lib.load().dil_verify_wire_core_dev(_dev(w1p, torch.uint8), _dev(verdict, torch.int32), _dev(A, torch.int32),
+                                                    _dev(pk, torch.uint8), _dev(sig, torch.uint8), level, B, int(shared_pk),
+                                                    _stream()), "dil_verify_wire_core_dev")
+    return w1p, verdict
+
+
 def sign(sk, mu, level, shared_sk=False, max_attempts=512):
     """wire-format deterministic signing: sk uint8 [B or 1, sk_bytes], mu uint8 [B,64] -> (sig uint8 [B,sig_bytes], attempts int32 [B])"""
     B = mu.shape[0]

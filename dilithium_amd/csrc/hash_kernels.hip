@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void pack_w1_kernel(uint32_t* __restrict__ out
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HASH_BS) void challenge_hash_kernel(uint64_t* __restrict__ out32, int32_t* __restrict__ verdict,
                                                             const uint64_t* __restrict__ mu, const uint64_t* __restrict__ w1p,
-                                                            int w1_words, const uint64_t* __restrict__ expect, size_t batch)
+                                                            int w1_words, const uint8_t* __restrict__ expect, size_t expect_stride,
+                                                            size_t batch)
 {
     const size_t i = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     if (i >= batch) return;
@@ -251,8 +252,13 @@ __global__ __launch_bounds__(HASH_BS) void challenge_hash_kernel(uint64_t* __res
     const int fill = sp.absorb<8>(w1p + i * (size_t)w1_words, w1_words);
     sp.finish_words(fill);
     if (expect) {
-        const uint64_t d = (sp.s[0] ^ expect[i * 4]) | (sp.s[1] ^ expect[i * 4 + 1]) | (sp.s[2] ^ expect[i * 4 + 2]) |
-                           (sp.s[3] ^ expect[i * 4 + 3]);
+        uint64_t d = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            uint64_t e;
+            __builtin_memcpy(&e, expect + i * expect_stride + 8 * t, 8);      // any alignment
+            d |= sp.s[t] ^ e;
+        }
         if (d) verdict[i] |= 1;
     } else {
 #pragma unroll
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(HASH_BS) void shake256_batch2_kernel(uint32_t* __re
 
 __global__ __launch_bounds__(HASH_BS) void challenge_hash2_kernel(uint32_t* __restrict__ out32, int32_t* __restrict__ verdict,
                                                              const uint32_t* __restrict__ mu, const uint32_t* __restrict__ w1p,
-                                                             int w1_words, const uint32_t* __restrict__ expect, size_t batch)
+                                                             int w1_words, const uint8_t* __restrict__ expect, size_t expect_stride,
+                                                             size_t batch)
 {
     const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     const size_t i = t >> 1;
@@ -319,7 +326,11 @@ __global__ __launch_bounds__(HASH_BS) void challenge_hash2_kernel(uint32_t* __re
     if (expect) {
         uint32_t d = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) d |= sp.s[w] ^ expect[i * 8 + 2 * w + hi];
+        for (int w = 0; w < 4; w++) {
+            uint32_t e;
+            __builtin_memcpy(&e, expect + i * expect_stride + 4 * (2 * w + hi), 4);   // any alignment
+            d |= sp.s[w] ^ e;
+        }
         if (d) atomicOr(&verdict[i], 1);                      // both halves may flag the same item
     } else {
 #pragma unroll
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(HASH_BS) void challenge_hash2_kernel(uint32_t* __re
 static inline bool few_sponges(size_t batch) { return batch < 65536; }
 
 hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,
-                                 const uint8_t* expect, size_t batch, hipStream_t s)
+                                 const uint8_t* expect, size_t batch, hipStream_t s, size_t expect_stride)
 {
     if (batch == 0) return hipSuccess;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
@@ -340,12 +351,12 @@ hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t
     if (few_sponges(batch)) {
         hipLaunchKernelGGL(challenge_hash2_kernel, (int)((2 * batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint32_t*>(out32),
                            verdict, reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words,
-                           reinterpret_cast<const uint32_t*>(expect), batch);
+                           expect, expect_stride, batch);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(challenge_hash_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint64_t*>(out32), verdict,
                        reinterpret_cast<const uint64_t*>(mu), reinterpret_cast<const uint64_t*>(w1p), words,
-                       reinterpret_cast<const uint64_t*>(expect), batch);
+                       expect, expect_stride, batch);
     return hipGetLastError();
 }
 

@@ -408,6 +408,25 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     return ws.close(ax.join());
 }
 
+// Everything of a wire-format verification between ExpandA and the challenge hash as ONE fused kernel
+// (wire_kernels.hip): c = SampleInBall(c~) in compact form, then packed z / t1 / hints in, packed w1 + verdict bits out.
+int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t* A, const uint8_t* pk, const uint8_t* sig, int level,
+                             size_t batch, int shared_pk, void* stream)
+{
+    LevelPar p;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
+    if (batch == 0) return 0;
+    hipStream_t s = S(stream);
+    StreamScratch ws(dv, s);
+    uint32_t* cbits = ws.take<uint32_t>(batch * 64);
+    if (ws.rc) return ws.rc;
+    const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
+    DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
+    return ws.close((int)dil::launch_verify_wire(level, w1_packed, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
+}
+
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                        int shared_pk, void* stream)
 {
@@ -421,6 +440,22 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     StreamScratch ws(dv, s);
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_pk ? 1 : batch;
+    const size_t w1b = (size_t)p.K * (level == 2 ? 192 : 128);
+    if (dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed)) {
+        // Fused path: ExpandA (helper stream when it is latency-bound) beside SampleInBall, then ONE kernel that reads
+        // the packed z / t1 / hints and writes packed w1 (+ the ||z|| and hint-encoding verdict bits), then the challenge
+        // hash compared with c~ in place.  No int32 z / t1 / h / c / w1 temporaries.
+        int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
+        uint32_t* cbits = ws.take<uint32_t>(batch * 64);
+        uint8_t* w1p = ws.take<uint8_t>(batch * w1b);
+        if (ws.rc) return ws.rc;
+        AuxFork ax(dv, s);
+        DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, ax.fork(nk * p.K * p.L)));
+        DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
+        if ((rc = ax.join())) return rc;
+        DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
+        return ws.close((int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb));
+    }
     int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
     int32_t* t1 = ws.take<int32_t>(nk * p.K * 256);
     int32_t* z = ws.take<int32_t>(batch * p.L * 256);
@@ -429,7 +464,7 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     uint8_t* ct = ws.take<uint8_t>(batch * 32);
     int32_t* c = ws.take<int32_t>(batch * 256);
     uint8_t* w1 = ws.take<uint8_t>(batch * p.K * 256);
-    uint8_t* w1p = ws.take<uint8_t>(batch * p.K * (level == 2 ? 192 : 128));
+    uint8_t* w1p = ws.take<uint8_t>(batch * w1b);
     if (ws.rc) return ws.rc;
     AuxFork ax(dv, s);
     {   // public-key side (helper stream when it is latency-bound): A = ExpandA(rho), t1

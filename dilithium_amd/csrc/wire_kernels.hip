@@ -1,0 +1,504 @@
+// wire_kernels.hip -- the verify pipeline with the reference's WIRE FORMATS in its load / store stages
+// (SURVEY 8(f) row N2 cashed in): the fused kernels read the packed signature and public key directly --
+//   z        18 / 20 bits per coefficient, gamma1 - z          decoder.v:89-143, uncenter_coeff.v:49-65
+//   t1       10 bits per coefficient (x 2^13 on the fly)        decoder.v:96-100
+//   hints    omega position bytes + K cumulative counts         usehint.v:92-114
+//   c        SampleInBall(c~) as 2 bits per coefficient         gen_c.v:163-196,318-339
+// -- and write w1 already packed (4 / 6 bits, encoder.v:96-133), so that no int32 z / t1 / h / w1 temporary ever
+// crosses HBM: a level-3 verification moves 30 KiB (A) + 3.2 (z) + 1.9 (t1) + 0.06 (hints) + 0.25 (c) + 0.75 KiB (w1)
+// instead of 45 KiB plus the codec kernels' own read + write of the same fields.  The ||z|| < gamma1 - beta check
+// (norm_check.v:84-105) and the hint-encoding validation ride along (z is in registers anyway).
+// Same arithmetic as verify_wpi_kernel / verify_shared_kernel (pipelines.hip): combined_top.v:1207-1469.
+#include "launch_util.hpp"
+#include "pipeline_common.hpp"
+#include "keccak.hpp"
+
+namespace dil {
+
+#define DIL_SCHED_FENCE_W() __builtin_amdgcn_sched_barrier(0)
+
+// one 4-byte load at any byte address (hipcc emits a single global_load_dword: the target runs in unaligned-access mode)
+__device__ __forceinline__ uint32_t ld_u32u(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// Lane addressing of one BITS-wide packed polynomial (32 * BITS bytes) in NTT-input order: lane j wants coefficients
+// j + 64 m.  Coefficient i sits at bit BITS * i; 64 coefficients are exactly 8 * BITS bytes, so the dword of (j, m) is
+// at byte off0 + 8 * BITS * m with the same shift for every m -- except that the last dwords of the polynomial would
+// reach past its end (and, for the last item of a batch, past the buffer): m = 3 clamps to the polynomial's last 4 bytes.
+template <int BITS>
+struct PackedLane {
+    uint32_t off0, sh0, off3, sh3;
+    __device__ __forceinline__ explicit PackedLane(int lane)
+    {
+        const uint32_t bit = BITS * (uint32_t)lane;
+        off0 = bit >> 3;
+        sh0 = bit & 7;
+        const uint32_t want = off0 + 24 * BITS, last = 32 * BITS - 4;
+        off3 = want < last ? want : last;
+        sh3 = sh0 + 8 * (want - off3);
+    }
+    __device__ __forceinline__ void load(uint32_t (&raw)[4], const uint8_t* __restrict__ poly) const
+    {
+        raw[0] = ld_u32u(poly + off0);
+        raw[1] = ld_u32u(poly + off0 + 8 * BITS);
+        raw[2] = ld_u32u(poly + off0 + 16 * BITS);
+        raw[3] = ld_u32u(poly + off3);
+    }
+    __device__ __forceinline__ void fields(uint32_t (&f)[4], const uint32_t (&raw)[4]) const
+    {
+        constexpr uint32_t MASK = (1u << BITS) - 1;
+        f[0] = (raw[0] >> sh0) & MASK;
+        f[1] = (raw[1] >> sh0) & MASK;
+        f[2] = (raw[2] >> sh0) & MASK;
+        f[3] = (raw[3] >> sh3) & MASK;
+    }
+};
+
+template <int LEVEL>
+struct Wire {
+    static constexpr int ZBITS = LEVEL == 2 ? 18 : 20;
+    static constexpr int W1BITS = LEVEL == 2 ? 6 : 4;
+    static constexpr int W1_ROW_BYTES = 32 * W1BITS;                    // 192 / 128
+    static constexpr int Z_BYTES = Par<LEVEL>::L * 32 * ZBITS;
+    static constexpr int HINT_BYTES = Par<LEVEL>::OMEGA + Par<LEVEL>::K;
+};
+
+// raw (packed) z of one item, prefetched a whole row phase ahead: 4 dwords per polynomial, as RawPolys
+template <int LEVEL>
+struct RawZ {
+    uint32_t v[Par<LEVEL>::L][4];
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ zbase, const PackedLane<Wire<LEVEL>::ZBITS>& pl)
+    {
+#pragma unroll
+        for (int l = 0; l < Par<LEVEL>::L; l++) pl.load(v[l], zbase + l * (32 * Wire<LEVEL>::ZBITS));
+    }
+};
+
+// Hint bytes -> per-row bitmap in LDS ([K][8] dwords), with the reference decoder's validity checks (usehint.v:92-114,
+// the same as hint_unpack_kernel): counts monotone and <= omega, positions strictly increasing inside a row, zero padding.
+// hb0 / hb1 = hint bytes `lane` and `64 + lane` of the item (prefetched).  Returns true if the encoding is malformed.
+template <int LEVEL>
+__device__ __forceinline__ bool hints_to_bitmap(uint32_t* bm, uint32_t* scratch, uint32_t hb0, uint32_t hb1, int lane)
+{
+    constexpr int K = Par<LEVEL>::K, OMEGA = Par<LEVEL>::OMEGA;
+    uint8_t* sc = reinterpret_cast<uint8_t*>(scratch);
+    sc[lane] = (uint8_t)hb0;
+    if (64 + lane < OMEGA + K) sc[64 + lane] = (uint8_t)hb1;
+    if (lane < K * 8) bm[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    bool err = false;
+    int cnt[K], prev = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        cnt[k] = sc[OMEGA + k];
+        if (cnt[k] < prev || cnt[k] > OMEGA) err = true;
+        prev = cnt[k];
+    }
+    const int total = err ? 0 : prev;
+#pragma unroll
+    for (int r = 0; r < (OMEGA + 63) / 64; r++) {
+        const int t = 64 * r + lane;
+        if (t < OMEGA) {
+            const int pos = sc[t];
+            if (t < total) {
+                int row = 0, row_start = 0;
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (cnt[k] <= t) {
+                        row = k + 1;
+                        row_start = cnt[k];
+                    }
+                if (t > row_start && pos <= (int)sc[t - 1]) err = true;
+                if (row < K) atomicOr(&bm[row * 8 + (pos >> 5)], 1u << (pos & 31));
+            } else if (pos != 0) {
+                err = true;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    return __ballot(err) != 0;
+}
+
+// w1 row (4 values per lane, strided order) -> packed bit stream, stored coalesced (encoder.v:96-133)
+template <int LEVEL>
+__device__ __forceinline__ void store_row_w1_packed(uint8_t* __restrict__ out_row, const uint32_t (&v)[4], uint32_t* scratch, int lane)
+{
+    uint8_t* sc = reinterpret_cast<uint8_t*>(scratch);
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[lane + 64 * m] = (uint8_t)v[m];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (Wire<LEVEL>::W1BITS == 4) {
+        if (lane < 32) {                  // 8 coefficients -> one dword
+            const uint32_t a = scratch[2 * lane], b = scratch[2 * lane + 1];
+            uint32_t x = (a | (a >> 4)) & 0x00FF00FFu;
+            x = (x | (x >> 8)) & 0xFFFFu;
+            uint32_t y = (b | (b >> 4)) & 0x00FF00FFu;
+            y = (y | (y >> 8)) & 0xFFFFu;
+            reinterpret_cast<uint32_t*>(out_row)[lane] = x | (y << 16);
+        }
+    } else {
+        if (lane < 16) {                  // 16 coefficients -> 96 bits
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = scratch[4 * lane + i];
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint64_t c = (w[k >> 2] >> (8 * (k & 3))) & 0x3Fu;
+                const int bit = 6 * k;
+                if (bit < 64) lo |= c << bit;
+                if (bit + 6 > 64) hi |= (bit >= 64) ? c << (bit - 64) : c >> (64 - bit);
+            }
+            uint32_t* o = reinterpret_cast<uint32_t*>(out_row) + 3 * lane;
+            o[0] = (uint32_t)lo;
+            o[1] = (uint32_t)(lo >> 32);
+            o[2] = (uint32_t)hi;
+        }
+    }
+}
+
+// hint bits of row k for the lane's coefficients lane + 64 m
+__device__ __forceinline__ void row_hint_bits(uint32_t (&hb)[4], const uint32_t* bm, int k, int lane)
+{
+#pragma unroll
+    for (int m = 0; m < 4; m++) hb[m] = (bm[k * 8 + 2 * m + (lane >> 5)] >> (lane & 31)) & 1u;
+}
+
+// c of SampleInBall in the compact per-lane form sample_in_ball_bits_kernel writes: bit m = c[lane + 64 m] != 0,
+// bit 4 + m = its sign (1 = -1)
+__device__ __forceinline__ void decode_c(int32_t (&c)[4], uint32_t cb)
+{
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int32_t nz = (int32_t)((cb >> m) & 1u), neg = (int32_t)((cb >> (4 + m)) & 1u);
+        c[m] = nz - 2 * (nz & neg);
+    }
+}
+
+// z = gamma1 - field (centred); tracks max |z| for the norm check
+template <int LEVEL>
+__device__ __forceinline__ void decode_z(int32_t (&z)[4], const uint32_t (&raw)[4], const PackedLane<Wire<LEVEL>::ZBITS>& pl, int32_t& zmax)
+{
+    uint32_t f[4];
+    pl.fields(f, raw);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        z[m] = Par<LEVEL>::GAMMA1 - (int32_t)f[m];
+        zmax = max(zmax, max(z[m], -z[m]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// distinct public keys: wave per item, A streamed from HBM (expanded by expand_a_kernel), everything else packed
+// ---------------------------------------------------------------------------------------------------------
+template <int LEVEL>
+__global__ __launch_bounds__(256) void verify_wire_wpi_kernel(
+    uint8_t* __restrict__ w1p_out, int32_t* __restrict__ verdict, const int32_t* __restrict__ A,
+    const uint8_t* __restrict__ pk, size_t pk_stride, const uint8_t* __restrict__ sig, size_t sig_stride,
+    const uint32_t* __restrict__ cbits, size_t batch, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    using W = Wire<LEVEL>;
+    // per wave: L KiB of z^ | 64 dwords byte scratch | 64 dwords hint bitmap
+    constexpr int WAVE_DW = L * 256 + 64 + 64;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * WAVE_DW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stage_tables(lds, fwd_tab, inv_tab);
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + wv * WAVE_DW;
+    uint32_t* sc = zl + L * 256;
+    uint32_t* bm = sc + 64;
+    const PackedLane<W::ZBITS> plz(lane);
+    const PackedLane<10> plt(lane);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    size_t it = (size_t)blockIdx.x * 4 + wv;
+    RawZ<LEVEL> zr;
+    uint32_t cb = 0, hb0 = 0, hb1 = 0;
+    auto load_item = [&](size_t i) {
+        const uint8_t* sg = sig + i * sig_stride;
+        zr.load(sg + 32, plz);
+        cb = cbits[i * 64 + lane];
+        hb0 = sg[32 + W::Z_BYTES + lane];
+        hb1 = (64 + lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + 64 + lane] : 0;
+    };
+    if (it < batch) load_item(it);
+    __syncthreads();                               // tables staged (the only barrier)
+    for (; it < batch; it += nwaves) {
+        const int32_t* Ait = A + it * (size_t)(K * L) * 256;
+        const uint8_t* t1it = pk + it * pk_stride + 32;
+        ARow<L> Ar;
+        Ar.load(Ait, lane, true);
+        uint32_t tn[4];
+        plt.load(tn, t1it);
+        const bool bad = hints_to_bitmap<LEVEL>(bm, sc, hb0, hb1, lane);
+        int32_t zmax = 0;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            int32_t r[4];
+            decode_z<LEVEL>(r, zr.v[l], plz, zmax);
+            ntt_fwd_core(r, twf, lm);
+            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        int32_t ch[4];
+        decode_c(ch, cb);
+        ntt_fwd_core(ch, twf, lm);
+        DIL_SCHED_FENCE_W();
+        const size_t itn = it + nwaves;
+        if (itn < batch) load_item(itn);
+        const bool zrej = __ballot(zmax >= Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA) != 0;
+        if (lane == 0) verdict[it] = (zrej ? 2 : 0) | (bad ? 4 : 0);
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, zl, lane);
+            int32_t th[4];
+            {
+                uint32_t f[4];
+                plt.fields(f, tn);
+#pragma unroll
+                for (int m = 0; m < 4; m++) th[m] = (int32_t)(f[m] << 13);   // decoder.v:96-100
+            }
+            uint32_t hb[4];
+            row_hint_bits(hb, bm, k, lane);
+            if (k + 1 < K) {
+                Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, true);
+                plt.load(tn, t1it + (k + 1) * 320);
+            }
+            DIL_SCHED_FENCE_W();
+            ntt_fwd_core(th, twf, lm);
+            DIL_SCHED_FENCE_W();
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE_W();
+            ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE_W();
+            uint32_t wb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+            store_row_w1_packed<LEVEL>(w1p_out + (it * K + k) * W::W1_ROW_BYTES, wb, sc, lane);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one public key for the batch: A (expanded once) and t1^ = NTT(t1 2^13) LDS-resident, per item only the signature
+// ---------------------------------------------------------------------------------------------------------
+template <int LEVEL, int NW>
+__global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
+    uint8_t* __restrict__ w1p_out, int32_t* __restrict__ verdict, const int32_t* __restrict__ A,
+    const uint8_t* __restrict__ pk, const uint8_t* __restrict__ sig, size_t sig_stride,
+    const uint32_t* __restrict__ cbits, size_t batch, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    using W = Wire<LEVEL>;
+    constexpr int WAVE_DW = L * 256 + 64 + 64;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K) * 256 + NW * WAVE_DW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    stage_tables(lds, fwd_tab, inv_tab);
+    uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
+    uint32_t* Tl = Al + K * L * 256;
+    for (int i = threadIdx.x; i < K * L * 64; i += blockDim.x)
+        reinterpret_cast<uint4*>(Al)[i] = reinterpret_cast<const uint4*>(A)[i];
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const LaneMasks lm(lane);
+    uint32_t* zl = Tl + K * 256 + wv * WAVE_DW;
+    uint32_t* sc = zl + L * 256;
+    uint32_t* bm = sc + 64;
+    const PackedLane<W::ZBITS> plz(lane);
+    const size_t nwaves = (size_t)gridDim.x * NW;
+    size_t it = (size_t)blockIdx.x * NW + wv;
+    RawZ<LEVEL> zr;
+    uint32_t cb = 0, hb0 = 0, hb1 = 0;
+    auto load_item = [&](size_t i) {
+        const uint8_t* sg = sig + i * sig_stride;
+        zr.load(sg + 32, plz);
+        cb = cbits[i * 64 + lane];
+        hb0 = sg[32 + W::Z_BYTES + lane];
+        hb1 = (64 + lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + 64 + lane] : 0;
+    };
+    if (it < batch) load_item(it);
+    __syncthreads();                               // tables + A staged
+    for (int k = wv; k < K; k += NW) {             // t1_k 2^13 -> NTT -> LDS, lazy residues (VY_NTT_T1, combined_top.v:1259)
+        const PackedLane<10> plt(lane);
+        uint32_t tn[4], f[4];
+        plt.load(tn, pk + 32 + k * 320);
+        plt.fields(f, tn);
+        int32_t th[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) th[m] = (int32_t)(f[m] << 13);
+        ntt_fwd_core(th, twf, lm);
+        *reinterpret_cast<int4*>(Tl + k * 256 + 4 * lane) = make_int4(th[0], th[1], th[2], th[3]);
+    }
+    __syncthreads();
+    for (; it < batch; it += nwaves) {
+        const bool bad = hints_to_bitmap<LEVEL>(bm, sc, hb0, hb1, lane);
+        int32_t zmax = 0;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            int32_t r[4];
+            decode_z<LEVEL>(r, zr.v[l], plz, zmax);
+            ntt_fwd_core(r, twf, lm);
+            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        int32_t ch[4];
+        decode_c(ch, cb);
+        ntt_fwd_core(ch, twf, lm);
+        DIL_SCHED_FENCE_W();
+        const size_t itn = it + nwaves;
+        if (itn < batch) load_item(itn);
+        const bool zrej = __ballot(zmax >= Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA) != 0;
+        if (lane == 0) verdict[it] = (zrej ? 2 : 0) | (bad ? 4 : 0);
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int4 a = *reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane);
+                const int4 z = *reinterpret_cast<const int4*>(zl + l * 256 + 4 * lane);
+                acc[0] += (int64_t)a.x * z.x;
+                acc[1] += (int64_t)a.y * z.y;
+                acc[2] += (int64_t)a.z * z.z;
+                acc[3] += (int64_t)a.w * z.w;
+            }
+            const int4 th = *reinterpret_cast<const int4*>(Tl + k * 256 + 4 * lane);
+            acc[0] -= (int64_t)ch[0] * th.x;
+            acc[1] -= (int64_t)ch[1] * th.y;
+            acc[2] -= (int64_t)ch[2] * th.z;
+            acc[3] -= (int64_t)ch[3] * th.w;
+            uint32_t hb[4];
+            row_hint_bits(hb, bm, k, lane);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE_W();
+            ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE_W();
+            uint32_t wb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+            store_row_w1_packed<LEVEL>(w1p_out + (it * K + k) * W::W1_ROW_BYTES, wb, sc, lane);
+        }
+    }
+}
+
+// LDS budget (160 KiB): tables 16 + A K*L + t1^ K + NW * (L KiB + 0.5)
+template <int LEVEL> struct WireNW;
+template <> struct WireNW<2> { static constexpr int N = 16; };   // 16 + 16 + 4 + 72   = 108 KiB
+template <> struct WireNW<3> { static constexpr int N = 16; };   // 16 + 30 + 6 + 88   = 140 KiB
+template <> struct WireNW<5> { static constexpr int N = 10; };   // 16 + 56 + 8 + 75   = 155 KiB
+
+// ---------------------------------------------------------------------------------------------------------
+// SampleInBall (gen_c.v:163-196,318-339) into the compact per-lane form the kernels above consume:
+// cbits[item][lane] bit m = c[lane + 64 m] != 0, bit 4 + m = sign.  c~ is read in place from the signature (any alignment).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sample_in_ball_bits_kernel(uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde,
+                                                                 size_t ct_stride, int tau, size_t nitems)
+{
+    __shared__ int8_t cl[256 * 64];           // c[idx][lane]
+    __shared__ uint8_t rb[136 * 64];          // rate block bytes [pos][lane]
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * 64;
+    const size_t item = base + lane;
+    const bool live = item < nitems;
+    for (int k = 0; k < 256; k++) cl[k * 64 + lane] = 0;
+    Shake<17> sp;
+    sp.init();
+    if (live) {
+        const uint8_t* ct = ctilde + item * ct_stride;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v |= (uint64_t)ct[8 * w + b] << (8 * b);
+            sp.s[w] = v;
+        }
+    }
+    sp.s[4] = 0x1Full;
+    sp.s[16] ^= 0x8000000000000000ull;
+    keccak_f1600(sp.s);
+    uint64_t signs = sp.s[0];
+    auto spill = [&]() {
+#pragma unroll
+        for (int w = 0; w < 17; w++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) rb[(8 * w + b) * 64 + lane] = (uint8_t)(sp.s[w] >> (8 * b));
+    };
+    spill();
+    int pos = 8;
+    for (int i = 256 - tau; i < 256; i++) {
+        int b;
+        do {
+            if (pos == 136) {
+                keccak_f1600(sp.s);
+                spill();
+                pos = 0;
+            }
+            b = rb[pos * 64 + lane];
+            pos++;
+        } while (b > i);
+        cl[i * 64 + lane] = cl[b * 64 + lane];
+        cl[b * 64 + lane] = (int8_t)(1 - 2 * (int)(signs & 1));
+        signs >>= 1;
+    }
+    __syncthreads();
+    // item t of this block, consumer lane `lane`: coefficients lane + 64 m
+    for (int t = 0; t < 64; t++) {
+        if (base + t >= nitems) break;
+        uint32_t w = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int v = cl[(lane + 64 * m) * 64 + t];
+            w |= (uint32_t)(v != 0) << m;
+            w |= (uint32_t)(v < 0) << (4 + m);
+        }
+        cbits[(base + t) * 64 + lane] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+template <int LEVEL>
+static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
+                                           const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
+                                           const Tables& t, hipStream_t s)
+{
+    if (shared_pk) {
+        constexpr int NW = WireNW<LEVEL>::N;
+        const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
+        hipLaunchKernelGGL((verify_wire_shared_kernel<LEVEL, NW>), g, 64 * NW, 0, s, w1p, verdict, A, pk, sig, sig_stride, cbits, batch,
+                           t.fwd, t.inv_pipe);
+    } else {
+        const int g = grid_for((batch + 3) / 4,
+                               t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL>, 256, t.wpi_blocks_per_cu, t.device));
+        hipLaunchKernelGGL(verify_wire_wpi_kernel<LEVEL>, g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
+                           t.fwd, t.inv_pipe);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
+                              const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
+                              const Tables& t, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    switch (level) {
+    case 2: return launch_verify_wire_level<2>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s);
+    case 3: return launch_verify_wire_level<3>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s);
+    case 5: return launch_verify_wire_level<5>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_sample_in_ball_bits(uint32_t* cbits, const uint8_t* ctilde, size_t ct_stride, int level, size_t nitems, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    hipLaunchKernelGGL(sample_in_ball_bits_kernel, (int)((nitems + 63) / 64), 64, 0, s, cbits, ctilde, ct_stride, tau, nitems);
+    return hipGetLastError();
+}
+
+}  // namespace dil

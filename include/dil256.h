@@ -177,6 +177,13 @@ size_t dil_sig_bytes(int level);
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                        int shared_pk, void* stream);
 
+/* The fused kernel inside dil_verify_sig_dev (wire_kernels.hip), exposed for parity tests and profiling: reads pk
+ * ([batch|1][pk_bytes]) and sig ([batch][sig_bytes]) in wire format -- packed z, t1, hints; c = SampleInBall(c~) -- with
+ * A [batch|1][K][L][256] already expanded, and writes w1 PACKED ([batch][K * 128|192] bytes, encoder.v:96-133) plus
+ * verdict[i] = bit1 (value 2) ||z|| >= gamma1 - beta | bit2 (value 4) malformed hint encoding. */
+int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t* A, const uint8_t* pk, const uint8_t* sig, int level,
+                             size_t batch, int shared_pk, void* stream);
+
 /* The whole deterministic signing loop (combined_top.v sign FSMs :1694-2229) for a batch: sk wire format
  * ([batch][sk_bytes], or one key if shared_sk), mu [batch][64] -> sig [batch][sig_bytes], attempts[i] = number of
  * ATTEMPTS (values of kappa / L tried, the accepted one included) item i took -- the count the sequential reference
