@@ -119,6 +119,7 @@ __device__ __forceinline__ void swap_quad(int32_t& x, int32_t& y, uint32_t mask)
 struct LaneMasks {
     uint32_t b1, b0;   // all-ones where lane bit 1 / bit 0 is set
     __device__ __forceinline__ explicit LaneMasks(int lane) : b1(0u - ((lane >> 1) & 1)), b0(0u - (lane & 1)) {}
+    __device__ __forceinline__ void operator()(int32_t (&r)[4]) const;     // the in-register (1:0) exchange, below
 };
 
 __device__ __forceinline__ void xchg_54(int32_t (&r)[4])
@@ -143,6 +144,43 @@ __device__ __forceinline__ void xchg_10(int32_t (&r)[4], const LaneMasks& lm)
     swap_quad<1>(r[2], r[3], lm.b0);
 }
 
+// The transforms take the (1:0) exchange as a policy object `x(r)`:
+//   X10Dpp  the in-register form above: 8 DPP moves + 8 v_bfi = 16 half-rate VALU instructions, ~70 issue cycles, a
+//           quarter of a transform's exchange + butterfly time (quad-granular DPP has no lane mask, hence the selects);
+//   X10Lds  the same 4x4 transpose through a 1 KiB per-wave LDS buffer: one ds_write_b128 + four ds_read_b32, no VALU
+//           work at all.  Used by the fused pipelines, whose VALUs are the co-limiter and whose LDS pipe is mostly idle.
+//           Lane (q, a) -- q = lane >> 2, a = lane & 3 -- writes its four registers to 16-byte slot lane ^ s,
+//           s = (q >> 1) & 3, and reads register a of lanes (q, 0..3): dword 16 q + 4 (b ^ s) + a.  The xor keeps the
+//           b128 store conflict-free (a group of 8 consecutive lanes still covers 8 consecutive slots) and spreads the
+//           32 lanes of each read over 32 banks (natural slots would be 4-way conflicts).
+struct X10Dpp {
+    LaneMasks lm;
+    __device__ __forceinline__ explicit X10Dpp(int lane) : lm(lane) {}
+    __device__ __forceinline__ X10Dpp(uint32_t*, int lane) : lm(lane) {}      // same signature as X10Lds
+    __device__ __forceinline__ void operator()(int32_t (&r)[4]) const { xchg_10(r, lm); }
+};
+struct X10Lds {
+    uint32_t* wslot;        // this lane's 16-byte slot in the wave's exchange buffer
+    const uint32_t* rd[4];  // the four dwords it reads back
+    __device__ __forceinline__ X10Lds(uint32_t* wave_buf /* 256 dwords */, int lane)
+    {
+        const uint32_t q = (uint32_t)lane >> 2, a = (uint32_t)lane & 3, s = (q >> 1) & 3;
+        wslot = wave_buf + 4 * ((uint32_t)lane ^ s);
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) rd[b] = wave_buf + 16 * q + 4 * (b ^ s) + a;
+    }
+    __device__ __forceinline__ void operator()(int32_t (&r)[4]) const
+    {
+        *reinterpret_cast<int4*>(wslot) = make_int4(r[0], r[1], r[2], r[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same-wave LDS accesses execute in order
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[b] = (int32_t)rd[b][0];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+__device__ __forceinline__ void LaneMasks::operator()(int32_t (&r)[4]) const { xchg_10(r, *this); }
+
 // one forward radix-2x2 pass on the lane's 4-tuple (ref_ntt2x2.cpp:57-79 / butterfly2x2.v)
 __device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
 {
@@ -158,8 +196,8 @@ __device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
 // LDS-resident tables (TwLds) each fetch is two ds_read_b128 whose latency would otherwise sit
 // exposed at the head of every pass (hipcc sinks the loads to their first use).
 #define DIL_TW_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <class TW>
-__device__ __forceinline__ void ntt_fwd_core(int32_t (&r)[4], const TW& tw, const LaneMasks& lm)
+template <class TW, class X10>
+__device__ __forceinline__ void ntt_fwd_core(int32_t (&r)[4], const TW& tw, const X10& x10)
 {
     const Tw8 t0 = tw.template get<0>();
     const Tw8 t1 = tw.template get<1>();
@@ -173,7 +211,7 @@ __device__ __forceinline__ void ntt_fwd_core(int32_t (&r)[4], const TW& tw, cons
     const Tw8 t3 = tw.template get<3>();
     DIL_TW_FENCE();
     fwd_pass(r, t2);
-    xchg_10(r, lm);
+    x10(r);
     fwd_pass(r, t3);
 }
 
@@ -194,14 +232,14 @@ __device__ __forceinline__ void inv_pass(int32_t (&r)[4], const Tw8& t)
 
 // Inverse NTT.  In: r[m] = a[4 lane + m] with |a| < q.  Out: r[m] in (-q, q) congruent to
 // invntt(a)[lane + 64 m] (the 256^-1 of ref_ntt.cpp:83-86 included); canon_small() for [0, q).
-template <class TW>
-__device__ __forceinline__ void ntt_inv_core(int32_t (&r)[4], const TW& tw, const LaneMasks& lm)
+template <class TW, class X10>
+__device__ __forceinline__ void ntt_inv_core(int32_t (&r)[4], const TW& tw, const X10& x10)
 {
     const Tw8 t0 = tw.template get<0>();
     const Tw8 t1 = tw.template get<1>();
     DIL_TW_FENCE();
     inv_pass<false>(r, t0);
-    xchg_10(r, lm);
+    x10(r);
     const Tw8 t2 = tw.template get<2>();
     DIL_TW_FENCE();
     inv_pass<false>(r, t1);

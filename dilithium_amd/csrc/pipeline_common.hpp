@@ -8,6 +8,31 @@
 
 namespace dil {
 
+// The wave's index inside its workgroup as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes, but the compiler does
+// not know that; read through v_readfirstlane it lands in an SGPR, and so does everything derived from it -- the item
+// number and every per-item base pointer of the wave-per-item kernels -- which turns 64-bit VGPR address arithmetic into
+// scalar arithmetic + `global_load ... v_off, s[base]` and frees the VGPR pairs the pointers were held in.
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// (1:0) exchange of the transforms inside the wave-per-item pipelines (ntt_core.hpp): through LDS where the kernel's
+// LDS budget has the 1 KiB per wave to spare (USE = true), else in registers.  -DDIL_X10_LDS=0 builds the in-register
+// form everywhere for A/B runs.
+#ifndef DIL_X10_LDS
+#define DIL_X10_LDS 1
+#endif
+template <bool USE>
+struct X10Pick {
+    using type = X10Dpp;
+    static constexpr int DW = 0;
+};
+#if DIL_X10_LDS
+template <>
+struct X10Pick<true> {
+    using type = X10Lds;
+    static constexpr int DW = 256;          // LDS dwords per wave
+};
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Dilithium element-wise tail: Decompose / UseHint / MakeHint / norm checks
 // ---------------------------------------------------------------------------------------
@@ -48,26 +73,27 @@ __device__ __forceinline__ void decompose(uint32_t a, uint32_t& a1, int32_t& a0)
     a0 = r;
 }
 
-// UseHint (usehint.v:140-159), compare-free: VCC-form v_cndmask costs ~22 cycles on gfx950
-// (profiles/r01_ubench_valu_rates.txt), so every select below is sign-bit arithmetic.
-//   a1' = a1 + 1 if a0 > 0 else a1 - 1 (mod 16 / mod 44), taken only where hint = 1
+// UseHint (usehint.v:140-159) without Decompose.  With v = ceil(a / gamma2) - 1 (half-buckets of width gamma2):
+//   a0 > 0  <=>  v even,  a1 = (v + 1) >> 1  (mod 16 / 44),  hinted: a1 + 1 if a0 > 0 else a1 - 1 = a1 + 1 - 2 (v & 1)
+// gamma2 = 2^8 * 1023 (levels 3, 5) / 2^9 * 186 (level 2), so v = ((a - 1) >> 8 | 9) * magic >> s exactly over all of
+// [0, q) (checked exhaustively against the Decompose form, tests/test_model_and_cabi.py).  One multiply, the rest
+// full-rate shifts / adds; compare-free (VCC-form v_cndmask costs ~22 cycles on gfx950, profiles/r01_ubench_valu_rates.txt).
 template <int LEVEL>
 __device__ __forceinline__ uint32_t use_hint(uint32_t a, uint32_t hint)
 {
-    uint32_t a1;
-    int32_t a0;
-    decompose<LEVEL>(a, a1, a0);
-    const int32_t pos = sgn(-a0);                          // all-ones iff a0 > 0
-    int32_t n = (int32_t)a1 + ((pos & 2) - 1);             // a1 +- 1
+    const int32_t x = ((int32_t)a - 1) >> (LEVEL == 2 ? 9 : 8);
+    const int32_t v = (x * (LEVEL == 2 ? 22551 : 32801)) >> (LEVEL == 2 ? 22 : 25);
+    int32_t hm = 0 - (int32_t)(hint & 1u);                 // all-ones iff hinted
+    asm("" : "+v"(hm));                                    // keep it a mask (no compare + select)
+    const int32_t odd = v & 1;
+    int32_t n = ((v + 1) >> 1) + (((odd ^ 1) - odd) & hm);
     if (LEVEL == 2) {
         n += sgn(n) & 44;                                  // -1 -> 43
         n -= sgn(43 - n) & 44;                             // 44 -> 0
     } else {
         n &= 15;
     }
-    uint32_t hm = 0u - (hint & 1u);                        // all-ones iff hinted
-    asm("" : "+v"(hm));                                   // keep it a mask (no compare + select)
-    return a1 ^ ((a1 ^ (uint32_t)n) & hm);
+    return (uint32_t)n;
 }
 
 // MakeHint (makehint.v:98-99), compare-free: hint unless s <= g2, or s > q - g2, or (s == q - g2 and a1 == 0)
@@ -122,7 +148,11 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out_row, cons
     uint8_t* sc = reinterpret_cast<uint8_t*>(scratch);
 #pragma unroll
     for (int m = 0; m < 4; m++) sc[lane + 64 * m] = (uint8_t)v[m];
+#ifdef DIL_ABL_W1_NT
+    __builtin_nontemporal_store(scratch[lane], reinterpret_cast<uint32_t*>(out_row) + lane);
+#else
     reinterpret_cast<uint32_t*>(out_row)[lane] = scratch[lane];
+#endif
 }
 __device__ __forceinline__ uint32_t load_row_u8(const uint8_t* __restrict__ row, int lane)   // issue early, unpack late
 {
@@ -142,28 +172,51 @@ __device__ __forceinline__ void unpack_row_u8(uint32_t (&v)[4], uint32_t packed,
 template <int LEVEL, int OUT>
 __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out,
                                                 int32_t* __restrict__ w0_out, size_t o, const int32_t (&r)[4],
-                                                uint32_t* scratch, int lane)
+                                                uint32_t* scratch, int lane, uint32_t* xbuf = nullptr)
 {
-    uint32_t wb[4];
+    // xbuf (optional, compile-time null or not after inlining): a 1 KiB per-wave LDS buffer through which the int32 row is
+    // turned from the INTT's strided order (lane + 64 m) into row order (4 lane + j), so that it leaves as ONE 1-KiB
+    // dwordx4 store per wave instead of four 256-byte dword stores
+    uint32_t wb[4], ov[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const uint32_t v = canon_small(r[m]);
         if (OUT == OUT_W) {
-            st_nt(w_out + o + lane + 64 * m, (int32_t)v);
+            ov[m] = v;
         } else {
             int32_t a0;
             decompose<LEVEL>(v, wb[m], a0);
-            st_nt(w0_out + o + lane + 64 * m, a0 + (sgn(a0) & Q));
+            ov[m] = (uint32_t)(a0 + (sgn(a0) & Q));
         }
+    }
+    int32_t* dst = (OUT == OUT_W ? w_out : w0_out) + o;
+    if (xbuf) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) xbuf[lane + 64 * m] = ov[m];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const uint4 q = *reinterpret_cast<const uint4*>(xbuf + 4 * lane);
+        st_nt4(dst + 4 * lane, q.x, q.y, q.z, q.w);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; m++) st_nt(dst + lane + 64 * m, (int32_t)ov[m]);
     }
     if (OUT != OUT_W) store_row_u8(w1_out + o, wb, scratch, lane);
 }
 
-// strided load of one polynomial (natural order) into NTT-input registers
+// strided load of one polynomial (natural order) into NTT-input registers.
+// Cache policy, measured with interleaved A/B runs at batch 8192 (profiles/r02_fused_ab.txt): non-temporal is right for the
+// mat-vec and sign phase-2 kernels (sign2 level 5: 81 vs 88 us), the DEFAULT policy is right for the verify kernels' z / c /
+// t1 loads (level 3 distinct pk: 61.4 vs 66.6 us) -- so the policy is the caller's choice.
+template <bool NT = true>
 __device__ __forceinline__ void load_strided(int32_t (&r)[4], const int32_t* __restrict__ a, int lane)
 {
+#if defined(DIL_ABL_NOSMALL)
 #pragma unroll
-    for (int m = 0; m < 4; m++) r[m] = ld_nt(a + lane + 64 * m);
+    for (int m = 0; m < 4; m++) r[m] = lane * 17 + m;            // ablation: no time-domain loads at all
+#else
+#pragma unroll
+    for (int m = 0; m < 4; m++) r[m] = NT ? ld_nt(a + lane + 64 * m) : a[lane + 64 * m];
+#endif
 }
 
 template <int L>
@@ -172,6 +225,9 @@ struct ARow {
     // stream = true: this row is read once (per-item A): non-temporal; false: shared A, keep it cached
     __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane, bool stream)
     {
+#ifdef DIL_ABL_A_PLAIN
+        stream = false;                                          // ablation: default cache policy for the matrix stream
+#endif
         if (stream) {
 #pragma unroll
             for (int l = 0; l < L; l++) v[l] = ld_nt4(Arow + l * 256 + 4 * lane);

@@ -209,17 +209,21 @@ void sign2_kernel(int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int3
 // the workgroup-per-item kernels above (which remain the low-latency path for small batches).
 // ---------------------------------------------------------------------------------------
 // raw (time-domain) inputs of one item, prefetched a whole row phase ahead
-template <int NP>
+template <int NP, bool NT = true>
 struct RawPolys {
     int32_t v[NP][4];
     __device__ __forceinline__ void load(const int32_t* __restrict__ base, int lane)
     {
 #pragma unroll
-        for (int p = 0; p < NP; p++) load_strided(v[p], base + p * 256, lane);
+        for (int p = 0; p < NP; p++) load_strided<NT>(v[p], base + p * 256, lane);
     }
 };
 
 #define DIL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef DIL_MV_XOUT
+#define DIL_MV_XOUT 0     // 1: mat-vec rows leave as one dwordx4 store per lane after an LDS transpose -- measured neutral
+                          // (74.6 vs 74.5 us level 3, 138.1 vs 134.3 us sign1 level 5), so the four strided dword stores stay
+#endif
 
 // mat-vec / sign phase 1, wave-per-item.  Per item: issue row-0 loads | L forward NTTs on registers
 // loaded during the PREVIOUS item's row phase, y^ -> this wave's LDS slice | issue the NEXT item's y
@@ -230,15 +234,17 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
     KeyMap km, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64];
-    const int lane = threadIdx.x & 63;
+    using XP = X10Pick<true>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + (threadIdx.x >> 6) * 64;   // byte-plane scratch
-    uint32_t* yl = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * (L * 256);
+    uint32_t* xb = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + wv * XP::DW;   // exchange buffer, also the output transpose
+    const typename XP::type lm(xb, lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + wv * 64;   // byte-plane scratch
+    uint32_t* yl = lds + 2 * TW_TABLE_DWORDS + wv * (L * 256);
     const size_t nwaves = (size_t)gridDim.x * 4;
-    size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    size_t it = (size_t)blockIdx.x * 4 + wv;
     RawPolys<L> yr;
     if (it < batch) yr.load(y + it * L * 256, lane);
     __syncthreads();                               // tables staged (the only barrier)
@@ -262,60 +268,84 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
             DIL_SCHED_FENCE();
             ntt_inv_core(r, twi, lm);
             DIL_SCHED_FENCE();
-            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane);
+            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, (DIL_MV_XOUT != 0 && XP::DW != 0) ? xb : nullptr);
         }
     }
 }
 
+// ablation hooks of verify_wpi_kernel (scripts/ab_verify.py; never defined in the shipped build)
+#ifdef DIL_ABL_NONTT
+#define VW_FWD(r, tw, x) ((void)0)
+#define VW_INV(r, tw, x) ((void)0)
+#else
+#define VW_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
+#define VW_INV(r, tw, x) ntt_inv_core(r, tw, x)
+#endif
+#ifdef DIL_ABL_NOALOAD
+#define VW_ALOAD(Ar, p, lane, st)                                                    \
+    do {                                                                             \
+        for (int l_ = 0; l_ < L; l_++) Ar.v[l_] = make_int4(lane + l_, lane * 3, 7 * l_ + 1, lane ^ l_); \
+    } while (0)
+#else
+#define VW_ALOAD(Ar, p, lane, st) Ar.load(p, lane, st)
+#endif
+// waves per SIMD the register allocator aims for: 4 at level 2 (118 VGPRs), 3 at levels 3 / 5 (138 / 168 VGPRs; forcing 4
+// there was measured slower in both rounds -- the HBM stream is throughput-limited, more waves only add pressure)
+#ifndef DIL_VW_WAVES
+#define DIL_VW_WAVES(LEVEL) ((LEVEL) == 2 ? 4 : 3)
+#endif
 template <int LEVEL>
-__global__ __launch_bounds__(256) void verify_wpi_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVES(LEVEL), DIL_VW_WAVES(LEVEL)))) void verify_wpi_kernel(
     uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
     const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint8_t* __restrict__ h, size_t batch,
-    int shared_pk, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64];
-    const int lane = threadIdx.x & 63;
+    using XP = X10Pick<true>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + (threadIdx.x >> 6) * 64;   // byte-plane scratch
-    uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * (L * 256);   // this wave's private slice
+    const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + wv * XP::DW, lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + wv * 64;   // byte-plane scratch
+    uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + wv * (L * 256);   // this wave's private slice
     const size_t nwaves = (size_t)gridDim.x * 4;
-    size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    RawPolys<L> zr;
+    size_t it = (size_t)blockIdx.x * 4 + wv;
+    RawPolys<L, false> zr;              // verify: default cache policy for the time-domain inputs
     int32_t cr[4] = {0, 0, 0, 0};
     if (it < batch) {
         zr.load(z + it * L * 256, lane);
-        load_strided(cr, c + it * 256, lane);
+        load_strided<false>(cr, c + it * 256, lane);
     }
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
-        const int32_t* Ait = A + (shared_pk ? 0 : it * K) * (size_t)L * 256;
-        const int32_t* t1it = t1 + (shared_pk ? 0 : it * K) * 256;
+        const int32_t* Ait = A + it * (size_t)(K * L) * 256;       // a key per item (one key for the batch: verify_shared_kernel)
+        const int32_t* t1it = t1 + it * (size_t)K * 256;
         const uint8_t* hit = h + it * K * 256;
         // row 0 operands fly under the z-phase
         ARow<L> Ar;
-        Ar.load(Ait, lane, !shared_pk);
+        VW_ALOAD(Ar, Ait, lane, true);
         int32_t tn[4];
         uint32_t hn;
-        load_strided(tn, t1it, lane);
+        load_strided<false>(tn, t1it, lane);
         hn = load_row_u8(hit, lane);
         // z-phase
 #pragma unroll
         for (int l = 0; l < L; l++) {
-            ntt_fwd_core(zr.v[l], twf, lm);
+            VW_FWD(zr.v[l], twf, lm);
             *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zr.v[l][0], zr.v[l][1], zr.v[l][2], zr.v[l][3]);
         }
         int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
-        ntt_fwd_core(ch, twf, lm);
+        VW_FWD(ch, twf, lm);
         DIL_SCHED_FENCE();
         // next item's time-domain inputs: a whole row phase to land
         const size_t itn = it + nwaves;
         if (itn < batch) {
             zr.load(z + itn * L * 256, lane);
-            load_strided(cr, c + itn * 256, lane);
+            load_strided<false>(cr, c + itn * 256, lane);
         }
+        // (a second row buffer -- two matrix rows in flight per wave -- was tried again in round 2: 150-168 VGPRs with
+        //  spills at level 5 and no gain; the HBM stream is throughput-, not latency-limited)
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, zl, lane);
@@ -325,18 +355,18 @@ __global__ __launch_bounds__(256) void verify_wpi_kernel(
             for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
             unpack_row_u8(hb, hn, sc, lane);
             if (k + 1 < K) {
-                Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_pk);
-                load_strided(tn, t1it + (k + 1) * 256, lane);
+                VW_ALOAD(Ar, Ait + (size_t)(k + 1) * L * 256, lane, true);
+                load_strided<false>(tn, t1it + (k + 1) * 256, lane);
                 hn = load_row_u8(hit + (k + 1) * 256, lane);
             }
             DIL_SCHED_FENCE();     // keep the stages from being interleaved (register pressure, not ILP, is the limit)
-            ntt_fwd_core(th, twf, lm);
+            VW_FWD(th, twf, lm);
             DIL_SCHED_FENCE();
 #pragma unroll
             for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
-            ntt_inv_core(r, twi, lm);
+            VW_INV(r, twi, lm);
             DIL_SCHED_FENCE();
             const size_t o = (it * K + k) * 256;
             uint32_t wb[4];
@@ -356,15 +386,16 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64];
-    const int lane = threadIdx.x & 63;
+    using XP = X10Pick<false>;       // neutral here (measured); keep the LDS footprint small
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW];
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     __syncthreads();
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * 64;   // byte-plane scratch
+    const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * 4;
-    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+    for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
         const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
         const int32_t* s2 = s2hat + (shared_key ? 0 : km.key(it) * K) * 256;
         const int32_t* t0 = t0hat + (shared_key ? 0 : km.key(it) * K) * 256;
@@ -437,15 +468,16 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
     const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64];
-    const int lane = threadIdx.x & 63;
+    using XP = X10Pick<false>;       // neutral here (measured); keep the LDS footprint small
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW];
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     __syncthreads();
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + (threadIdx.x >> 6) * 64;   // byte-plane scratch
+    const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
+    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * 4;
-    for (size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < batch; it += nwaves) {
+    for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
         const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
         const int32_t* s2 = s2hat + (shared_key ? 0 : km.key(it) * K) * 256;
         const int32_t* t0 = t0hat + (shared_key ? 0 : km.key(it) * K) * 256;
@@ -571,13 +603,16 @@ __global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch,
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + NW * L) * 256 + NW * 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // (1:0) exchange in registers: both MAC operands come from LDS here, the LDS pipe is the busy one (measured: the LDS
+    // form costs 12 % in this kernel and gains 1-2 % in the HBM-streaming ones, profiles/r02_fused_ab.txt)
+    using XP = X10Pick<false>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + NW * L) * 256 + NW * 64 + NW * XP::DW];
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
     stage_polys(Al, A, K * L);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
+    const typename XP::type lm(Al + (K * L + NW * L) * 256 + NW * 64 + wv * XP::DW, lane);
     uint32_t* yl = Al + K * L * 256 + wv * (L * 256);
     uint32_t* sc = Al + (K * L + NW * L) * 256 + wv * 64;   // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * NW;
@@ -615,23 +650,24 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K + NW * L) * 256 + NW * 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    using XP = X10Pick<false>;       // both MAC operands come from LDS here: the LDS pipe is the busy one, keep the exchange in registers
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K + NW * L) * 256 + NW * 64 + NW * XP::DW];
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
     uint32_t* Tl = Al + K * L * 256;
     stage_polys(Al, A, K * L);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
+    const typename XP::type lm(Tl + (K + NW * L) * 256 + NW * 64 + wv * XP::DW, lane);
     uint32_t* zl = Tl + K * 256 + wv * (L * 256);
     uint32_t* sc = Tl + (K + NW * L) * 256 + wv * 64;        // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * NW;
     size_t it = (size_t)blockIdx.x * NW + wv;
-    RawPolys<L> zr;
+    RawPolys<L, false> zr;
     int32_t cr[4] = {0, 0, 0, 0};
     if (it < batch) {
         zr.load(z + it * L * 256, lane);
-        load_strided(cr, c + it * 256, lane);
+        load_strided<false>(cr, c + it * 256, lane);
     }
     __syncthreads();                               // tables + A staged
     if (wv < K) {                                  // t1_k * 2^13 (decoder.v:96-100) -> NTT -> LDS, lazy residues
@@ -656,7 +692,7 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
         const size_t itn = it + nwaves;
         if (itn < batch) {
             zr.load(z + itn * L * 256, lane);
-            load_strided(cr, c + itn * 256, lane);
+            load_strided<false>(cr, c + itn * 256, lane);
         }
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
@@ -751,7 +787,7 @@ static void launch_verify_wpi(uint8_t* w1, const int32_t* A, const int32_t* z, c
         hipLaunchKernelGGL((verify_shared_kernel<LEVEL, NW>), g, 64 * NW, 0, s, w1, A, z, c, t1, h, batch, t.fwd, t.inv_pipe);
     } else {
         const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<LEVEL>, 256, t.wpi_blocks_per_cu, t.device));
-        hipLaunchKernelGGL((verify_wpi_kernel<LEVEL>), g, 256, 0, s, w1, A, z, c, t1, h, batch, shared_pk, t.fwd, t.inv_pipe);
+        hipLaunchKernelGGL((verify_wpi_kernel<LEVEL>), g, 256, 0, s, w1, A, z, c, t1, h, batch, t.fwd, t.inv_pipe);
     }
 }
 

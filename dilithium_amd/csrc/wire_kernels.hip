@@ -204,15 +204,16 @@ __global__ __launch_bounds__(256) void verify_wire_wpi_kernel(
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using W = Wire<LEVEL>;
     // per wave: L KiB of z^ | 64 dwords byte scratch | 64 dwords hint bitmap
-    constexpr int WAVE_DW = L * 256 + 64 + 64;
+    using XP = X10Pick<true>;
+    constexpr int WAVE_DW = L * 256 + 64 + 64 + XP::DW;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * WAVE_DW];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
     uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + wv * WAVE_DW;
     uint32_t* sc = zl + L * 256;
     uint32_t* bm = sc + 64;
+    const typename XP::type lm(bm + 64, lane);
     const PackedLane<W::ZBITS> plz(lane);
     const PackedLane<10> plt(lane);
     const size_t nwaves = (size_t)gridDim.x * 4;
@@ -296,19 +297,20 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using W = Wire<LEVEL>;
-    constexpr int WAVE_DW = L * 256 + 64 + 64;
+    using XP = X10Pick<false>;       // LDS-resident key: exchange in registers (see matvec_shared_kernel)
+    constexpr int WAVE_DW = L * 256 + 64 + 64 + XP::DW;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K) * 256 + NW * WAVE_DW];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
     uint32_t* Tl = Al + K * L * 256;
     for (int i = threadIdx.x; i < K * L * 64; i += blockDim.x)
         reinterpret_cast<uint4*>(Al)[i] = reinterpret_cast<const uint4*>(A)[i];
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const LaneMasks lm(lane);
     uint32_t* zl = Tl + K * 256 + wv * WAVE_DW;
     uint32_t* sc = zl + L * 256;
     uint32_t* bm = sc + 64;
+    const typename XP::type lm(bm + 64, lane);
     const PackedLane<W::ZBITS> plz(lane);
     const size_t nwaves = (size_t)gridDim.x * NW;
     size_t it = (size_t)blockIdx.x * NW + wv;
