@@ -13,12 +13,13 @@ L3-resident one (the L3-resident rate is reported beside it as `llc_resident_val
 metric value = transforms / second over all GPUs (weak scaling: per-GPU work fixed).
 
 Also reported on the same JSON line:
-  roofline      dominant kernels (forward / inverse NTT, alternating, same bytes): algorithmic bytes
-                (2048 B x 65536 per launch) / the average launch duration over the timed region, from
-                two HIP events on the launch stream around the region (no events inside it: an event
-                record between launches costs microseconds of GPU idle time); a separate untimed
-                instrumented pass splits forward from inverse.  peak 8 TB/s (MI355X_MICROARCH.md);
-                traffic from the committed rocprofv3 PMC pass (profiles/), or null.
+  roofline      dominant kernels (forward / inverse NTT, alternating, same bytes).  `frac` is the SINGLE-KERNEL
+                fraction: algorithmic bytes (2048 B x 65536 per launch) / the average launch duration of
+                the same K steps on ONE stream (two HIP events around that region, no events inside it:
+                an event record between launches costs microseconds of GPU idle time) -- the duration
+                rocprofv3 reports for the kernel.  `frac_overlapped` is the aggregate of the timed region
+                (`value`), where --streams launches overlap.  peak 8 TB/s (MI355X_MICROARCH.md);
+                traffic = HBM bytes per launch from the committed rocprofv3 PMC pass (`traffic_source`).
   cpu_baseline  the reference's own ntt()+invntt() (oracle/_ref, kind "reference") -- or our C
                 restatement (kind "port") -- on one host core, bounded sample.
   secondary     Dilithium-3 verify cores / s (configs[3], batch 8192, distinct pk) with its own
@@ -156,7 +157,8 @@ def main():
                     help="HIP streams the steps alternate over (step i runs on stream i %% S; a batch always stays on one "
                          "stream).  2 keeps a second launch in flight, which fills the dispatch gap and the ramp/tail of "
                          "every kernel: +15 %% over one stream")
-    ap.add_argument("--verify-streams", type=int, default=1, help="streams of the secondary (fused verify) metric")
+    ap.add_argument("--min-ms", type=float, default=25.0,
+                    help="every secondary leg is timed for at least this long, whatever --steps says")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
@@ -172,6 +174,7 @@ def main():
     api.init(local)
     L = dlib.load()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
     def ev():
         e = C.c_void_p()
@@ -183,6 +186,23 @@ def main():
         dlib.check(L.dil_event_elapsed_ms(C.byref(ms), a, b))
         return float(ms.value)
 
+    def timed(fn, st=None, min_ms=None):
+        """average milliseconds per call of fn() (direct C-ABI launches on stream `st`): HIP events around a region that is
+        at least min_ms long -- the repeat count comes from a calibration pass, not from --steps"""
+        st = stream if st is None else st
+        min_ms = args.min_ms if min_ms is None else min_ms
+        e0, e1 = ev(), ev()
+        reps, rc = 4, 0
+        for _ in range(3):                       # warm-up, then calibrate, then the measured region
+            L.dil_event_record(e0, st)
+            for i in range(reps):
+                rc |= fn(i)
+            L.dil_event_record(e1, st)
+            per = max(elapsed(e0, e1) / reps, 1e-4)
+            reps = max(10, int(min_ms / per) + 1)
+        dlib.check(rc, "timed launches")
+        return per, reps
+
     # ---- inputs, resident in HBM ------------------------------------------------------------
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     NS = max(1, args.streams)
@@ -192,28 +212,29 @@ def main():
     check = bufs[0][:64].clone()
     torch.cuda.synchronize()
 
-    ptrs = [C.c_void_p(b.data_ptr()) for b in bufs]      # direct C-ABI calls: minimal host overhead
+    ptrs = [P(b) for b in bufs]                           # direct C-ABI calls: minimal host overhead
     tstreams = [torch.cuda.Stream() for _ in range(NS)] if NS > 1 else [torch.cuda.current_stream()]
     hstreams = [C.c_void_p(ts.cuda_stream) for ts in tstreams]
 
-    def step(i, fixed=None):
+    def step(i, fixed=None, one=False):
         p = ptrs[(i % R) if fixed is None else (fixed + i % NS)]
-        st = hstreams[i % NS]
+        st = hstreams[0] if one else hstreams[i % NS]
         return L.dil_ntt_dev(p, BATCH, st) | L.dil_invntt_dev(p, BATCH, st)
 
-    def region(k, fixed=None):
+    def region(k, fixed=None, one=False):
         """EXACTLY k steps, bracketed by one HIP event pair per stream; returns (wall seconds, per-stream event ms)"""
-        e0 = [ev() for _ in range(NS)]
-        e1 = [ev() for _ in range(NS)]
+        ns = 1 if one else NS
+        e0 = [ev() for _ in range(ns)]
+        e1 = [ev() for _ in range(ns)]
         sharding.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rc = 0
-        for j in range(NS):
+        for j in range(ns):
             rc |= L.dil_event_record(e0[j], hstreams[j])
         for i in range(k):
-            rc |= step(i, fixed)
-        for j in range(NS):
+            rc |= step(i, fixed, one)
+        for j in range(ns):
             rc |= L.dil_event_record(e1[j], hstreams[j])
         torch.cuda.synchronize()
         sharding.barrier()
@@ -235,38 +256,15 @@ def main():
     dt, ev_ms = region(K)
     assert torch.equal(bufs[0][:64], check), "fwd+inv round trip is not the identity"
     value = world * K * 2 * BATCH / dt
-    launches = [2 * len(range(j, K, NS)) for j in range(NS)]            # per stream
-    # average duration of one launch as the stream (and rocprof) sees it: with NS streams NS launches overlap
-    launch_ms = float(np.mean([m / n for m, n in zip(ev_ms, launches) if n]))
     region_ms = max(ev_ms)
-    ntt_gbs = NTT_BYTES * BATCH * 2 * K / (region_ms * 1e-3) / 1e9      # aggregate over the timed region
+    overlapped_gbs = NTT_BYTES * BATCH * 2 * K / (region_ms * 1e-3) / 1e9    # aggregate over the timed region (NS launches overlap)
 
-    # instrumented pass (NOT timed for `value`): one stream, events around single launches split forward from inverse;
-    # each figure includes the event/dispatch overhead the timed region does not pay
-    s_one = hstreams[0]
-    ni = max(8, min(40, K // 4))
-    evs = [(ev(), ev(), ev()) for _ in range(ni)]
-    for i, (e0, e1, e2) in enumerate(evs):
-        p = ptrs[(i * NS) % R]
-        L.dil_event_record(e0, s_one)
-        L.dil_ntt_dev(p, BATCH, s_one)
-        L.dil_event_record(e1, s_one)
-        L.dil_invntt_dev(p, BATCH, s_one)
-        L.dil_event_record(e2, s_one)
-    torch.cuda.synchronize()
-    fwd_ms = float(np.mean([elapsed(e0, e1) for e0, e1, _ in evs]))
-    inv_ms = float(np.mean([elapsed(e1, e2) for _, e1, e2 in evs]))
-    # the same K steps on ONE stream, for reference
-    one_stream_value = None
-    if NS > 1:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(K):
-            p = ptrs[i % R]
-            L.dil_ntt_dev(p, BATCH, s_one)
-            L.dil_invntt_dev(p, BATCH, s_one)
-        torch.cuda.synchronize()
-        one_stream_value = world * K * 2 * BATCH / sharding.max_over_ranks(time.perf_counter() - t1)
+    # the SAME K steps on ONE stream: the per-kernel roofline (no overlap between launches; each launch's share of the
+    # region includes its ~2 us dispatch gap, so this is a lower bound of what rocprofv3 reports per kernel)
+    one_dt, one_ev = region(K, one=True)
+    one_stream_value = world * K * 2 * BATCH / one_dt
+    launch_ms = one_ev[0] / (2 * K)
+    kernel_gbs = NTT_BYTES * BATCH / (launch_ms * 1e-3) / 1e9
 
     # LLC-resident variant (the same NS batches every step: 64 MiB each, inside the 256 MiB Infinity Cache) for context
     for i in range(8):
@@ -275,6 +273,7 @@ def main():
     llc_dt, _ = region(K, fixed=0)
     llc_value = world * K * 2 * BATCH / llc_dt
 
+    traffic = pmc_traffic("ntt_fwd_kernel")
     out = {
         "metric": "ntt256_transforms_per_sec", "value": value, "unit": "NTT/s", "n_gpus": world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -284,131 +283,84 @@ def main():
                    "batch_per_gpu": BATCH, "rotating_resident_batches": R, "streams": NS,
                    "parallelism": f"shard x{world}", "bytes_per_transform": NTT_BYTES},
         "roofline": {"bound": "hbm",
-                     "kernel": "ntt_fwd_kernel<LAYOUT_POLY> / ntt_inv_kernel<LAYOUT_POLY> (alternating launches of the "
-                               "timed region, identical algorithmic bytes)",
-                     "achieved": ntt_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic("ntt_fwd_kernel"), "avg_launch_ms": launch_ms,
-                     "concurrent_launches": NS,
-                     "algorithmic_bytes_per_launch": NTT_BYTES * BATCH,
-                     "timing": "one HIP event pair per launch stream around the whole timed region; avg_launch_ms = that "
-                               "stream's elapsed time / its launches (the per-kernel duration rocprofv3 reports); "
-                               "achieved = all launches' algorithmic bytes / the region's elapsed time "
-                               "(= concurrent_launches x bytes per launch / avg_launch_ms)",
-                     "per_kernel_instrumented": {
-                         "note": "separate untimed pass, events around single launches (adds event/dispatch overhead)",
-                         "ntt_fwd_kernel_ms": fwd_ms, "ntt_inv_kernel_ms": inv_ms,
-                         "ntt_fwd_kernel_GBps": NTT_BYTES * BATCH / (fwd_ms * 1e-3) / 1e9,
-                         "ntt_inv_kernel_GBps": NTT_BYTES * BATCH / (inv_ms * 1e-3) / 1e9}},
+                     "kernel": "ntt_fwd_kernel<LAYOUT_POLY> / ntt_inv_kernel<LAYOUT_POLY> (alternating launches, identical "
+                               "algorithmic bytes)",
+                     "achieved": kernel_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernel_gbs / HBM_PEAK_GBS,
+                     "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": NTT_BYTES * BATCH,
+                     "achieved_overlapped": overlapped_gbs, "frac_overlapped": overlapped_gbs / HBM_PEAK_GBS,
+                     "concurrent_launches_overlapped": NS,
+                     "traffic": traffic,
+                     "traffic_source": "profiles/pmc_summary.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "this kernel (bytes per launch; not re-measured in this run)" if traffic else None,
+                     "timing": "achieved / frac = algorithmic bytes per launch / avg_launch_ms, the per-launch share of K steps "
+                               "(2K launches) on ONE stream between two HIP events; achieved_overlapped / frac_overlapped = all "
+                               "launches' bytes / the elapsed time of the timed region behind `value`, in which "
+                               "`concurrent_launches_overlapped` launches are in flight"},
         "llc_resident_value": llc_value,
         "one_stream_value": one_stream_value,
-        # context: the same kernel without its loads/stores, i.e. the integer-ALU ceiling of this arithmetic
-        "valu_ceiling": {"value": 3.74e9, "unit": "NTT/s per GPU", "source": "profiles/r01_tune_ntt.txt, compute-only variant "
-                                                                             "(not measured in this run)"},
     }
 
-    # ---- secondary: Dilithium-3 verify core, configs[3] ----------------------------------------
+    # ---- secondary: Dilithium-3 verify core, configs[3], and the other configs -------------------
     if not args.no_secondary:
         cu = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
-        # The fused kernel holds its items' vectors in LDS and sizes its persistent grid to fill every CU, so a second
-        # launch in flight cannot become resident beside it: measured 108 M/s on two streams vs 119 M/s on one -> one stream.
-        VNS = max(1, min(NS, args.verify_streams))
-        VSETS = max(2, VNS)          # rotate over >= 2 input sets (2 x 360 MiB > the 256 MiB Infinity Cache): HBM-streaming
+        VSETS = 2                    # rotate over 2 input sets (2 x 360 MiB > the 256 MiB Infinity Cache): HBM-streaming
         vsets = []
         for j in range(VSETS):
             A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank + 100 * j)
             vsets.append((cu(A), cu(z), cu(c), cu(t1_), cu(h), torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
         dA, dz, dc, dt1, dh, w1 = vsets[0]
-        vptr = [[C.c_void_p(t.data_ptr()) for t in vs_] for vs_ in vsets]
+        vptr = [[P(t) for t in vs_] for vs_ in vsets]
         torch.cuda.synchronize()
 
         def vstep(i):
             pA, pz, pc, pt1, ph, pw1 = vptr[i % VSETS]
-            return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, hstreams[i % VNS])
+            return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, stream)
 
-        vs = max(10, K // 4)
-        for i in range(2 * VNS + 2):
-            vstep(i)
-        torch.cuda.synchronize()
         sharding.barrier()
-        ve0 = [ev() for _ in range(VNS)]
-        ve1 = [ev() for _ in range(VNS)]
-        tv = time.perf_counter()
-        rcv = 0
-        for j in range(VNS):
-            rcv |= L.dil_event_record(ve0[j], hstreams[j])
-        for i in range(vs):
-            rcv |= vstep(i)
-        for j in range(VNS):
-            rcv |= L.dil_event_record(ve1[j], hstreams[j])
-        torch.cuda.synchronize()
-        sharding.barrier()
-        tv = sharding.max_over_ranks(time.perf_counter() - tv)
-        dlib.check(rcv, "timed verify launches")
-        v_ev = [elapsed(a_, b_) for a_, b_ in zip(ve0, ve1)]
-        v_launches = [len(range(j, vs, VNS)) for j in range(VNS)]
-        v_ms = float(np.mean([m / n for m, n in zip(v_ev, v_launches) if n]))     # per-kernel duration (NS overlap)
-        v_gbs = VERIFY3_BYTES * VBATCH * vs / (max(v_ev) * 1e-3) / 1e9            # aggregate over the region
-        sec = {"metric": "dilithium3_verify_cores_per_sec", "value": world * vs * VBATCH / tv, "unit": "verify/s",
+        v_ms, v_reps = timed(vstep)
+        v_ms = sharding.max_over_ranks(v_ms)
+        v_gbs = VERIFY3_BYTES * VBATCH / (v_ms * 1e-3) / 1e9
+        vtraffic = pmc_traffic("verify_kernel")
+        sec = {"metric": "dilithium3_verify_cores_per_sec", "value": world * VBATCH / (v_ms * 1e-3), "unit": "verify/s",
                "config": {"workload": "BASELINE configs[3]: level-3 verify core (NTT z, A.z - c.t1.2^d, INTT, "
                                       "UseHint -> w1), batch=8192 per GPU, distinct pk (A, t1 per item)",
-                          "bytes_per_verify": VERIFY3_BYTES, "streams": VNS, "rotating_input_sets": VSETS},
+                          "bytes_per_verify": VERIFY3_BYTES, "streams": 1, "rotating_input_sets": VSETS, "timed_launches": v_reps},
                "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("verify_kernel"),
-                            "avg_launch_ms": v_ms, "concurrent_launches": VNS}}
+                            "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": vtraffic,
+                            "traffic_source": "profiles/pmc_summary.json (committed PMC passes)" if vtraffic else None,
+                            "avg_launch_ms": v_ms}}
         # the same launches over ONE input set (360 MiB, partly served by the 256 MiB Infinity Cache), for context
-        torch.cuda.synchronize()
-        ea, eb = ev(), ev()
-        L.dil_event_record(ea, hstreams[0])
-        for i in range(vs):
-            pA, pz, pc, pt1, ph, pw1 = vptr[0]
-            L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, hstreams[0])
-        L.dil_event_record(eb, hstreams[0])
-        torch.cuda.synchronize()
-        sec["llc_assisted_value"] = world * VBATCH / (elapsed(ea, eb) / vs * 1e-3)
+        l_ms, _ = timed(lambda i: L.dil_verify_core_dev(vptr[0][5], vptr[0][0], vptr[0][1], vptr[0][2], vptr[0][3], vptr[0][4], 3,
+                                                        VBATCH, 0, stream))
+        sec["llc_assisted_value"] = world * VBATCH / (l_ms * 1e-3)
         # same pipeline with ONE public key for the whole batch (A, t1 staged in LDS): VALU-bound, reported beside it
-        torch.cuda.synchronize()
-        e2, e3 = ev(), ev()
-        L.dil_event_record(e2, stream)
-        for _ in range(vs):
-            api.verify_core(dA[:1], dz, dc, dt1[:1], dh, 3, shared_pk=True, out=w1)
-        L.dil_event_record(e3, stream)
-        torch.cuda.synchronize()
-        s_ms = elapsed(e2, e3) / vs
+        s_ms, _ = timed(lambda i: L.dil_verify_core_dev(vptr[i % VSETS][5], vptr[0][0], vptr[i % VSETS][1], vptr[i % VSETS][2],
+                                                        vptr[0][3], vptr[i % VSETS][4], 3, VBATCH, 1, stream))
         sec["shared_pk"] = {"value": VBATCH / (s_ms * 1e-3), "unit": "verify/s per GPU", "avg_launch_ms": s_ms,
                             "bytes_per_verify": 15 * 1024, "kernel": "verify_shared_kernel<3,16>",
                             "bound": "valu (key material LDS-resident)"}
         # configs[2] and configs[4] of BASELINE.json (parity-test configs; timed here for the record only)
+        g2 = torch.Generator(device="cuda").manual_seed(5)
+        rnd = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=g2)  # noqa: E731
         try:
-            g2 = torch.Generator(device="cuda").manual_seed(5)
-            rnd = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=g2)  # noqa: E731
-            A2, y2 = rnd(4096, 4, 4, 256), rnd(4096, 4, 256)
-            wout = torch.empty((4096, 4, 256), dtype=torch.int32, device="cuda")
-            for _ in range(3):
-                api.matvec(A2, y2, 2, out=wout)
-            e4, e5 = ev(), ev()
-            L.dil_event_record(e4, stream)
-            for _ in range(vs):
-                api.matvec(A2, y2, 2, out=wout)
-            L.dil_event_record(e5, stream)
-            torch.cuda.synchronize()
-            m_ms = elapsed(e4, e5) / vs
+            A2 = [rnd(4096, 4, 4, 256) for _ in range(4)]           # 4 x 64 MiB of A: rotating, HBM-streaming
+            y2, wout = rnd(4096, 4, 256), torch.empty((4096, 4, 256), dtype=torch.int32, device="cuda")
+            m_ms, _ = timed(lambda i: L.dil_matvec_dev(P(wout), P(A2[i % 4]), P(y2), 2, 4096, 0, stream))
             A5, y5, c5 = rnd(1, 8, 7, 256), rnd(8192, 7, 256), rnd(8192, 256)
             s1h, s2h, t0h = rnd(1, 7, 256), rnd(1, 8, 256), rnd(1, 8, 256)
-            w1s, w0s = api.sign_phase1(A5, y5, 5, shared_key=True)
-            for _ in range(2):
-                api.sign_phase1(A5, y5, 5, shared_key=True)
-                api.sign_phase2(c5, y5, w0s, w1s, s1h, s2h, t0h, 5, shared_key=True)
-            e6, e7 = ev(), ev()
-            L.dil_event_record(e6, stream)
-            for _ in range(vs):
-                api.sign_phase1(A5, y5, 5, shared_key=True)
-                api.sign_phase2(c5, y5, w0s, w1s, s1h, s2h, t0h, 5, shared_key=True)
-            L.dil_event_record(e7, stream)
-            torch.cuda.synchronize()
-            a_ms = elapsed(e6, e7) / vs
+            w1s = torch.empty((8192, 8, 256), dtype=torch.uint8, device="cuda")
+            w0s = torch.empty((8192, 8, 256), dtype=torch.int32, device="cuda")
+            z5 = torch.empty((8192, 7, 256), dtype=torch.int32, device="cuda")
+            h5 = torch.empty((8192, 8, 256), dtype=torch.uint8, device="cuda")
+            f5 = torch.empty((8192,), dtype=torch.int32, device="cuda")
+
+            def attempt(i):
+                return L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream) | \
+                    L.dil_sign_phase2_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1, stream)
+            a_ms, _ = timed(attempt)
             sec["other_configs"] = {
-                "configs[2] level-2 A.y matvec batch=4096 distinct A": {"matvecs_per_s": 4096 / (m_ms * 1e-3), "ms": m_ms,
-                                                                         "GBps": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9},
+                "configs[2] level-2 A.y matvec batch=4096 distinct A (4 rotating matrices)": {
+                    "matvecs_per_s": 4096 / (m_ms * 1e-3), "ms": m_ms, "GBps": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9},
                 "configs[4] level-5 sign attempt (phase1+phase2) batch=8192 per GPU, shared key": {
                     "attempts_per_s": 8192 / (a_ms * 1e-3), "ms": a_ms}}
         except Exception as e:  # noqa: BLE001
@@ -418,51 +370,64 @@ def main():
             g3 = torch.Generator(device="cuda").manual_seed(9 + rank)
             u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g3)  # noqa: E731
             seed, mu = u8(VBATCH, 32), u8(VBATCH, 64)
-
-            def ev_time(fn, reps):
-                fn()
-                ea, eb = ev(), ev()
-                L.dil_event_record(ea, stream)
-                for _ in range(reps):
-                    fn()
-                L.dil_event_record(eb, stream)
-                torch.cuda.synchronize()
-                return elapsed(ea, eb) / reps
-
-            kg_ms = ev_time(lambda: api.keygen(seed, 3), 5)
-            pk, sk = api.keygen(seed, 3)
-            sg_ms = ev_time(lambda: api.sign(sk[:1], mu, 3, shared_sk=True), 3)
-            sig, att = api.sign(sk[:1], mu, 3, shared_sk=True)
-            sgd_ms = ev_time(lambda: api.sign(sk, mu, 3), 2)
-            vf_ms = ev_time(lambda: api.verify_sig(pk[:1], sig, mu, 3, shared_pk=True), 5)
-            sigd, _ = api.sign(sk, mu, 3)
-            vfd_ms = ev_time(lambda: api.verify_sig(pk, sigd, mu, 3), 5)
-            ok = int(api.verify_sig(pk, sigd, mu, 3).abs().sum()) == 0 and \
-                int(api.verify_sig(pk[:1], sig, mu, 3, shared_pk=True).abs().sum()) == 0
+            pkb, skb, sgb = api.pk_bytes(3), api.sk_bytes(3), api.sig_bytes(3)
+            pk = torch.empty((VBATCH, pkb), dtype=torch.uint8, device="cuda")
+            sk = torch.empty((VBATCH, skb), dtype=torch.uint8, device="cuda")
+            sig = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
+            sigd = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
+            att = torch.empty((VBATCH,), dtype=torch.int32, device="cuda")
+            vd = torch.empty((VBATCH,), dtype=torch.int32, device="cuda")
+            kg_ms, _ = timed(lambda i: L.dil_keygen_dev(P(pk), P(sk), P(seed), 3, VBATCH, stream))
+            sg_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, VBATCH, 1, 512, stream))
+            mean_att = float(att.float().mean())
+            sgd_ms, _ = timed(lambda i: L.dil_sign_dev(P(sigd), P(att), P(sk), P(mu), 3, VBATCH, 0, 512, stream))
+            vf_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
+            ok = int(vd.abs().sum()) == 0
+            vfd_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd), P(pk), P(sigd), P(mu), 3, VBATCH, 0, stream))
+            ok = ok and int(vd.abs().sum()) == 0
+            # the fused wire-format kernel alone (A expanded beforehand): bytes = 30 KiB A + packed z, t1, hints, c, w1
+            A3 = api.expand_a(pk[:, :32].contiguous(), 3)
+            w1p = torch.empty((VBATCH, 6 * 128), dtype=torch.uint8, device="cuda")
+            wk_ms, _ = timed(lambda i: L.dil_verify_wire_core_dev(P(w1p), P(vd), P(A3), P(pk), P(sigd), 3, VBATCH, 0, stream))
             # the same at 8 x the batch (65536 per GPU): the latency-bound hash kernels are amortised
             BIG = 8 * VBATCH
             mu_b = u8(BIG, 64)
-            sgb_ms = ev_time(lambda: api.sign(sk[:1], mu_b, 3, shared_sk=True), 2)
-            sig_b, _ = api.sign(sk[:1], mu_b, 3, shared_sk=True)
-            vfb_ms = ev_time(lambda: api.verify_sig(pk[:1], sig_b, mu_b, 3, shared_pk=True), 3)
-            ok = ok and int(api.verify_sig(pk[:1], sig_b, mu_b, 3, shared_pk=True).abs().sum()) == 0
+            sig_b = torch.empty((BIG, sgb), dtype=torch.uint8, device="cuda")
+            att_b = torch.empty((BIG,), dtype=torch.int32, device="cuda")
+            vd_b = torch.empty((BIG,), dtype=torch.int32, device="cuda")
+            sgb_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig_b), P(att_b), P(sk), P(mu_b), 3, BIG, 1, 512, stream))
+            vfb_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd_b), P(pk), P(sig_b), P(mu_b), 3, BIG, 1, stream))
+            ok = ok and int(vd_b.abs().sum()) == 0
             per_s = lambda ms: VBATCH / (ms * 1e-3)  # noqa: E731
             sec["scheme_level3_wire_format"] = {
-                "note": "pk/sk/sig bytes in HBM -> bytes in HBM; SHAKE, samplers, codecs, rejection loop all on the device",
+                "note": "pk/sk/sig bytes in HBM -> bytes in HBM; SHAKE, samplers, codecs, rejection loop all on the device; "
+                        "verification reads the packed fields inside the fused kernel (no int32 temporaries)",
                 "keygen_per_s": per_s(kg_ms), "sign_shared_key_per_s": per_s(sg_ms), "sign_distinct_keys_per_s": per_s(sgd_ms),
                 "verify_shared_pk_per_s": per_s(vf_ms), "verify_distinct_pk_per_s": per_s(vfd_ms),
-                "mean_sign_attempts": float(att.float().mean()), "all_signatures_verify": ok, "batch": VBATCH,
+                "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "sample_in_ball_bits_kernel + "
+                                                 "verify_wire_wpi_kernel<3>", "wire_bytes_per_verify": 30 * 1024 + 3200 + 61 + 1920 + 256 + 768},
+                "mean_sign_attempts": mean_att, "all_signatures_verify": ok, "batch": VBATCH,
                 "batch_65536": {"sign_shared_key_per_s": BIG / (sgb_ms * 1e-3), "verify_shared_pk_per_s": BIG / (vfb_ms * 1e-3)}}
+            # small-batch latency of one whole call (launch-bound): wall time per call incl. the host side
+            lat = {}
+            for nb in (1, 64, 1024):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                reps = 20
+                for _ in range(reps):
+                    L.dil_verify_sig_dev(P(vd), P(pk), P(sigd), P(mu), 3, nb, 0, stream)
+                torch.cuda.synchronize()
+                lat[f"verify_sig_batch_{nb}_ms"] = (time.perf_counter() - t0) / reps * 1e3
+            sec["scheme_level3_wire_format"]["latency"] = lat
         except Exception as e:  # noqa: BLE001
             sec["scheme_level3_wire_format"] = {"error": repr(e)}
-        # the one collective of the design: final gather of the result slabs over RCCL/xGMI
-        if world > 1:
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            allw1 = sharding.gather_slabs(w1, world * VBATCH)
-            torch.cuda.synchronize()
-            sec["final_gather_ms"] = (time.perf_counter() - tg) * 1e3
-            sec["final_gather_bytes"] = int(allw1.numel())
+        # ---- BASELINE configs[4] as north_star describes it: ONE batch of level-5 signing work, 8192 items per GPU, sharded by
+        # contiguous slices over the ranks (sharding.run_sharded), HIP compute on every rank, then the one collective of the
+        # design: the gather of the (z, h, flag) result slabs over RCCL/xGMI -- timed separately.
+        try:
+            sec["configs4_sharded"] = bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api)
+        except Exception as e:  # noqa: BLE001
+            sec["configs4_sharded"] = {"error": repr(e)}
         out["secondary"] = sec
 
     if rank == 0:
@@ -478,6 +443,79 @@ def main():
     sharding.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
+    """level-5 sign inner loop (phase 1 + phase 2, one signing key) and the whole signing loop on one batch of
+    8192 x world items: every rank builds the SAME batch (same seed), run_sharded hands it its contiguous slice, the
+    HIP kernels run on the slice, gather_slabs all-gathers the result slabs"""
+    per, K5, L5 = 8192, 8, 7
+    total = per * world
+    gq = torch.Generator(device="cuda").manual_seed(4242)          # same on every rank: one logical batch
+    rnd = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=gq)  # noqa: E731
+    A5, s1h, s2h, t0h = rnd(1, K5, L5, 256), rnd(1, L5, 256), rnd(1, K5, 256), rnd(1, K5, 256)
+    g1 = 1 << 19
+    y = (torch.randint(-(g1 - 1), g1 + 1, (total, L5, 256), dtype=torch.int64, device="cuda", generator=gq) % 8380417).to(torch.int32)
+    cc = torch.zeros((total, 256), dtype=torch.int32, device="cuda")
+    cc[:, ::5] = 1
+    cc[:, 1::9] = 8380416
+    out = {}
+
+    def attempt(ys, cs):
+        n = ys.shape[0]
+        w1 = torch.empty((n, K5, 256), dtype=torch.uint8, device="cuda")
+        w0 = torch.empty((n, K5, 256), dtype=torch.int32, device="cuda")
+        z = torch.empty((n, L5, 256), dtype=torch.int32, device="cuda")
+        h = torch.empty((n, K5, 256), dtype=torch.uint8, device="cuda")
+        f = torch.empty((n,), dtype=torch.int32, device="cuda")
+
+        def one(i):
+            return L.dil_sign_phase1_dev(P(w1), P(w0), P(A5), P(ys), 5, n, 1, stream) | \
+                L.dil_sign_phase2_dev(P(z), P(h), P(f), P(cs), P(ys), P(w0), P(w1), P(s1h), P(s2h), P(t0h), 5, n, 1, stream)
+        ms, _ = timed(one)
+        out["attempt_ms_per_rank_slice"] = sharding.max_over_ranks(ms)
+        return z, h, f
+
+    z, h, f = sharding.run_sharded(attempt, total, y, cc, gather=False)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    t0 = time.perf_counter()
+    gz, gh, gf = (sharding.gather_slabs(t, total) for t in (z, h, f))
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    assert gz.shape[0] == total and gf.shape[0] == total
+    out.update({"workload": "BASELINE configs[4]: level 5 (K=8, L=7) sign inner loop, one key, batch = 8192 per GPU x "
+                            f"{world} GPU(s) = {total}, contiguous slices (run_sharded), gather of z + h + flag slabs",
+                "attempts_per_s": total / (out["attempt_ms_per_rank_slice"] * 1e-3),
+                "final_gather_ms": sharding.max_over_ranks(gather_ms),
+                "final_gather_bytes": int(gz.numel() * 4 + gh.numel() + gf.numel() * 4),
+                "accept_rate": float((gf == 0).float().mean())})
+    # the whole signing loop (rejection sampling to completion) on the same sharding: KAT-style deterministic signatures
+    gm = torch.Generator(device="cuda").manual_seed(777)
+    seed = torch.randint(0, 256, (1, 32), dtype=torch.uint8, device="cuda", generator=gm)
+    mu = torch.randint(0, 256, (total, 64), dtype=torch.uint8, device="cuda", generator=gm)
+    pk, sk = api.keygen(seed, 5)
+
+    def sign(mus):
+        n = mus.shape[0]
+        sig = torch.empty((n, api.sig_bytes(5)), dtype=torch.uint8, device="cuda")
+        att = torch.empty((n,), dtype=torch.int32, device="cuda")
+        ms, _ = timed(lambda i: L.dil_sign_dev(P(sig), P(att), P(sk), P(mus), 5, n, 1, 512, stream))
+        out["sign_ms_per_rank_slice"] = sharding.max_over_ranks(ms)
+        return sig
+    sig = sharding.run_sharded(sign, total, mu, gather=False)
+    torch.cuda.synchronize()
+    sharding.barrier()
+    t0 = time.perf_counter()
+    gsig = sharding.gather_slabs(sig, total)
+    torch.cuda.synchronize()
+    out["signatures_per_s"] = total / (out["sign_ms_per_rank_slice"] * 1e-3)
+    out["signature_gather_ms"] = sharding.max_over_ranks((time.perf_counter() - t0) * 1e3)
+    out["signature_gather_bytes"] = int(gsig.numel())
+    lo = 0 if world == 1 else (total // 2)
+    vd = api.verify_sig(pk, gsig[lo:lo + 2048].contiguous(), mu[lo:lo + 2048].contiguous(), 5, shared_pk=True)
+    out["gathered_signatures_verify"] = int(vd.abs().sum()) == 0
+    return out
 
 
 if __name__ == "__main__":

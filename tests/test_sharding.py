@@ -78,3 +78,91 @@ def test_two_rank_gloo_shard_and_gather(n_items, oracle):
     y = splitmix64_polys(n_items * 5, seed=7).reshape(n_items, 5, 256)
     assert (got_mv == oracle.matvec(6, 5, A, y, shared_A=True)).all()
     assert t == 2.0
+
+
+def _worker_sign_slabs(rank, world, port, n_items, q):
+    """configs[4] shape: the sign inner loop's (z, h, flag) slabs, tuple-valued fn, ragged batch, gathered on gloo"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle.oracle import Oracle
+    o = Oracle()
+    sharding.init_distributed("gloo")
+    c, y, w0, w1, s1h, s2h, t0h = _sign_inputs(n_items)
+
+    def fn(cc, yy, ww0, ww1):
+        z, h, f = o.sign_phase2(2, cc.numpy(), yy.numpy(), ww0.numpy(), ww1.numpy(), s1h, s2h, t0h)
+        return torch.from_numpy(z), torch.from_numpy(h), torch.from_numpy(f)
+
+    z, h, f = sharding.run_sharded(fn, n_items, *(torch.from_numpy(x) for x in (c, y, w0, w1)))
+    if rank == 0:
+        q.put((z.numpy(), h.numpy(), f.numpy()))
+    sharding.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _sign_inputs(n):
+    from oracle.oracle import Oracle, splitmix64_polys, Q
+    o = Oracle()
+    K = L = 4
+    rng = np.random.default_rng(11)
+    g1 = 1 << 17
+    y = np.mod(rng.integers(-(g1 - 1), g1 + 1, (n, L, 256)), Q).astype(np.int32)
+    A = splitmix64_polys(K * L, seed=3).reshape(1, K, L, 256)
+    w1, w0 = o.sign_phase1(2, A, y)
+    c = np.zeros((n, 256), np.int32)
+    c[:, ::7] = 1
+    c[:, 3::11] = Q - 1
+    s1h = o.ntt(np.mod(rng.integers(-2, 3, (1, L, 256)), Q).astype(np.int32))
+    s2h = o.ntt(np.mod(rng.integers(-2, 3, (1, K, 256)), Q).astype(np.int32))
+    t0h = o.ntt(np.mod(rng.integers(-4095, 4097, (1, K, 256)), Q).astype(np.int32))
+    return c, y, w0, w1, s1h, s2h, t0h
+
+
+def test_two_rank_gloo_sign_slabs(oracle):
+    n_items = 21
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sign_slabs, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    z, h, f = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    c, y, w0, w1, s1h, s2h, t0h = _sign_inputs(n_items)
+    oz, oh, of = oracle.sign_phase2(2, c, y, w0, w1, s1h, s2h, t0h)
+    assert (z == oz).all() and (h == oh).all() and (f == of).all()
+
+
+@pytest.mark.gpu
+def test_run_sharded_with_hip_compute_single_rank(gpu, oracle):
+    """the sharding harness around HIP compute (what bench.py --gpus N runs on every rank), world size 1: slices, the
+    level-5 sign phases on the GPU, (z, h, flag) slabs 'gathered' -- against the oracle"""
+    from dilithium_amd import api
+    from oracle import dilithium_kat as dk
+    from oracle.oracle import splitmix64_polys, Q
+    level, K, L, n = 5, 8, 7, 2304
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(9)
+    A = splitmix64_polys(K * L, seed=8).reshape(1, K, L, 256)
+    y = np.mod(rng.integers(-(p.gamma1 - 1), p.gamma1 + 1, (n, L, 256)), Q).astype(np.int32)
+    c = np.zeros((n, 256), np.int32)
+    c[:, ::5] = 1
+    c[:, 1::9] = Q - 1
+    s1h = oracle.ntt(np.mod(rng.integers(-p.eta, p.eta + 1, (1, L, 256)), Q).astype(np.int32))
+    s2h = oracle.ntt(np.mod(rng.integers(-p.eta, p.eta + 1, (1, K, 256)), Q).astype(np.int32))
+    t0h = oracle.ntt(np.mod(rng.integers(-4095, 4097, (1, K, 256)), Q).astype(np.int32))
+    d = lambda a: gpu.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    dA, ds1, ds2, dt0 = d(A), d(s1h), d(s2h), d(t0h)
+
+    def fn(yy, cc):
+        w1, w0 = api.sign_phase1(dA, yy.contiguous(), level, shared_key=True)
+        return api.sign_phase2(cc.contiguous(), yy.contiguous(), w0, w1, ds1, ds2, dt0, level, shared_key=True)
+
+    z, h, f = sharding.run_sharded(fn, n, d(y), d(c))
+    ow1, ow0 = oracle.sign_phase1(level, A, y)
+    oz, oh, of = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
+    assert (f.cpu().numpy() == of).all() and (z.cpu().numpy() == oz).all() and (h.cpu().numpy() == oh).all()
