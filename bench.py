@@ -453,12 +453,14 @@ def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
     total = per * world
     gq = torch.Generator(device="cuda").manual_seed(4242)          # same on every rank: one logical batch
     rnd = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=gq)  # noqa: E731
-    A5, s1h, s2h, t0h = rnd(1, K5, L5, 256), rnd(1, L5, 256), rnd(1, K5, 256), rnd(1, K5, 256)
+    small = lambda lo, hi, *sh: (torch.randint(lo, hi + 1, sh, dtype=torch.int64, device="cuda", generator=gq) % 8380417).to(torch.int32)  # noqa: E731
+    A5 = rnd(1, K5, L5, 256)
+    s1h, s2h, t0h = small(-2, 2, 1, L5, 256), small(-2, 2, 1, K5, 256), small(-4095, 4096, 1, K5, 256)   # eta = 2, d = 13
+    for t in (s1h, s2h, t0h):
+        api.ntt(t)
     g1 = 1 << 19
-    y = (torch.randint(-(g1 - 1), g1 + 1, (total, L5, 256), dtype=torch.int64, device="cuda", generator=gq) % 8380417).to(torch.int32)
-    cc = torch.zeros((total, 256), dtype=torch.int32, device="cuda")
-    cc[:, ::5] = 1
-    cc[:, 1::9] = 8380416
+    y = small(-(g1 - 1), g1, total, L5, 256)
+    cc = api.sample_in_ball(torch.randint(0, 256, (total, 32), dtype=torch.uint8, device="cuda", generator=gq), 5)
     out = {}
 
     def attempt(ys, cs):

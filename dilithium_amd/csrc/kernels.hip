@@ -24,6 +24,16 @@
 
 namespace dil {
 
+// cache-policy A/B hooks of the standalone transforms (scripts/ab_verify.py --kind ntt): the strided 256-byte-per-instruction
+// accesses (forward loads, inverse stores) can be built with the default policy instead of non-temporal
+#ifdef DIL_NTT_STRIDED_PLAIN
+__device__ __forceinline__ int32_t ld_s(const int32_t* p) { return *p; }
+__device__ __forceinline__ void st_s(int32_t* p, int32_t v) { *p = v; }
+#else
+__device__ __forceinline__ int32_t ld_s(const int32_t* p) { return ld_nt(p); }
+__device__ __forceinline__ void st_s(int32_t* p, int32_t v) { st_nt(p, v); }
+#endif
+
 // ---------------------------------------------------------------------------------------
 // address translation of the hardware model's `bram` (address_encoder_decoder.cpp:34-55)
 // ---------------------------------------------------------------------------------------
@@ -99,14 +109,14 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
     }
     int32_t nxt[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++) nxt[m] = ld_nt(polys + wave * 256 + off[m]);
+    for (int m = 0; m < 4; m++) nxt[m] = ld_s(polys + wave * 256 + off[m]);
     tw.load(tw_tab, lane);
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
         const size_t pn = p + nwaves;
         if (pn < batch) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) nxt[m] = ld_nt(polys + pn * 256 + off[m]);
+            for (int m = 0; m < 4; m++) nxt[m] = ld_s(polys + pn * 256 + off[m]);
         }
         ntt_fwd_core(r, tw, lm);
         st_nt4(polys + p * 256 + out_off, canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ poly
             continue;
         }
 #pragma unroll
-        for (int m = 0; m < 4; m++) st_nt(polys + p * 256 + off[m], (int32_t)canon_small(r[m]));
+        for (int m = 0; m < 4; m++) st_s(polys + p * 256 + off[m], (int32_t)canon_small(r[m]));
     }
 }
 

@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--level", type=int, default=3)
 ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--shared", action="store_true")
-ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1", "sign2"])
+ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1", "sign2", "ntt"])
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("libs", nargs="+")
@@ -45,10 +45,13 @@ nk = 1 if a.shared else n
 s1h, s2h, t0h = rnd(nk, L, 256), rnd(nk, K, 256), rnd(nk, K, 256)
 w1in = torch.randint(0, 16, (n, K, 256), dtype=torch.uint8, device="cuda", generator=g)
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+nttb = [rnd(65536, 256) for _ in range(8)] if a.kind == "ntt" else []
 libs = []
 for path in a.libs:
     L_ = C.CDLL(_build.LIB if path == "default" else os.path.abspath(path))
     L_.dil_verify_core_dev.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+    L_.dil_ntt_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L_.dil_invntt_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L_.dil_matvec_dev.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
     L_.dil_sign_phase1_dev.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
     L_.dil_sign_phase2_dev.argtypes = [C.c_void_p] * 10 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
@@ -65,7 +68,10 @@ def run(L_, reps):
     for i in range(reps):
         A, z, c, t1, h = sets[i & 1]
         sh = 1 if a.shared else 0
-        if a.kind == "verify":
+        if a.kind == "ntt":
+            b = nttb[i & 7]
+            rc = L_.dil_ntt_dev(p(b), 65536, None) | L_.dil_invntt_dev(p(b), 65536, None)
+        elif a.kind == "verify":
             rc = L_.dil_verify_core_dev(p(w1), p(A), p(z), p(c), p(t1), p(h), a.level, n, sh, None)
         elif a.kind == "matvec":
             rc = L_.dil_matvec_dev(p(w), p(A), p(z), a.level, n, sh, None)
@@ -80,7 +86,7 @@ ref = None
 for name, L_ in libs:            # all builds must agree bit for bit
     run(L_, 2)
     torch.cuda.synchronize()
-    out = {"verify": w1, "matvec": w, "sign1": w0, "sign2": zo}[a.kind].clone()
+    out = {"verify": w1, "matvec": w, "sign1": w0, "sign2": zo, "ntt": nttb[0] if nttb else w1}[a.kind].clone()
     if ref is None:
         ref = out
     if "_no" not in name:            # ablation builds (libdil256_no*.so) compute something else on purpose
