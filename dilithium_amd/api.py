@@ -390,6 +390,47 @@ def sign(sk, mu, level, shared_sk=False, max_attempts=512):
     return sig, att
 
 
+# ---- messages in, not digests: mu = SHAKE256(tr || M) on the device ---------------------------------------------------
+def pack_messages(msgs, device="cuda"):
+    """list of bytes -> (blob uint8 [sum len], offsets int64 [B], lengths int32 [B]) device tensors (ragged batch)"""
+    lens = np.array([len(m) for m in msgs], dtype=np.int32)
+    offs = np.zeros(len(msgs), dtype=np.int64)
+    offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+    blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8).copy()
+    return torch.from_numpy(blob).to(device), torch.from_numpy(offs).to(device), torch.from_numpy(lens).to(device)
+
+
+def mu(tr, blob, offsets, lengths):
+    """mu uint8 [B,64] = SHAKE256(tr_i || M_i); tr uint8 [B,32] or [1,32] (one tr for the batch)"""
+    B = lengths.shape[0]
+    out = torch.empty((B, 64), dtype=torch.uint8, device=blob.device)
+    stride = 0 if tr.shape[0] == 1 and B > 1 else tr.stride(0)
+    _lib.check(_lib.load().dil_mu_dev(_dev(out, torch.uint8), C.c_void_p(tr.data_ptr()), stride, _dev(blob, torch.uint8),
+                                      _dev(offsets, torch.int64), _dev(lengths, torch.int32), B, _stream()), "dil_mu_dev")
+    return out
+
+
+def sign_msg(sk, blob, offsets, lengths, level, shared_sk=False, max_attempts=512):
+    """deterministic signing of ragged messages: (sig uint8 [B,sig_bytes], attempts int32 [B])"""
+    B = lengths.shape[0]
+    sig = torch.empty((B, sig_bytes(level)), dtype=torch.uint8, device=blob.device)
+    att = torch.empty((B,), dtype=torch.int32, device=blob.device)
+    _lib.check(_lib.load().dil_sign_msg_dev(_dev(sig, torch.uint8), _dev(att, torch.int32), _dev(sk, torch.uint8), _dev(blob, torch.uint8),
+                                            _dev(offsets, torch.int64), _dev(lengths, torch.int32), level, B, int(shared_sk),
+                                            max_attempts, _stream()), "dil_sign_msg_dev")
+    return sig, att
+
+
+def verify_msg(pk, sig, blob, offsets, lengths, level, shared_pk=False):
+    """verification of (pk, M, sig): verdict int32 [B], 0 = accept"""
+    B = sig.shape[0]
+    verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
+    _lib.check(_lib.load().dil_verify_msg_dev(_dev(verdict, torch.int32), _dev(pk, torch.uint8), _dev(sig, torch.uint8),
+                                              _dev(blob, torch.uint8), _dev(offsets, torch.int64), _dev(lengths, torch.int32),
+                                              level, B, int(shared_pk), _stream()), "dil_verify_msg_dev")
+    return verdict
+
+
 # ---- host-buffer forms (numpy uint8 arrays in, numpy out) ---------------------------------------------
 def _np8(a, cols=None):
     if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags.c_contiguous and a.ndim == 2):

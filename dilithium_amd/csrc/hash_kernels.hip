@@ -266,6 +266,81 @@ __global__ __launch_bounds__(HASH_BS) void challenge_hash_kernel(uint64_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// mu[i] = SHAKE256(tr[i] (32 B) || M_i, 64) for RAGGED messages: M_i = msgs[offsets[i] .. + lengths[i]), any alignment.
+// What the reference's top level absorbs itself: rtl_src/expandmask_ext.v:131-185, bus order (mlen, tr, m)
+// rtl_tb/tb_sign_top.v:57-69, tb_verify_top.v:58-68.  One sponge per lane; every lane walks its own message 8 bytes
+// at a time with static state indices (a lane's predicate selects "full word", "last partial word + pad" or "done");
+// the wave runs as many permutations as its longest message needs, a lane latches its digest after its own last one.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld_u64u(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__global__ __launch_bounds__(HASH_BS) void mu_kernel(uint64_t* __restrict__ mu, const uint8_t* __restrict__ tr, size_t tr_stride,
+                                                     const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ lengths, size_t batch)
+{
+    const size_t i = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
+    const bool live = i < batch;
+    Shake<17> sp;
+    sp.init();
+    const uint8_t* mp = msgs;
+    uint32_t rem = 0;
+    if (live) {
+        const uint64_t* t = reinterpret_cast<const uint64_t*>(tr + i * tr_stride);
+#pragma unroll
+        for (int w = 0; w < 4; w++) sp.s[w] = t[w];
+        mp = msgs + offsets[i];
+        rem = lengths[i];
+    }
+    bool padded = !live, finished = !live;
+    uint64_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int first = 4;                                   // the first block already holds tr in words 0..3
+    while (true) {
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+            if (w < first || padded) continue;
+            if (rem >= 8) {
+                sp.s[w] ^= ld_u64u(mp);
+                mp += 8;
+                rem -= 8;
+            } else {                                  // the message ends inside this word: its bytes, then the SHAKE suffix
+                uint64_t v = 0;
+                for (uint32_t b = 0; b < rem; b++) v |= (uint64_t)mp[b] << (8 * b);
+                v |= 0x1Full << (8 * rem);
+                sp.s[w] ^= v;
+                sp.s[16] ^= 0x8000000000000000ull;
+                rem = 0;
+                padded = true;
+            }
+        }
+        first = 0;
+        keccak_f1600(sp.s);
+        if (padded && !finished) {
+#pragma unroll
+            for (int w = 0; w < 8; w++) out[w] = sp.s[w];
+            finished = true;
+        }
+        if (__all(finished)) break;
+    }
+    if (live) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) mu[i * 8 + w] = out[w];
+    }
+}
+
+hipError_t launch_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, const uint64_t* offsets,
+                     const uint32_t* lengths, size_t batch, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(mu_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint64_t*>(mu), tr, tr_stride, msgs,
+                       offsets, lengths, batch);
+    return hipGetLastError();
+}
+
 // verdict[i] = 2 if ||z_i||_inf >= bound else 0 (norm_check.v:84-105 on canonical residues); one wave per item
 __global__ __launch_bounds__(256) void z_norm_kernel(int32_t* __restrict__ verdict, const int32_t* __restrict__ z, int npolys,
                                                      uint32_t bound, size_t batch)

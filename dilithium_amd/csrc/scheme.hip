@@ -427,17 +427,12 @@ int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t
     return ws.close((int)dil::launch_verify_wire(level, w1_packed, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
 }
 
-int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
-                       int shared_pk, void* stream)
+namespace {
+// wire-format verification on a caller-provided scratch (dil_verify_sig_dev, dil_verify_msg_dev)
+int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t* verdict, const uint8_t* pk, const uint8_t* sig,
+                    const uint8_t* mu, int level, const LevelPar& p, size_t batch, int shared_pk, hipStream_t s)
 {
-    LevelPar p;
     int rc;
-    if ((rc = level_par(level, &p))) return rc;
-    DIL_ENTER(dv, T);
-    if (batch == 0) return 0;
-    if ((reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // read as 64-bit words
-    hipStream_t s = S(stream);
-    StreamScratch ws(dv, s);
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_pk ? 1 : batch;
     const size_t w1b = (size_t)p.K * (level == 2 ? 192 : 128);
@@ -454,7 +449,7 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
         DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
         if ((rc = ax.join())) return rc;
         DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
-        return ws.close((int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb));
+        return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
     }
     int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
     int32_t* t1 = ws.take<int32_t>(nk * p.K * 256);
@@ -482,8 +477,24 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     DIL_TRY(dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, T, s));
     DIL_TRY(dil::launch_pack_w1(w1p, w1, level, batch, T, s));
     DIL_TRY(dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, ct, batch, s));
-    return ws.close((int)dil::launch_or_flag(verdict, bad, 4, batch, T, s));
+    return (int)dil::launch_or_flag(verdict, bad, 4, batch, T, s);
 }
+}  // namespace
+
+int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                       int shared_pk, void* stream)
+{
+    LevelPar p;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
+    if (batch == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // read as 64-bit words
+    hipStream_t s = S(stream);
+    StreamScratch ws(dv, s);
+    return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s));
+}
+
 
 // ---- row N3: the whole signing rejection loop on the device ---------------------------------------
 // combined_top.v's sign FSMs (:1694-2229) retry one signature until it passes.  A batch engine is
@@ -492,19 +503,12 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
 // the first accepted attempt of an item wins, which is exactly the signature the sequential loop
 // produces.  The pending set shrinks geometrically while S grows, so the loop needs ~5 rounds
 // instead of the ~35 the unluckiest signature of a large batch takes.
-int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
-                 int max_attempts, void* stream)
+namespace {
+int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu,
+              int level, const LevelPar& p, size_t batch, int shared_sk, int max_attempts, hipStream_t s)
 {
-    LevelPar p;
     int rc;
-    if ((rc = level_par(level, &p))) return rc;
-    DIL_ENTER(dv, T);
-    if (batch == 0) return 0;
-    if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
-    if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // hashed as 64-bit words
     if (batch == 1) shared_sk = 1;
-    hipStream_t s = S(stream);
-    StreamScratch ws(dv, s);
     const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), sb = (size_t)32 * p.eta_bits, zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
     // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
@@ -613,7 +617,85 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
         idx_cur = idx_next;
         idx_next = idx_cur == idx0 ? idx1 : idx0;
     }
-    return ws.close(n == 0 ? 0 : DIL_ERR_UNFINISHED);
+    return n == 0 ? 0 : DIL_ERR_UNFINISHED;
+}
+}  // namespace
+
+int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                 int max_attempts, void* stream)
+{
+    LevelPar p;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
+    if (batch == 0) return 0;
+    if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(mu)) & 7) return (int)hipErrorInvalidValue;   // hashed as 64-bit words
+    hipStream_t s = S(stream);
+    StreamScratch ws(dv, s);
+    return ws.close(sign_core(dv, T, ws, sig, attempts, sk, mu, level, p, batch, shared_sk, max_attempts, s));
+}
+
+// ---- message hashing on the device: mu = SHAKE256(tr || M, 64) for ragged M, then the operations on (key, M[, sig]) ----
+// What the reference's top level absorbs itself (rtl_src/expandmask_ext.v:131-185; bus order mlen, tr, m in
+// rtl_tb/tb_sign_top.v:57-69 and tb_verify_top.v:58-68).
+namespace {
+int check_msgs(const uint8_t* msgs, const uint64_t* offsets, const uint32_t* lengths)
+{
+    if (!msgs || !offsets || !lengths) return (int)hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(offsets) & 7) || (reinterpret_cast<uintptr_t>(lengths) & 3)) return (int)hipErrorInvalidValue;
+    return 0;
+}
+}  // namespace
+
+int dil_mu_dev(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, const uint64_t* offsets, const uint32_t* lengths,
+               size_t batch, void* stream)
+{
+    int rc;
+    if ((rc = check_msgs(msgs, offsets, lengths))) return rc;
+    if ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(tr) | tr_stride) & 7) return (int)hipErrorInvalidValue;
+    DIL_ENTER(dv, T);
+    return (int)dil::launch_mu(mu, tr, tr_stride, msgs, offsets, lengths, batch, S(stream));
+}
+
+int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* msgs, const uint64_t* offsets,
+                     const uint32_t* lengths, int level, size_t batch, int shared_sk, int max_attempts, void* stream)
+{
+    LevelPar p;
+    int rc;
+    if ((rc = level_par(level, &p)) || (rc = check_msgs(msgs, offsets, lengths))) return rc;
+    DIL_ENTER(dv, T);
+    if (batch == 0) return 0;
+    if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
+    if (reinterpret_cast<uintptr_t>(sk) & 7) return (int)hipErrorInvalidValue;
+    hipStream_t s = S(stream);
+    StreamScratch ws(dv, s);
+    uint8_t* mu = ws.take<uint8_t>(batch * 64);
+    if (ws.rc) return ws.rc;
+    // tr sits at byte 64 of the secret key (rho | key | tr | ...)
+    DIL_TRY(dil::launch_mu(mu, sk + 64, (shared_sk || batch == 1) ? 0 : dil_sk_bytes(level), msgs, offsets, lengths, batch, s));
+    return ws.close(sign_core(dv, T, ws, sig, attempts, sk, mu, level, p, batch, shared_sk, max_attempts, s));
+}
+
+int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* offsets,
+                       const uint32_t* lengths, int level, size_t batch, int shared_pk, void* stream)
+{
+    LevelPar p;
+    int rc;
+    if ((rc = level_par(level, &p)) || (rc = check_msgs(msgs, offsets, lengths))) return rc;
+    DIL_ENTER(dv, T);
+    if (batch == 0) return 0;
+    if (reinterpret_cast<uintptr_t>(pk) & 7) return (int)hipErrorInvalidValue;
+    hipStream_t s = S(stream);
+    StreamScratch ws(dv, s);
+    const size_t nk = shared_pk ? 1 : batch, pkb = dil_pk_bytes(level);
+    uint8_t* tr = ws.take<uint8_t>(nk * 32);
+    uint8_t* mu = ws.take<uint8_t>(batch * 64);
+    if (ws.rc) return ws.rc;
+    // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level), then mu = SHAKE256(tr || M, 64)
+    DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, nk, s));
+    DIL_TRY(dil::launch_mu(mu, tr, shared_pk ? 0 : 32, msgs, offsets, lengths, batch, s));
+    return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s));
 }
 
 // ---- host-buffer forms of the whole operations (H2D -> device call -> D2H on the null stream) --------

@@ -63,6 +63,9 @@ SIGNATURES = {
     "dil_verify_sig_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_verify_wire_core_dev": [_vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
+    "dil_mu_dev": [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp],
+    "dil_sign_msg_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
+    "dil_verify_msg_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_keygen_host": [_vp, _vp, _vp, C.c_int, _sz],
     "dil_sign_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int],
     "dil_verify_sig_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int],

@@ -173,7 +173,7 @@ size_t dil_pk_bytes(int level);
 size_t dil_sk_bytes(int level);
 size_t dil_sig_bytes(int level);
 /* wire-format verification: verdict[i] = 0 accept; bit0 challenge mismatch, bit1 ||z|| bound, bit2 malformed hint.
- * mu [batch][64] = SHAKE256(tr || message) (message hashing stays with the caller); shared_pk: one pk for all */
+ * mu [batch][64] = SHAKE256(tr || message) (dil_mu_dev / dil_verify_msg_dev hash the message on the device); shared_pk: one pk for all */
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                        int shared_pk, void* stream);
 
@@ -193,6 +193,20 @@ int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t
 #define DIL_ERR_UNFINISHED (-2)
 int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
                  int max_attempts, void* stream);
+
+/* ---- messages in, not digests: mu = SHAKE256(tr || M, 64) on the device --------------------------------------------------
+ * The reference's top level absorbs (mlen, tr, m) itself (rtl_src/expandmask_ext.v:131-185; bus order rtl_tb/tb_sign_top.v:57-69,
+ * tb_verify_top.v:58-68; its KAT messages are 33 ... 3300 bytes).  Messages are RAGGED: one byte blob `msgs` plus, per item,
+ * offsets[i] (uint64, byte offset into the blob) and lengths[i] (uint32); any alignment, zero length allowed.
+ * dil_mu_dev:         mu[i] (64 B, 8-byte aligned) from tr at tr + i * tr_stride (32 B, 8-byte aligned; stride 0 = one tr)
+ * dil_sign_msg_dev:   dil_sign_dev on (sk, M): tr is read from the secret key
+ * dil_verify_msg_dev: dil_verify_sig_dev on (pk, M, sig): tr = SHAKE256(pk) is computed on the device first */
+int dil_mu_dev(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, const uint64_t* offsets, const uint32_t* lengths,
+               size_t batch, void* stream);
+int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* msgs, const uint64_t* offsets,
+                     const uint32_t* lengths, int level, size_t batch, int shared_sk, int max_attempts, void* stream);
+int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* offsets,
+                       const uint32_t* lengths, int level, size_t batch, int shared_pk, void* stream);
 
 /* host-buffer forms of the three whole operations (what the reference's test benches tb_keygen_top.v / tb_sign_top.v /
  * tb_verify_top.v stream through the 64-bit port): H2D, the device call, D2H; synchronous */

@@ -18,7 +18,7 @@ if has cover; then
   cd /tmp
   timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_cover -o cover -- python -m pytest $GRAFT_REPO_ROOT/tests/test_gpu_dispatch_parity.py \
       $GRAFT_REPO_ROOT/tests/test_gpu_pipelines.py $GRAFT_REPO_ROOT/tests/test_gpu_codecs.py $GRAFT_REPO_ROOT/tests/test_gpu_hash.py \
-      $GRAFT_REPO_ROOT/tests/test_gpu_ntt.py $GRAFT_REPO_ROOT/tests/test_gpu_wire.py -m gpu -x -q -p no:cacheprovider > $OUT/${TAG}_cover.log 2>&1
+      $GRAFT_REPO_ROOT/tests/test_gpu_ntt.py $GRAFT_REPO_ROOT/tests/test_gpu_wire.py $GRAFT_REPO_ROOT/tests/test_gpu_msg.py -m gpu -x -q -p no:cacheprovider > $OUT/${TAG}_cover.log 2>&1
   echo "cover exit $?" >> $OUT/${TAG}_cover.log
   cd $GRAFT_REPO_ROOT
   python scripts/kernel_coverage.py $OUT/${TAG}_cover/cover_results.db > $OUT/${TAG}_pytest_kernel_coverage.txt 2>&1
