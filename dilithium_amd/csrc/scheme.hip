@@ -444,9 +444,14 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         uint32_t* cbits = ws.take<uint32_t>(batch * 64);
         uint8_t* w1p = ws.take<uint8_t>(batch * w1b);
         if (ws.rc) return ws.rc;
+        // Two independent Keccak jobs: ExpandA (nk * K * L sponges) and SampleInBall (batch sponges, one lane each).  The
+        // smaller one is latency-bound and goes to the helper stream, under the larger one.
         AuxFork ax(dv, s);
-        DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, ax.fork(nk * p.K * p.L)));
-        DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
+        const size_t a_sponges = nk * p.K * p.L;
+        hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;
+        hipStream_t sc = a_sponges <= batch ? s : ax.fork(batch);
+        DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, sa));
+        DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, sc));
         if ((rc = ax.join())) return rc;
         DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
         return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);

@@ -69,6 +69,11 @@ SIGNATURES = {
     "dil_keygen_host": [_vp, _vp, _vp, C.c_int, _sz],
     "dil_sign_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int],
     "dil_verify_sig_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int],
+    "dil_shard_range": [_sz, C.c_int, C.c_int, C.POINTER(_sz), C.POINTER(_sz)],
+    "dil_ntt_multi_host": [_i32p, _sz, C.c_int, C.c_int],
+    "dil_keygen_multi_host": [_vp, _vp, _vp, C.c_int, _sz, C.c_int],
+    "dil_sign_multi_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, C.c_int],
+    "dil_verify_sig_multi_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int],
     "dil_verify_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_attempt_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_event_create": [C.POINTER(_vp)],
@@ -78,7 +83,7 @@ SIGNATURES = {
     "dil_stream_sync": [_vp],
 }
 _RESTYPE = {"dil_error_string": C.c_char_p, "dil_host_twiddle_tables": None, "dil_host_zetas": None,
-            "dil_pk_bytes": C.c_size_t, "dil_sk_bytes": C.c_size_t, "dil_sig_bytes": C.c_size_t}
+            "dil_shard_range": None, "dil_pk_bytes": C.c_size_t, "dil_sk_bytes": C.c_size_t, "dil_sig_bytes": C.c_size_t}
 
 _lib = None
 

@@ -216,6 +216,17 @@ int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint
 int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                         int shared_pk);
 
+/* ---- all GPUs of the node from one C++ process: contiguous slices [g*B/G, (g+1)*B/G) of a HOST batch, one host
+ * thread per device running the single-device host-pointer entry point on its slice; ndev <= 0 = every visible device.
+ * dil_shard_range gives the slice of `rank` (sizes differ by at most one item; same rule as dilithium_amd/sharding.py). */
+void dil_shard_range(size_t n_items, int rank, int world, size_t* lo, size_t* hi);
+int dil_ntt_multi_host(int32_t* polys, size_t batch, int inverse, int ndev);
+int dil_keygen_multi_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch, int ndev);
+int dil_sign_multi_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
+                        int max_attempts, int ndev);
+int dil_verify_sig_multi_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
+                              int shared_pk, int ndev);
+
 /* ---- SURVEY 8(f) row N3 (first step): whole verify / sign-attempt sequences as ONE call --------
  * Everything between the wire-format codecs runs on the device, on `stream`, with no host round trip;
  * temporaries come from the stream-ordered allocator (hipMallocAsync) and are freed on the stream.

@@ -166,3 +166,45 @@ def test_run_sharded_with_hip_compute_single_rank(gpu, oracle):
     ow1, ow0 = oracle.sign_phase1(level, A, y)
     oz, oh, of = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
     assert (f.cpu().numpy() == of).all() and (z.cpu().numpy() == oz).all() and (h.cpu().numpy() == oh).all()
+
+
+def test_c_abi_shard_range_matches_python():
+    """dil_shard_range (the C++ multi-GPU host layer, csrc/multi_gpu.hip) cuts the same slices as sharding.shard_range"""
+    import ctypes as C
+    from dilithium_amd import lib as dlib
+    L = dlib.load()
+    for n in (0, 1, 7, 8, 100, 65536, 8191):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lo, hi = C.c_size_t(), C.c_size_t()
+                L.dil_shard_range(n, r, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == sharding.shard_range(n, r, world)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_host_layer(gpu, oracle, kat_msgs):
+    """the C++ host layer over every visible device (one here): NTT of a ragged host batch vs the oracle, and KAT
+    sign / verify through dil_sign_multi_host / dil_verify_sig_multi_host"""
+    import ctypes as C
+    import hashlib
+    from dilithium_amd import lib as dlib
+    from oracle.oracle import splitmix64_polys
+    from tests.test_gpu_codecs import kat_wire
+    L = dlib.load()
+    a = splitmix64_polys(1001, seed=3)
+    b = a.copy()
+    dlib.check(L.dil_ntt_multi_host(b.ctypes.data_as(C.POINTER(C.c_int32)), 1001, 0, 0))
+    assert (b == oracle.ntt(a)).all()
+    dlib.check(L.dil_ntt_multi_host(b.ctypes.data_as(C.POINTER(C.c_int32)), 1001, 1, 1))
+    assert (b == a).all()
+    k, pk, sk, sig = kat_wire(3)
+    mu = np.stack([np.frombuffer(hashlib.shake_256(k["tr"][i].tobytes() + kat_msgs[i]).digest(64), dtype=np.uint8) for i in range(100)])
+    pk, sk = np.ascontiguousarray(pk), np.ascontiguousarray(sk)
+    got = np.zeros_like(sig)
+    att = np.zeros(100, np.int32)
+    vp = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
+    dlib.check(L.dil_sign_multi_host(vp(got), vp(att), vp(sk), vp(mu), 3, 100, 0, 512, 0))
+    assert (got == sig).all() and (att == k["attempts"]).all()
+    v = np.ones(100, np.int32)
+    dlib.check(L.dil_verify_sig_multi_host(vp(v), vp(pk), vp(got), vp(mu), 3, 100, 0, 0))
+    assert (v == 0).all()
