@@ -162,3 +162,25 @@ def test_fused_and_unfused_wire_verify_agree(gpu, level, shared, kat_msgs):
         api.set_option("fuse_wire", 1)
     assert (out[0] == out[1]).all()
     assert set(np.nonzero(out[1])[0]) == tampered
+
+
+def test_lane_per_sponge_hash_kernels_at_65536(gpu):
+    """batches >= 65536 switch the hash launchers to the lane-per-sponge kernels (shake256_batch_kernel,
+    challenge_hash_kernel -- the two-lane forms serve everything smaller): SHAKE256 vs hashlib on sampled items, and
+    65536 level-2 signatures under one key signed (digest path) and verified (compare path), one of them tampered"""
+    import hashlib
+    from dilithium_amd import api
+    rng = np.random.default_rng(8)
+    n = 65536 + 64
+    data = rng.integers(0, 256, (n, 72), dtype=np.uint8)
+    out = api.shake256(cu(gpu, data), 64).cpu().numpy()
+    for i in list(range(0, n, 4099)) + [n - 1]:
+        assert out[i].tobytes() == hashlib.shake_256(data[i].tobytes()).digest(64)
+    k, pk, sk, _ = kat_wire(2)
+    mu = cu(gpu, rng.integers(0, 256, (65536, 64), dtype=np.uint8))
+    sig, att = api.sign(cu(gpu, sk[:1]), mu, 2, shared_sk=True)
+    assert int(att.min()) >= 1
+    assert int(api.verify_sig(cu(gpu, pk[:1]), sig, mu, 2, shared_pk=True).abs().sum()) == 0
+    sig[65535, 3] ^= 1
+    v = api.verify_sig(cu(gpu, pk[:1]), sig, mu, 2, shared_pk=True).cpu().numpy()
+    assert v[65535] == 1 and int(np.abs(v[:65535]).sum()) == 0
