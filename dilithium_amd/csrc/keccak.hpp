@@ -364,7 +364,78 @@ struct CoeffSink {
                 v.y = (int32_t)ring[(base + 4 * q + 1) * 64];
                 v.z = (int32_t)ring[(base + 4 * q + 2) * 64];
                 v.w = (int32_t)ring[(base + 4 * q + 3) * 64];
+#if defined(DIL_EA_ABL) && DIL_EA_ABL == 3
+                if (v.x == 0x7fffffff) *reinterpret_cast<int4*>(dst + flushed + 4 * q) = v;   // ablation: (almost) never stores
+#else
                 *reinterpret_cast<int4*>(dst + flushed + 4 * q) = v;
+#endif
+            }
+            flushed += CHUNK;
+        }
+    }
+};
+
+// Wave-synchronous variant of the staging above for the one-wave-per-workgroup samplers whose 64 lanes advance almost in
+// step (ExpandA: a lane falls behind only through 0.1 % rejections).  When EVERY lane of the wave has 16 unflushed
+// coefficients the wave writes that chunk for all 64 polynomials TRANSPOSED: lane l stores the 16-byte piece l & 3 of
+// polynomial 16 j + (l >> 2), j = 0..3, so each store instruction writes 16 complete, contiguous 64-byte segments instead
+// of 64 separate 16-byte pieces of 64 different cache lines (measured: the per-lane stores cost ExpandA 70 of its 190 us,
+// profiles/r02_expand_a.txt).  Lanes may run ahead of the slowest by up to RING - CHUNK - 8 coefficients; if one ever gets
+// further (probability ~ 0 for hashed seeds, but it must stay correct) the wave drops to the per-lane flush for good.
+struct CoeffSinkWave {
+    static constexpr int RING = 32, CHUNK = 16;
+    static constexpr int LDS_DWORDS_PER_WAVE = RING * 64;
+    uint32_t* wave_ring;      // [slot][lane]
+    uint32_t* ring;           // wave_ring + lane
+    int32_t* wave_dst;        // polynomial of lane 0 (1 KiB per lane, consecutive)
+    int lane;
+    int live_polys;           // polynomials of this wave that exist (lanes >= live_polys have none)
+    int flushed;              // wave-uniform while `uniform`
+    bool uniform;
+    __device__ __forceinline__ CoeffSinkWave(uint32_t* wr, int ln, int32_t* dst0, int nlive)
+        : wave_ring(wr), ring(wr + ln), wave_dst(dst0), lane(ln), live_polys(nlive), flushed(0), uniform(true) {}
+    __device__ __forceinline__ void flush_if_ready(int cnt)
+    {
+        if (uniform) {
+            if (__all(cnt - flushed >= CHUNK)) {
+                const int base = flushed & (RING - 1), q = lane & 3;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int p = 16 * j + (lane >> 2);
+                    int4 v;
+                    v.x = (int32_t)wave_ring[(base + 4 * q) * 64 + p];
+                    v.y = (int32_t)wave_ring[(base + 4 * q + 1) * 64 + p];
+                    v.z = (int32_t)wave_ring[(base + 4 * q + 2) * 64 + p];
+                    v.w = (int32_t)wave_ring[(base + 4 * q + 3) * 64 + p];
+#if defined(DIL_EA_ABL) && DIL_EA_ABL == 4
+                    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x7fffffff) *reinterpret_cast<int4*>(wave_dst + p * 256 + flushed + 4 * q) = v;   // ablation: all LDS reads, (almost) no stores
+#elif defined(DIL_EA_ABL) && DIL_EA_ABL == 5
+                    if (p < live_polys) *reinterpret_cast<int4*>(wave_dst + (p & 3) * 256 + flushed + 4 * q) = v;   // ablation: all stores, 4 KiB footprint per wave (L2-resident)
+#elif defined(DIL_EA_NT)
+                    if (p < live_polys) {
+                        int32_t* d_ = wave_dst + p * 256 + flushed + 4 * q;
+                        __builtin_nontemporal_store(v.x, d_); __builtin_nontemporal_store(v.y, d_ + 1);
+                        __builtin_nontemporal_store(v.z, d_ + 2); __builtin_nontemporal_store(v.w, d_ + 3);
+                    }
+#else
+                    if (p < live_polys) *reinterpret_cast<int4*>(wave_dst + p * 256 + flushed + 4 * q) = v;
+#endif
+                }
+                flushed += CHUNK;
+            } else if (__any(cnt - flushed > RING - 8)) {
+                uniform = false;                  // a lane is about to lap the ring: per-lane flushing from here on
+            }
+        }
+        if (!uniform && lane < live_polys && cnt - flushed >= CHUNK) {
+            const int base = flushed & (RING - 1);
+#pragma unroll
+            for (int q = 0; q < CHUNK / 4; q++) {
+                int4 v;
+                v.x = (int32_t)ring[(base + 4 * q) * 64];
+                v.y = (int32_t)ring[(base + 4 * q + 1) * 64];
+                v.z = (int32_t)ring[(base + 4 * q + 2) * 64];
+                v.w = (int32_t)ring[(base + 4 * q + 3) * 64];
+                *reinterpret_cast<int4*>(wave_dst + lane * 256 + flushed + 4 * q) = v;
             }
             flushed += CHUNK;
         }

@@ -45,6 +45,8 @@ def main():
             out["ntt_inv_kernel"] = out[key]
         if base(key) in ("verify_wpi_kernel", "verify_kernel") and "<3>" in key:
             out["verify_kernel"] = out[key]
+        if base(key) == "verify_wire_wpi_kernel" and "<3>" in key:
+            out["verify_wire_kernel"] = out[key]
     json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
     for k, d in sorted(out.items()):
         if "hbm_bytes_per_launch" in d:

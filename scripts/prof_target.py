@@ -18,7 +18,8 @@ def main():
     api.init(0)
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randint(0, Q, s, dtype=torch.int32, device="cuda", generator=g)  # noqa: E731
-    if what == "bench":            # exactly the two workloads bench.py times: configs[1] and configs[3] (distinct pk)
+    bench = what == "bench"       # the workloads bench.py times: configs[1], configs[3] (distinct pk), the wire-format verify
+    if bench:
         what = "ntt+verify"
     if what in ("ntt", "all", "ntt+verify"):
         bufs = [rnd(65536, 256) for _ in range(8)]           # 512 MiB rotating: HBM, not LLC
@@ -47,6 +48,16 @@ def main():
         for i in range(2 * reps + 2):
             A, z, c, t1, h = sets[i % 2]
             api.verify_core(A, z, c, t1, h, 3, out=w1)
+    if what == "wire" or bench:     # the fused wire-format verify kernel, distinct pk (bench.py's verify_wire_core leg)
+        n = 8192
+        u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g)  # noqa: E731
+        seed, mu = u8(n, 32), u8(n, 64)
+        pk, sk = api.keygen(seed, 3)
+        sig, _ = api.sign(sk, mu, 3)
+        A = api.expand_a(pk[:, :32].contiguous(), 3)
+        for _ in range(reps):
+            api.verify_wire_core(A, pk, sig, 3)
+            api.verify_sig(pk, sig, mu, 3)
     if what in ("matvec_shared", "matvec"):
         n, K, L = 8192, 6, 5
         A, y = rnd(n if what == "matvec" else 1, K, L, 256), rnd(n, L, 256)
