@@ -9,7 +9,14 @@
 #include "keccak.hpp"
 #include "kernels.hpp"
 
+#include <atomic>
+
 namespace dil {
+
+// Up to this many sponges ExpandMask runs the two-lanes-per-sponge form (1.45 x shorter dependency chain, 1.4 x the
+// instructions).  Measured again in round 2 (scripts/bench_two_lane.py, profiles/r02_sign_round.txt): equal at 10-14 k
+// sponges, the lane-per-sponge form ahead from 33 k on (level 3, 81920 sponges: 93 vs 101 us) -- 16384 stays.
+std::atomic<int> two_lane_max_sponges{16384};
 
 constexpr uint32_t QU = 8380417u;
 
@@ -566,7 +573,7 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
     const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t total = nitems * (size_t)L;
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
-    if (total <= 16384) {        // latency-bound: two lanes per sponge
+    if (total <= (size_t)two_lane_max_sponges.load(std::memory_order_relaxed)) {        // latency-bound: two lanes per sponge
         const int grid = (int)((2 * total + HASH_BS - 1) / HASH_BS);
         if (level == 2) hipLaunchKernelGGL((expand_mask_kernel<18, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
         else hipLaunchKernelGGL((expand_mask_kernel<20, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);

@@ -4,7 +4,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace dil {
+
+extern std::atomic<int> two_lane_max_sponges;      // hash_kernels.hip (option "two_lane_max_sponges")
 
 enum { MAP_NATURAL = 0, MAP_AFTER_NTT = 1, MAP_AFTER_INVNTT = 2 };   // config.h:45-50 (enum MAPPING)
 enum { LAYOUT_POLY = 0, LAYOUT_BRAM = 1 };
