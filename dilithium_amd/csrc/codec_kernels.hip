@@ -298,6 +298,62 @@ __global__ __launch_bounds__(256) void sign_collect_kernel(int32_t* __restrict__
     }
 }
 
+// Start of a signing round in ONE launch (was two gathers, the kappa kernel and a memset): for entry e of pending item
+// i = e / S:  mu_c[e] = mu[item(i)], rp_c[e] = rho'[item(i)] (64 bytes each, as 4 x 16 B per thread), kappa[e] = (a0 + e % S) * L,
+// and the round's two counters are cleared.  gather == false (first round of a full batch, S == 1): only kappa + counters.
+__global__ __launch_bounds__(256) void sign_round_setup_kernel(uint4* __restrict__ mu_c, uint4* __restrict__ rp_c,
+                                                               uint32_t* __restrict__ kappa, int32_t* __restrict__ counts,
+                                                               const uint4* __restrict__ mu, const uint4* __restrict__ rp,
+                                                               const int32_t* __restrict__ idx, uint32_t a0, uint32_t L, uint32_t S,
+                                                               size_t entries, int gather)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < 2) counts[g] = 0;
+    const size_t e = g >> 2, w = g & 3;
+    if (e >= entries) return;
+    if (w == 0) kappa[e] = (a0 + (uint32_t)(e % S)) * L;
+    if (gather) {
+        const size_t i = e / S, item = idx ? (size_t)idx[i] : i;
+        mu_c[g] = mu[item * 4 + w];
+        rp_c[g] = rp[item * 4 + w];
+    }
+}
+
+// End of a signing round, winners' side: sign_collect_kernel's bookkeeping PLUS the copy of the winner's c~ (32 bytes,
+// any alignment) into its signature slot -- one thread per pending item.
+__global__ __launch_bounds__(256) void sign_collect_ct_kernel(int32_t* __restrict__ attempts, int32_t* __restrict__ next_idx,
+                                                              int32_t* __restrict__ win_entry, int32_t* __restrict__ win_item,
+                                                              int32_t* __restrict__ counts, const int32_t* __restrict__ flags,
+                                                              const int32_t* __restrict__ idx, int a0, int S, size_t n,
+                                                              uint8_t* __restrict__ sig, size_t sig_stride, const uint8_t* __restrict__ ct)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t item = idx ? idx[i] : (int32_t)i;
+    int win = -1;
+    for (int j = 0; j < S; j++)
+        if (flags[i * (size_t)S + j] == 0) {
+            win = j;
+            break;
+        }
+    if (win < 0) {
+        next_idx[atomicAdd(&counts[0], 1)] = item;
+    } else {
+        const int w = atomicAdd(&counts[1], 1);
+        const size_t entry = i * (size_t)S + win;
+        win_entry[w] = (int32_t)entry;
+        win_item[w] = item;
+        attempts[item] = a0 + win + 1;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ct + entry * 32);      // scratch: 4-byte aligned
+        uint8_t* dst = sig + (size_t)item * sig_stride;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t v = src[q];
+            __builtin_memcpy(dst + 4 * q, &v, 4);
+        }
+    }
+}
+
 // verdict[i] |= flag[i] ? bit : 0
 __global__ __launch_bounds__(256) void or_flag_kernel(int32_t* __restrict__ verdict, const int32_t* __restrict__ flag, int bit, size_t n)
 {
@@ -354,6 +410,29 @@ hipError_t launch_sign_collect(int32_t* attempts, int32_t* next_idx, int32_t* wi
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(sign_collect_kernel, (int)((n + 255) / 256), 256, 0, s, attempts, next_idx, win_entry, win_item, counts, flags,
                        idx, a0, S, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* counts, const uint8_t* mu, const uint8_t* rp,
+                                   const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, hipStream_t s)
+{
+    if (entries == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(mu_c) | reinterpret_cast<uintptr_t>(rp_c) | reinterpret_cast<uintptr_t>(mu) |
+         reinterpret_cast<uintptr_t>(rp)) & 15)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sign_round_setup_kernel, (int)((entries * 4 + 255) / 256), 256, 0, s, reinterpret_cast<uint4*>(mu_c),
+                       reinterpret_cast<uint4*>(rp_c), kappa, counts, reinterpret_cast<const uint4*>(mu), reinterpret_cast<const uint4*>(rp),
+                       idx, a0, L, S, entries, gather ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_sign_collect_ct(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
+                                  const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, uint8_t* sig, size_t sig_stride,
+                                  const uint8_t* ct, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sign_collect_ct_kernel, (int)((n + 255) / 256), 256, 0, s, attempts, next_idx, win_entry, win_item, counts, flags,
+                       idx, a0, S, n, sig, sig_stride, ct);
     return hipGetLastError();
 }
 

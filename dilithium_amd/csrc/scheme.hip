@@ -591,28 +591,31 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         }
         const size_t E = n * (size_t)S_;
         const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
-        const uint8_t *mur = mu, *rpr = rp;
-        if (!direct) {
-            DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, T, s));
-            DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, T, s));
-            mur = mu_c;
-            rpr = rp_c;
-        }
+        const uint8_t *mur = direct ? mu : mu_c, *rpr = direct ? rp : rp_c;
         dil::KeyMap keys;                                // per-item keys are read in place through the pending list
         keys.idx = idx_cur;
         keys.S = (uint32_t)S_;
-        DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
+        // one launch: gathers of mu / rho' for the entries, kappa = (a0 + e % S) L, counters cleared
+        if (((reinterpret_cast<uintptr_t>(mu)) & 15) == 0) {
+            DIL_TRY(dil::launch_sign_round_setup(mu_c, rp_c, kap, counts, mu, rp, idx_cur, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E,
+                                                 !direct, s));
+        } else {                                         // caller's mu only 8-byte aligned: the generic kernels
+            if (!direct) {
+                DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, T, s));
+                DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, T, s));
+            }
+            DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
+            DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
+        }
         if ((rc = sign_attempt_range(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, 0, E, shared_sk, s, keys, 3,
                                      sign_early)))
             return rc;
-        // winners (first accepted attempt per item) -> packed straight into their signature slots
-        DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
-        DIL_TRY(dil::launch_sign_collect(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, s));
+        // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
+        DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s));
         dil::RowMap win;
         win.src_row = wine;
         win.dst_row = wini;
         win.count = counts + 1;
-        DIL_TRY(dil::launch_copy_field(sig, sgb, 0, ct, 32, 0, 32, n, T, s, win));
         DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, T, s, win));
         DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n, s, win));
         DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
