@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void verify_wire_wpi_kernel(
         const uint8_t* sg = sig + i * sig_stride;
         zr.load(sg + 32, plz);
         cb = cbits[i * 64 + lane];
-        hb0 = sg[32 + W::Z_BYTES + lane];
+        hb0 = (lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + lane] : 0;          // (61 hint bytes at level 3: never read past the signature)
         hb1 = (64 + lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + 64 + lane] : 0;
     };
     if (it < batch) load_item(it);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
         const uint8_t* sg = sig + i * sig_stride;
         zr.load(sg + 32, plz);
         cb = cbits[i * 64 + lane];
-        hb0 = sg[32 + W::Z_BYTES + lane];
+        hb0 = (lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + lane] : 0;          // (61 hint bytes at level 3: never read past the signature)
         hb1 = (64 + lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + 64 + lane] : 0;
     };
     if (it < batch) load_item(it);
