@@ -523,7 +523,13 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     const int sign_waste = dil::rt::cfg.sign_waste.load(std::memory_order_relaxed);
     const bool sign_early = dil::rt::cfg.sign_early.load(std::memory_order_relaxed) != 0;
     // (a round never uses more than batch * s_max entries: a single signature gets 64 entries, not 16384)
-    const size_t cap = std::min<size_t>(std::max<size_t>(batch, opt_cap > 0 ? (size_t)opt_cap : 16384), batch * (size_t)s_max);
+    // default width: about one expected signature's worth of attempts per item in the first round (mean attempts 4.3 / 5.1 /
+    // 3.9 at levels 2 / 3 / 5), between 16384 and 32768 entries -- below that the round's kernels sit on their latency
+    // floors anyway, above it the speculation wastes more than a saved round is worth (scripts/bench_sign_cap.py,
+    // profiles/r02_sign_round.txt: level 3, 8192 messages 1.69 -> 1.57 ms with 24576 entries; 65536 messages: width = batch)
+    const size_t s0 = level == 2 ? 4 : level == 3 ? 3 : 2;
+    const size_t dflt_cap = std::min<size_t>(std::max<size_t>(batch * s0, 16384), 32768);
+    const size_t cap = std::min<size_t>(std::max<size_t>(batch, opt_cap > 0 ? (size_t)opt_cap : dflt_cap), batch * (size_t)s_max);
     ws.secret = true;            // s1^ s2^ t0^, key, rho', y, rejected z: wiped on close when option `zeroize` is set
     // per key
     int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
