@@ -324,7 +324,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
         const uint8_t* hit = h + it * K * 256;
         // row 0 operands fly under the z-phase
         ARow<L> Ar;
-        VW_ALOAD(Ar, Ait, lane, true);
+#ifdef DIL_ABL_AROWMAJOR     // ablation: read the matrix as if it were laid out [k][item][l] (row k of ALL items contiguous)
+#define VW_AROW(k) (A + ((size_t)(k) * batch + it) * (size_t)L * 256)
+#else
+#define VW_AROW(k) (Ait + (size_t)(k) * L * 256)
+#endif
+        VW_ALOAD(Ar, VW_AROW(0), lane, true);
         int32_t tn[4];
         uint32_t hn;
         load_strided<false>(tn, t1it, lane);
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
             for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
             unpack_row_u8(hb, hn, sc, lane);
             if (k + 1 < K) {
-                VW_ALOAD(Ar, Ait + (size_t)(k + 1) * L * 256, lane, true);
+                VW_ALOAD(Ar, VW_AROW(k + 1), lane, true);
                 load_strided<false>(tn, t1it + (k + 1) * 256, lane);
                 hn = load_row_u8(hit + (k + 1) * 256, lane);
             }
