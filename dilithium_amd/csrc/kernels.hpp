@@ -44,7 +44,8 @@ struct KeyMap {
     }
 };
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
-                         size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km = KeyMap());
+                         size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km = KeyMap(),
+                         uint8_t* w1_packed = nullptr);   // OUT_W1W0 only: w1 also written packed (4 | 6 bits), [batch][K * 128|192]
 hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
                          const uint8_t* h, size_t batch, int shared_pk, const Tables& t, hipStream_t s);
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,

@@ -166,9 +166,55 @@ __device__ __forceinline__ void unpack_row_u8(uint32_t (&v)[4], uint32_t packed,
     for (int m = 0; m < 4; m++) v[m] = sc[lane + 64 * m];
 }
 
+// w1 on the wire: 4 bits (levels 3, 5) or 6 bits (level 2) per coefficient (encoder.v:96-133)
+template <int LEVEL>
+struct W1Pack {
+    static constexpr int BITS = LEVEL == 2 ? 6 : 4;
+    static constexpr int ROW_BYTES = 32 * BITS;       // 192 / 128 per polynomial
+};
+
+// w1 row (4 values per lane, strided order) -> packed bit stream, stored coalesced (encoder.v:96-133)
+template <int LEVEL>
+__device__ __forceinline__ void store_row_w1_packed(uint8_t* __restrict__ out_row, const uint32_t (&v)[4], uint32_t* scratch, int lane)
+{
+    uint8_t* sc = reinterpret_cast<uint8_t*>(scratch);
+#pragma unroll
+    for (int m = 0; m < 4; m++) sc[lane + 64 * m] = (uint8_t)v[m];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (W1Pack<LEVEL>::BITS == 4) {
+        if (lane < 32) {                  // 8 coefficients -> one dword
+            const uint32_t a = scratch[2 * lane], b = scratch[2 * lane + 1];
+            uint32_t x = (a | (a >> 4)) & 0x00FF00FFu;
+            x = (x | (x >> 8)) & 0xFFFFu;
+            uint32_t y = (b | (b >> 4)) & 0x00FF00FFu;
+            y = (y | (y >> 8)) & 0xFFFFu;
+            reinterpret_cast<uint32_t*>(out_row)[lane] = x | (y << 16);
+        }
+    } else {
+        if (lane < 16) {                  // 16 coefficients -> 96 bits
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = scratch[4 * lane + i];
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint64_t c = (w[k >> 2] >> (8 * (k & 3))) & 0x3Fu;
+                const int bit = 6 * k;
+                if (bit < 64) lo |= c << bit;
+                if (bit + 6 > 64) hi |= (bit >= 64) ? c << (bit - 64) : c >> (64 - bit);
+            }
+            uint32_t* o = reinterpret_cast<uint32_t*>(out_row) + 3 * lane;
+            o[0] = (uint32_t)lo;
+            o[1] = (uint32_t)(lo >> 32);
+            o[2] = (uint32_t)hi;
+        }
+    }
+}
+
 // Output stage of one mat-vec row: r[] = INTT output (|r| < q, strided order) ->
 //   OUT_W   : w row, canonical int32             (matvec)
-//   OUT_W1W0: w1 = HighBits as bytes, w0 = LowBits as residue in [0,q)  (sign phase 1, DECOMP :1946)
+//   OUT_W1W0: w1 = HighBits as bytes, w0 = LowBits as residue in [0,q)  (sign phase 1, DECOMP :1946); if w_out is not
+//             null in this mode it is the PACKED w1 plane ([rows][W1Pack::ROW_BYTES] bytes)
 template <int LEVEL, int OUT>
 __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out,
                                                 int32_t* __restrict__ w0_out, size_t o, const int32_t (&r)[4],
@@ -189,6 +235,8 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
             ov[m] = (uint32_t)(a0 + (sgn(a0) & Q));
         }
     }
+    if (OUT != OUT_W && w_out)       // sign phase 1: w1 ALSO leaves packed (the challenge hash's input) -- no pack_w1 launch
+        store_row_w1_packed<LEVEL>(reinterpret_cast<uint8_t*>(w_out) + (o >> 8) * W1Pack<LEVEL>::ROW_BYTES, wb, scratch, lane);
     int32_t* dst = (OUT == OUT_W ? w_out : w0_out) + o;
     if (xbuf) {
 #pragma unroll

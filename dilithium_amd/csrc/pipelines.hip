@@ -767,9 +767,10 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
 }
 
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A,
-                         const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km)
+                         const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km, uint8_t* w1_packed)
 {
     if (batch == 0) return hipSuccess;
+    if (out_mode != OUT_W) w = reinterpret_cast<int32_t*>(w1_packed);      // the kernels' w slot carries packed w1 in this mode
 #define DIL_MV(LV)                                                                                       \
     return out_mode == OUT_W ? launch_matvec_level<LV, OUT_W>(w, w1, w0, A, y, batch, shared_A, t, s, km) \
                              : launch_matvec_level<LV, OUT_W1W0>(w, w1, w0, A, y, batch, shared_A, t, s, km)

@@ -210,8 +210,8 @@ int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ct
 {
     if (phases & 1) DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
     if (!(phases & 2)) return 0;
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km));
-    DIL_TRY(dil::launch_pack_w1(t.w1p, t.w1, level, batch, T, s));
+    // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p));
     DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
     DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
     DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,

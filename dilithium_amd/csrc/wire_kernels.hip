@@ -61,8 +61,7 @@ struct PackedLane {
 template <int LEVEL>
 struct Wire {
     static constexpr int ZBITS = LEVEL == 2 ? 18 : 20;
-    static constexpr int W1BITS = LEVEL == 2 ? 6 : 4;
-    static constexpr int W1_ROW_BYTES = 32 * W1BITS;                    // 192 / 128
+    static constexpr int W1_ROW_BYTES = W1Pack<LEVEL>::ROW_BYTES;     // 192 / 128
     static constexpr int Z_BYTES = Par<LEVEL>::L * 32 * ZBITS;
     static constexpr int HINT_BYTES = Par<LEVEL>::OMEGA + Par<LEVEL>::K;
 };
@@ -121,44 +120,6 @@ __device__ __forceinline__ bool hints_to_bitmap(uint32_t* bm, uint32_t* scratch,
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     return __ballot(err) != 0;
-}
-
-// w1 row (4 values per lane, strided order) -> packed bit stream, stored coalesced (encoder.v:96-133)
-template <int LEVEL>
-__device__ __forceinline__ void store_row_w1_packed(uint8_t* __restrict__ out_row, const uint32_t (&v)[4], uint32_t* scratch, int lane)
-{
-    uint8_t* sc = reinterpret_cast<uint8_t*>(scratch);
-#pragma unroll
-    for (int m = 0; m < 4; m++) sc[lane + 64 * m] = (uint8_t)v[m];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (Wire<LEVEL>::W1BITS == 4) {
-        if (lane < 32) {                  // 8 coefficients -> one dword
-            const uint32_t a = scratch[2 * lane], b = scratch[2 * lane + 1];
-            uint32_t x = (a | (a >> 4)) & 0x00FF00FFu;
-            x = (x | (x >> 8)) & 0xFFFFu;
-            uint32_t y = (b | (b >> 4)) & 0x00FF00FFu;
-            y = (y | (y >> 8)) & 0xFFFFu;
-            reinterpret_cast<uint32_t*>(out_row)[lane] = x | (y << 16);
-        }
-    } else {
-        if (lane < 16) {                  // 16 coefficients -> 96 bits
-            uint32_t w[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) w[i] = scratch[4 * lane + i];
-            uint64_t lo = 0, hi = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint64_t c = (w[k >> 2] >> (8 * (k & 3))) & 0x3Fu;
-                const int bit = 6 * k;
-                if (bit < 64) lo |= c << bit;
-                if (bit + 6 > 64) hi |= (bit >= 64) ? c << (bit - 64) : c >> (64 - bit);
-            }
-            uint32_t* o = reinterpret_cast<uint32_t*>(out_row) + 3 * lane;
-            o[0] = (uint32_t)lo;
-            o[1] = (uint32_t)(lo >> 32);
-            o[2] = (uint32_t)hi;
-        }
-    }
 }
 
 // hint bits of row k for the lane's coefficients lane + 64 m
