@@ -158,6 +158,9 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_fast_kernel(int32_t* __restr
     CoeffSinkWave sink(ring, threadIdx.x & 63, A + first * 256, (int)(total - first < 64 ? total - first : 64));
 #endif
     int cnt = 0;
+    // (Tried: staggering the waves' start with s_sleep so that their store bursts do not coincide -- worse, 183 -> 196-260 us;
+    //  issuing the batch as four concurrent launches inside a composite call -- worse, the fork / join barriers cost more than
+    //  the overlap of ramp and tail gives back: verify 283 -> 345 us.  profiles/r02_expand_a.txt)
 #pragma unroll 1
     for (int blk = 0; blk < 4; blk++) {
         keccak_f1600(sp.s);
