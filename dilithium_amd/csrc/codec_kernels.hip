@@ -270,34 +270,6 @@ __global__ __launch_bounds__(256) void sign_kappa_kernel(uint32_t* __restrict__ 
     if (e < entries) kappa[e] = (a0 + (uint32_t)(e % S)) * L;
 }
 
-// One thread per pending item: the FIRST accepted of its S speculative attempts wins -> the
-// (entry, item) pair goes on the winners list (packed into the item's signature slot by the
-// RowMap-driven codec launches that follow) and the attempt count is recorded; none accepted ->
-// the item goes on the next pending list.  counts[0] = pending, counts[1] = winners.
-__global__ __launch_bounds__(256) void sign_collect_kernel(int32_t* __restrict__ attempts, int32_t* __restrict__ next_idx,
-                                                           int32_t* __restrict__ win_entry, int32_t* __restrict__ win_item,
-                                                           int32_t* __restrict__ counts, const int32_t* __restrict__ flags,
-                                                           const int32_t* __restrict__ idx, int a0, int S, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t item = idx ? idx[i] : (int32_t)i;
-    int win = -1;
-    for (int j = 0; j < S; j++)
-        if (flags[i * (size_t)S + j] == 0) {
-            win = j;
-            break;
-        }
-    if (win < 0) {
-        next_idx[atomicAdd(&counts[0], 1)] = item;
-    } else {
-        const int w = atomicAdd(&counts[1], 1);
-        win_entry[w] = (int32_t)(i * (size_t)S + win);
-        win_item[w] = item;
-        attempts[item] = a0 + win + 1;
-    }
-}
-
 // Start of a signing round in ONE launch (was two gathers, the kappa kernel and a memset): for entry e of pending item
 // i = e / S:  mu_c[e] = mu[item(i)], rp_c[e] = rho'[item(i)] (64 bytes each, as 4 x 16 B per thread), kappa[e] = (a0 + e % S) * L,
 // and the round's two counters are cleared.  gather == false (first round of a full batch, S == 1): only kappa + counters.
@@ -319,8 +291,10 @@ __global__ __launch_bounds__(256) void sign_round_setup_kernel(uint4* __restrict
     }
 }
 
-// End of a signing round, winners' side: sign_collect_kernel's bookkeeping PLUS the copy of the winner's c~ (32 bytes,
-// any alignment) into its signature slot -- one thread per pending item.
+// End of a signing round, one thread per pending item: the FIRST accepted of its S speculative attempts wins -> the
+// (entry, item) pair goes on the winners list (packed into the item's signature slot by the RowMap-driven codec launches
+// that follow), the attempt count is recorded and the winner's c~ (32 bytes, any alignment) is copied into its signature
+// slot; none accepted -> the item goes on the next pending list.  counts[0] = pending, counts[1] = winners.
 __global__ __launch_bounds__(256) void sign_collect_ct_kernel(int32_t* __restrict__ attempts, int32_t* __restrict__ next_idx,
                                                               int32_t* __restrict__ win_entry, int32_t* __restrict__ win_item,
                                                               int32_t* __restrict__ counts, const int32_t* __restrict__ flags,
@@ -401,15 +375,6 @@ hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, uint32_t 
 {
     if (entries == 0) return hipSuccess;
     hipLaunchKernelGGL(sign_kappa_kernel, (int)((entries + 255) / 256), 256, 0, s, kappa, a0, L, S, entries);
-    return hipGetLastError();
-}
-
-hipError_t launch_sign_collect(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
-                               const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, hipStream_t s)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(sign_collect_kernel, (int)((n + 255) / 256), 256, 0, s, attempts, next_idx, win_entry, win_item, counts, flags,
-                       idx, a0, S, n);
     return hipGetLastError();
 }
 
