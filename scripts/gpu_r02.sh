@@ -22,6 +22,7 @@ if has cover; then
   echo "cover exit $?" >> $OUT/${TAG}_cover.log
   cd $GRAFT_REPO_ROOT
   python scripts/kernel_coverage.py $OUT/${TAG}_cover/cover_results.db > $OUT/${TAG}_pytest_kernel_coverage.txt 2>&1
+  rm -rf $OUT/${TAG}_cover          # the raw trace database is tens of MiB: only the summary travels back
   tail -3 $OUT/${TAG}_cover.log; tail -12 $OUT/${TAG}_pytest_kernel_coverage.txt
 fi
 if has smoke; then
@@ -38,6 +39,7 @@ if has prof; then
   echo "prof_full exit $?" >> $OUT/${TAG}_prof_full.log
   cd $GRAFT_REPO_ROOT
   python scripts/rocpd_stats.py $OUT/${TAG}_prof_full/${TAG}_results.db $OUT/${TAG}_kernel_stats_full.txt > /dev/null 2>&1
+  rm -rf $OUT/${TAG}_prof_full
   head -30 $OUT/${TAG}_kernel_stats_full.txt | cut -c1-160
 fi
 if has pmc; then
@@ -48,5 +50,6 @@ if has pmc; then
   done
   cd $GRAFT_REPO_ROOT
   python scripts/pmc_summary.py $OUT/${TAG}_pmc_summary.json $OUT/${TAG}_pmc_FETCH_SIZE/p_results.db $OUT/${TAG}_pmc_WRITE_SIZE/p_results.db > $OUT/${TAG}_pmc_summary.txt 2>&1
+  rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
   cat $OUT/${TAG}_pmc_summary.txt
 fi
