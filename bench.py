@@ -389,6 +389,11 @@ def main():
             A3 = api.expand_a(pk[:, :32].contiguous(), 3)
             w1p = torch.empty((VBATCH, 6 * 128), dtype=torch.uint8, device="cuda")
             wk_ms, _ = timed(lambda i: L.dil_verify_wire_core_dev(P(w1p), P(vd), P(A3), P(pk), P(sigd), 3, VBATCH, 0, stream))
+            # verification against keys whose matrix was expanded once and is kept across calls (dil_verify_sig_expanded_dev)
+            vxd_ms, _ = timed(lambda i: L.dil_verify_sig_expanded_dev(P(vd), P(A3), P(pk), P(sigd), P(mu), 3, VBATCH, 0, stream))
+            ok = ok and int(vd.abs().sum()) == 0
+            vxs_ms, _ = timed(lambda i: L.dil_verify_sig_expanded_dev(P(vd), P(A3), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
+            ok = ok and int(vd.abs().sum()) == 0
             # the same at 8 x the batch (65536 per GPU): the latency-bound hash kernels are amortised
             BIG = 8 * VBATCH
             mu_b = u8(BIG, 64)
@@ -406,6 +411,8 @@ def main():
                 "verify_shared_pk_per_s": per_s(vf_ms), "verify_distinct_pk_per_s": per_s(vfd_ms),
                 "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "sample_in_ball_bits_kernel + "
                                                  "verify_wire_wpi_kernel<3>", "wire_bytes_per_verify": 30 * 1024 + 3200 + 61 + 1920 + 256 + 768},
+                "verify_expanded_keys": {"distinct_pk_per_s": per_s(vxd_ms), "shared_pk_per_s": per_s(vxs_ms),
+                                         "note": "A = ExpandA(rho) expanded once by the caller and kept across calls"},
                 "mean_sign_attempts": mean_att, "all_signatures_verify": ok, "batch": VBATCH,
                 "batch_65536": {"sign_shared_key_per_s": BIG / (sgb_ms * 1e-3), "verify_shared_pk_per_s": BIG / (vfb_ms * 1e-3)}}
             # small-batch latency of one whole call (launch-bound): wall time per call incl. the host side

@@ -368,6 +368,16 @@ def verify_sig(pk, sig, mu, level, shared_pk=False):
     return verdict
 
 
+def verify_sig_expanded(A, pk, sig, mu, level, shared_pk=False):
+    """verify_sig with the keys' matrix A = expand_a(rho) expanded once by the caller and kept across calls"""
+    B = sig.shape[0]
+    verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
+    _lib.check(_lib.load().dil_verify_sig_expanded_dev(_dev(verdict, torch.int32), _dev(A, torch.int32), _dev(pk, torch.uint8),
+                                                       _dev(sig, torch.uint8), _dev(mu, torch.uint8), level, B, int(shared_pk),
+                                                       _stream()), "dil_verify_sig_expanded_dev")
+    return verdict
+
+
 def verify_wire_core(A, pk, sig, level, shared_pk=False):
     """the fused wire-format verify kernel: (w1 packed uint8 [B, K*128|192], verdict int32 [B] with bits 2 | 4)"""
     K, _ = _kl(level)

@@ -156,8 +156,11 @@ __device__ __forceinline__ void decode_z(int32_t (&z)[4], const uint32_t (&raw)[
 // ---------------------------------------------------------------------------------------------------------
 // distinct public keys: wave per item, A streamed from HBM (expanded by expand_a_kernel), everything else packed
 // ---------------------------------------------------------------------------------------------------------
+#ifndef DIL_WW_WAVES
+#define DIL_WW_WAVES(LEVEL) 3      // waves per SIMD the register allocator aims for (168 VGPRs)
+#endif
 template <int LEVEL>
-__global__ __launch_bounds__(256) void verify_wire_wpi_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVES(LEVEL), DIL_WW_WAVES(LEVEL)))) void verify_wire_wpi_kernel(
     uint8_t* __restrict__ w1p_out, int32_t* __restrict__ verdict, const int32_t* __restrict__ A,
     const uint8_t* __restrict__ pk, size_t pk_stride, const uint8_t* __restrict__ sig, size_t sig_stride,
     const uint32_t* __restrict__ cbits, size_t batch, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "dil_sk_bytes": [C.c_int],
     "dil_sig_bytes": [C.c_int],
     "dil_verify_sig_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_verify_sig_expanded_dev": [_vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_verify_wire_core_dev": [_vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
     "dil_mu_dev": [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp],

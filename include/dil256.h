@@ -177,6 +177,12 @@ size_t dil_sig_bytes(int level);
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                        int shared_pk, void* stream);
 
+/* dil_verify_sig_dev against keys whose matrix A = ExpandA(rho) the caller expanded ONCE (dil_expand_a_dev on the keys' rho,
+ * [batch|1][K][L][256] int32, 16-byte aligned) and keeps across calls: many signatures under few public keys.  pk is still
+ * read for t1.  Same verdict bits.  (ExpandA is 2/3 of a distinct-key verification batch and 1/3 of a one-key batch.) */
+int dil_verify_sig_expanded_dev(int32_t* verdict, const int32_t* A, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level,
+                                size_t batch, int shared_pk, void* stream);
+
 /* The fused kernel inside dil_verify_sig_dev (wire_kernels.hip), exposed for parity tests and profiling: reads pk
  * ([batch|1][pk_bytes]) and sig ([batch][sig_bytes]) in wire format -- packed z, t1, hints; c = SampleInBall(c~) -- with
  * A [batch|1][K][L][256] already expanded, and writes w1 PACKED ([batch][K * 128|192] bytes, encoder.v:96-133) plus

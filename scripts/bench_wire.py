@@ -44,3 +44,7 @@ for level in (2, 3, 5):
         ok = int(api.verify_sig(pk, sig, mu, level).abs().sum()) == 0 and int(api.verify_sig(pk[:1], sig1, mu, level, shared_pk=True).abs().sum()) == 0
         print(f"L{level} verify_sig fuse_wire={mode}  n={n}: distinct {t*1e3:8.1f} us {n/t/1e3:7.2f} M/s | shared {ts*1e3:8.1f} us {n/t/1e3 if False else n/ts/1e3:7.2f} M/s | all accept {ok}")
     api.set_option("fuse_wire", 1)
+    Aall = sets[0][0]
+    t = timeit(lambda: api.verify_sig_expanded(Aall, pk, sig, mu, level), 5)
+    ts = timeit(lambda: api.verify_sig_expanded(A1, pk[:1], sig1, mu, level, shared_pk=True), 5)
+    print(f"L{level} verify_sig_expanded (A kept across calls) n={n}: distinct {t*1e3:8.1f} us {n/t/1e3:7.2f} M/s | shared {ts*1e3:8.1f} us {n/ts/1e3:7.2f} M/s")

@@ -184,3 +184,25 @@ def test_lane_per_sponge_hash_kernels_at_65536(gpu):
     sig[65535, 3] ^= 1
     v = api.verify_sig(cu(gpu, pk[:1]), sig, mu, 2, shared_pk=True).cpu().numpy()
     assert v[65535] == 1 and int(np.abs(v[:65535]).sum()) == 0
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_verify_sig_with_expanded_keys(gpu, level, kat_msgs):
+    """dil_verify_sig_expanded_dev (A expanded once by the caller) == dil_verify_sig_dev: the 100 KAT signatures with a key
+    per signature, tampered ones rejected with the same verdict words; and one key for a batch"""
+    from dilithium_amd import api
+    k, pk, sk, sig = kat_wire(level)
+    mu = mus(k, kat_msgs)
+    sg = sig.copy()
+    sg[3, 100] ^= 0x10
+    sg[4, 1] ^= 1
+    sg[9, -2] = dk.PARAMS[level].omega + 9
+    pkd, sgd, mud = cu(gpu, pk), cu(gpu, sg), cu(gpu, mu)
+    A = api.expand_a(pkd[:, :32].contiguous(), level)
+    v = api.verify_sig_expanded(A, pkd, sgd, mud, level).cpu().numpy()
+    assert (v == api.verify_sig(pkd, sgd, mud, level).cpu().numpy()).all()
+    assert set(np.nonzero(v)[0]) == {3, 4, 9}
+    rng = np.random.default_rng(level)
+    m = cu(gpu, rng.integers(0, 256, (2100, 64), dtype=np.uint8))
+    s1, _ = api.sign(cu(gpu, sk[:1]), m, level, shared_sk=True)
+    assert int(api.verify_sig_expanded(A[:1].contiguous(), pkd[:1], s1, m, level, shared_pk=True).abs().sum()) == 0
