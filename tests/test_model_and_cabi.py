@@ -113,3 +113,40 @@ def test_wire_sizes_and_scheme_entry_points_without_gpu(lib):
         api.sign_host(np.zeros((1, 4000), dtype=np.uint8), np.zeros((1, 64), dtype=np.uint8), 3)
     with pytest.raises(DilError):
         api.verify_sig_host(np.zeros((1, 1952), dtype=np.uint8), np.zeros((1, 3293), dtype=np.uint8), np.zeros((1, 64), dtype=np.uint8), 3)
+
+
+def test_use_hint_half_bucket_form_over_the_whole_field():
+    """pipeline_common.hpp use_hint<LEVEL>: v = ceil(a / gamma2) - 1 by one multiply, a1 = (v + 1) >> 1, hinted value
+    a1 + 1 - 2 (v & 1) -- the integer operations of the kernel restated in numpy -- against the round-3 Decompose / UseHint
+    formulas (the oracle's orc_decompose is pinned to the RTL threshold map by tests/test_oracle.py) for EVERY
+    a in [0, q), both hint values, all three levels"""
+    import numpy as np
+    q = 8380417
+    a = np.arange(q, dtype=np.int64)
+    for level in (2, 3, 5):
+        g2 = (q - 1) // 88 if level == 2 else (q - 1) // 32
+        t = (a + 127) >> 7
+        if level == 2:
+            t = (t * 11275 + (1 << 23)) >> 24
+            t = np.where(t > 43, 0, t)
+            m = 44
+        else:
+            t = ((t * 1025 + (1 << 21)) >> 22) & 15
+            m = 16
+        a0 = a - t * 2 * g2
+        a0 = np.where(a0 > (q - 1) // 2, a0 - q, a0)
+        want0, want1 = t, np.where(a0 > 0, (t + 1) % m, (t - 1) % m)
+        # the kernel's arithmetic, 32-bit
+        x = ((a - 1).astype(np.int32)) >> (9 if level == 2 else 8)
+        prod = x.astype(np.int64) * (22551 if level == 2 else 32801)
+        assert np.abs(prod).max() < 2 ** 31                       # the product fits the 32-bit multiply
+        v = (prod.astype(np.int32)) >> (22 if level == 2 else 25)
+        odd = v & 1
+        for hint, want in ((0, want0), (1, want1)):
+            n = ((v + 1) >> 1) + (((odd ^ 1) - odd) & (-hint))
+            if level == 2:
+                n = n + ((n >> 31) & 44)
+                n = n - (((43 - n) >> 31) & 44)
+            else:
+                n = n & 15
+            assert (n == want).all(), (level, hint)
