@@ -159,3 +159,13 @@ def test_reference_style_cpp_mains(gpu, exe):
     out = subprocess.run([os.path.join(CPP, exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout and "ERROR" not in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_cpp_host_program_on_the_cabi(gpu, level):
+    """tests/cpp/test_cabi_scheme.cpp: a C++ host (HIP runtime + include/dil256.h only) generating a key, signing and
+    verifying ragged messages on a stream, through mu, the multi-GPU host layer and the options"""
+    _build()
+    out = subprocess.run([os.path.join(CPP, "test_cabi_scheme"), str(level), "300"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
