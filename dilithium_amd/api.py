@@ -379,12 +379,13 @@ def verify_sig_expanded(A, pk, sig, mu, level, shared_pk=False):
 
 
 def verify_wire_core(A, pk, sig, level, shared_pk=False):
-    """the fused wire-format verify kernel: (w1 packed uint8 [B, K*128|192], verdict int32 [B] with bits 2 | 4)"""
+    """the fused wire-format verify kernel: (w1 packed uint8 [B, K*128|192], verdict int32 [B] with bits 2 | 4);
+    A = None: the kernel that samples A from the keys' rho itself (a key per signature)"""
     K, _ = _kl(level)
     B = sig.shape[0]
     w1p = torch.empty((B, K * (192 if level == 2 else 128)), dtype=torch.uint8, device=sig.device)
     verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
-    _lib.check(_lib.load().dil_verify_wire_core_dev(_dev(w1p, torch.uint8), _dev(verdict, torch.int32), _dev(A, torch.int32),
+    _lib.check(_lib.load().dil_verify_wire_core_dev(_dev(w1p, torch.uint8), _dev(verdict, torch.int32), None if A is None else _dev(A, torch.int32),
                                                     _dev(pk, torch.uint8), _dev(sig, torch.uint8), level, B, int(shared_pk),
                                                     _stream()), "dil_verify_wire_core_dev")
     return w1p, verdict

@@ -36,6 +36,7 @@ const OptName* option_table(int* n)
         {"aux_overlap", "DIL_AUX_OVERLAP", &cfg.aux_overlap},
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
+        {"gen_a", "DIL_GEN_A", &cfg.gen_a},
         {"two_lane_max_sponges", "DIL_TWO_LANE_MAX", &dil::two_lane_max_sponges},
     };
     *n = (int)(sizeof(tab) / sizeof(tab[0]));

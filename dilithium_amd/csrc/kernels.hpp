@@ -67,6 +67,9 @@ hipError_t launch_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uin
 hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t batch, hipStream_t s);
 
 // ---- wire-format fused verify (wire_kernels.hip): packed z / t1 / hints / c in, packed w1 + verdict bits 2|4 out ----
+// wire-format verify with ExpandA inside the kernel (gen_kernels.hip): distinct public keys only
+hipError_t launch_verify_wire_gen(int level, uint8_t* w1p, int32_t* verdict, const uint8_t* pk, size_t pk_stride, const uint8_t* sig,
+                                  size_t sig_stride, const uint32_t* cbits, size_t batch, const Tables& t, hipStream_t s);
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
                               const Tables& t, hipStream_t s);

@@ -424,6 +424,10 @@ int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t
     if (ws.rc) return ws.rc;
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
     DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
+    if (!A) {                    // no expanded matrix: the kernel that samples A itself (a key per signature only)
+        if (shared_pk || (reinterpret_cast<uintptr_t>(pk) & 7)) return ws.close((int)hipErrorInvalidValue);
+        return ws.close((int)dil::launch_verify_wire_gen(level, w1_packed, verdict, pk, pkb, sig, sgb, cbits, batch, T, s));
+    }
     return ws.close((int)dil::launch_verify_wire(level, w1_packed, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
 }
 
@@ -441,10 +445,19 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         // Fused path: ExpandA (helper stream when it is latency-bound) beside SampleInBall, then ONE kernel that reads
         // the packed z / t1 / hints and writes packed w1 (+ the ||z|| and hint-encoding verdict bits), then the challenge
         // hash compared with c~ in place.  No int32 z / t1 / h / c / w1 temporaries.
-        int32_t* A = A_ready ? const_cast<int32_t*>(A_ready) : ws.take<int32_t>(nk * p.K * p.L * 256);
+        const bool gen_a = !A_ready && !shared_pk && dil::rt::cfg.gen_a.load(std::memory_order_relaxed);
+        int32_t* A = A_ready ? const_cast<int32_t*>(A_ready) : gen_a ? nullptr : ws.take<int32_t>(nk * p.K * p.L * 256);
         uint32_t* cbits = ws.take<uint32_t>(batch * 64);
         uint8_t* w1p = ws.take<uint8_t>(batch * w1b);
         if (ws.rc) return ws.rc;
+        if (gen_a) {
+            // option gen_a, a key per signature: A is sampled inside the verifying kernel and consumed coefficient by
+            // coefficient (gen_kernels.hip) -- no ExpandA launch, no A in HBM.  Not the default: the lane-per-sponge
+            // multiply-accumulate and the LDS-capped occupancy cost more than the A stream (profiles/r02_gen_a.txt)
+            DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
+            DIL_TRY(dil::launch_verify_wire_gen(level, w1p, verdict, pk, pkb, sig, sgb, cbits, batch, T, s));
+            return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
+        }
         if (A_ready) {               // the matrix is already there: SampleInBall, the fused kernel, the challenge hash
             DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
             DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));

@@ -63,6 +63,9 @@ int dil_shutdown(void);
  *                                   Both shapes compute identical results; tests run both on the same input.
  *   "fuse_wire"   (DIL_FUSE_WIRE)   1 = wire-format verification reads packed z / t1 / hints in the fused kernel
  *                                   (default), 0 = separate codec kernels + int32 verify core
+ *   "gen_a"       (DIL_GEN_A)       1 = wire-format verification with a public key per signature samples A = ExpandA(rho)
+ *                                   INSIDE the verifying kernel (gen_kernels.hip; A never crosses HBM); 0 (default) = ExpandA
+ *                                   to HBM, then the fused kernel -- measured faster on MI355X (profiles/r02_gen_a.txt)
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it
@@ -186,7 +189,10 @@ int dil_verify_sig_expanded_dev(int32_t* verdict, const int32_t* A, const uint8_
 /* The fused kernel inside dil_verify_sig_dev (wire_kernels.hip), exposed for parity tests and profiling: reads pk
  * ([batch|1][pk_bytes]) and sig ([batch][sig_bytes]) in wire format -- packed z, t1, hints; c = SampleInBall(c~) -- with
  * A [batch|1][K][L][256] already expanded, and writes w1 PACKED ([batch][K * 128|192] bytes, encoder.v:96-133) plus
- * verdict[i] = bit1 (value 2) ||z|| >= gamma1 - beta | bit2 (value 4) malformed hint encoding. */
+ * verdict[i] = bit1 (value 2) ||z|| >= gamma1 - beta | bit2 (value 4) malformed hint encoding.
+ * A == NULL (shared_pk must be 0, pk 8-byte aligned): the kernel that samples A = ExpandA(rho) itself while it multiplies
+ * (gen_kernels.hip; gen_a_ext.v / sampler_a_ext.v feeding the MAC, combined_top.v:1149-1207) -- what dil_verify_sig_dev runs
+ * for a key per signature. */
 int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t* A, const uint8_t* pk, const uint8_t* sig, int level,
                              size_t batch, int shared_pk, void* stream);
 
