@@ -107,12 +107,7 @@ __device__ __forceinline__ void emit23b(uint32_t v, uint32_t* ring_lane, int& cn
     if (CLAMP) acc &= (int)((uint32_t)(cnt - 256) >> 31);        // ... and cnt < 256
     cnt += acc;
 }
-#ifdef DIL_EA_LANESINK
-using EaSink = CoeffSink;          // A/B: the per-lane flush
-#else
-using EaSink = CoeffSinkWave;
-#endif
-template <bool CLAMP>
+template <bool CLAMP, class EaSink>
 __device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink, int& cnt)
 {
 #if DIL_EA_ABL == 2
@@ -135,6 +130,7 @@ __device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink
 #endif
     }
 }
+template <bool P24>        // P24: A leaves as 24-bit packed coefficients, 768 bytes per polynomial (the internal format of the composite calls)
 __global__ __launch_bounds__(HASH_BS) void expand_a_fast_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
                                                                 size_t rho_stride_words, int K, int L, size_t nitems)
 {
@@ -151,12 +147,8 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_fast_kernel(int32_t* __restr
     sp.s[20] ^= 0x8000000000000000ull;
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
     // a lane without a polynomial runs along (its ring column is its own) but never stores
-#ifdef DIL_EA_LANESINK
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, A + (live ? p : 0) * 256, live);
-#else
     const size_t first = (size_t)blockIdx.x * HASH_BS;             // one wave per workgroup: polynomial of lane 0
-    CoeffSinkWave sink(ring, threadIdx.x & 63, A + first * 256, (int)(total - first < 64 ? total - first : 64));
-#endif
+    CoeffSinkWaveT<P24> sink(ring, threadIdx.x & 63, A + first * CoeffSinkWaveT<P24>::POLY_DW, (int)(total - first < 64 ? total - first : 64));
     int cnt = 0;
     // (Tried: staggering the waves' start with s_sleep so that their store bursts do not coincide -- worse, 183 -> 196-260 us;
     //  issuing the batch as four concurrent launches inside a composite call -- worse, the fork / join barriers cost more than
@@ -549,13 +541,17 @@ hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int
     return hipGetLastError();
 }
 
-hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s)
+hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s, int a_fmt)
 {
     if (rho_stride_bytes & 7) return hipErrorInvalidValue;
     if (nitems == 0) return hipSuccess;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const size_t total = nitems * (size_t)(K * L);
+    if (a_fmt == A_P24) {        // packed output: always the throughput kernel (callers ask for it only on large batches)
+        hipLaunchKernelGGL(expand_a_fast_kernel<true>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
+        return hipGetLastError();
+    }
     if (total <= 16384) {        // latency-bound: two lanes per sponge
         hipLaunchKernelGGL(expand_a_kernel<true>, (int)((2 * total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A,
                            reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
@@ -564,7 +560,7 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
 #ifdef DIL_EA_OLD
     hipLaunchKernelGGL(expand_a_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
 #else
-    hipLaunchKernelGGL(expand_a_fast_kernel, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
+    hipLaunchKernelGGL(expand_a_fast_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
 #endif
     return hipGetLastError();
 }

@@ -382,7 +382,22 @@ struct CoeffSink {
 // of 64 separate 16-byte pieces of 64 different cache lines (measured: the per-lane stores cost ExpandA 70 of its 190 us,
 // profiles/r02_expand_a.txt).  Lanes may run ahead of the slowest by up to RING - CHUNK - 8 coefficients; if one ever gets
 // further (probability ~ 0 for hashed seeds, but it must stay correct) the wave drops to the per-lane flush for good.
-struct CoeffSinkWave {
+template <bool P24>      // P24: polynomials leave as 24-bit packed coefficients (768 bytes each) instead of int32 (1 KiB)
+struct CoeffSinkWaveT {
+    static constexpr int POLY_DW = P24 ? 192 : 256;
+    // store coefficients [at, at + 4) of the polynomial starting at dword pointer `poly`
+    __device__ __forceinline__ static void put4(int32_t* poly, int at, int4 v)
+    {
+        if (P24) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(poly) + (at >> 2) * 3;
+            const uint32_t a = (uint32_t)v.x, b = (uint32_t)v.y, c = (uint32_t)v.z, e = (uint32_t)v.w;
+            d[0] = a | (b << 24);
+            d[1] = (b >> 8) | (c << 16);
+            d[2] = (c >> 16) | (e << 8);
+        } else {
+            *reinterpret_cast<int4*>(poly + at) = v;
+        }
+    }
     static constexpr int RING = 32, CHUNK = 16;
     static constexpr int LDS_DWORDS_PER_WAVE = RING * 64;
     uint32_t* wave_ring;      // [slot][lane]
@@ -392,7 +407,7 @@ struct CoeffSinkWave {
     int live_polys;           // polynomials of this wave that exist (lanes >= live_polys have none)
     int flushed;              // wave-uniform while `uniform`
     bool uniform;
-    __device__ __forceinline__ CoeffSinkWave(uint32_t* wr, int ln, int32_t* dst0, int nlive)
+    __device__ __forceinline__ CoeffSinkWaveT(uint32_t* wr, int ln, int32_t* dst0, int nlive)
         : wave_ring(wr), ring(wr + ln), wave_dst(dst0), lane(ln), live_polys(nlive), flushed(0), uniform(true) {}
     __device__ __forceinline__ void flush_if_ready(int cnt)
     {
@@ -418,7 +433,7 @@ struct CoeffSinkWave {
                         __builtin_nontemporal_store(v.z, d_ + 2); __builtin_nontemporal_store(v.w, d_ + 3);
                     }
 #else
-                    if (p < live_polys) *reinterpret_cast<int4*>(wave_dst + p * 256 + flushed + 4 * q) = v;
+                    if (p < live_polys) put4(wave_dst + p * POLY_DW, flushed + 4 * q, v);
 #endif
                 }
                 flushed += CHUNK;
@@ -435,11 +450,12 @@ struct CoeffSinkWave {
                 v.y = (int32_t)ring[(base + 4 * q + 1) * 64];
                 v.z = (int32_t)ring[(base + 4 * q + 2) * 64];
                 v.w = (int32_t)ring[(base + 4 * q + 3) * 64];
-                *reinterpret_cast<int4*>(wave_dst + lane * 256 + flushed + 4 * q) = v;
+                put4(wave_dst + lane * POLY_DW, flushed + 4 * q, v);
             }
             flushed += CHUNK;
         }
     }
 };
+using CoeffSinkWave = CoeffSinkWaveT<false>;
 
 }  // namespace dil

@@ -14,6 +14,10 @@ enum { MAP_NATURAL = 0, MAP_AFTER_NTT = 1, MAP_AFTER_INVNTT = 2 };   // config.h
 enum { LAYOUT_POLY = 0, LAYOUT_BRAM = 1 };
 enum { OP_MUL = 0, OP_MAC = 1, OP_ADD = 2, OP_SUB = 3 };              // butterfly.v modes MULT / ADD / SUB
 enum { OUT_W = 0, OUT_W1W0 = 1 };
+// Matrix formats in HBM.  A_I32: the public one, [K][L][256] int32 (the reference's bram words).  A_P24: the composite
+// calls' internal one for a matrix per item -- coefficients are < 2^23, so they travel as 3 bytes: [K][L][768 bytes], a
+// quarter less write traffic for ExpandA and read traffic for the wave-per-item kernels, which are HBM-bound on exactly that stream.
+enum { A_I32 = 0, A_P24 = 1 };
 
 struct Tables {
     const uint32_t* fwd = nullptr;   // device, [4][64][8]
@@ -45,7 +49,8 @@ struct KeyMap {
 };
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
                          size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km = KeyMap(),
-                         uint8_t* w1_packed = nullptr);   // OUT_W1W0 only: w1 also written packed (4 | 6 bits), [batch][K * 128|192]
+                         uint8_t* w1_packed = nullptr,    // OUT_W1W0 only: w1 also written packed (4 | 6 bits), [batch][K * 128|192]
+                         int a_fmt = A_I32);              // A_P24: a matrix per key in packed form (never with shared_A)
 hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
                          const uint8_t* h, size_t batch, int shared_pk, const Tables& t, hipStream_t s);
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
@@ -55,7 +60,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
 
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
-hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s);
+hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s, int a_fmt = A_I32);
 hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s);
 hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s);
@@ -72,7 +77,7 @@ hipError_t launch_verify_wire_gen(int level, uint8_t* w1p, int32_t* verdict, con
                                   size_t sig_stride, const uint32_t* cbits, size_t batch, const Tables& t, hipStream_t s);
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
-                              const Tables& t, hipStream_t s);
+                              const Tables& t, hipStream_t s, int a_fmt = A_I32);
 hipError_t launch_sample_in_ball_bits(uint32_t* cbits, const uint8_t* ctilde, size_t ct_stride, int level, size_t nitems, hipStream_t s);
 
 // ---- rows N2 / N4: codecs, ExpandS, Power2Round (codec_kernels.hip) ----

@@ -267,8 +267,11 @@ __device__ __forceinline__ void load_strided(int32_t (&r)[4], const int32_t* __r
 #endif
 }
 
+template <int L, int FMT = A_I32>
+struct ARow;
 template <int L>
-struct ARow {
+struct ARow<L, A_I32> {
+    static constexpr int PD = 256;           // dwords per polynomial in HBM
     int4 v[L];
     // stream = true: this row is read once (per-item A): non-temporal; false: shared A, keep it cached
     __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane, bool stream)
@@ -284,19 +287,50 @@ struct ARow {
             for (int l = 0; l < L; l++) v[l] = *reinterpret_cast<const int4*>(Arow + l * 256 + 4 * lane);
         }
     }
+    __device__ __forceinline__ int4 get(int l) const { return v[l]; }
+};
+// 24-bit packed coefficients (kernels.hpp A_P24): the lane's 4 coefficients are 12 contiguous bytes = one dwordx3 load,
+// unpacked when used (3 VGPRs per polynomial in flight instead of 4)
+template <int L>
+struct ARow<L, A_P24> {
+    static constexpr int PD = 192;
+    uint32_t v[L][3];
+    __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane, bool stream)
+    {
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            const int32_t* p = Arow + l * 192 + 3 * lane;
+            if (stream) {
+                v[l][0] = (uint32_t)__builtin_nontemporal_load(p);
+                v[l][1] = (uint32_t)__builtin_nontemporal_load(p + 1);
+                v[l][2] = (uint32_t)__builtin_nontemporal_load(p + 2);
+            } else {
+                v[l][0] = (uint32_t)p[0];
+                v[l][1] = (uint32_t)p[1];
+                v[l][2] = (uint32_t)p[2];
+            }
+        }
+    }
+    __device__ __forceinline__ int4 get(int l) const
+    {
+        const uint32_t a = v[l][0], b = v[l][1], c = v[l][2];
+        return make_int4((int32_t)(a & 0xFFFFFFu), (int32_t)(__builtin_amdgcn_alignbit(b, a, 24) & 0xFFFFFFu),
+                         (int32_t)(__builtin_amdgcn_alignbit(c, b, 16) & 0xFFFFFFu), (int32_t)(c >> 8));
+    }
 };
 
 // acc += sum_l A[k][l] o vhat[l] for the lane's 4 coefficients, as 64-bit integers
-template <int L>
-__device__ __forceinline__ void mac_row(int64_t (&acc)[4], const ARow<L>& A, const uint32_t* vec_lds, int lane)
+template <int L, int FMT>
+__device__ __forceinline__ void mac_row(int64_t (&acc)[4], const ARow<L, FMT>& A, const uint32_t* vec_lds, int lane)
 {
 #pragma unroll
     for (int l = 0; l < L; l++) {
         const int4 z = *reinterpret_cast<const int4*>(vec_lds + l * 256 + 4 * lane);
-        acc[0] += (int64_t)A.v[l].x * z.x;
-        acc[1] += (int64_t)A.v[l].y * z.y;
-        acc[2] += (int64_t)A.v[l].z * z.z;
-        acc[3] += (int64_t)A.v[l].w * z.w;
+        const int4 a = A.get(l);
+        acc[0] += (int64_t)a.x * z.x;
+        acc[1] += (int64_t)a.y * z.y;
+        acc[2] += (int64_t)a.z * z.z;
+        acc[3] += (int64_t)a.w * z.w;
     }
 }
 

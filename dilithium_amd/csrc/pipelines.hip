@@ -8,7 +8,7 @@
 namespace dil {
 
 // H9 mat-vec  w = INTT(A o NTT(y))   (OUT_W)   and sign phase 1 = mat-vec + Decompose (OUT_W1W0)
-template <int K, int L, int LEVEL, int OUT>
+template <int K, int L, int LEVEL, int OUT, int AF>
 __global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
@@ -23,8 +23,8 @@ __global__ __launch_bounds__(64 * (K > L ? K : L)) void matvec_kernel(
     uint32_t* sc = lds + LDS_SCR + wv * 64;      // this wave's byte-plane scratch
     uint32_t* vec = lds + LDS_VEC;
     for (size_t it = blockIdx.x; it < batch; it += gridDim.x) {
-        ARow<L> Ar;
-        if (wv < K) Ar.load(A + ((shared_A ? 0 : km.key(it) * K) + wv) * (size_t)L * 256, lane, !shared_A && km.S == 1);
+        ARow<L, AF> Ar;
+        if (wv < K) Ar.load(A + ((shared_A ? 0 : km.key(it) * K) + wv) * (size_t)L * ARow<L, AF>::PD, lane, !shared_A && km.S == 1);
         if (wv < L) {
             int32_t r[4];
             load_strided(r, y + (it * L + wv) * 256, lane);
@@ -228,7 +228,7 @@ struct RawPolys {
 // mat-vec / sign phase 1, wave-per-item.  Per item: issue row-0 loads | L forward NTTs on registers
 // loaded during the PREVIOUS item's row phase, y^ -> this wave's LDS slice | issue the NEXT item's y
 // loads | K rows: MAC from LDS, prefetch row k+1, INTT, (Decompose), store.
-template <int K, int L, int LEVEL, int OUT>
+template <int K, int L, int LEVEL, int OUT, int AF>
 __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     if (it < batch) yr.load(y + it * L * 256, lane);
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
-        const int32_t* Ait = A + (shared_A ? 0 : km.key(it) * K) * (size_t)L * 256;
-        ARow<L> Ar;
+        constexpr int PD = ARow<L, AF>::PD;
+        const int32_t* Ait = A + (shared_A ? 0 : km.key(it) * K) * (size_t)L * PD;
+        ARow<L, AF> Ar;
         Ar.load(Ait, lane, !shared_A && km.S == 1);
 #pragma unroll
         for (int l = 0; l < L; l++) {
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, yl, lane);
-            if (k + 1 < K) Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, !shared_A && km.S == 1);
+            if (k + 1 < K) Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, !shared_A && km.S == 1);
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
             ntt_inv_core(r, twi, lm);
@@ -741,12 +742,13 @@ static inline bool use_wpi(size_t batch, const Tables& t)
     return batch >= (size_t)t.num_cus * 8;
 }
 
-template <int LEVEL, int OUT>
+template <int LEVEL, int OUT, int AF>
 static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
                                       size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    if (use_wpi(batch, t) && shared_A) {
+    if (AF == A_P24 && shared_A) return hipErrorInvalidValue;      // the shared-key kernels keep A in LDS: nothing to save
+    if (AF == A_I32 && use_wpi(batch, t) && shared_A) {
         constexpr int NW = SharedNW<LEVEL>::MATVEC;
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
         hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, t.fwd,
@@ -755,25 +757,29 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
     }
     if (use_wpi(batch, t)) {
         const int g = grid_for((batch + 3) / 4,
-                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT>, 256, t.wpi_blocks_per_cu, t.device));
-        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, km, t.fwd,
+                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT, AF>, 256, t.wpi_blocks_per_cu, t.device));
+        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT, AF>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, km, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
     }
     const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);
-    hipLaunchKernelGGL((matvec_kernel<K, L, LEVEL, OUT>), grid, 64 * (K > L ? K : L), 0, s, w, w1, w0, A, y, batch,
+    hipLaunchKernelGGL((matvec_kernel<K, L, LEVEL, OUT, AF>), grid, 64 * (K > L ? K : L), 0, s, w, w1, w0, A, y, batch,
                        shared_A, km, t.fwd, t.inv_pipe);
     return hipGetLastError();
 }
 
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A,
-                         const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km, uint8_t* w1_packed)
+                         const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km, uint8_t* w1_packed,
+                         int a_fmt)
 {
     if (batch == 0) return hipSuccess;
     if (out_mode != OUT_W) w = reinterpret_cast<int32_t*>(w1_packed);      // the kernels' w slot carries packed w1 in this mode
-#define DIL_MV(LV)                                                                                       \
-    return out_mode == OUT_W ? launch_matvec_level<LV, OUT_W>(w, w1, w0, A, y, batch, shared_A, t, s, km) \
-                             : launch_matvec_level<LV, OUT_W1W0>(w, w1, w0, A, y, batch, shared_A, t, s, km)
+#define DIL_MV2(LV, AF)                                                                                       \
+    return out_mode == OUT_W ? launch_matvec_level<LV, OUT_W, AF>(w, w1, w0, A, y, batch, shared_A, t, s, km) \
+                             : launch_matvec_level<LV, OUT_W1W0, AF>(w, w1, w0, A, y, batch, shared_A, t, s, km)
+#define DIL_MV(LV)                      \
+    if (a_fmt == A_P24) DIL_MV2(LV, A_P24); \
+    DIL_MV2(LV, A_I32)
     switch (level) {
     case 2: DIL_MV(2);
     case 3: DIL_MV(3);
@@ -781,6 +787,7 @@ hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32
     default: return hipErrorInvalidValue;
     }
 #undef DIL_MV
+#undef DIL_MV2
 }
 
 template <int LEVEL>

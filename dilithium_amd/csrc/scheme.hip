@@ -193,6 +193,7 @@ namespace {
 // temporaries of one signing attempt over `batch` entries
 struct AttemptScratch {
     int32_t* y; uint8_t* w1; int32_t* w0; uint8_t* w1p; int32_t* c;
+    int a_fmt = dil::A_I32;      // format of the matrix the attempts multiply by (kernels.hpp)
     int alloc(StreamScratch& ws, int level, int K, int L, size_t batch)
     {
         y = ws.take<int32_t>(batch * L * 256);
@@ -203,6 +204,12 @@ struct AttemptScratch {
         return ws.rc;
     }
 };
+// A matrix per item travels through HBM as 24-bit packed coefficients (kernels.hpp A_P24) when the batch is large enough for
+// the throughput form of ExpandA; one shared matrix, small batches and everything in the public API stay int32.
+inline int matrix_format(size_t nkeys, int K, int L)
+{
+    return (nkeys > 1 && nkeys * (size_t)(K * L) > 16384 && dil::rt::cfg.a24.load(std::memory_order_relaxed)) ? dil::A_P24 : dil::A_I32;
+}
 int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                       const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
@@ -211,7 +218,7 @@ int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ct
     if (phases & 1) DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
     if (!(phases & 2)) return 0;
     // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt));
     DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
     DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
     DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
@@ -385,9 +392,10 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(e), 128, reinterpret_cast<const uint64_t*>(seed), 32, batch, s));
     // ExpandS (helper stream, when it is latency-bound) runs beside ExpandA: independent, both Keccak-bound
     DIL_TRY(dil::launch_expand_s(s1, s2, e + 32, 128, p.eta, p.L, p.K, batch, ax.fork(batch * p.K * p.L)));
-    DIL_TRY(dil::launch_expand_a(A, e, 128, level, batch, s));
+    const int a_fmt = matrix_format(batch, p.K, p.L);
+    DIL_TRY(dil::launch_expand_a(A, e, 128, level, batch, s, a_fmt));
     if ((rc = ax.join())) return rc;
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, s1, batch, 0, T, s));
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, s1, batch, 0, T, s, dil::KeyMap(), nullptr, a_fmt));
     DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, T, s));
     // pk = rho | t1
     DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, T, s));
@@ -469,10 +477,14 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         const size_t a_sponges = nk * p.K * p.L;
         hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;
         hipStream_t sc = a_sponges <= batch ? s : ax.fork(batch);
-        DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, sa));
+        // (int32 matrix here: the fused verify kernel is not bound by the A stream -- with 24-bit packed A it runs 64.7 vs
+        //  63.1 us and ExpandA's 48-byte pieces cost 8 us more than its 64-byte ones; profiles/r02_a24.txt.  The format
+        //  parameter stays for A/B runs: option a24 = 2 forces the packed form here too.)
+        const int a_fmt = (!shared_pk && dil::rt::cfg.a24.load(std::memory_order_relaxed) == 2) ? matrix_format(nk, p.K, p.L) : dil::A_I32;
+        DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, sa, a_fmt));
         DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, sc));
         if ((rc = ax.join())) return rc;
-        DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
+        DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s, a_fmt));
         return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
     }
     int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
@@ -601,7 +613,8 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         // key material: A = ExpandA(rho) -- on the helper stream when it is latency-bound (one or few keys), beside the
         // rest of the set-up -- and s1^ s2^ t0^ = NTT(unpack(sk))
         AuxFork ax(dv, s);
-        DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, ax.fork(nk * p.K * p.L)));
+        att.a_fmt = matrix_format(nk, p.K, p.L);
+        DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, ax.fork(nk * p.K * p.L), att.a_fmt));
         DIL_TRY(dil::launch_unpack(p.eta_bits, s1h, sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, T, s));
         DIL_TRY(dil::launch_unpack(p.eta_bits, s2h, sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, T, s));
         DIL_TRY(dil::launch_unpack(13, t0h, sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, T, s));

@@ -23,7 +23,7 @@ namespace dil {
 #ifndef DIL_WW_WAVES
 #define DIL_WW_WAVES(LEVEL) 3      // waves per SIMD the register allocator aims for (168 VGPRs)
 #endif
-template <int LEVEL>
+template <int LEVEL, int AF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVES(LEVEL), DIL_WW_WAVES(LEVEL)))) void verify_wire_wpi_kernel(
     uint8_t* __restrict__ w1p_out, int32_t* __restrict__ verdict, const int32_t* __restrict__ A,
     const uint8_t* __restrict__ pk, size_t pk_stride, const uint8_t* __restrict__ sig, size_t sig_stride,
@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
     if (it < batch) load_item(it);
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
-        const int32_t* Ait = A + it * (size_t)(K * L) * 256;
+        constexpr int PD = ARow<L, AF>::PD;
+        const int32_t* Ait = A + it * (size_t)(K * L) * PD;
         const uint8_t* t1it = pk + it * pk_stride + 32;
-        ARow<L> Ar;
+        ARow<L, AF> Ar;
         Ar.load(Ait, lane, true);
         uint32_t tn[4];
         plt.load(tn, t1it);
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
             uint32_t hb[4];
             row_hint_bits(hb, bm, k, lane);
             if (k + 1 < K) {
-                Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, true);
+                Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, true);
                 plt.load(tn, t1it + (k + 1) * 320);
             }
             DIL_SCHED_FENCE_W();
@@ -293,17 +294,23 @@ __global__ __launch_bounds__(64) void sample_in_ball_bits_kernel(uint32_t* __res
 template <int LEVEL>
 static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                                            const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
-                                           const Tables& t, hipStream_t s)
+                                           const Tables& t, hipStream_t s, int a_fmt)
 {
+    if (shared_pk && a_fmt != A_I32) return hipErrorInvalidValue;
     if (shared_pk) {
         constexpr int NW = WireNW<LEVEL>::N;
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
         hipLaunchKernelGGL((verify_wire_shared_kernel<LEVEL, NW>), g, 64 * NW, 0, s, w1p, verdict, A, pk, sig, sig_stride, cbits, batch,
                            t.fwd, t.inv_pipe);
+    } else if (a_fmt == A_P24) {
+        const int g = grid_for((batch + 3) / 4,
+                               t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_P24>, 256, t.wpi_blocks_per_cu, t.device));
+        hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_P24>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
+                           t.fwd, t.inv_pipe);
     } else {
         const int g = grid_for((batch + 3) / 4,
-                               t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL>, 256, t.wpi_blocks_per_cu, t.device));
-        hipLaunchKernelGGL(verify_wire_wpi_kernel<LEVEL>, g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
+                               t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_I32>, 256, t.wpi_blocks_per_cu, t.device));
+        hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_I32>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
                            t.fwd, t.inv_pipe);
     }
     return hipGetLastError();
@@ -311,13 +318,13 @@ static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const
 
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
-                              const Tables& t, hipStream_t s)
+                              const Tables& t, hipStream_t s, int a_fmt)
 {
     if (batch == 0) return hipSuccess;
     switch (level) {
-    case 2: return launch_verify_wire_level<2>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s);
-    case 3: return launch_verify_wire_level<3>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s);
-    case 5: return launch_verify_wire_level<5>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s);
+    case 2: return launch_verify_wire_level<2>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
+    case 3: return launch_verify_wire_level<3>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
+    case 5: return launch_verify_wire_level<5>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
     default: return hipErrorInvalidValue;
     }
 }

@@ -66,6 +66,11 @@ int dil_shutdown(void);
  *   "gen_a"       (DIL_GEN_A)       1 = wire-format verification with a public key per signature samples A = ExpandA(rho)
  *                                   INSIDE the verifying kernel (gen_kernels.hip; A never crosses HBM); 0 (default) = ExpandA
  *                                   to HBM, then the fused kernel -- measured faster on MI355X (profiles/r02_gen_a.txt)
+ *   "a24"         (DIL_A24)         1 (default) = inside dil_keygen_dev / dil_sign_* a matrix per key crosses HBM as 24-bit
+ *                                   packed coefficients (768 bytes per polynomial) when the batch is large: the mat-vec kernels are
+ *                                   bound by that stream (level 3, 8192 keys: 85 -> 51 us); 0 = as int32; 2 = packed in
+ *                                   dil_verify_sig_dev too (measured neutral there).  Internal only: every A in this header's
+ *                                   signatures is int32 [K][L][256]
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it

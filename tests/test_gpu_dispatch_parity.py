@@ -141,6 +141,36 @@ def test_both_kernel_shapes_on_the_same_input(gpu, oracle, level, fused_mode):
                 (mode, shared, "sign2")
 
 
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_packed_matrix_format_same_bytes(gpu, level, fused_mode):
+    """option a24: inside keygen / sign / verify a matrix per key crosses HBM as 24-bit packed coefficients
+    (expand_a_fast_kernel<true> -> matvec_wpi_kernel / matvec_kernel / verify_wire_wpi_kernel with ARow<L, A_P24>) or as
+    int32: byte-identical keys, signatures, attempt counts and verdicts at a dispatch-size batch, in both kernel shapes"""
+    from dilithium_amd import api
+    rng = np.random.default_rng(40 + level)
+    n = 2304
+    seed = dev(gpu, rng.integers(0, 256, (n, 32), dtype=np.uint8), np.uint8)
+    mu = dev(gpu, rng.integers(0, 256, (n, 64), dtype=np.uint8), np.uint8)
+    out = {}
+    try:
+        for a24, mode in ((0, 0), (1, 0), (1, 1)):
+            api.set_option("a24", a24)
+            fused_mode(mode)
+            pk, sk = api.keygen(seed, level)
+            sig, att = api.sign(sk, mu, level)
+            bad = sig.clone()
+            bad[5, 40] ^= 4
+            v = api.verify_sig(pk, bad, mu, level)
+            out[a24, mode] = [t.cpu().numpy() for t in (pk, sk, sig, att, v)]
+    finally:
+        api.set_option("a24", 1)
+    for key in ((1, 0), (1, 1)):
+        for a, b in zip(out[0, 0], out[key]):
+            assert (a == b).all(), key
+    v = out[1, 0][4]
+    assert v[5] != 0 and int(np.abs(np.delete(v, 5)).sum()) == 0
+
+
 def test_options_api(gpu):
     from dilithium_amd import api, DilError
     assert api.get_option("fused_mode") == 0
