@@ -33,6 +33,7 @@ struct Config {
     std::atomic<int> aux_overlap{1};       // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream
     std::atomic<int> zeroize{0};           // DIL_ZEROIZE: 1 = signing / keygen clear their device scratch before returning
     std::atomic<int> fuse_wire{1};         // DIL_FUSE_WIRE: 0 = wire-format verify runs the unfused (codec + core) sequence
+    std::atomic<int> fuse_keygen{1};       // DIL_FUSE_KEYGEN: 0 = keygen's mat-vec, Power2Round and t1 / t0 packing as separate kernels
     std::atomic<int> a24{1};               // DIL_A24: 0 = the composite calls keep per-item matrices as int32 in HBM (1: 24-bit packed)
     std::atomic<int> gen_a{0};             // DIL_GEN_A: 1 = wire-format verify with a key per signature samples A inside the verifying kernel
 };

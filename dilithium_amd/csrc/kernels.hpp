@@ -51,6 +51,11 @@ hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32
                          size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km = KeyMap(),
                          uint8_t* w1_packed = nullptr,    // OUT_W1W0 only: w1 also written packed (4 | 6 bits), [batch][K * 128|192]
                          int a_fmt = A_I32);              // A_P24: a matrix per key in packed form (never with shared_A)
+// keygen: t = A s1 + s2, Power2Round, t1 -> pk (10 bit), 2^12 - t0 -> sk (13 bit) in one wave-per-key kernel (pipelines.hip)
+bool keygen_fused_available(size_t batch, const Tables& t);
+hipError_t launch_keygen_matvec(int level, uint8_t* pk, size_t pk_stride, uint8_t* sk, size_t sk_stride, size_t sk_t0_offset,
+                                const int32_t* A, const int32_t* s1, const int32_t* s2, size_t batch, const Tables& t, hipStream_t s,
+                                int a_fmt = A_I32);
 hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
                          const uint8_t* h, size_t batch, int shared_pk, const Tables& t, hipStream_t s);
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,

@@ -274,6 +274,99 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     }
 }
 
+// A row of 256 BITS-wide fields, given in an LDS buffer in natural order, as the reference's packed byte stream
+// (encoder.v:96-133): 8 BITS dwords, one per lane and pass; dword d takes bits [32 d, 32 d + 32) of the stream from the
+// (at most 5) fields that overlap it.  dst must be 4-byte aligned.
+template <int BITS>
+__device__ __forceinline__ void pack_fields_from_lds(uint8_t* __restrict__ dst, const uint32_t* vals, int lane)
+{
+    constexpr int NDW = 8 * BITS, TERMS = (BITS - 1 + 32 + BITS - 1) / BITS;
+#pragma unroll
+    for (int pass = 0; pass < (NDW + 63) / 64; pass++) {
+        const int d = 64 * pass + lane;
+        if (d < NDW) {
+            const uint32_t bit0 = 32u * (uint32_t)d, i0 = bit0 / BITS, o = bit0 - i0 * BITS;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int t = 0; t < TERMS; t++) acc |= (uint64_t)vals[min(i0 + t, 255u)] << (BITS * t);
+            reinterpret_cast<uint32_t*>(dst)[d] = (uint32_t)(acc >> o);
+        }
+    }
+}
+
+// Key generation's t = A s1 + s2 with its output stage fused in (combined_top.v keygen :921-1079): wave per key, as
+// matvec_wpi_kernel, then per row  t = w + s2,  (t1, t0) = Power2Round(t, 13),  t1 packed (10 bits) straight into the
+// public key and 2^12 - t0 packed (13 bits) straight into the secret key -- no int32 w / t1 / t0 in HBM, no power2round /
+// pack launches on the critical path to tr = H(pk).  s1, s2: ExpandS output, canonical.
+template <int LEVEL, int AF>
+__global__ __launch_bounds__(256) void keygen_wpi_kernel(
+    uint8_t* __restrict__ pk, size_t pk_stride, uint8_t* __restrict__ sk, size_t sk_stride, size_t sk_t0_offset,
+    const int32_t* __restrict__ A, const int32_t* __restrict__ s1, const int32_t* __restrict__ s2, size_t batch,
+    const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L, PD = ARow<L, AF>::PD;
+    using XP = X10Pick<true>;
+    static_assert(XP::DW >= 256, "the exchange buffer doubles as the packing buffer");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * XP::DW];
+    const int lane = threadIdx.x & 63, wv = wave_in_block();
+    stage_tables(lds, fwd_tab, inv_tab);
+    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    uint32_t* xb = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + wv * XP::DW;
+    const typename XP::type lm(xb, lane);
+    uint32_t* yl = lds + 2 * TW_TABLE_DWORDS + wv * (L * 256);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    size_t it = (size_t)blockIdx.x * 4 + wv;
+    RawPolys<L> yr;
+    if (it < batch) yr.load(s1 + it * L * 256, lane);
+    __syncthreads();                               // tables staged (the only barrier)
+    for (; it < batch; it += nwaves) {
+        const int32_t* Ait = A + it * (size_t)(K * L) * PD;
+        const int32_t* s2it = s2 + it * (size_t)K * 256;
+        ARow<L, AF> Ar;
+        Ar.load(Ait, lane, true);
+        int32_t e[4];
+        load_strided(e, s2it, lane);
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            ntt_fwd_core(yr.v[l], twf, lm);
+            *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
+        }
+        DIL_SCHED_FENCE();
+        const size_t itn = it + nwaves;
+        if (itn < batch) yr.load(s1 + itn * L * 256, lane);
+        for (int k = 0; k < K; k++) {
+            int64_t acc[4] = {0, 0, 0, 0};
+            mac_row<L>(acc, Ar, yl, lane);
+            int32_t e2[4] = {e[0], e[1], e[2], e[3]};
+            if (k + 1 < K) {
+                Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, true);
+                load_strided(e, s2it + (k + 1) * 256, lane);
+            }
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            DIL_SCHED_FENCE();
+            ntt_inv_core(r, twi, lm);
+            DIL_SCHED_FENCE();
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t t = canon_small((int32_t)canon_small(r[m]) + e2[m] - Q);     // w + s2 mod q, both canonical
+                hi[m] = (t + (1u << 12) - 1) >> 13;
+                lo[m] = (1u << 12) - (t - (hi[m] << 13));                                    // 2^12 - t0, 13 bits
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) xb[lane + 64 * m] = hi[m];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            pack_fields_from_lds<10>(pk + it * pk_stride + 32 + (size_t)k * 320, xb, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int m = 0; m < 4; m++) xb[lane + 64 * m] = lo[m];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            pack_fields_from_lds<13>(sk + it * sk_stride + sk_t0_offset + (size_t)k * 416, xb, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+    }
+}
+
 // ablation hooks of verify_wpi_kernel (scripts/ab_verify.py; never defined in the shipped build)
 #ifdef DIL_ABL_NONTT
 #define VW_FWD(r, tw, x) ((void)0)
@@ -788,6 +881,36 @@ hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32
     }
 #undef DIL_MV
 #undef DIL_MV2
+}
+
+// keygen's fused mat-vec + Power2Round + t1 / t0 packing; false: this batch is served by the unfused kernels instead
+bool keygen_fused_available(size_t batch, const Tables& t) { return use_wpi(batch, t); }
+
+template <int LEVEL>
+static hipError_t launch_keygen_level(uint8_t* pk, size_t pk_stride, uint8_t* sk, size_t sk_stride, size_t sk_t0_offset, const int32_t* A,
+                                      const int32_t* s1, const int32_t* s2, size_t batch, const Tables& t, hipStream_t s, int a_fmt)
+{
+    if (a_fmt == A_P24) {
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(keygen_wpi_kernel<LEVEL, A_P24>, 256, t.wpi_blocks_per_cu, t.device));
+        hipLaunchKernelGGL((keygen_wpi_kernel<LEVEL, A_P24>), g, 256, 0, s, pk, pk_stride, sk, sk_stride, sk_t0_offset, A, s1, s2, batch, t.fwd, t.inv_pipe);
+    } else {
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(keygen_wpi_kernel<LEVEL, A_I32>, 256, t.wpi_blocks_per_cu, t.device));
+        hipLaunchKernelGGL((keygen_wpi_kernel<LEVEL, A_I32>), g, 256, 0, s, pk, pk_stride, sk, sk_stride, sk_t0_offset, A, s1, s2, batch, t.fwd, t.inv_pipe);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_keygen_matvec(int level, uint8_t* pk, size_t pk_stride, uint8_t* sk, size_t sk_stride, size_t sk_t0_offset,
+                                const int32_t* A, const int32_t* s1, const int32_t* s2, size_t batch, const Tables& t, hipStream_t s, int a_fmt)
+{
+    if (batch == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(sk) | pk_stride | sk_stride | sk_t0_offset) & 3) return hipErrorInvalidValue;
+    switch (level) {
+    case 2: return launch_keygen_level<2>(pk, pk_stride, sk, sk_stride, sk_t0_offset, A, s1, s2, batch, t, s, a_fmt);
+    case 3: return launch_keygen_level<3>(pk, pk_stride, sk, sk_stride, sk_t0_offset, A, s1, s2, batch, t, s, a_fmt);
+    case 5: return launch_keygen_level<5>(pk, pk_stride, sk, sk_stride, sk_t0_offset, A, s1, s2, batch, t, s, a_fmt);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <int LEVEL>

@@ -382,9 +382,12 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     int32_t* A = ws.take<int32_t>(batch * p.K * p.L * 256);
     int32_t* s1 = ws.take<int32_t>(batch * p.L * 256);
     int32_t* s2 = ws.take<int32_t>(batch * p.K * 256);
-    int32_t* w = ws.take<int32_t>(batch * p.K * 256);
-    int32_t* t1 = ws.take<int32_t>(batch * p.K * 256);
-    int32_t* t0 = ws.take<int32_t>(batch * p.K * 256);
+    // fused output stage (large batches): t1 / t0 leave the mat-vec kernel packed, straight into pk / sk
+    const bool fused = dil::keygen_fused_available(batch, T) && !(reinterpret_cast<uintptr_t>(sk) & 3) &&
+                       dil::rt::cfg.fuse_keygen.load(std::memory_order_relaxed);
+    int32_t* w = fused ? nullptr : ws.take<int32_t>(batch * p.K * 256);
+    int32_t* t1 = fused ? nullptr : ws.take<int32_t>(batch * p.K * 256);
+    int32_t* t0 = fused ? nullptr : ws.take<int32_t>(batch * p.K * 256);
     uint8_t* tr = ws.take<uint8_t>(batch * 32);
     if (ws.rc) return ws.rc;
     ws.secret = true;            // rho', key, s1, s2, t0
@@ -395,11 +398,15 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     const int a_fmt = matrix_format(batch, p.K, p.L);
     DIL_TRY(dil::launch_expand_a(A, e, 128, level, batch, s, a_fmt));
     if ((rc = ax.join())) return rc;
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, s1, batch, 0, T, s, dil::KeyMap(), nullptr, a_fmt));
-    DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, T, s));
     // pk = rho | t1
     DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, T, s));
-    DIL_TRY(dil::launch_pack(10, pk, pkb, 32, t1, p.K, dil::XF_PLAIN, 0, batch, T, s));
+    if (fused) {
+        DIL_TRY(dil::launch_keygen_matvec(level, pk, pkb, sk, skb, 96 + (p.L + p.K) * sb, A, s1, s2, batch, T, s, a_fmt));
+    } else {
+        DIL_TRY(dil::launch_matvec(level, dil::OUT_W, w, nullptr, nullptr, A, s1, batch, 0, T, s, dil::KeyMap(), nullptr, a_fmt));
+        DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, T, s));
+        DIL_TRY(dil::launch_pack(10, pk, pkb, 32, t1, p.K, dil::XF_PLAIN, 0, batch, T, s));
+    }
     // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level): one long sponge per key, latency-bound --
     // on the helper stream, under the packing of the rest of sk
     {
@@ -412,7 +419,7 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     DIL_TRY(dil::launch_copy_field(sk, skb, 32, e, 128, 96, 32, batch, T, s));
     DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, s1, p.L, dil::XF_OFFSET_MINUS, p.eta, batch, T, s));
     DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, s2, p.K, dil::XF_OFFSET_MINUS, p.eta, batch, T, s));
-    DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, T, s));
+    if (!fused) DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, T, s));
     return ws.close(ax.join());
 }
 

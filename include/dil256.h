@@ -71,6 +71,8 @@ int dil_shutdown(void);
  *                                   bound by that stream (level 3, 8192 keys: 85 -> 51 us); 0 = as int32; 2 = packed in
  *                                   dil_verify_sig_dev too (measured neutral there).  Internal only: every A in this header's
  *                                   signatures is int32 [K][L][256]
+ *   "fuse_keygen" (DIL_FUSE_KEYGEN) 1 (default) = large key-generation batches run t = A s1 + s2, Power2Round and the packing of
+ *                                   t1 into pk / t0 into sk as ONE kernel; 0 = mat-vec, power2round and pack kernels
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it

@@ -145,7 +145,8 @@ def test_both_kernel_shapes_on_the_same_input(gpu, oracle, level, fused_mode):
 def test_packed_matrix_format_same_bytes(gpu, level, fused_mode):
     """option a24: inside keygen / sign / verify a matrix per key crosses HBM as 24-bit packed coefficients
     (expand_a_fast_kernel<true> -> matvec_wpi_kernel / matvec_kernel / verify_wire_wpi_kernel with ARow<L, A_P24>) or as
-    int32: byte-identical keys, signatures, attempt counts and verdicts at a dispatch-size batch, in both kernel shapes"""
+    int32: byte-identical keys, signatures, attempt counts and verdicts at a dispatch-size batch, in both kernel shapes;
+    likewise keygen with its output stage fused (keygen_wpi_kernel) or not (option fuse_keygen)"""
     from dilithium_amd import api
     rng = np.random.default_rng(40 + level)
     n = 2304
@@ -153,7 +154,9 @@ def test_packed_matrix_format_same_bytes(gpu, level, fused_mode):
     mu = dev(gpu, rng.integers(0, 256, (n, 64), dtype=np.uint8), np.uint8)
     out = {}
     try:
-        for a24, mode in ((0, 0), (1, 0), (1, 1)):
+        for a24, mode in ((0, 0), (1, 0), (1, 1), (2, 0), (3, 0)):       # 2: the packed matrix in verification too
+            api.set_option("fuse_keygen", 0 if a24 == 3 else 1)                # 3: packed matrix, keygen's output stage unfused
+            a24 = 1 if a24 == 3 else a24
             api.set_option("a24", a24)
             fused_mode(mode)
             pk, sk = api.keygen(seed, level)
@@ -161,13 +164,14 @@ def test_packed_matrix_format_same_bytes(gpu, level, fused_mode):
             bad = sig.clone()
             bad[5, 40] ^= 4
             v = api.verify_sig(pk, bad, mu, level)
-            out[a24, mode] = [t.cpu().numpy() for t in (pk, sk, sig, att, v)]
+            out[a24, mode, api.get_option("fuse_keygen")] = [t.cpu().numpy() for t in (pk, sk, sig, att, v)]
     finally:
         api.set_option("a24", 1)
-    for key in ((1, 0), (1, 1)):
-        for a, b in zip(out[0, 0], out[key]):
+        api.set_option("fuse_keygen", 1)
+    for key in ((1, 0, 1), (1, 1, 1), (2, 0, 1), (1, 0, 0)):
+        for a, b in zip(out[0, 0, 1], out[key]):
             assert (a == b).all(), key
-    v = out[1, 0][4]
+    v = out[1, 0, 1][4]
     assert v[5] != 0 and int(np.abs(np.delete(v, 5)).sum()) == 0
 
 
