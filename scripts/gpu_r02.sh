@@ -35,7 +35,7 @@ if has bench; then
 fi
 if has prof; then
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_full -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_prof_full.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_full -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify-overlap > $OUT/${TAG}_prof_full.log 2>&1
   echo "prof_full exit $?" >> $OUT/${TAG}_prof_full.log
   cd $GRAFT_REPO_ROOT
   python scripts/rocpd_stats.py $OUT/${TAG}_prof_full/${TAG}_results.db $OUT/${TAG}_kernel_stats_full.txt > /dev/null 2>&1
