@@ -55,6 +55,22 @@ def test_verify_wpi_kernel_vs_oracle_all_items(gpu, oracle, level):
     assert (w1 == oracle.verify_core(level, A, z, c, t1, h)).all()
 
 
+@pytest.mark.parametrize("n", [2047, 2048, 2049, 2063, 2065, 3071])
+def test_dispatch_boundary_sizes(gpu, oracle, n):
+    """around the kernel-shape switch (2048 = 8 x #CUs) and around whole workgroups of the shared-key kernels (16 waves):
+    one item below, on, and above -- verify core and mat-vec, a key per item and one key, every output vs the oracle"""
+    from dilithium_amd import api
+    level, (K, L) = 3, KL[3]
+    A, z, c, t1, h = synth(level, n, 9000 + n)
+    for shared in (False, True):
+        k = 1 if shared else n
+        w1 = api.verify_core(dev(gpu, A[:k]), dev(gpu, z), dev(gpu, c), dev(gpu, t1[:k]), dev(gpu, h, np.uint8), level,
+                             shared_pk=shared).cpu().numpy()
+        assert (w1 == oracle.verify_core(level, A[:k], z, c, t1[:k], h, shared_pk=shared)).all(), ("verify", shared)
+        w = api.matvec(dev(gpu, A[:k]), dev(gpu, z), level, shared_A=shared).cpu().numpy()
+        assert (w == oracle.matvec(K, L, A[:k], z, shared_A=shared)).all(), ("matvec", shared)
+
+
 def test_full_config4_batch_all_items(gpu, oracle):
     """BASELINE configs[3] exactly: level 3, batch 8192, distinct pk -- ALL 8192 x 6 x 256 outputs vs the oracle"""
     from dilithium_amd import api
@@ -173,6 +189,23 @@ def test_packed_matrix_format_same_bytes(gpu, level, fused_mode):
             assert (a == b).all(), key
     v = out[1, 0, 1][4]
     assert v[5] != 0 and int(np.abs(np.delete(v, 5)).sum()) == 0
+
+
+def test_keygen_into_unaligned_secret_key_buffer(gpu):
+    """the fused keygen output stage stores whole dwords: a secret-key buffer that is not 4-byte aligned takes the unfused
+    kernels instead -- same bytes"""
+    import ctypes as C
+    from dilithium_amd import api, lib as dlib
+    level, n = 3, 2304
+    rng = np.random.default_rng(77)
+    seed = dev(gpu, rng.integers(0, 256, (n, 32), dtype=np.uint8), np.uint8)
+    pk, sk = api.keygen(seed, level)
+    skb = api.sk_bytes(level)
+    raw = gpu.zeros(n * skb + 8, dtype=gpu.uint8, device="cuda")
+    pk2 = gpu.empty_like(pk)
+    dlib.check(dlib.load().dil_keygen_dev(C.c_void_p(pk2.data_ptr()), C.c_void_p(raw.data_ptr() + 1), C.c_void_p(seed.data_ptr()), level, n, None))
+    gpu.cuda.synchronize()
+    assert (pk2 == pk).all() and (raw[1:1 + n * skb].view(n, skb) == sk).all() and int(raw[0]) == 0 and int(raw[1 + n * skb:].sum()) == 0
 
 
 def test_options_api(gpu):
