@@ -145,7 +145,10 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_fast_kernel(int32_t* __restr
     for (int w = 0; w < 4; w++) sp.s[w] = rho[item * rho_stride_words + w];
     sp.s[4] = (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16);
     sp.s[20] ^= 0x8000000000000000ull;
-    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
+#ifndef DIL_EA_LDS_PAD_DW
+#define DIL_EA_LDS_PAD_DW 0       // occupancy experiments: extra LDS dwords per workgroup (fewer resident waves)
+#endif
+    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE + DIL_EA_LDS_PAD_DW];
     // a lane without a polynomial runs along (its ring column is its own) but never stores
     const size_t first = (size_t)blockIdx.x * HASH_BS;             // one wave per workgroup: polynomial of lane 0
     CoeffSinkWaveT<P24> sink(ring, threadIdx.x & 63, A + first * CoeffSinkWaveT<P24>::POLY_DW, (int)(total - first < 64 ? total - first : 64));
