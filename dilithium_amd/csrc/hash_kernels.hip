@@ -10,6 +10,7 @@
 #include "kernels.hpp"
 
 #include <atomic>
+#include <type_traits>
 
 namespace dil {
 
@@ -167,6 +168,20 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_fast_kernel(int32_t* __restr
     } while (__any(cnt < 256));
 }
 
+template <bool TWO>
+__device__ __forceinline__ typename std::conditional<TWO, CoeffSink, CoeffSinkWave>::type make_sink(uint32_t* ring, int32_t* y, size_t p,
+                                                                                                      size_t first, size_t total, bool wr);
+template <>
+__device__ __forceinline__ CoeffSink make_sink<true>(uint32_t* ring, int32_t* y, size_t p, size_t, size_t, bool wr)
+{
+    return CoeffSink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, y + p * 256, wr);
+}
+template <>
+__device__ __forceinline__ CoeffSinkWave make_sink<false>(uint32_t* ring, int32_t* y, size_t, size_t first, size_t total, bool)
+{
+    return CoeffSinkWave(ring, threadIdx.x & 63, y + first * 256, (int)(total - first < 64 ? total - first : 64));
+}
+
 // ---------------------------------------------------------------------------------------
 // ExpandMask: y[item][l] = gamma1 - Unpack_B(SHAKE256(rho' || LE16(kappa[item] + l))),
 // B = 18 (gamma1 = 2^17) or 20 (2^19) bits.  Output canonical in [0, q).  One lane per polynomial.
@@ -177,9 +192,10 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
 {
     constexpr int32_t GAMMA1 = 1 << (B - 1);
     constexpr uint64_t MASK = (1ull << B) - 1;
-    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
-    const size_t p = TWO ? t >> 1 : t;
-    if (p >= nitems * (size_t)L) return;               // (two-lane: whole pairs leave together)
+    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x, total = nitems * (size_t)L;
+    size_t p = TWO ? t >> 1 : t;
+    if (TWO && p >= total) return;                     // (two-lane: whole pairs leave together)
+    if (p >= total) p = total - 1;                     // lane per sponge: lanes past the end run along -- they store for others
     const size_t item = p / (size_t)L;
     const uint32_t nonce = (kappa[item] + (uint32_t)(p % (size_t)L)) & 0xFFFFu;
     LaneSponge<17, TWO> sp;
@@ -190,7 +206,16 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
     sp.pad_end();
     const bool wr = sp.writer();
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, y + p * 256, wr);
+    // Nothing in this sampler depends on the data (no rejection: every lane is at the same coefficient), so the lane-per-
+    // sponge form always takes the wave-synchronous transposed flush: whole 64-byte segments per store instruction
+    // instead of a 16-byte piece per lane.
+    const size_t first = (size_t)blockIdx.x * HASH_BS;
+#ifdef DIL_EM_LANESINK          // A/B: the per-lane flush in the lane-per-sponge form too
+    constexpr bool LS = true;
+#else
+    constexpr bool LS = TWO;
+#endif
+    typename std::conditional<LS, CoeffSink, CoeffSinkWave>::type sink = make_sink<LS>(ring, y, p, first, total, wr && t < total);
     uint64_t buf = 0;
     int nbits = 0, cnt = 0;          // wave-uniform
     while (cnt < 256) {

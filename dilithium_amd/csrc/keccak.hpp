@@ -409,6 +409,7 @@ struct CoeffSinkWaveT {
     bool uniform;
     __device__ __forceinline__ CoeffSinkWaveT(uint32_t* wr, int ln, int32_t* dst0, int nlive)
         : wave_ring(wr), ring(wr + ln), wave_dst(dst0), lane(ln), live_polys(nlive), flushed(0), uniform(true) {}
+    __device__ __forceinline__ void put(int cnt, int32_t v) { ring[(cnt & (RING - 1)) * 64] = (uint32_t)v; }
     __device__ __forceinline__ void flush_if_ready(int cnt)
     {
         if (uniform) {

@@ -74,6 +74,28 @@ def test_expand_mask_vs_host_sampler(gpu, level):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
+def test_expand_mask_throughput_kernel(gpu, level):
+    """expand_mask_kernel<18|20, false> (lane per sponge, above `two_lane_max_sponges` = 16384 polynomials; wave-synchronous
+    transposed stores): ragged last wave, kappa near the 16-bit wrap, sampled items vs the host sampler, and the whole
+    batch against the two-lane kernel run in small pieces"""
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(310 + level)
+    n = 16384 // p.L + 77
+    rhop = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    kappa = rng.integers(0, 65536, n).astype(np.int32)
+    kappa[:4] = [65535, 65530, 0, 65536 - p.L]
+    y = api.expand_mask(cu(gpu, rhop), cu(gpu, kappa), level)
+    yh = y.cpu().numpy()
+    assert yh.min() >= 0 and yh.max() < dk.Q
+    for i in (0, 1, 2, 3, 63, 64, n // 2, n - 2, n - 1):
+        want = np.stack([dk.expand_mask_poly(p, rhop[i].tobytes(), (int(kappa[i]) + l) & 0xFFFF) for l in range(p.L)])
+        assert (yh[i] == dk.canon(want)).all(), i
+    small = gpu.cat([api.expand_mask(cu(gpu, rhop[i:i + 512]), cu(gpu, kappa[i:i + 512]), level) for i in range(0, n, 512)])
+    assert gpu.equal(y, small)
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
 def test_sample_in_ball_vs_host_sampler(gpu, level):
     from dilithium_amd import api
     p = dk.PARAMS[level]
