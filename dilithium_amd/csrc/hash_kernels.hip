@@ -215,7 +215,7 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
 #else
     constexpr bool LS = TWO;
 #endif
-    typename std::conditional<LS, CoeffSink, CoeffSinkWave>::type sink = make_sink<LS>(ring, y, p, first, total, wr && t < total);
+    typename std::conditional<LS, CoeffSink, CoeffSinkWave>::type sink = make_sink<LS>(ring, y, p, first, total, wr && (TWO || t < total));
     uint64_t buf = 0;
     int nbits = 0, cnt = 0;          // wave-uniform
     while (cnt < 256) {

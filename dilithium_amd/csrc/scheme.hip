@@ -636,6 +636,11 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         if ((rc = ax.join())) return rc;
     }
 
+    struct EventGuard {
+        hipEvent_t ev = nullptr;
+        ~EventGuard() { if (ev) (void)hipEventDestroy(ev); }
+    } counted;
+    DIL_TRY(hipEventCreateWithFlags(&counted.ev, hipEventDisableTiming));
     int32_t *idx_cur = nullptr, *idx_next = idx0;
     size_t n = batch;
     int a0 = 0;                                          // attempts every pending item has already failed
@@ -676,14 +681,17 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
             return rc;
         // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
         DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s));
+        // the pending count goes home NOW, marked by an event; the winners' packing is queued behind it, so the host wakes up,
+        // sizes the next round and has its launches in the queue while the packing kernels still run
+        DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
+        DIL_TRY(hipEventRecord(counted.ev, s));
         dil::RowMap win;
         win.src_row = wine;
         win.dst_row = wini;
         win.count = counts + 1;
         DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, T, s, win));
         DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n, s, win));
-        DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
-        DIL_TRY(hipStreamSynchronize(s));
+        DIL_TRY(hipEventSynchronize(counted.ev));
         n = (size_t)host_counts[0];
         a0 += S_;
         idx_cur = idx_next;
