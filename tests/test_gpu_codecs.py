@@ -399,6 +399,38 @@ def test_random_keys_and_messages_vs_host_harness(gpu, level):
     assert (api.verify_sig(pk, sig, cu(gpu, mu), level).cpu().numpy() == 0).all()
 
 
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_hardest_items_of_a_dispatch_size_batch_vs_host_harness(gpu, level):
+    """2500 messages under one key go through every shape of the signing loop (wide first rounds on the lane-per-sponge
+    samplers, narrow last rounds with 64 speculative attempts per item on the two-lane ones).  A signature that merely
+    VERIFIES proves little -- any y gives one -- so the items that needed the most attempts (the ones the late rounds
+    produced) and a few others are re-signed by the host harness: same bytes, same attempt count; and a second device run
+    is identical to the first"""
+    from dilithium_amd import api
+    from oracle.oracle import Oracle
+    p = dk.PARAMS[level]
+    eng = dk.OracleEngine(Oracle())
+    k, pk, sk, _ = kat_wire(level)
+    rng = np.random.default_rng(7000 + level)
+    n = 2500
+    msgs = [rng.integers(0, 256, 48, dtype=np.uint8).tobytes() for _ in range(n)]
+    tr = k["tr"][0].tobytes()
+    mu = np.stack([np.frombuffer(hashlib.shake_256(tr + m).digest(64), dtype=np.uint8) for m in msgs])
+    skd, mud = cu(gpu, sk[:1]), cu(gpu, mu)
+    sig, att = api.sign(skd, mud, level, shared_sk=True)
+    sig2, att2 = api.sign(skd, mud, level, shared_sk=True)
+    assert gpu.equal(sig, sig2) and gpu.equal(att, att2)
+    sigh, atth = sig.cpu().numpy(), att.cpu().numpy()
+    hard = list(np.argsort(atth)[-5:]) + [0, 1, n - 1]
+    assert atth[hard[4]] >= 20
+    key = dict(rho=k["rho"][0].tobytes(), key=k["key"][0].tobytes(), tr=tr, s1_packed=k["s1"][0].tobytes(),
+               s2_packed=k["s2"][0].tobytes(), t0_packed=k["t0"][0].tobytes())
+    want = dk.sign_batch(level, [dict(key, msg=msgs[i]) for i in hard], eng, max_attempts=256)
+    for j, i in enumerate(hard):
+        assert atth[i] == want[j][3], (i, atth[i], want[j][3])
+        assert sigh[i].tobytes() == want[j][0] + want[j][1] + want[j][2], i
+
+
 def test_scheme_entry_points_edge_cases(gpu):
     from dilithium_amd import api, lib
     L = lib.load()
