@@ -130,10 +130,15 @@ struct Shake {
     // (compile time), permuting after each full block; returns the fill of the last, partial block.
     // Whole blocks are absorbed with static state indices and all RATE_WORDS loads in flight at once
     // (n is wave-uniform, so the partial tail is a run of scalar-predicated static accesses too).
+    // Software-pipelined: the words of block b + 1 (or of the partial tail) are LOADED before the permutation that follows
+    // block b and xored in after it -- a lane's message is a strided stream of its own (64 cache lines per load
+    // instruction), and with the loads at their first use every block of a long sponge (H(mu || w1): 7 blocks, tr = H(pk):
+    // 15) paid a memory round trip in front of its permutation.
     template <int W0>
     __device__ __forceinline__ int absorb(const uint64_t* __restrict__ src, int n)
     {
         int k = 0;
+        bool pend = false;                           // a full block is absorbed and waits for its permutation
         if (W0 != 0) {
             if (n < RATE_WORDS - W0) {
 #pragma unroll
@@ -143,23 +148,24 @@ struct Shake {
             }
 #pragma unroll
             for (int t = W0; t < RATE_WORDS; t++) s[t] ^= src[t - W0];
-            keccak_f1600(s);
             k = RATE_WORDS - W0;
+            pend = true;
         }
 #pragma unroll 1
-        for (; k + RATE_WORDS <= n; k += RATE_WORDS) {
+        for (;;) {
+            const int left = n - k;                  // wave-uniform
+            const bool full = left >= RATE_WORDS;
             uint64_t v[RATE_WORDS];
 #pragma unroll
-            for (int t = 0; t < RATE_WORDS; t++) v[t] = src[k + t];
+            for (int t = 0; t < RATE_WORDS; t++) v[t] = (full || t < left) ? src[k + t] : 0;
+            __builtin_amdgcn_sched_barrier(0);
+            if (pend) keccak_f1600(s);
 #pragma unroll
             for (int t = 0; t < RATE_WORDS; t++) s[t] ^= v[t];
-            keccak_f1600(s);
+            if (!full) return left;
+            k += RATE_WORDS;
+            pend = true;
         }
-        const int r = n - k;
-#pragma unroll
-        for (int t = 0; t < RATE_WORDS - 1; t++)
-            if (t < r) s[t] ^= src[k + t];
-        return r;
     }
     // pad (SHAKE suffix) after a message that left `fill` whole words in the current block, permute
     __device__ __forceinline__ void finish_words(int fill)
@@ -255,11 +261,12 @@ struct Shake2 {
 #pragma unroll
         for (int i = 0; i < 25; i++) s[i] = 0;
     }
-    template <int W0>
+    template <int W0>          // software-pipelined as Shake::absorb
     __device__ __forceinline__ int absorb(const uint32_t* __restrict__ src32, int n)
     {
         const uint32_t* src = src32 + (hi ? 1 : 0);
         int k = 0;
+        bool pend = false;
         if (W0 != 0) {
             if (n < RATE_WORDS - W0) {
 #pragma unroll
@@ -269,23 +276,24 @@ struct Shake2 {
             }
 #pragma unroll
             for (int t = W0; t < RATE_WORDS; t++) s[t] ^= src[2 * (t - W0)];
-            keccak2_f1600(s, hi);
             k = RATE_WORDS - W0;
+            pend = true;
         }
 #pragma unroll 1
-        for (; k + RATE_WORDS <= n; k += RATE_WORDS) {
+        for (;;) {
+            const int left = n - k;
+            const bool full = left >= RATE_WORDS;
             uint32_t v[RATE_WORDS];
 #pragma unroll
-            for (int t = 0; t < RATE_WORDS; t++) v[t] = src[2 * (k + t)];
+            for (int t = 0; t < RATE_WORDS; t++) v[t] = (full || t < left) ? src[2 * (k + t)] : 0u;
+            __builtin_amdgcn_sched_barrier(0);
+            if (pend) keccak2_f1600(s, hi);
 #pragma unroll
             for (int t = 0; t < RATE_WORDS; t++) s[t] ^= v[t];
-            keccak2_f1600(s, hi);
+            if (!full) return left;
+            k += RATE_WORDS;
+            pend = true;
         }
-        const int r = n - k;
-#pragma unroll
-        for (int t = 0; t < RATE_WORDS - 1; t++)
-            if (t < r) s[t] ^= src[2 * (k + t)];
-        return r;
     }
     __device__ __forceinline__ void finish_words(int fill)
     {
