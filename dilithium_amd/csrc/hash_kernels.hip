@@ -97,12 +97,12 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__
 #ifndef DIL_EA_ABL
 #define DIL_EA_ABL 0          // ablations: 1 = no ring / global stores, 2 = permutations only
 #endif
-template <bool CLAMP>
+template <bool CLAMP, int RING>
 __device__ __forceinline__ void emit23b(uint32_t v, uint32_t* ring_lane, int& cnt)
 {
     v &= 0x7FFFFFu;
 #if DIL_EA_ABL != 1
-    ring_lane[(cnt & (CoeffSink::RING - 1)) * 64] = v;
+    ring_lane[(cnt & (RING - 1)) * 64] = v;
 #endif
     int acc = (int)((v - QU) >> 31);                             // 1 iff v < q
     if (CLAMP) acc &= (int)((uint32_t)(cnt - 256) >> 31);        // ... and cnt < 256
@@ -118,14 +118,14 @@ __device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink
 #pragma unroll
     for (int g = 0; g < 7; g++) {
         const uint64_t w0 = sp.s[3 * g], w1 = sp.s[3 * g + 1], w2 = sp.s[3 * g + 2];
-        emit23b<CLAMP>((uint32_t)w0, sink.ring, cnt);
-        emit23b<CLAMP>((uint32_t)(w0 >> 24), sink.ring, cnt);
-        emit23b<CLAMP>((uint32_t)((w0 >> 48) | (w1 << 16)), sink.ring, cnt);
-        emit23b<CLAMP>((uint32_t)(w1 >> 8), sink.ring, cnt);
-        emit23b<CLAMP>((uint32_t)(w1 >> 32), sink.ring, cnt);
-        emit23b<CLAMP>((uint32_t)((w1 >> 56) | (w2 << 8)), sink.ring, cnt);
-        emit23b<CLAMP>((uint32_t)(w2 >> 16), sink.ring, cnt);
-        emit23b<CLAMP>((uint32_t)(w2 >> 40), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)w0, sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w0 >> 24), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)((w0 >> 48) | (w1 << 16)), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 8), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 32), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)((w1 >> 56) | (w2 << 8)), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 16), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 40), sink.ring, cnt);
 #if DIL_EA_ABL == 0
         sink.flush_if_ready(cnt);
 #endif
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_fast_kernel(int32_t* __restr
 #ifndef DIL_EA_LDS_PAD_DW
 #define DIL_EA_LDS_PAD_DW 0       // occupancy experiments: extra LDS dwords per workgroup (fewer resident waves)
 #endif
-    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE + DIL_EA_LDS_PAD_DW];
+    __shared__ uint32_t ring[CoeffSinkWaveT<P24>::LDS_DWORDS_PER_WAVE + DIL_EA_LDS_PAD_DW];
     // a lane without a polynomial runs along (its ring column is its own) but never stores
     const size_t first = (size_t)blockIdx.x * HASH_BS;             // one wave per workgroup: polynomial of lane 0
     CoeffSinkWaveT<P24> sink(ring, threadIdx.x & 63, A + first * CoeffSinkWaveT<P24>::POLY_DW, (int)(total - first < 64 ? total - first : 64));

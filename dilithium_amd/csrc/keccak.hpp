@@ -406,7 +406,12 @@ struct CoeffSinkWaveT {
             *reinterpret_cast<int4*>(poly + at) = v;
         }
     }
-    static constexpr int RING = 32, CHUNK = 16;
+    // 16 coefficients per polynomial and flush: one 64-byte segment (int32) or a 48-byte piece (24-bit).  The 48-byte pieces
+    // straddle the memory system's 32-byte sectors (PMC: 263 MB written for 188 MB of payload); flushing 32 coefficients =
+    // 96 bytes = three whole sectors from a ring twice as deep was tried and is SLOWER (keygen level 3, 8192 keys: 473 vs
+    // 426 us -- the deeper ring halves the resident waves), so 16 it stays.
+    static constexpr int CHUNK = 16, RING = 2 * CHUNK;
+    static constexpr int LPP = CHUNK / 4, PPI = 64 / LPP;        // lanes per polynomial, polynomials per store instruction
     static constexpr int LDS_DWORDS_PER_WAVE = RING * 64;
     uint32_t* wave_ring;      // [slot][lane]
     uint32_t* ring;           // wave_ring + lane
@@ -422,10 +427,10 @@ struct CoeffSinkWaveT {
     {
         if (uniform) {
             if (__all(cnt - flushed >= CHUNK)) {
-                const int base = flushed & (RING - 1), q = lane & 3;
+                const int base = flushed & (RING - 1), q = lane % LPP;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int p = 16 * j + (lane >> 2);
+                for (int j = 0; j < 64 / PPI; j++) {
+                    const int p = PPI * j + lane / LPP;
                     int4 v;
                     v.x = (int32_t)wave_ring[(base + 4 * q) * 64 + p];
                     v.y = (int32_t)wave_ring[(base + 4 * q + 1) * 64 + p];
