@@ -8,6 +8,7 @@
 // v3.1); parity is checked against hashlib and the KAT vectors.
 #include "keccak.hpp"
 #include "kernels.hpp"
+#include "sampler_bodies.hpp"
 
 #include <atomic>
 #include <type_traits>
@@ -41,52 +42,12 @@ __global__ __launch_bounds__(HASH_BS) void shake256_batch_kernel(uint64_t* __res
 // ExpandA: A[item][i][j] = RejUniform(SHAKE128(rho || byte j || byte i)), 3-byte little-endian
 // candidates masked to 23 bits, accepted when < q.  One lane per polynomial.
 // ---------------------------------------------------------------------------------------
-// every lane counts, only `writer` lanes store (two-lane sponges: both lanes of a pair run this with the same words)
-__device__ __forceinline__ void emit23(uint32_t v, CoeffSink& sink, int& cnt, bool writer)
-{
-    v &= 0x7FFFFFu;
-    if (v < QU && cnt < 256) {
-        if (writer) sink.put(cnt, (int32_t)v);
-        cnt++;
-    }
-}
-
 template <bool TWO>            // TWO: two lanes per sponge (one or a few keys: the five permutations per polynomial are pure latency)
 __global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho,
                                                       size_t rho_stride_words, int K, int L, size_t nitems)
 {
-    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
-    const size_t p = TWO ? t >> 1 : t;
-    const size_t total = nitems * (size_t)(K * L);
-    const bool live = p < total;                       // (two-lane: whole pairs are live or dead together)
-    const size_t item = live ? p / (size_t)(K * L) : 0;
-    const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
-    LaneSponge<21, TWO> sp;
-    sp.init(TWO && (t & 1));
-#pragma unroll
-    for (int w = 0; w < 4; w++) sp.set(w, rho[item * rho_stride_words + w]);
-    sp.set(4, (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16));
-    sp.pad_end();
-    const bool wr = live && sp.writer();
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, A + p * 256, wr);
-    int cnt = live ? 0 : 256;
-    while (__any(cnt < 256)) {
-        sp.permute();
-#pragma unroll
-        for (int g = 0; g < 7; g++) {
-            const uint64_t w0 = sp.word(3 * g), w1 = sp.word(3 * g + 1), w2 = sp.word(3 * g + 2);
-            emit23((uint32_t)w0, sink, cnt, wr);
-            emit23((uint32_t)(w0 >> 24), sink, cnt, wr);
-            emit23((uint32_t)((w0 >> 48) | (w1 << 16)), sink, cnt, wr);
-            emit23((uint32_t)(w1 >> 8), sink, cnt, wr);
-            emit23((uint32_t)(w1 >> 32), sink, cnt, wr);
-            emit23((uint32_t)((w1 >> 56) | (w2 << 8)), sink, cnt, wr);
-            emit23((uint32_t)(w2 >> 16), sink, cnt, wr);
-            emit23((uint32_t)(w2 >> 40), sink, cnt, wr);
-            if (wr) sink.flush_if_ready(cnt);
-        }
-    }
+    expand_a_body<TWO>(A, rho, rho_stride_words, K, L, nitems, blockIdx.x, ring);
 }
 
 // Lane-per-sponge ExpandA, branch-free candidate handling (the throughput form; the kernel above stays for the latency-

@@ -83,6 +83,9 @@ hipError_t launch_verify_wire_gen(int level, uint8_t* w1p, int32_t* verdict, con
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
                               const Tables& t, hipStream_t s, int a_fmt = A_I32);
+// ExpandA (two lanes per sponge) of `nkeys` keys and SampleInBall of `nitems` signatures in ONE launch (wire_kernels.hip)
+hipError_t launch_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, size_t nkeys, uint32_t* cbits, const uint8_t* ctilde,
+                               size_t ct_stride, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball_bits(uint32_t* cbits, const uint8_t* ctilde, size_t ct_stride, int level, size_t nitems, hipStream_t s);
 
 // ---- rows N2 / N4: codecs, ExpandS, Power2Round (codec_kernels.hip) ----

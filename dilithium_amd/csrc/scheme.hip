@@ -478,8 +478,16 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
             DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
             return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
         }
-        // Two independent Keccak jobs: ExpandA (nk * K * L sponges) and SampleInBall (batch sponges, one lane each).  The
-        // smaller one is latency-bound and goes to the helper stream, under the larger one.
+        // Two independent Keccak jobs: ExpandA (nk * K * L sponges) and SampleInBall (batch sponges, one lane each).
+        const size_t a_sp = nk * p.K * p.L;
+        if (a_sp <= 16384 && dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed)) {
+            // few keys: both jobs are latency-bound dependency chains -- ONE launch runs them side by side on different CUs
+            // (wire_kernels.hip expand_a_sib_kernel; no helper stream, no fork / join events)
+            DIL_TRY(dil::launch_expand_a_sib(A, pk, pkb, nk, cbits, sig, sgb, level, batch, s));
+            DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
+            return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
+        }
+        // Many keys: the smaller job goes to the helper stream, under the larger one.
         AuxFork ax(dv, s);
         const size_t a_sponges = nk * p.K * p.L;
         hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;

@@ -12,6 +12,7 @@
 #include "launch_util.hpp"
 #include "wire_common.hpp"
 #include "keccak.hpp"
+#include "sampler_bodies.hpp"
 
 namespace dil {
 
@@ -227,65 +228,25 @@ template <> struct WireNW<5> { static constexpr int N = 10; };   // 16 + 56 + 8 
 __global__ __launch_bounds__(64) void sample_in_ball_bits_kernel(uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde,
                                                                  size_t ct_stride, int tau, size_t nitems)
 {
-    __shared__ int8_t cl[256 * 64];           // c[idx][lane]
-    __shared__ uint8_t rb[136 * 64];          // rate block bytes [pos][lane]
-    const int lane = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * 64;
-    const size_t item = base + lane;
-    const bool live = item < nitems;
-    for (int k = 0; k < 256; k++) cl[k * 64 + lane] = 0;
-    Shake<17> sp;
-    sp.init();
-    if (live) {
-        const uint8_t* ct = ctilde + item * ct_stride;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            uint64_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 8; b++) v |= (uint64_t)ct[8 * w + b] << (8 * b);
-            sp.s[w] = v;
-        }
-    }
-    sp.s[4] = 0x1Full;
-    sp.s[16] ^= 0x8000000000000000ull;
-    keccak_f1600(sp.s);
-    uint64_t signs = sp.s[0];
-    auto spill = [&]() {
-#pragma unroll
-        for (int w = 0; w < 17; w++)
-#pragma unroll
-            for (int b = 0; b < 8; b++) rb[(8 * w + b) * 64 + lane] = (uint8_t)(sp.s[w] >> (8 * b));
-    };
-    spill();
-    int pos = 8;
-    for (int i = 256 - tau; i < 256; i++) {
-        int b;
-        do {
-            if (pos == 136) {
-                keccak_f1600(sp.s);
-                spill();
-                pos = 0;
-            }
-            b = rb[pos * 64 + lane];
-            pos++;
-        } while (b > i);
-        cl[i * 64 + lane] = cl[b * 64 + lane];
-        cl[b * 64 + lane] = (int8_t)(1 - 2 * (int)(signs & 1));
-        signs >>= 1;
-    }
-    __syncthreads();
-    // item t of this block, consumer lane `lane`: coefficients lane + 64 m
-    for (int t = 0; t < 64; t++) {
-        if (base + t >= nitems) break;
-        uint32_t w = 0;
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int v = cl[(lane + 64 * m) * 64 + t];
-            w |= (uint32_t)(v != 0) << m;
-            w |= (uint32_t)(v < 0) << (4 + m);
-        }
-        cbits[(base + t) * 64 + lane] = w;
-    }
+    __shared__ int8_t cl[256 * 64];
+    __shared__ uint8_t rb[136 * 64];
+    sample_in_ball_bits_body(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x, cl, rb);
+}
+
+// Verification under few public keys: ExpandA of the key(s) -- two lanes per sponge, a 5-permutation dependency chain -- and
+// SampleInBall of the signatures -- one lane per item, a serial loop -- are both latency-bound and independent.  They used to
+// meet through a helper stream (fork event, join event: ~15 us of a 140-us call); here they are ONE launch whose first
+// `a_blocks` workgroups expand the matrix and whose other workgroups sample the challenges, side by side on different CUs.
+__global__ __launch_bounds__(64) void expand_a_sib_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho, size_t rho_stride_words,
+                                                          int K, int L, size_t nkeys, unsigned a_blocks, uint32_t* __restrict__ cbits,
+                                                          const uint8_t* __restrict__ ctilde, size_t ct_stride, int tau, size_t nitems)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * 64 + 136 * 64];
+    if (blockIdx.x < a_blocks)
+        expand_a_body<true>(A, rho, rho_stride_words, K, L, nkeys, blockIdx.x, reinterpret_cast<uint32_t*>(lds));
+    else
+        sample_in_ball_bits_body(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x - a_blocks, reinterpret_cast<int8_t*>(lds),
+                                 lds + 256 * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -327,6 +288,21 @@ hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const i
     case 5: return launch_verify_wire_level<5>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, size_t nkeys, uint32_t* cbits, const uint8_t* ctilde,
+                               size_t ct_stride, int level, size_t nitems, hipStream_t s)
+{
+    if (nitems == 0 || nkeys == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    if ((rho_stride_bytes & 7) || (reinterpret_cast<uintptr_t>(rho) & 7)) return hipErrorInvalidValue;
+    const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    const unsigned a_blocks = (unsigned)((2 * nkeys * (size_t)(K * L) + 63) / 64);
+    const unsigned c_blocks = (unsigned)((nitems + 63) / 64);
+    hipLaunchKernelGGL(expand_a_sib_kernel, a_blocks + c_blocks, 64, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L,
+                       nkeys, a_blocks, cbits, ctilde, ct_stride, tau, nitems);
+    return hipGetLastError();
 }
 
 hipError_t launch_sample_in_ball_bits(uint32_t* cbits, const uint8_t* ctilde, size_t ct_stride, int level, size_t nitems, hipStream_t s)
