@@ -83,6 +83,10 @@ hipError_t launch_verify_wire_gen(int level, uint8_t* w1p, int32_t* verdict, con
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
                               const Tables& t, hipStream_t s, int a_fmt = A_I32);
+// set-up of a signing call in one launch: [ExpandA of few keys,] s1^ s2^ t0^ = NTT(unpack(sk)), rho' = SHAKE256(key || mu), attempts = 0
+hipError_t launch_sign_setup(int level, int32_t* A, bool expand_a_here, int32_t* s1h, int32_t* s2h, int32_t* t0h, const uint8_t* sk,
+                             size_t nk, uint8_t* rp, int32_t* attempts, const uint8_t* mu, size_t key_stride, size_t batch, const Tables& t,
+                             hipStream_t s);
 // ExpandA (two lanes per sponge) of `nkeys` keys and SampleInBall of `nitems` signatures in ONE launch (wire_kernels.hip)
 hipError_t launch_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, size_t nkeys, uint32_t* cbits, const uint8_t* ctilde,
                                size_t ct_stride, int level, size_t nitems, hipStream_t s);

@@ -579,7 +579,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
 {
     int rc;
     if (batch == 1) shared_sk = 1;
-    const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), sb = (size_t)32 * p.eta_bits, zb = (size_t)p.L * 32 * p.zbits;
+    const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
     // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
     // speculate for free
@@ -602,7 +602,6 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     int32_t* s2h = ws.take<int32_t>(nk * p.K * 256);
     int32_t* t0h = ws.take<int32_t>(nk * p.K * 256);
     // per item
-    uint8_t* km = ws.take<uint8_t>(batch * 96);          // key || mu
     uint8_t* rp = ws.take<uint8_t>(batch * 64);          // rho'
     int32_t* idx0 = ws.take<int32_t>(batch);             // pending lists (ping-pong)
     int32_t* idx1 = ws.take<int32_t>(batch);
@@ -625,23 +624,14 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     if (ws.rc) return ws.rc;
 
     {
-        // key material: A = ExpandA(rho) -- on the helper stream when it is latency-bound (one or few keys), beside the
-        // rest of the set-up -- and s1^ s2^ t0^ = NTT(unpack(sk))
-        AuxFork ax(dv, s);
+        // Set-up in one launch (wire_kernels.hip sign_setup_kernel): s1^ s2^ t0^ = NTT(unpack(sk)) read from the packed key,
+        // rho' = SHAKE256(key || mu, 64) with the key read in place (deterministic signing, as the reference's KATs), the attempt
+        // counters cleared -- and, when the keys are few, A = ExpandA(rho) by the same launch's first workgroups (latency-bound,
+        // two lanes per sponge).  Many keys: the throughput ExpandA first, on the same stream.
         att.a_fmt = matrix_format(nk, p.K, p.L);
-        DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, ax.fork(nk * p.K * p.L), att.a_fmt));
-        DIL_TRY(dil::launch_unpack(p.eta_bits, s1h, sk, skb, 96, p.L, dil::XF_OFFSET_MINUS, p.eta, nk, T, s));
-        DIL_TRY(dil::launch_unpack(p.eta_bits, s2h, sk, skb, 96 + p.L * sb, p.K, dil::XF_OFFSET_MINUS, p.eta, nk, T, s));
-        DIL_TRY(dil::launch_unpack(13, t0h, sk, skb, 96 + (p.L + p.K) * sb, p.K, dil::XF_OFFSET_MINUS, 1 << 12, nk, T, s));
-        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s1h, nk * p.L, T, s));
-        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, s2h, nk * p.K, T, s));
-        DIL_TRY(dil::launch_ntt(false, dil::LAYOUT_POLY, 0, t0h, nk * p.K, T, s));
-        // rho' = SHAKE256(key || mu, 64)  (deterministic signing, as the reference's KATs)
-        DIL_TRY(dil::launch_copy_field(km, 96, 0, sk, sk_stride, 32, 32, batch, T, s));
-        DIL_TRY(dil::launch_copy_field(km, 96, 32, mu, 64, 0, 64, batch, T, s));
-        DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(rp), 64, reinterpret_cast<uint64_t*>(km), 96, batch, s));
-        DIL_TRY(hipMemsetAsync(attempts, 0, batch * 4, s));
-        if ((rc = ax.join())) return rc;
+        const bool few = nk * p.K * p.L <= 16384;            // (then the matrix format is int32)
+        if (!few) DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s, att.a_fmt));
+        DIL_TRY(dil::launch_sign_setup(level, A, few, s1h, s2h, t0h, sk, nk, rp, attempts, mu, sk_stride, batch, T, s));
     }
 
     struct EventGuard {

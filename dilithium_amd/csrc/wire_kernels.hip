@@ -250,6 +250,79 @@ __global__ __launch_bounds__(64) void expand_a_sib_kernel(int32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Set-up of a signing call in ONE launch (was: ExpandA on a helper stream beside three unpack launches, three NTT launches,
+// two field copies, a SHAKE256 launch and a memset on the caller's stream, joined by events).  Workgroups of one wave, three roles:
+//   [0, a_blocks)                A = ExpandA(rho) of the key(s), two lanes per sponge -- only when the keys are few (latency-bound);
+//                                many keys run the throughput kernel beside this launch instead (a_blocks = 0)
+//   [a_blocks, +nk (L + 2K))     one polynomial of a secret key: s1 / s2 (eta - x, 3 | 4 bits) or t0 (2^12 - x, 13 bits) read from
+//                                the packed key (decoder.v:89-143), NTT, canonical out -- s1^ s2^ t0^ never exist in time domain
+//   the rest                     rho' = SHAKE256(key || mu, 64) for 64 messages per workgroup, key read in place from sk; the
+//                                message's attempt counter is cleared on the way (combined_top.v sign set-up, :1694-1790)
+// ---------------------------------------------------------------------------------------------------------
+template <int LEVEL>
+__global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A, unsigned a_blocks, int32_t* __restrict__ s1h,
+                                                        int32_t* __restrict__ s2h, int32_t* __restrict__ t0h, const uint8_t* __restrict__ sk,
+                                                        size_t sk_bytes, size_t nk, uint64_t* __restrict__ rp, int32_t* __restrict__ attempts,
+                                                        const uint64_t* __restrict__ mu, size_t key_stride, size_t batch,
+                                                        const uint32_t* __restrict__ fwd_tab)
+{
+    constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L, ETA = LEVEL == 3 ? 4 : 2, EB = LEVEL == 3 ? 4 : 3, NP = L + 2 * K;
+    __shared__ uint32_t ring[CoeffSink::LDS_DWORDS_PER_WAVE];
+    const int lane = threadIdx.x;
+    if (blockIdx.x < a_blocks) {
+        expand_a_body<true>(A, reinterpret_cast<const uint64_t*>(sk), sk_bytes / 8, K, L, nk, blockIdx.x, ring);
+        return;
+    }
+    const size_t u = blockIdx.x - a_blocks;
+    if (u < nk * NP) {
+        const size_t key = u / NP;
+        const int q = (int)(u % NP);
+        const uint8_t* base = sk + key * sk_bytes + 96;
+        int32_t r[4];
+        int32_t* out;
+        if (q < L + K) {
+            const PackedLane<EB> pl(lane);
+            uint32_t raw[4], f[4];
+            pl.load(raw, base + (size_t)q * (32 * EB));
+            pl.fields(f, raw);
+#pragma unroll
+            for (int m = 0; m < 4; m++) r[m] = ETA - (int32_t)f[m];
+            out = q < L ? s1h + (key * L + q) * 256 : s2h + (key * K + (q - L)) * 256;
+        } else {
+            const PackedLane<13> pl(lane);
+            uint32_t raw[4], f[4];
+            pl.load(raw, base + (size_t)(L + K) * (32 * EB) + (size_t)(q - L - K) * 416);
+            pl.fields(f, raw);
+#pragma unroll
+            for (int m = 0; m < 4; m++) r[m] = (1 << 12) - (int32_t)f[m];
+            out = t0h + (key * K + (q - L - K)) * 256;
+        }
+        TwRegs tw;
+        tw.load(fwd_tab, lane);
+        const X10Dpp lm(lane);
+        ntt_fwd_core(r, tw, lm);
+        *reinterpret_cast<int4*>(out + 4 * lane) = make_int4((int32_t)canon_any(r[0]), (int32_t)canon_any(r[1]), (int32_t)canon_any(r[2]),
+                                                             (int32_t)canon_any(r[3]));
+        return;
+    }
+    const size_t item = (u - nk * NP) * 64 + lane;
+    if (item >= batch) return;
+    const uint64_t* key = reinterpret_cast<const uint64_t*>(sk + item * key_stride + 32);
+    Shake<17> sp;
+    sp.init();
+#pragma unroll
+    for (int w = 0; w < 4; w++) sp.s[w] = key[w];
+#pragma unroll
+    for (int w = 0; w < 8; w++) sp.s[4 + w] = mu[item * 8 + w];
+    sp.s[12] = 0x1Full;
+    sp.s[16] ^= 0x8000000000000000ull;
+    keccak_f1600(sp.s);
+#pragma unroll
+    for (int w = 0; w < 8; w++) rp[item * 8 + w] = sp.s[w];
+    attempts[item] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 template <int LEVEL>
@@ -288,6 +361,28 @@ hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const i
     case 5: return launch_verify_wire_level<5>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_sign_setup(int level, int32_t* A, bool expand_a_here, int32_t* s1h, int32_t* s2h, int32_t* t0h, const uint8_t* sk,
+                             size_t nk, uint8_t* rp, int32_t* attempts, const uint8_t* mu, size_t key_stride, size_t batch, const Tables& t,
+                             hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(rp) | key_stride) & 7) return hipErrorInvalidValue;
+    const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    const size_t skb = 96 + (size_t)(L + K) * 32 * (level == 3 ? 4 : 3) + (size_t)K * 416;
+    const unsigned a_blocks = expand_a_here ? (unsigned)((2 * nk * (size_t)(K * L) + 63) / 64) : 0u;
+    const size_t blocks = a_blocks + nk * (size_t)(L + 2 * K) + (batch + 63) / 64;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+#define DIL_SS(LV)                                                                                                                   \
+    hipLaunchKernelGGL(sign_setup_kernel<LV>, (unsigned)blocks, 64, 0, s, A, a_blocks, s1h, s2h, t0h, sk, skb, nk,                   \
+                       reinterpret_cast<uint64_t*>(rp), attempts, reinterpret_cast<const uint64_t*>(mu), key_stride, batch, t.fwd)
+    if (level == 2) DIL_SS(2);
+    else if (level == 3) DIL_SS(3);
+    else DIL_SS(5);
+#undef DIL_SS
+    return hipGetLastError();
 }
 
 hipError_t launch_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, size_t nkeys, uint32_t* cbits, const uint8_t* ctilde,
