@@ -115,7 +115,10 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_fast_kernel(int32_t* __restr
     const size_t first = (size_t)blockIdx.x * HASH_BS;             // one wave per workgroup: polynomial of lane 0
     CoeffSinkWaveT<P24> sink(ring, threadIdx.x & 63, A + first * CoeffSinkWaveT<P24>::POLY_DW, (int)(total - first < 64 ? total - first : 64));
     int cnt = 0;
-    // (Tried: staggering the waves' start with s_sleep so that their store bursts do not coincide -- worse, 183 -> 196-260 us;
+    // (Tried, profiles/r02_expand_a.txt: the kernel costs [permutations] + [bytes written / 5.1 TB/s], ADDITIVELY, at every batch size, whatever
+    //  the layout of the stores (chunks rotated per polynomial; one contiguous 4 KiB per flush), the number of resident waves (1.25 - 5 per
+    //  SIMD) or the waves' relative phase (odd workgroups shifted by half a permutation of real work); clocks and power are the same.
+    //  Earlier: staggering the waves' start with s_sleep so that their store bursts do not coincide -- worse, 183 -> 196-260 us;
     //  issuing the batch as four concurrent launches inside a composite call -- worse, the fork / join barriers cost more than
     //  the overlap of ramp and tail gives back: verify 283 -> 345 us.  profiles/r02_expand_a.txt)
 #pragma unroll 1
