@@ -86,6 +86,60 @@ __global__ __launch_bounds__(256) void pack_kernel(uint8_t* __restrict__ out, si
 }
 
 // ---------------------------------------------------------------------------------------
+// End of key generation in ONE launch (large batches; was: tr = H(pk) on a helper stream beside two field copies and two
+// pack launches, joined by events).  Workgroups of one wave, two roles:
+//   [0, h_blocks)   tr = SHAKE256(pk, 32), two lanes per sponge (a 10 .. 20-permutation dependency chain per key), written
+//                   straight into sk[64:96]; the same lanes copy rho and key from the seed expansion into sk[0:64]
+//   the rest        s1 and s2 packed (eta - x, 3 | 4 bits) into sk[96:...], 8 coefficients per thread as pack_kernel
+// pk / sk 4-byte aligned (the fused keygen path), e = rho(32) | rho'(64) | key(32) per key.
+// ---------------------------------------------------------------------------------------
+template <int EB>
+__global__ __launch_bounds__(64) void keygen_finish_kernel(uint8_t* __restrict__ sk, size_t sk_bytes, const uint8_t* __restrict__ pk,
+                                                           size_t pk_bytes, const uint8_t* __restrict__ e, const int32_t* __restrict__ s1,
+                                                           const int32_t* __restrict__ s2, int L, int K, int32_t eta, unsigned h_blocks,
+                                                           size_t nkeys)
+{
+    if (blockIdx.x < h_blocks) {
+        const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+        const size_t i = t >> 1;
+        if (i >= nkeys) return;                                   // whole pairs leave together
+        const int hi = (int)(t & 1);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sk + i * sk_bytes);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(e + i * 128);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            dst[4 * hi + w] = src[4 * hi + w];                    // rho
+            dst[8 + 4 * hi + w] = src[24 + 4 * hi + w];           // key
+        }
+        Shake2<17> sp;
+        sp.init(hi);
+        const int fill = sp.absorb<0>(reinterpret_cast<const uint32_t*>(pk + i * pk_bytes), (int)(pk_bytes / 8));
+        sp.finish_words(fill);
+        sp.squeeze(dst + 16, 4);
+        return;
+    }
+    const size_t g = (size_t)(blockIdx.x - h_blocks) * 64 + threadIdx.x;
+    const int polys = L + K;
+    if (g >= nkeys * (size_t)polys * 32) return;
+    const size_t item = g / ((size_t)polys * 32);
+    const uint32_t r = (uint32_t)(g % ((size_t)polys * 32)), poly = r >> 5, grp = r & 31;
+    const int32_t* base = poly < (uint32_t)L ? s1 + (item * L + poly) * 256 : s2 + (item * K + (poly - L)) * 256;
+    const int4* src = reinterpret_cast<const int4*>(base + grp * 8);
+    const int4 lo = src[0], hi4 = src[1];
+    const int32_t c[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int32_t v = c[i];                                          // ExpandS output: canonical
+        v -= (((QC - 1) / 2 - v) >> 31) & QC;                      // centred
+        w |= ((uint32_t)(eta - v) & ((1u << EB) - 1)) << (i * EB);
+    }
+    uint8_t* dst = sk + item * sk_bytes + 96 + (size_t)poly * (32 * EB) + (size_t)grp * EB;
+#pragma unroll
+    for (int bt = 0; bt < EB; bt++) dst[bt] = (uint8_t)(w >> (8 * bt));
+}
+
+// ---------------------------------------------------------------------------------------
 // hints.  Wire form: omega position bytes then K cumulative counts (usehint.v:92-114).
 // unpack: one wave per item -> h [K][256] bytes 0/1; bad[item] = 1 when the encoding is malformed
 // (counts not monotone / > omega, positions not strictly increasing inside a row, non-zero padding).
@@ -498,6 +552,22 @@ hipError_t launch_pack(int bits, uint8_t* out, size_t out_stride, size_t out_off
     default: return hipErrorInvalidValue;
     }
 #undef DIL_PK
+    return hipGetLastError();
+}
+
+hipError_t launch_keygen_finish(uint8_t* sk, size_t sk_bytes, const uint8_t* pk, size_t pk_bytes, const uint8_t* e, const int32_t* s1,
+                                const int32_t* s2, int L, int K, int eta, int eta_bits, size_t nkeys, hipStream_t s)
+{
+    if (nkeys == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(e) | sk_bytes | pk_bytes) & 3)
+        return hipErrorInvalidValue;
+    const unsigned h_blocks = (unsigned)((2 * nkeys + 63) / 64);
+    const size_t p_blocks = (nkeys * (size_t)(L + K) * 32 + 63) / 64;
+    if (h_blocks + p_blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(h_blocks + p_blocks);
+    if (eta_bits == 3) hipLaunchKernelGGL(keygen_finish_kernel<3>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys);
+    else if (eta_bits == 4) hipLaunchKernelGGL(keygen_finish_kernel<4>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

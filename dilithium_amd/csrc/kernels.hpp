@@ -105,6 +105,9 @@ hipError_t launch_unpack(int bits, int32_t* out, const uint8_t* in, size_t in_st
                          int32_t offset, size_t nitems, const Tables& t, hipStream_t s);
 hipError_t launch_pack(int bits, uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int polys, int xf,
                        int32_t offset, size_t nitems, const Tables& t, hipStream_t s, RowMap map = RowMap());
+// end of key generation in one launch: tr = H(pk) -> sk, rho / key -> sk, s1 / s2 packed -> sk  (codec_kernels.hip)
+hipError_t launch_keygen_finish(uint8_t* sk, size_t sk_bytes, const uint8_t* pk, size_t pk_bytes, const uint8_t* e, const int32_t* s1,
+                                const int32_t* s2, int L, int K, int eta, int eta_bits, size_t nkeys, hipStream_t s);
 hipError_t launch_hint_unpack(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int K, int omega,
                               size_t nitems, hipStream_t s);
 hipError_t launch_hint_pack(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int K, int omega, size_t nitems,

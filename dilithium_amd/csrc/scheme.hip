@@ -407,6 +407,12 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
         DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, T, s));
         DIL_TRY(dil::launch_pack(10, pk, pkb, 32, t1, p.K, dil::XF_PLAIN, 0, batch, T, s));
     }
+    if (fused) {
+        // the rest of sk in ONE launch: tr = SHAKE256(pk, 32) (a long two-lane sponge per key) beside the copies of rho / key
+        // and the packing of s1 / s2 (codec_kernels.hip keygen_finish_kernel) -- no helper stream
+        DIL_TRY(dil::launch_keygen_finish(sk, skb, pk, pkb, e, s1, s2, p.L, p.K, p.eta, p.eta_bits, batch, s));
+        return ws.close(ax.join());
+    }
     // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level): one long sponge per key, latency-bound --
     // on the helper stream, under the packing of the rest of sk
     {
@@ -419,7 +425,7 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     DIL_TRY(dil::launch_copy_field(sk, skb, 32, e, 128, 96, 32, batch, T, s));
     DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96, s1, p.L, dil::XF_OFFSET_MINUS, p.eta, batch, T, s));
     DIL_TRY(dil::launch_pack(p.eta_bits, sk, skb, 96 + p.L * sb, s2, p.K, dil::XF_OFFSET_MINUS, p.eta, batch, T, s));
-    if (!fused) DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, T, s));
+    DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, T, s));
     return ws.close(ax.join());
 }
 
