@@ -58,16 +58,99 @@ __device__ __forceinline__ void expand_a_body(int32_t* __restrict__ A, const uin
 }
 
 
+// Lane-per-sponge ExpandA, branch-free candidate handling (the throughput form; the kernel above stays for the latency-
+// bound two-lane case).  A candidate is written to the lane's LDS ring slot `cnt` UNCONDITIONALLY and cnt advances by
+// (v < q) as sign-bit arithmetic: a rejected candidate is simply overwritten by the next one -- no compare, no divergent
+// branch, no VCC (56 candidates per rate block; VCC-form selects cost ~22 cycles each on gfx950).  The first four blocks
+// cannot reach 256 coefficients (4 x 56 = 224), so only later blocks pay for the `cnt < 256` clamp.
+#ifndef DIL_EA_ABL
+#define DIL_EA_ABL 0          // ablations: 1 = no ring / global stores, 2 = permutations only
+#endif
+template <bool CLAMP, int RING>
+__device__ __forceinline__ void emit23b(uint32_t v, uint32_t* ring_lane, int& cnt)
+{
+    v &= 0x7FFFFFu;
+#if DIL_EA_ABL != 1
+    ring_lane[(cnt & (RING - 1)) * 64] = v;
+#endif
+    int acc = (int)((v - QU_BODY) >> 31);                             // 1 iff v < q
+    if (CLAMP) acc &= (int)((uint32_t)(cnt - 256) >> 31);        // ... and cnt < 256
+    cnt += acc;
+}
+template <bool CLAMP, class EaSink>
+__device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink, int& cnt)
+{
+#if DIL_EA_ABL == 2
+    cnt += 52;
+    return;
+#endif
+#pragma unroll
+    for (int g = 0; g < 7; g++) {
+        const uint64_t w0 = sp.s[3 * g], w1 = sp.s[3 * g + 1], w2 = sp.s[3 * g + 2];
+        emit23b<CLAMP, EaSink::RING>((uint32_t)w0, sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w0 >> 24), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)((w0 >> 48) | (w1 << 16)), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 8), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 32), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)((w1 >> 56) | (w2 << 8)), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 16), sink.ring, cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 40), sink.ring, cnt);
+#if DIL_EA_ABL == 0
+        sink.flush_if_ready(cnt);
+#endif
+    }
+}
+// body of expand_a_fast_kernel<P24> (hash_kernels.hip) for workgroup `block`; `ring`: CoeffSinkWaveT<P24>::LDS_DWORDS_PER_WAVE dwords
+template <bool P24>        // P24: A leaves as 24-bit packed coefficients, 768 bytes per polynomial (the internal format of the composite calls)
+__device__ __forceinline__ void expand_a_fast_body(int32_t* __restrict__ A, const uint64_t* __restrict__ rho, size_t rho_stride_words, int K,
+                                                   int L, size_t nitems, unsigned block, uint32_t* ring)
+{
+    const size_t p = (size_t)block * HASH_BS + threadIdx.x;
+    const size_t total = nitems * (size_t)(K * L);
+    const bool live = p < total;
+    const size_t item = live ? p / (size_t)(K * L) : 0;
+    const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
+    Shake<21> sp;
+    sp.init();
+#pragma unroll
+    for (int w = 0; w < 4; w++) sp.s[w] = rho[item * rho_stride_words + w];
+    sp.s[4] = (uint64_t)j | ((uint64_t)i << 8) | (0x1Full << 16);
+    sp.s[20] ^= 0x8000000000000000ull;
+    // a lane without a polynomial runs along (its ring column is its own) but never stores
+    const size_t first = (size_t)block * HASH_BS;             // one wave per workgroup: polynomial of lane 0
+    CoeffSinkWaveT<P24> sink(ring, threadIdx.x & 63, A + first * CoeffSinkWaveT<P24>::POLY_DW, (int)(total - first < 64 ? total - first : 64));
+    int cnt = 0;
+    // (Tried, profiles/r02_expand_a.txt: the kernel costs [permutations] + [bytes written / 5.1 TB/s], ADDITIVELY, at every batch size, whatever
+    //  the layout of the stores (chunks rotated per polynomial; one contiguous 4 KiB per flush), the number of resident waves (1.25 - 5 per
+    //  SIMD) or the waves' relative phase (odd workgroups shifted by half a permutation of real work); clocks and power are the same.
+    //  Earlier: staggering the waves' start with s_sleep so that their store bursts do not coincide -- worse, 183 -> 196-260 us;
+    //  issuing the batch as four concurrent launches inside a composite call -- worse, the fork / join barriers cost more than
+    //  the overlap of ramp and tail gives back: verify 283 -> 345 us.  profiles/r02_expand_a.txt)
+#pragma unroll 1
+    for (int blk = 0; blk < 4; blk++) {
+        keccak_f1600(sp.s);
+        expand_a_block<false>(sp, sink, cnt);
+    }
+    do {
+        keccak_f1600(sp.s);
+        expand_a_block<true>(sp, sink, cnt);
+    } while (__any(cnt < 256));
+}
+
+
 // body of sample_in_ball_bits_kernel (wire_kernels.hip) for workgroup `block`; LDS: cl[256 * 64] = c[idx][lane],
 // rb[136 * 64] = rate block bytes [pos][lane]
+// ITEMS (64 or 32) signatures per workgroup: with 32, lanes 32..63 mirror lanes 0..31 (same item, same LDS cells, same values)
+// and the LDS footprint halves (cl[256 * ITEMS], rb[136 * ITEMS]) -- for launches that share the CU with LDS-hungry neighbours.
+template <int ITEMS>
 __device__ __forceinline__ void sample_in_ball_bits_body(uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde, size_t ct_stride,
                                                          int tau, size_t nitems, unsigned block, int8_t* cl, uint8_t* rb)
 {
-    const int lane = threadIdx.x;
-    const size_t base = (size_t)block * 64;
-    const size_t item = base + lane;
+    const int lane = threadIdx.x, col = lane & (ITEMS - 1);
+    const size_t base = (size_t)block * ITEMS;
+    const size_t item = base + col;
     const bool live = item < nitems;
-    for (int k = 0; k < 256; k++) cl[k * 64 + lane] = 0;
+    for (int k = 0; k < 256; k++) cl[k * ITEMS + col] = 0;
     Shake<17> sp;
     sp.init();
     if (live) {
@@ -88,7 +171,7 @@ __device__ __forceinline__ void sample_in_ball_bits_body(uint32_t* __restrict__ 
 #pragma unroll
         for (int w = 0; w < 17; w++)
 #pragma unroll
-            for (int b = 0; b < 8; b++) rb[(8 * w + b) * 64 + lane] = (uint8_t)(sp.s[w] >> (8 * b));
+            for (int b = 0; b < 8; b++) rb[(8 * w + b) * ITEMS + col] = (uint8_t)(sp.s[w] >> (8 * b));
     };
     spill();
     int pos = 8;
@@ -100,21 +183,21 @@ __device__ __forceinline__ void sample_in_ball_bits_body(uint32_t* __restrict__ 
                 spill();
                 pos = 0;
             }
-            b = rb[pos * 64 + lane];
+            b = rb[pos * ITEMS + col];
             pos++;
         } while (b > i);
-        cl[i * 64 + lane] = cl[b * 64 + lane];
-        cl[b * 64 + lane] = (int8_t)(1 - 2 * (int)(signs & 1));
+        cl[i * ITEMS + col] = cl[b * ITEMS + col];
+        cl[b * ITEMS + col] = (int8_t)(1 - 2 * (int)(signs & 1));
         signs >>= 1;
     }
     __syncthreads();
     // item t of this block, consumer lane `lane`: coefficients lane + 64 m
-    for (int t = 0; t < 64; t++) {
+    for (int t = 0; t < ITEMS; t++) {
         if (base + t >= nitems) break;
         uint32_t w = 0;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const int v = cl[(lane + 64 * m) * 64 + t];
+            const int v = cl[(lane + 64 * m) * ITEMS + t];
             w |= (uint32_t)(v != 0) << m;
             w |= (uint32_t)(v < 0) << (4 + m);
         }

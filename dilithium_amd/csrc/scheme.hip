@@ -493,7 +493,9 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
             DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
             return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
         }
-        // Many keys: the smaller job goes to the helper stream, under the larger one.
+        // Many keys: the smaller job goes to the helper stream, under the larger one.  (Tried: SampleInBall riding in the
+        // first workgroups of the throughput ExpandA's launch -- level 2 +8 %, level 3 -1.5 %, level 5 +2.5 % at 8192 keys,
+        // -3 % at 65536 keys at every level: not kept.)
         AuxFork ax(dv, s);
         const size_t a_sponges = nk * p.K * p.L;
         hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;

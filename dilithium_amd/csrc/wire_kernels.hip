@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64) void sample_in_ball_bits_kernel(uint32_t* __res
 {
     __shared__ int8_t cl[256 * 64];
     __shared__ uint8_t rb[136 * 64];
-    sample_in_ball_bits_body(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x, cl, rb);
+    sample_in_ball_bits_body<64>(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x, cl, rb);
 }
 
 // Verification under few public keys: ExpandA of the key(s) -- two lanes per sponge, a 5-permutation dependency chain -- and
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(64) void expand_a_sib_kernel(int32_t* __restrict__ 
     if (blockIdx.x < a_blocks)
         expand_a_body<true>(A, rho, rho_stride_words, K, L, nkeys, blockIdx.x, reinterpret_cast<uint32_t*>(lds));
     else
-        sample_in_ball_bits_body(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x - a_blocks, reinterpret_cast<int8_t*>(lds),
-                                 lds + 256 * 64);
+        sample_in_ball_bits_body<64>(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x - a_blocks, reinterpret_cast<int8_t*>(lds),
+                                     lds + 256 * 64);
 }
 
 // ---------------------------------------------------------------------------------------------------------
