@@ -456,12 +456,17 @@ namespace {
 // wire-format verification on a caller-provided scratch (dil_verify_sig_dev, dil_verify_msg_dev)
 int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t* verdict, const uint8_t* pk, const uint8_t* sig,
                     const uint8_t* mu, int level, const LevelPar& p, size_t batch, int shared_pk, hipStream_t s,
-                    const int32_t* A_ready = nullptr)      // A_ready: the caller's ExpandA(rho) of every key (dil_expand_a_dev), kept across calls
+                    const int32_t* A_ready = nullptr,      // A_ready: the caller's ExpandA(rho) of every key (dil_expand_a_dev), kept across calls
+                    AuxFork* mu_pending = nullptr)         // mu is still being computed on the helper stream: joined before its first use
 {
     int rc;
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_pk ? 1 : batch;
     const size_t w1b = (size_t)p.K * (level == 2 ? 192 : 128);
+    const bool few_keys_path = dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed) && !A_ready &&
+                               !(!shared_pk && dil::rt::cfg.gen_a.load(std::memory_order_relaxed)) && nk * p.K * p.L <= 16384 &&
+                               dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed);
+    if (mu_pending && !few_keys_path && (rc = mu_pending->join())) return rc;      // only that path defers the join to mu's first use
     if (dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed)) {
         // Fused path: ExpandA (helper stream when it is latency-bound) beside SampleInBall, then ONE kernel that reads
         // the packed z / t1 / hints and writes packed w1 (+ the ||z|| and hint-encoding verdict bits), then the challenge
@@ -491,6 +496,7 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
             // (wire_kernels.hip expand_a_sib_kernel; no helper stream, no fork / join events)
             DIL_TRY(dil::launch_expand_a_sib(A, pk, pkb, nk, cbits, sig, sgb, level, batch, s));
             DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
+            if (mu_pending && (rc = mu_pending->join())) return rc;
             return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
         }
         // Many keys: the smaller job goes to the helper stream, under the larger one.  (Tried: SampleInBall riding in the
@@ -778,10 +784,14 @@ int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     uint8_t* tr = ws.take<uint8_t>(nk * 32);
     uint8_t* mu = ws.take<uint8_t>(batch * 64);
     if (ws.rc) return ws.rc;
-    // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level), then mu = SHAKE256(tr || M, 64)
-    DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, nk, s));
-    DIL_TRY(dil::launch_mu(mu, tr, shared_pk ? 0 : 32, msgs, offsets, lengths, batch, s));
-    return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s));
+    // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level), then mu = SHAKE256(tr || M, 64): with few keys a
+    // latency-bound chain (15 + permutations in a row) that nothing needs before the challenge hash at the very end -- it runs
+    // on the helper stream beside ExpandA / SampleInBall / the fused kernel and is joined there
+    AuxFork ax(dv, s);
+    hipStream_t h = nk * p.K * p.L <= 16384 ? ax.fork(nk) : s;
+    DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, nk, h));
+    DIL_TRY(dil::launch_mu(mu, tr, shared_pk ? 0 : 32, msgs, offsets, lengths, batch, h));
+    return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s, nullptr, &ax));
 }
 
 // ---- host-buffer forms of the whole operations (H2D -> device call -> D2H on the null stream) --------
