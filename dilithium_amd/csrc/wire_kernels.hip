@@ -9,6 +9,7 @@
 // instead of 45 KiB plus the codec kernels' own read + write of the same fields.  The ||z|| < gamma1 - beta check
 // (norm_check.v:84-105) and the hint-encoding validation ride along (z is in registers anyway).
 // Same arithmetic as verify_wpi_kernel / verify_shared_kernel (pipelines.hip): combined_top.v:1207-1469.
+#include <algorithm>
 #include "launch_util.hpp"
 #include "wire_common.hpp"
 #include "keccak.hpp"
@@ -254,13 +255,13 @@ __global__ __launch_bounds__(64) void expand_a_sib_kernel(int32_t* __restrict__ 
 // two field copies, a SHAKE256 launch and a memset on the caller's stream, joined by events).  Workgroups of one wave, three roles:
 //   [0, a_blocks)                A = ExpandA(rho) of the key(s), two lanes per sponge -- only when the keys are few (latency-bound);
 //                                many keys run the throughput kernel beside this launch instead (a_blocks = 0)
-//   [a_blocks, +nk (L + 2K))     one polynomial of a secret key: s1 / s2 (eta - x, 3 | 4 bits) or t0 (2^12 - x, 13 bits) read from
+//   [a_blocks, +u_blocks)        grid-stride over the nk (L + 2K) polynomials of the secret key(s), one per wave and step: s1 / s2 (eta - x, 3 | 4 bits) or t0 (2^12 - x, 13 bits) read from
 //                                the packed key (decoder.v:89-143), NTT, canonical out -- s1^ s2^ t0^ never exist in time domain
 //   the rest                     rho' = SHAKE256(key || mu, 64) for 64 messages per workgroup, key read in place from sk; the
 //                                message's attempt counter is cleared on the way (combined_top.v sign set-up, :1694-1790)
 // ---------------------------------------------------------------------------------------------------------
 template <int LEVEL>
-__global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A, unsigned a_blocks, int32_t* __restrict__ s1h,
+__global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A, unsigned a_blocks, unsigned u_blocks, int32_t* __restrict__ s1h,
                                                         int32_t* __restrict__ s2h, int32_t* __restrict__ t0h, const uint8_t* __restrict__ sk,
                                                         size_t sk_bytes, size_t nk, uint64_t* __restrict__ rp, int32_t* __restrict__ attempts,
                                                         const uint64_t* __restrict__ mu, size_t key_stride, size_t batch,
@@ -273,8 +274,12 @@ __global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A,
         expand_a_body<true>(A, reinterpret_cast<const uint64_t*>(sk), sk_bytes / 8, K, L, nk, blockIdx.x, ring);
         return;
     }
-    const size_t u = blockIdx.x - a_blocks;
-    if (u < nk * NP) {
+    const size_t u0 = blockIdx.x - a_blocks;
+    if (u0 < u_blocks) {                       // persistent over the polynomials: the twiddles stay in registers
+      TwRegs tw;
+      tw.load(fwd_tab, lane);
+      const X10Dpp lm(lane);
+      for (size_t u = u0; u < nk * NP; u += u_blocks) {
         const size_t key = u / NP;
         const int q = (int)(u % NP);
         const uint8_t* base = sk + key * sk_bytes + 96;
@@ -297,15 +302,13 @@ __global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A,
             for (int m = 0; m < 4; m++) r[m] = (1 << 12) - (int32_t)f[m];
             out = t0h + (key * K + (q - L - K)) * 256;
         }
-        TwRegs tw;
-        tw.load(fwd_tab, lane);
-        const X10Dpp lm(lane);
         ntt_fwd_core(r, tw, lm);
         *reinterpret_cast<int4*>(out + 4 * lane) = make_int4((int32_t)canon_any(r[0]), (int32_t)canon_any(r[1]), (int32_t)canon_any(r[2]),
                                                              (int32_t)canon_any(r[3]));
-        return;
+      }
+      return;
     }
-    const size_t item = (u - nk * NP) * 64 + lane;
+    const size_t item = (u0 - u_blocks) * 64 + lane;
     if (item >= batch) return;
     const uint64_t* key = reinterpret_cast<const uint64_t*>(sk + item * key_stride + 32);
     Shake<17> sp;
@@ -373,10 +376,12 @@ hipError_t launch_sign_setup(int level, int32_t* A, bool expand_a_here, int32_t*
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t skb = 96 + (size_t)(L + K) * 32 * (level == 3 ? 4 : 3) + (size_t)K * 416;
     const unsigned a_blocks = expand_a_here ? (unsigned)((2 * nk * (size_t)(K * L) + 63) / 64) : 0u;
-    const size_t blocks = a_blocks + nk * (size_t)(L + 2 * K) + (batch + 63) / 64;
+    const size_t npoly = nk * (size_t)(L + 2 * K);
+    const unsigned u_blocks = (unsigned)std::min<size_t>(npoly, (size_t)t.num_cus * 32);       // 8 waves per SIMD, grid-stride over the polynomials
+    const size_t blocks = a_blocks + u_blocks + (batch + 63) / 64;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
 #define DIL_SS(LV)                                                                                                                   \
-    hipLaunchKernelGGL(sign_setup_kernel<LV>, (unsigned)blocks, 64, 0, s, A, a_blocks, s1h, s2h, t0h, sk, skb, nk,                   \
+    hipLaunchKernelGGL(sign_setup_kernel<LV>, (unsigned)blocks, 64, 0, s, A, a_blocks, u_blocks, s1h, s2h, t0h, sk, skb, nk,                   \
                        reinterpret_cast<uint64_t*>(rp), attempts, reinterpret_cast<const uint64_t*>(mu), key_stride, batch, t.fwd)
     if (level == 2) DIL_SS(2);
     else if (level == 3) DIL_SS(3);
