@@ -147,54 +147,9 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
 __global__ __launch_bounds__(64) void sample_in_ball_kernel(int32_t* __restrict__ c_out, const uint64_t* __restrict__ ctilde,
                                                             int tau, size_t nitems)
 {
-    __shared__ int8_t cl[256 * 64];           // c[idx][lane]
-    __shared__ uint8_t rb[136 * 64];          // rate block bytes [pos][lane]
-    const int lane = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * 64;
-    const size_t item = base + lane;
-    const bool live = item < nitems;
-    for (int k = 0; k < 256; k++) cl[k * 64 + lane] = 0;
-    Shake<17> sp;
-    sp.init();
-#pragma unroll
-    for (int w = 0; w < 4; w++) sp.s[w] = live ? ctilde[item * 4 + w] : 0;
-    sp.s[4] = 0x1Full;
-    sp.s[16] ^= 0x8000000000000000ull;
-    keccak_f1600(sp.s);
-    uint64_t signs = sp.s[0];
-    auto spill = [&]() {
-#pragma unroll
-        for (int w = 0; w < 17; w++)
-#pragma unroll
-            for (int b = 0; b < 8; b++) rb[(8 * w + b) * 64 + lane] = (uint8_t)(sp.s[w] >> (8 * b));
-    };
-    spill();
-    int pos = 8;
-    for (int i = 256 - tau; i < 256; i++) {
-        int b;
-        do {
-            if (pos == 136) {
-                keccak_f1600(sp.s);
-                spill();
-                pos = 0;
-            }
-            b = rb[pos * 64 + lane];
-            pos++;
-        } while (b > i);
-        cl[i * 64 + lane] = cl[b * 64 + lane];
-        cl[b * 64 + lane] = (int8_t)(1 - 2 * (int)(signs & 1));
-        signs >>= 1;
-    }
-    __syncthreads();
-    // coalesced write-out: item t of this block, coefficients lane + 64 m
-    for (int t = 0; t < 64; t++) {
-        if (base + t >= nitems) break;
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int v = cl[(lane + 64 * m) * 64 + t];
-            c_out[(base + t) * 256 + lane + 64 * m] = v + ((v >> 31) & (int32_t)QU);
-        }
-    }
+    __shared__ __attribute__((aligned(16))) uint8_t lds[SibLds<64>::BYTES];
+    sample_in_ball_poly_body<64>(c_out, reinterpret_cast<const uint8_t*>(ctilde), 32, tau, nitems, blockIdx.x, reinterpret_cast<int8_t*>(lds),
+                                 reinterpret_cast<uint32_t*>(lds + SibLds<64>::CL_BYTES));
 }
 
 // ---------------------------------------------------------------------------------------

@@ -138,72 +138,131 @@ __device__ __forceinline__ void expand_a_fast_body(int32_t* __restrict__ A, cons
 }
 
 
-// body of sample_in_ball_bits_kernel (wire_kernels.hip) for workgroup `block`; LDS: cl[256 * 64] = c[idx][lane],
-// rb[136 * 64] = rate block bytes [pos][lane]
-// ITEMS (64 or 32) signatures per workgroup: with 32, lanes 32..63 mirror lanes 0..31 (same item, same LDS cells, same values)
-// and the LDS footprint halves (cl[256 * ITEMS], rb[136 * ITEMS]) -- for launches that share the CU with LDS-hungry neighbours.
+// SampleInBall (gen_c.v:163-196,318-339), one lane per signature: c~ -> SHAKE256 -> 8 sign bytes, then for i = 256 - tau .. 255
+// bytes b until b <= i;  c[i] = c[b];  c[b] = +-1.  The lane's c[] and its current rate block live in LDS:
+//   cl   int8 [256][PITCH]   PITCH = ITEMS + 4 bytes: a multiple of 4 (dword reads in the output stage) whose dword count per
+//                            row is odd, so the transposed reads of the output stage are bank-conflict-free
+//   rb   uint32 [34][ITEMS]  the 136-byte rate block as dwords (spilled with 34 stores instead of 136 byte stores)
+// ITEMS (64 or 32) signatures per workgroup of one wave: with 32, lanes 32..63 mirror lanes 0..31 (same item, same LDS cells,
+// same values) and the footprint halves -- for launches that share the CU with LDS-hungry neighbours.
 template <int ITEMS>
-__device__ __forceinline__ void sample_in_ball_bits_body(uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde, size_t ct_stride,
-                                                         int tau, size_t nitems, unsigned block, int8_t* cl, uint8_t* rb)
+struct SibLds {
+    static constexpr int PITCH = ITEMS + 4;
+    static constexpr int CL_BYTES = 256 * PITCH, RB_DWORDS = 34 * ITEMS, BYTES = CL_BYTES + 4 * RB_DWORDS;
+};
+
+// fills cl for the workgroup's signatures (item = base + (lane & (ITEMS - 1)); c~ at ctilde + item * ct_stride, any alignment)
+template <int ITEMS>
+__device__ __forceinline__ void sample_in_ball_core(const uint8_t* __restrict__ ctilde, size_t ct_stride, int tau, size_t nitems, size_t base,
+                                                    int8_t* cl, uint32_t* rb)
 {
+    constexpr int PITCH = SibLds<ITEMS>::PITCH;
     const int lane = threadIdx.x, col = lane & (ITEMS - 1);
-    const size_t base = (size_t)block * ITEMS;
     const size_t item = base + col;
     const bool live = item < nitems;
-    for (int k = 0; k < 256; k++) cl[k * ITEMS + col] = 0;
+    for (int k = lane; k < SibLds<ITEMS>::CL_BYTES / 16; k += 64) reinterpret_cast<uint4*>(cl)[k] = make_uint4(0, 0, 0, 0);
     Shake<17> sp;
     sp.init();
     if (live) {
         const uint8_t* ct = ctilde + item * ct_stride;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            uint64_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 8; b++) v |= (uint64_t)ct[8 * w + b] << (8 * b);
-            sp.s[w] = v;
+            uint32_t lo, hi;
+            __builtin_memcpy(&lo, ct + 8 * w, 4);
+            __builtin_memcpy(&hi, ct + 8 * w + 4, 4);
+            sp.s[w] = ((uint64_t)hi << 32) | lo;
         }
     }
     sp.s[4] = 0x1Full;
     sp.s[16] ^= 0x8000000000000000ull;
     keccak_f1600(sp.s);
+    __syncthreads();                              // cl cleared by all lanes before any lane writes its column
     uint64_t signs = sp.s[0];
     auto spill = [&]() {
 #pragma unroll
-        for (int w = 0; w < 17; w++)
-#pragma unroll
-            for (int b = 0; b < 8; b++) rb[(8 * w + b) * ITEMS + col] = (uint8_t)(sp.s[w] >> (8 * b));
+        for (int w = 0; w < 17; w++) {
+            rb[(2 * w) * ITEMS + col] = (uint32_t)sp.s[w];
+            rb[(2 * w + 1) * ITEMS + col] = (uint32_t)(sp.s[w] >> 32);
+        }
     };
     spill();
-    int pos = 8;
-    for (int i = 256 - tau; i < 256; i++) {
-        int b;
-        do {
-            if (pos == 136) {
-                keccak_f1600(sp.s);
-                spill();
-                pos = 0;
-            }
-            b = rb[pos * ITEMS + col];
-            pos++;
-        } while (b > i);
-        cl[i * ITEMS + col] = cl[b * ITEMS + col];
-        cl[b * ITEMS + col] = (int8_t)(1 - 2 * (int)(signs & 1));
-        signs >>= 1;
+    // Every lane consumes ONE byte per step (so the read position is wave-uniform and the loop is flat): the byte is either
+    // taken for the lane's current i or skipped.  The wave runs max-over-lanes(bytes consumed) ~ tau + 12 steps, where a loop
+    // over i with an inner rejection loop runs sum-over-i(max-over-lanes(tries)) ~ 2.7 tau.
+    int pos = 8, i = 256 - tau;
+    while (__any(i < 256)) {
+        if (pos == 136) {
+            keccak_f1600(sp.s);
+            spill();
+            pos = 0;
+        }
+        const int b = (int)((rb[(pos >> 2) * ITEMS + col] >> (8 * (pos & 3))) & 255u);
+        pos++;
+        if (i < 256 && b <= i) {
+            cl[i * PITCH + col] = cl[b * PITCH + col];
+            cl[b * PITCH + col] = (int8_t)(1 - 2 * (int)(signs & 1));
+            signs >>= 1;
+            i++;
+        }
     }
     __syncthreads();
-    // item t of this block, consumer lane `lane`: coefficients lane + 64 m
-    for (int t = 0; t < ITEMS; t++) {
-        if (base + t >= nitems) break;
-        uint32_t w = 0;
+}
+
+// output stage, compact form (wire_kernels.hip decode_c): cbits[item][lane] bit m = c[lane + 64 m] != 0, bit 4 + m = its sign
+template <int ITEMS>
+__device__ __forceinline__ void sample_in_ball_bits_body(uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde, size_t ct_stride,
+                                                         int tau, size_t nitems, unsigned block, int8_t* cl, uint32_t* rb)
+{
+    constexpr int PITCH = SibLds<ITEMS>::PITCH;
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)block * ITEMS;
+    sample_in_ball_core<ITEMS>(ctilde, ct_stride, tau, nitems, base, cl, rb);
+    for (int t0 = 0; t0 < ITEMS; t0 += 4) {                           // four signatures per step: one dword of each row
+        if (base + t0 >= nitems) break;
+        uint32_t d[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int v = cl[(lane + 64 * m) * ITEMS + t];
-            w |= (uint32_t)(v != 0) << m;
-            w |= (uint32_t)(v < 0) << (4 + m);
+        for (int m = 0; m < 4; m++) d[m] = *reinterpret_cast<const uint32_t*>(cl + (lane + 64 * m) * PITCH + t0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (base + t0 + j < nitems) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t b = d[m] >> (8 * j);            // the byte is 0x00, 0x01 or 0xFF: bit 0 = non-zero, bit 7 = negative
+                    w |= (b & 1u) << m;                            // (compare-free: a VCC-form select costs ~22 cycles on this chip)
+                    w |= ((b >> 7) & 1u) << (4 + m);
+                }
+                cbits[(base + t0 + j) * 64 + lane] = w;
+            }
         }
-        cbits[(base + t) * 64 + lane] = w;
     }
 }
 
+// output stage, polynomial form (the signing loop): c[item][256] int32, canonical (+1 -> 1, -1 -> q - 1)
+template <int ITEMS>
+__device__ __forceinline__ void sample_in_ball_poly_body(int32_t* __restrict__ c_out, const uint8_t* __restrict__ ctilde, size_t ct_stride,
+                                                         int tau, size_t nitems, unsigned block, int8_t* cl, uint32_t* rb)
+{
+    constexpr int PITCH = SibLds<ITEMS>::PITCH;
+    const int lane = threadIdx.x;
+    const size_t base = (size_t)block * ITEMS;
+    sample_in_ball_core<ITEMS>(ctilde, ct_stride, tau, nitems, base, cl, rb);
+    for (int t0 = 0; t0 < ITEMS; t0 += 4) {
+        if (base + t0 >= nitems) break;
+        uint32_t d[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) d[m] = *reinterpret_cast<const uint32_t*>(cl + (lane + 64 * m) * PITCH + t0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (base + t0 + j < nitems) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int v = (int)(int8_t)(d[m] >> (8 * j));
+                    c_out[(base + t0 + j) * 256 + lane + 64 * m] = v + ((v >> 31) & (int32_t)QU_BODY);
+                }
+            }
+        }
+    }
+}
 
 }  // namespace dil

@@ -229,9 +229,9 @@ template <> struct WireNW<5> { static constexpr int N = 10; };   // 16 + 56 + 8 
 __global__ __launch_bounds__(64) void sample_in_ball_bits_kernel(uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde,
                                                                  size_t ct_stride, int tau, size_t nitems)
 {
-    __shared__ int8_t cl[256 * 64];
-    __shared__ uint8_t rb[136 * 64];
-    sample_in_ball_bits_body<64>(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x, cl, rb);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[SibLds<64>::BYTES];
+    sample_in_ball_bits_body<64>(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x, reinterpret_cast<int8_t*>(lds),
+                                 reinterpret_cast<uint32_t*>(lds + SibLds<64>::CL_BYTES));
 }
 
 // Verification under few public keys: ExpandA of the key(s) -- two lanes per sponge, a 5-permutation dependency chain -- and
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(64) void expand_a_sib_kernel(int32_t* __restrict__ 
                                                           int K, int L, size_t nkeys, unsigned a_blocks, uint32_t* __restrict__ cbits,
                                                           const uint8_t* __restrict__ ctilde, size_t ct_stride, int tau, size_t nitems)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[256 * 64 + 136 * 64];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[SibLds<64>::BYTES];
     if (blockIdx.x < a_blocks)
         expand_a_body<true>(A, rho, rho_stride_words, K, L, nkeys, blockIdx.x, reinterpret_cast<uint32_t*>(lds));
     else
         sample_in_ball_bits_body<64>(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x - a_blocks, reinterpret_cast<int8_t*>(lds),
-                                     lds + 256 * 64);
+                                     reinterpret_cast<uint32_t*>(lds + SibLds<64>::CL_BYTES));
 }
 
 // ---------------------------------------------------------------------------------------------------------
