@@ -67,13 +67,11 @@ __device__ __forceinline__ void expand_a_body(int32_t* __restrict__ A, const uin
 #define DIL_EA_ABL 0          // ablations: 1 = no ring / global stores, 2 = permutations only
 #endif
 template <bool CLAMP, int RING>
-__device__ __forceinline__ void emit23b(uint32_t v, uint32_t* ring_lane, int& cnt)
+__device__ __forceinline__ void emit23b(uint32_t v, uint32_t& val, uint32_t& slot, int& cnt)
 {
-    v &= 0x7FFFFFu;
-#if DIL_EA_ABL != 1
-    ring_lane[(cnt & (RING - 1)) * 64] = v;
-#endif
-    int acc = (int)((v - QU_BODY) >> 31);                             // 1 iff v < q
+    val = v & 0x7FFFFFu;
+    slot = (uint32_t)(cnt & (RING - 1)) * 64u;
+    int acc = (int)((val - QU_BODY) >> 31);                      // 1 iff v < q
     if (CLAMP) acc &= (int)((uint32_t)(cnt - 256) >> 31);        // ... and cnt < 256
     cnt += acc;
 }
@@ -87,16 +85,28 @@ __device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink
 #pragma unroll
     for (int g = 0; g < 7; g++) {
         const uint64_t w0 = sp.s[3 * g], w1 = sp.s[3 * g + 1], w2 = sp.s[3 * g + 2];
-        emit23b<CLAMP, EaSink::RING>((uint32_t)w0, sink.ring, cnt);
-        emit23b<CLAMP, EaSink::RING>((uint32_t)(w0 >> 24), sink.ring, cnt);
-        emit23b<CLAMP, EaSink::RING>((uint32_t)((w0 >> 48) | (w1 << 16)), sink.ring, cnt);
-        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 8), sink.ring, cnt);
-        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 32), sink.ring, cnt);
-        emit23b<CLAMP, EaSink::RING>((uint32_t)((w1 >> 56) | (w2 << 8)), sink.ring, cnt);
-        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 16), sink.ring, cnt);
-        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 40), sink.ring, cnt);
-#if DIL_EA_ABL == 0
-        sink.flush_if_ready(cnt);
+        // the eight candidates of three state words: values and ring slots first (a chain of adds), then the eight LDS
+        // writes back to back from eight different registers
+        uint32_t val[8], slot[8];
+        emit23b<CLAMP, EaSink::RING>((uint32_t)w0, val[0], slot[0], cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w0 >> 24), val[1], slot[1], cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)((w0 >> 48) | (w1 << 16)), val[2], slot[2], cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 8), val[3], slot[3], cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w1 >> 32), val[4], slot[4], cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)((w1 >> 56) | (w2 << 8)), val[5], slot[5], cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 16), val[6], slot[6], cnt);
+        emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 40), val[7], slot[7], cnt);
+#if DIL_EA_ABL != 1
+        uint32_t* at[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) at[e] = sink.ring + slot[e];
+        __builtin_amdgcn_sched_barrier(0);          // addresses and values complete: eight stores in a row, no register reused between them
+#pragma unroll
+        for (int e = 0; e < 8; e++) *at[e] = val[e];
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if DIL_EA_ABL == 0 || DIL_EA_ABL == 3 || DIL_EA_ABL == 4 || DIL_EA_ABL == 5
+        sink.flush_if_ready(cnt);           // (ablation 6: ring writes, no flush; 4: flush reads, no stores; 5: stores into 4 KiB per wave)
 #endif
     }
 }
@@ -120,12 +130,11 @@ __device__ __forceinline__ void expand_a_fast_body(int32_t* __restrict__ A, cons
     const size_t first = (size_t)block * HASH_BS;             // one wave per workgroup: polynomial of lane 0
     CoeffSinkWaveT<P24> sink(ring, threadIdx.x & 63, A + first * CoeffSinkWaveT<P24>::POLY_DW, (int)(total - first < 64 ? total - first : 64));
     int cnt = 0;
-    // (Tried, profiles/r02_expand_a.txt: the kernel costs [permutations] + [bytes written / 5.1 TB/s], ADDITIVELY, at every batch size, whatever
-    //  the layout of the stores (chunks rotated per polynomial; one contiguous 4 KiB per flush), the number of resident waves (1.25 - 5 per
-    //  SIMD) or the waves' relative phase (odd workgroups shifted by half a permutation of real work); clocks and power are the same.
-    //  Earlier: staggering the waves' start with s_sleep so that their store bursts do not coincide -- worse, 183 -> 196-260 us;
-    //  issuing the batch as four concurrent launches inside a composite call -- worse, the fork / join barriers cost more than
-    //  the overlap of ramp and tail gives back: verify 283 -> 345 us.  profiles/r02_expand_a.txt)
+    // Where the time goes (profiles/r02_expand_a.txt, ablations with the sponge kept observable; level 3, 8192 keys): permutations +
+    // candidate arithmetic 160 of 183 us (7.7 G perm/s: ONE generation of 3.75 waves per SIMD, i.e. four waves deep on most SIMDs;
+    // 9.6 G perm/s at 32768 keys), ring writes 8, flush reads 5, store issue 3, the HBM write stream 8.  Tried and not kept: chunk
+    // rotation / chunk-major store layouts, 1.25 - 5 resident waves per SIMD, phase-shifted workgroups, s_sleep staggering, several
+    // concurrent launches inside a composite call.
 #pragma unroll 1
     for (int blk = 0; blk < 4; blk++) {
         keccak_f1600(sp.s);
@@ -135,6 +144,9 @@ __device__ __forceinline__ void expand_a_fast_body(int32_t* __restrict__ A, cons
         keccak_f1600(sp.s);
         expand_a_block<true>(sp, sink, cnt);
     } while (__any(cnt < 256));
+#if DIL_EA_ABL != 0            // ablation builds: keep the sponge and the counters observable (without this hipcc deletes most of the kernel)
+    if (cnt != 256 || sp.s[0] == 0x0123456789abcdefull) A[p & 1023] = cnt;
+#endif
 }
 
 
