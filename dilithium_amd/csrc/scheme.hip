@@ -407,9 +407,11 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
         DIL_TRY(dil::launch_power2round(t1, t0, w, s2, batch * p.K * 256, T, s));
         DIL_TRY(dil::launch_pack(10, pk, pkb, 32, t1, p.K, dil::XF_PLAIN, 0, batch, T, s));
     }
-    if (fused) {
+    if (fused || (!(reinterpret_cast<uintptr_t>(sk) & 3) && dil::rt::cfg.fuse_keygen.load(std::memory_order_relaxed))) {
         // the rest of sk in ONE launch: tr = SHAKE256(pk, 32) (a long two-lane sponge per key) beside the copies of rho / key
-        // and the packing of s1 / s2 (codec_kernels.hip keygen_finish_kernel) -- no helper stream
+        // and the packing of s1 / s2 (codec_kernels.hip keygen_finish_kernel) -- no helper stream.  (Small batches, whose
+        // mat-vec ran unfused, still pack t0 with the codec kernel: a different region of sk.)
+        if (!fused) DIL_TRY(dil::launch_pack(13, sk, skb, 96 + (p.L + p.K) * sb, t0, p.K, dil::XF_OFFSET_MINUS, 1 << 12, batch, T, s));
         DIL_TRY(dil::launch_keygen_finish(sk, skb, pk, pkb, e, s1, s2, p.L, p.K, p.eta, p.eta_bits, batch, s));
         return ws.close(ax.join());
     }
