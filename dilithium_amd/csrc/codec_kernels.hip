@@ -10,6 +10,7 @@
 #include "keccak.hpp"
 #include "kernels.hpp"
 #include "modarith.hpp"
+#include "sampler_bodies.hpp"
 
 namespace dil {
 
@@ -220,55 +221,8 @@ __global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__
                                                       const uint8_t* __restrict__ rhoprime, size_t rp_stride, int eta, int nonce0,
                                                       int polys, size_t nitems)
 {
-    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
-    const size_t p = TWO ? t >> 1 : t;
-    const bool live = p < nitems * (size_t)polys;
-    const size_t item = live ? p / (size_t)polys : 0;
-    const int j = (int)(p % (size_t)polys);
-    const uint32_t nonce = (uint32_t)(nonce0 + j);
-    // polynomials [0, split) of an item go to s [item][split][256], the rest to s_tail [item][polys - split][256]
-    int32_t* out = j < split ? s + (item * split + j) * 256 : s_tail + (item * (size_t)(polys - split) + (j - split)) * 256;
-    LaneSponge<17, TWO> sp;
-    sp.init(TWO && (t & 1));
-    const uint8_t* rp = rhoprime + item * rp_stride;
-#pragma unroll
-    for (int w = 0; w < 8; w++) {
-        uint64_t v = 0;
-        for (int b = 0; b < 8; b++) v |= (uint64_t)rp[8 * w + b] << (8 * b);
-        sp.set(w, v);
-    }
-    sp.set(8, (uint64_t)nonce | (0x1Full << 16));
-    sp.pad_end();
-    const bool wr = live && sp.writer();
     __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, out, wr);
-    int cnt = live ? 0 : 256;
-    while (__any(cnt < 256)) {
-        sp.permute();
-#pragma unroll
-        for (int w = 0; w < 17; w++) {
-            uint64_t word = sp.word(w);
-#pragma unroll
-            for (int n = 0; n < 16; n++) {
-                const int nib = (int)(word & 15);
-                word >>= 4;
-                int v;
-                bool ok;
-                if (eta == 2) {
-                    ok = nib < 15;
-                    v = 2 - (nib - (205 * nib >> 10) * 5);
-                } else {
-                    ok = nib < 9;
-                    v = 4 - nib;
-                }
-                if (ok && cnt < 256) {
-                    if (wr) sink.put(cnt, v + ((v >> 31) & QC));
-                    cnt++;
-                }
-            }
-            if (wr) sink.flush_if_ready(cnt);  // <= 16 coefficients per 64-bit word
-        }
-    }
+    expand_s_body<TWO>(s, s_tail, split, rhoprime, rp_stride, eta, nonce0, polys, nitems, blockIdx.x, ring);
 }
 
 // Throughput form of ExpandS (lane per sponge, large batches).  The kernel above spends most of its time in the per-nibble

@@ -66,6 +66,9 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
 hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s, int a_fmt = A_I32);
+// few keys: A = ExpandA(rho) and (s1, s2) = ExpandS(rho') in one launch, two lanes per sponge (hash_kernels.hip)
+hipError_t launch_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int32_t* s1, int32_t* s2, const uint8_t* rhoprime,
+                             size_t rp_stride, int level, int eta, size_t nkeys, hipStream_t s);
 hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s);
 hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s);

@@ -393,11 +393,16 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     ws.secret = true;            // rho', key, s1, s2, t0
     AuxFork ax(dv, s);
     DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(e), 128, reinterpret_cast<const uint64_t*>(seed), 32, batch, s));
-    // ExpandS (helper stream, when it is latency-bound) runs beside ExpandA: independent, both Keccak-bound
-    DIL_TRY(dil::launch_expand_s(s1, s2, e + 32, 128, p.eta, p.L, p.K, batch, ax.fork(batch * p.K * p.L)));
     const int a_fmt = matrix_format(batch, p.K, p.L);
-    DIL_TRY(dil::launch_expand_a(A, e, 128, level, batch, s, a_fmt));
-    if ((rc = ax.join())) return rc;
+    if (batch * p.K * p.L <= 16384 && dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed)) {
+        // few keys: ExpandA and ExpandS are latency-bound two-lane sponges -- side by side in one launch
+        DIL_TRY(dil::launch_expand_a_s(A, e, 128, s1, s2, e + 32, 128, level, p.eta, batch, s));
+    } else {
+        // ExpandS (helper stream, when it is latency-bound) runs beside ExpandA: independent, both Keccak-bound
+        DIL_TRY(dil::launch_expand_s(s1, s2, e + 32, 128, p.eta, p.L, p.K, batch, ax.fork(batch * p.K * p.L)));
+        DIL_TRY(dil::launch_expand_a(A, e, 128, level, batch, s, a_fmt));
+        if ((rc = ax.join())) return rc;
+    }
     // pk = rho | t1
     DIL_TRY(dil::launch_copy_field(pk, pkb, 0, e, 128, 0, 32, batch, T, s));
     if (fused) {
