@@ -436,7 +436,7 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
         hipLaunchKernelGGL(expand_a_fast_kernel<true>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
         return hipGetLastError();
     }
-    if (total <= 16384) {        // latency-bound: two lanes per sponge
+    if (total <= EA_TWO_LANE_MAX) {        // latency-bound: two lanes per sponge
         hipLaunchKernelGGL(expand_a_kernel<true>, (int)((2 * total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A,
                            reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
         return hipGetLastError();

@@ -8,6 +8,10 @@
 
 namespace dil {
 
+// ExpandA switches from two lanes per sponge (latency-bound) to one at this many polynomials: measured crossover at level 3 between
+// 1000 keys (49 vs 60 us) and 1500 keys (69 vs 61 us) -- about one wave of sponges per SIMD.  The composite calls' "few keys" paths
+// (one launch for ExpandA + its latency-bound neighbours) use the same bound.
+constexpr size_t EA_TWO_LANE_MAX = 32768;
 extern std::atomic<int> two_lane_max_sponges;      // hash_kernels.hip (option "two_lane_max_sponges")
 
 enum { MAP_NATURAL = 0, MAP_AFTER_NTT = 1, MAP_AFTER_INVNTT = 2 };   // config.h:45-50 (enum MAPPING)

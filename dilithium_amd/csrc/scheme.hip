@@ -208,7 +208,7 @@ struct AttemptScratch {
 // the throughput form of ExpandA; one shared matrix, small batches and everything in the public API stay int32.
 inline int matrix_format(size_t nkeys, int K, int L)
 {
-    return (nkeys > 1 && nkeys * (size_t)(K * L) > 16384 && dil::rt::cfg.a24.load(std::memory_order_relaxed)) ? dil::A_P24 : dil::A_I32;
+    return (nkeys > 1 && nkeys * (size_t)(K * L) > dil::EA_TWO_LANE_MAX && dil::rt::cfg.a24.load(std::memory_order_relaxed)) ? dil::A_P24 : dil::A_I32;
 }
 int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
@@ -394,7 +394,7 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
     AuxFork ax(dv, s);
     DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(e), 128, reinterpret_cast<const uint64_t*>(seed), 32, batch, s));
     const int a_fmt = matrix_format(batch, p.K, p.L);
-    if (batch * p.K * p.L <= 16384 && dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed)) {
+    if (batch * p.K * p.L <= dil::EA_TWO_LANE_MAX && dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed)) {
         // few keys: ExpandA and ExpandS are latency-bound two-lane sponges -- side by side in one launch
         DIL_TRY(dil::launch_expand_a_s(A, e, 128, s1, s2, e + 32, 128, level, p.eta, batch, s));
     } else {
@@ -471,7 +471,7 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
     const size_t nk = shared_pk ? 1 : batch;
     const size_t w1b = (size_t)p.K * (level == 2 ? 192 : 128);
     const bool few_keys_path = dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed) && !A_ready &&
-                               !(!shared_pk && dil::rt::cfg.gen_a.load(std::memory_order_relaxed)) && nk * p.K * p.L <= 16384 &&
+                               !(!shared_pk && dil::rt::cfg.gen_a.load(std::memory_order_relaxed)) && nk * p.K * p.L <= dil::EA_TWO_LANE_MAX &&
                                dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed);
     if (mu_pending && !few_keys_path && (rc = mu_pending->join())) return rc;      // only that path defers the join to mu's first use
     if (dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed)) {
@@ -498,7 +498,7 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         }
         // Two independent Keccak jobs: ExpandA (nk * K * L sponges) and SampleInBall (batch sponges, one lane each).
         const size_t a_sp = nk * p.K * p.L;
-        if (a_sp <= 16384 && dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed)) {
+        if (a_sp <= dil::EA_TWO_LANE_MAX && dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed)) {
             // few keys: both jobs are latency-bound dependency chains -- ONE launch runs them side by side on different CUs
             // (wire_kernels.hip expand_a_sib_kernel; no helper stream, no fork / join events)
             DIL_TRY(dil::launch_expand_a_sib(A, pk, pkb, nk, cbits, sig, sgb, level, batch, s));
@@ -650,7 +650,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         // counters cleared -- and, when the keys are few, A = ExpandA(rho) by the same launch's first workgroups (latency-bound,
         // two lanes per sponge).  Many keys: the throughput ExpandA first, on the same stream.
         att.a_fmt = matrix_format(nk, p.K, p.L);
-        const bool few = nk * p.K * p.L <= 16384;            // (then the matrix format is int32)
+        const bool few = nk * p.K * p.L <= dil::EA_TWO_LANE_MAX;            // (then the matrix format is int32)
         if (!few) DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s, att.a_fmt));
         DIL_TRY(dil::launch_sign_setup(level, A, few, s1h, s2h, t0h, sk, nk, rp, attempts, mu, sk_stride, batch, T, s));
     }
@@ -795,7 +795,7 @@ int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     // latency-bound chain (15 + permutations in a row) that nothing needs before the challenge hash at the very end -- it runs
     // on the helper stream beside ExpandA / SampleInBall / the fused kernel and is joined there
     AuxFork ax(dv, s);
-    hipStream_t h = nk * p.K * p.L <= 16384 ? ax.fork(nk) : s;
+    hipStream_t h = nk * p.K * p.L <= dil::EA_TWO_LANE_MAX ? ax.fork(nk) : s;
     DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, nk, h));
     DIL_TRY(dil::launch_mu(mu, tr, shared_pk ? 0 : 32, msgs, offsets, lengths, batch, h));
     return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s, nullptr, &ax));

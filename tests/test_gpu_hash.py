@@ -43,13 +43,13 @@ def test_expand_a_vs_host_sampler(gpu, level):
 
 @pytest.mark.parametrize("level", [2, 3, 5])
 def test_expand_a_throughput_kernel_vs_host_sampler(gpu, level):
-    """more than 16384 polynomials switch ExpandA to the lane-per-sponge kernel with the wave-synchronous transposed
+    """more than 32768 polynomials switch ExpandA to the lane-per-sponge kernel with the wave-synchronous transposed
     flush (expand_a_fast_kernel): ragged key count (the last wave is partly empty), sampled keys vs the host sampler, and
     ALL keys vs the two-lane kernel (the same rho expanded 8 keys at a time)"""
     from dilithium_amd import api
     p = dk.PARAMS[level]
     rng = np.random.default_rng(100 + level)
-    n = 16384 // (p.K * p.L) + 37
+    n = 32768 // (p.K * p.L) + 37
     rho = cu(gpu, rng.integers(0, 256, (n, 32), dtype=np.uint8))
     A = api.expand_a(rho, level)
     for i in (0, 1, n // 2, n - 2, n - 1):
