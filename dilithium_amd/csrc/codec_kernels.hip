@@ -216,17 +216,8 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ ou
 // eta = 2: nibble < 15 -> 2 - (nibble mod 5);  eta = 4: nibble < 9 -> 4 - nibble.  Canonical out.
 // One lane per polynomial.
 // ---------------------------------------------------------------------------------------
-template <bool TWO>            // TWO: two lanes per sponge (few keys: latency-bound)
-__global__ __launch_bounds__(HASH_BS) void expand_s_kernel(int32_t* __restrict__ s, int32_t* __restrict__ s_tail, int split,
-                                                      const uint8_t* __restrict__ rhoprime, size_t rp_stride, int eta, int nonce0,
-                                                      int polys, size_t nitems)
-{
-    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    expand_s_body<TWO>(s, s_tail, split, rhoprime, rp_stride, eta, nonce0, polys, nitems, blockIdx.x, ring);
-}
-
-// Throughput form of ExpandS (lane per sponge, large batches).  The kernel above spends most of its time in the per-nibble
-// branch and the per-lane 16-byte flushes; here an accepted nibble costs six straight-line instructions: the RAW nibble is
+// ExpandS, one lane per sponge (every batch size: measured faster than a two-lane form with per-nibble branches even for 100
+// keys, 39 vs 59 us).  An accepted nibble costs six straight-line instructions: the RAW nibble is
 // written to the lane's byte row in LDS at its running count (a rejected one is overwritten by the next), the count
 // advances by the accept mask, and the `cnt < 256` guard is evaluated once per 64-bit word (a row has 16 spare bytes for
 // the overshoot).  Only when every lane of the wave has its 256 nibbles does the wave turn to polynomial layout: lane t
@@ -238,62 +229,8 @@ __global__ __launch_bounds__(HASH_BS) void expand_s_fast_kernel(int32_t* __restr
                                                                 const uint8_t* __restrict__ rhoprime, size_t rp_stride, int nonce0,
                                                                 int polys, size_t nitems)
 {
-    constexpr int ROW_DW = 69, LIM = ETA == 2 ? 15 : 9;
-    __shared__ uint32_t buf[64 * ROW_DW];
-    const int lane = threadIdx.x;
-    const size_t first = (size_t)blockIdx.x * HASH_BS, total = nitems * (size_t)polys;
-    const size_t p = first + lane;
-    const bool live = p < total;
-    const size_t item = live ? p / (size_t)polys : 0;
-    const int j = (int)(p % (size_t)polys);
-    Shake<17> sp;
-    sp.init();
-    const uint8_t* rp = rhoprime + item * rp_stride;
-#pragma unroll
-    for (int w = 0; w < 8; w++) {
-        uint32_t lo, hi;
-        __builtin_memcpy(&lo, rp + 8 * w, 4);          // any alignment (single dword loads on this target)
-        __builtin_memcpy(&hi, rp + 8 * w + 4, 4);
-        sp.s[w] = ((uint64_t)hi << 32) | lo;
-    }
-    sp.s[8] = (uint64_t)(uint32_t)(nonce0 + j) | (0x1Full << 16);
-    sp.s[16] ^= 0x8000000000000000ull;
-    uint8_t* mine = reinterpret_cast<uint8_t*>(buf) + lane * (ROW_DW * 4);
-    int cnt = live ? 0 : 256;
-    do {
-        keccak_f1600(sp.s);
-#pragma unroll
-        for (int w = 0; w < 17; w++) {
-            const int32_t act = sgn(cnt - 256);                       // this word still counts (<= 15 bytes of overshoot)
-            const uint32_t half[2] = {(uint32_t)sp.s[w], (uint32_t)(sp.s[w] >> 32)};
-#pragma unroll
-            for (int n = 0; n < 16; n++) {
-                const uint32_t nib = (half[n >> 3] >> (4 * (n & 7))) & 15u;
-                mine[cnt] = (uint8_t)nib;
-                cnt -= sgn((int32_t)nib - LIM) & act;
-            }
-        }
-    } while (__any(cnt < 256));
-    __syncthreads();
-    const int nlive = (int)(total - first < 64 ? total - first : 64);
-    size_t it = first / (size_t)polys;                                // wave-uniform walk over this wave's polynomials
-    int jj = (int)(first % (size_t)polys);
-    for (int q = 0; q < nlive; q++) {
-        const uint32_t d = buf[q * ROW_DW + lane];
-        int32_t c[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int nib = (int)((d >> (8 * m)) & 15u);
-            const int v = ETA == 2 ? 2 - (nib - ((205 * nib) >> 10) * 5) : 4 - nib;
-            c[m] = v + ((v >> 31) & QC);
-        }
-        int32_t* out = jj < split ? s + (it * split + jj) * 256 : s_tail + (it * (size_t)(polys - split) + (jj - split)) * 256;
-        *reinterpret_cast<int4*>(out + 4 * lane) = make_int4(c[0], c[1], c[2], c[3]);
-        if (++jj == polys) {
-            jj = 0;
-            it++;
-        }
-    }
+    __shared__ uint32_t buf[EXPAND_S_LDS_DWORDS];
+    expand_s_fast_body<ETA>(s, s_tail, split, rhoprime, rp_stride, nonce0, polys, nitems, blockIdx.x, buf);
 }
 
 // t = w + s2 (mod q);  (t1, t0) = Power2Round(t), d = 13  (combined_top.v keygen :921-1079)
@@ -546,21 +483,12 @@ hipError_t launch_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, si
 {
     if (nitems == 0) return hipSuccess;
     const size_t total = nitems * (size_t)(L + K);
-    if (total <= 16384)
-        hipLaunchKernelGGL(expand_s_kernel<true>, (int)((2 * total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime,
-                           rp_stride, eta, 0, L + K, nitems);
-#ifdef DIL_ES_OLD
-    else
-        hipLaunchKernelGGL(expand_s_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime,
-                           rp_stride, eta, 0, L + K, nitems);
-#else
-    else if (eta == 2)
+    if (eta == 2)
         hipLaunchKernelGGL(expand_s_fast_kernel<2>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime, rp_stride, 0,
                            L + K, nitems);
     else
         hipLaunchKernelGGL(expand_s_fast_kernel<4>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime, rp_stride, 0,
                            L + K, nitems);
-#endif
     return hipGetLastError();
 }
 

@@ -50,15 +50,17 @@ __global__ __launch_bounds__(HASH_BS) void expand_a_kernel(int32_t* __restrict__
     expand_a_body<TWO>(A, rho, rho_stride_words, K, L, nitems, blockIdx.x, ring);
 }
 
-// Key generation with few keys: ExpandA and ExpandS are both latency-bound two-lane sponges and independent -- one launch
-// (was: ExpandS on a helper stream, fork / join events).  First `a_blocks` workgroups: A; the others: s1, s2.
+// Key generation with few keys: ExpandA (two lanes per sponge) and ExpandS (a lane per sponge) are both latency-bound and
+// independent -- one launch (was: ExpandS on a helper stream, fork / join events).  First `a_blocks` workgroups: A; the others: s1, s2.
+template <int ETA>
 __global__ __launch_bounds__(HASH_BS) void expand_a_s_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho, size_t rho_stride_words,
                                                              int K, int L, unsigned a_blocks, int32_t* __restrict__ s1, int32_t* __restrict__ s2,
-                                                             const uint8_t* __restrict__ rhoprime, size_t rp_stride, int eta, size_t nkeys)
+                                                             const uint8_t* __restrict__ rhoprime, size_t rp_stride, size_t nkeys)
 {
-    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
-    if (blockIdx.x < a_blocks) expand_a_body<true>(A, rho, rho_stride_words, K, L, nkeys, blockIdx.x, ring);
-    else expand_s_body<true>(s1, s2, L, rhoprime, rp_stride, eta, 0, L + K, nkeys, blockIdx.x - a_blocks, ring);
+    __shared__ uint32_t lds[EXPAND_S_LDS_DWORDS];
+    static_assert(EXPAND_S_LDS_DWORDS >= (HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE, "ExpandA's ring fits");
+    if (blockIdx.x < a_blocks) expand_a_body<true>(A, rho, rho_stride_words, K, L, nkeys, blockIdx.x, lds);
+    else expand_s_fast_body<ETA>(s1, s2, L, rhoprime, rp_stride, 0, L + K, nkeys, blockIdx.x - a_blocks, lds);
 }
 
 template <bool P24>        // P24: A leaves as 24-bit packed coefficients, 768 bytes per polynomial (the internal format of the composite calls)
@@ -457,9 +459,13 @@ hipError_t launch_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_stride_b
     if ((rho_stride_bytes & 7) || (reinterpret_cast<uintptr_t>(rho) & 7)) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const unsigned a_blocks = (unsigned)((2 * nkeys * (size_t)(K * L) + HASH_BS - 1) / HASH_BS);
-    const unsigned s_blocks = (unsigned)((2 * nkeys * (size_t)(K + L) + HASH_BS - 1) / HASH_BS);
-    hipLaunchKernelGGL(expand_a_s_kernel, a_blocks + s_blocks, HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L,
-                       a_blocks, s1, s2, rhoprime, rp_stride, eta, nkeys);
+    const unsigned s_blocks = (unsigned)((nkeys * (size_t)(K + L) + HASH_BS - 1) / HASH_BS);
+    if (eta == 2)
+        hipLaunchKernelGGL(expand_a_s_kernel<2>, a_blocks + s_blocks, HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8,
+                           K, L, a_blocks, s1, s2, rhoprime, rp_stride, nkeys);
+    else
+        hipLaunchKernelGGL(expand_a_s_kernel<4>, a_blocks + s_blocks, HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8,
+                           K, L, a_blocks, s1, s2, rhoprime, rp_stride, nkeys);
     return hipGetLastError();
 }
 

@@ -150,58 +150,66 @@ __device__ __forceinline__ void expand_a_fast_body(int32_t* __restrict__ A, cons
 }
 
 
-// body of expand_s_kernel<TWO> (codec_kernels.hip: gen_s.v / rejection_s.v) for workgroup `block`; `ring` as expand_a_body's
-template <bool TWO>            // TWO: two lanes per sponge (few keys: latency-bound)
-__device__ __forceinline__ void expand_s_body(int32_t* __restrict__ s, int32_t* __restrict__ s_tail, int split,
-                                              const uint8_t* __restrict__ rhoprime, size_t rp_stride, int eta, int nonce0, int polys,
-                                              size_t nitems, unsigned block, uint32_t* ring)
+constexpr int EXPAND_S_LDS_DWORDS = 64 * 69;
+// body of expand_s_fast_kernel<ETA> (codec_kernels.hip: gen_s.v / rejection_s.v) for workgroup `block`; buf: EXPAND_S_LDS_DWORDS of LDS
+template <int ETA>
+__device__ __forceinline__ void expand_s_fast_body(int32_t* __restrict__ s, int32_t* __restrict__ s_tail, int split,
+                                                   const uint8_t* __restrict__ rhoprime, size_t rp_stride, int nonce0, int polys,
+                                                   size_t nitems, unsigned block, uint32_t* buf)
 {
-    const size_t t = (size_t)block * HASH_BS + threadIdx.x;
-    const size_t p = TWO ? t >> 1 : t;
-    const bool live = p < nitems * (size_t)polys;
+    constexpr int ROW_DW = 69, LIM = ETA == 2 ? 15 : 9;
+    const int lane = threadIdx.x;
+    const size_t first = (size_t)block * HASH_BS, total = nitems * (size_t)polys;
+    const size_t p = first + lane;
+    const bool live = p < total;
     const size_t item = live ? p / (size_t)polys : 0;
     const int j = (int)(p % (size_t)polys);
-    const uint32_t nonce = (uint32_t)(nonce0 + j);
-    // polynomials [0, split) of an item go to s [item][split][256], the rest to s_tail [item][polys - split][256]
-    int32_t* out = j < split ? s + (item * split + j) * 256 : s_tail + (item * (size_t)(polys - split) + (j - split)) * 256;
-    LaneSponge<17, TWO> sp;
-    sp.init(TWO && (t & 1));
+    Shake<17> sp;
+    sp.init();
     const uint8_t* rp = rhoprime + item * rp_stride;
 #pragma unroll
     for (int w = 0; w < 8; w++) {
-        uint64_t v = 0;
-        for (int b = 0; b < 8; b++) v |= (uint64_t)rp[8 * w + b] << (8 * b);
-        sp.set(w, v);
+        uint32_t lo, hi;
+        __builtin_memcpy(&lo, rp + 8 * w, 4);          // any alignment (single dword loads on this target)
+        __builtin_memcpy(&hi, rp + 8 * w + 4, 4);
+        sp.s[w] = ((uint64_t)hi << 32) | lo;
     }
-    sp.set(8, (uint64_t)nonce | (0x1Full << 16));
-    sp.pad_end();
-    const bool wr = live && sp.writer();
-    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, out, wr);
+    sp.s[8] = (uint64_t)(uint32_t)(nonce0 + j) | (0x1Full << 16);
+    sp.s[16] ^= 0x8000000000000000ull;
+    uint8_t* mine = reinterpret_cast<uint8_t*>(buf) + lane * (ROW_DW * 4);
     int cnt = live ? 0 : 256;
-    while (__any(cnt < 256)) {
-        sp.permute();
+    do {
+        keccak_f1600(sp.s);
 #pragma unroll
         for (int w = 0; w < 17; w++) {
-            uint64_t word = sp.word(w);
+            const int32_t act = sgn(cnt - 256);                       // this word still counts (<= 15 bytes of overshoot)
+            const uint32_t half[2] = {(uint32_t)sp.s[w], (uint32_t)(sp.s[w] >> 32)};
 #pragma unroll
             for (int n = 0; n < 16; n++) {
-                const int nib = (int)(word & 15);
-                word >>= 4;
-                int v;
-                bool ok;
-                if (eta == 2) {
-                    ok = nib < 15;
-                    v = 2 - (nib - (205 * nib >> 10) * 5);
-                } else {
-                    ok = nib < 9;
-                    v = 4 - nib;
-                }
-                if (ok && cnt < 256) {
-                    if (wr) sink.put(cnt, v + ((v >> 31) & (int32_t)QU_BODY));
-                    cnt++;
-                }
+                const uint32_t nib = (half[n >> 3] >> (4 * (n & 7))) & 15u;
+                mine[cnt] = (uint8_t)nib;
+                cnt -= sgn((int32_t)nib - LIM) & act;
             }
-            if (wr) sink.flush_if_ready(cnt);  // <= 16 coefficients per 64-bit word
+        }
+    } while (__any(cnt < 256));
+    __syncthreads();
+    const int nlive = (int)(total - first < 64 ? total - first : 64);
+    size_t it = first / (size_t)polys;                                // wave-uniform walk over this wave's polynomials
+    int jj = (int)(first % (size_t)polys);
+    for (int q = 0; q < nlive; q++) {
+        const uint32_t d = buf[q * ROW_DW + lane];
+        int32_t c[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int nib = (int)((d >> (8 * m)) & 15u);
+            const int v = ETA == 2 ? 2 - (nib - ((205 * nib) >> 10) * 5) : 4 - nib;
+            c[m] = v + ((v >> 31) & (int32_t)QU_BODY);
+        }
+        int32_t* out = jj < split ? s + (it * split + jj) * 256 : s_tail + (it * (size_t)(polys - split) + (jj - split)) * 256;
+        *reinterpret_cast<int4*>(out + 4 * lane) = make_int4(c[0], c[1], c[2], c[3]);
+        if (++jj == polys) {
+            jj = 0;
+            it++;
         }
     }
 }

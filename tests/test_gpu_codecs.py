@@ -171,9 +171,10 @@ def test_expand_s(gpu, level):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
-def test_expand_s_throughput_kernel(gpu, level):
-    """expand_s_fast_kernel<eta> (batches above 16384 polynomials; raw nibbles to LDS byte rows, transposed out): sampled
-    items, including the last -- ragged -- wave, against the host sampler; unaligned rho' rows"""
+def test_expand_s_large_ragged_batch(gpu, level):
+    """expand_s_fast_kernel<eta> (raw nibbles to LDS byte rows, transposed out) on a batch whose last wave is ragged:
+    sampled items -- first, wave boundaries, last -- against the host sampler; unaligned rho' rows; every coefficient in
+    [-eta, eta]; and the whole batch equal to the same rows expanded in small pieces"""
     from dilithium_amd import api
     p = dk.PARAMS[level]
     rng = np.random.default_rng(140 + level)
@@ -188,12 +189,11 @@ def test_expand_s_throughput_kernel(gpu, level):
             assert (s1[i, j] == dk.canon(dk.expand_s_poly(p, seed, j))).all()
         for j in range(p.K):
             assert (s2[i, j] == dk.canon(dk.expand_s_poly(p, seed, p.L + j))).all()
-    # every polynomial: coefficients in [-eta, eta], and the whole batch equals the latency-form kernel's output in two halves
     c1 = np.where(s1 > dk.Q // 2, s1 - dk.Q, s1)
     assert np.abs(c1).max() <= p.eta
-    h = n // 2
-    a1, a2 = api.expand_s(cu(gpu, rp[:h // 2]), level)          # small batch -> expand_s_kernel<true>
-    assert (a1.cpu().numpy() == s1[:h // 2]).all() and (a2.cpu().numpy() == s2[:h // 2]).all()
+    for lo in range(0, n, 401):                                   # pieces of 401 keys: other wave boundaries, same rows
+        a1, a2 = api.expand_s(cu(gpu, rp[lo:lo + 401]), level)
+        assert (a1.cpu().numpy() == s1[lo:lo + 401]).all() and (a2.cpu().numpy() == s2[lo:lo + 401]).all()
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
