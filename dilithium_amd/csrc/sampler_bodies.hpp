@@ -12,11 +12,14 @@ constexpr uint32_t QU_BODY = 8380417u;
 // every lane counts, only `writer` lanes store (two-lane sponges: both lanes of a pair run this with the same words)
 __device__ __forceinline__ void emit23(uint32_t v, CoeffSink& sink, int& cnt, bool writer)
 {
+    // branch-free (a lone wave pays ~5 cycles per instruction, and a divergent branch per candidate costs a dozen): the candidate is
+    // written to the lane's ring column unconditionally -- a rejected one, or one after the 256th, is overwritten or never flushed --
+    // and the count advances by the accept mask.  (`writer` lanes are the ones that flush; the partner lane's column is its own.)
+    (void)writer;
     v &= 0x7FFFFFu;
-    if (v < QU_BODY && cnt < 256) {
-        if (writer) sink.put(cnt, (int32_t)v);
-        cnt++;
-    }
+    sink.put(cnt, (int32_t)v);
+    const int acc = (int)((v - QU_BODY) >> 31) & (int)((uint32_t)(cnt - 256) >> 31);      // v < q and cnt < 256
+    cnt += acc;
 }
 
 // body of expand_a_kernel<TWO> (hash_kernels.hip) for workgroup `block`; `ring`: CoeffSink::LDS_DWORDS_PER_WAVE dwords of LDS
