@@ -151,6 +151,65 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
     }
 }
 
+// Two-lane form of ExpandMask for few entries (the narrow late rounds of the signing loop, single signatures): a lone wave
+// pays ~5 cycles per dependent instruction, so the extraction is unrolled at compile time -- nothing in it depends on the data.
+// Lane 2i holds the even dwords of sponge i's output stream, lane 2i + 1 the odd ones; after each permutation both lanes fetch
+// the partner's 17 dwords (one DPP move each) and see the block as 34 stream dwords; coefficient c is bits [B c, B c + B) of the
+// 5-block stream: one v_bfe, or one v_alignbit across two dwords (`carry` = the previous block's last dword).  ~360 instructions
+// per block instead of ~1800 in the generic bit-buffer loop of expand_mask_kernel<B, true>.
+template <int B>
+__global__ __launch_bounds__(HASH_BS) void expand_mask2_kernel(int32_t* __restrict__ y, const uint64_t* __restrict__ rhoprime,
+                                                               const uint32_t* __restrict__ kappa, int L, size_t nitems)
+{
+    constexpr int32_t GAMMA1 = 1 << (B - 1);
+    constexpr uint32_t MASK = (1u << B) - 1;
+    constexpr int BLOCK_BITS = 17 * 64;
+    const size_t t = (size_t)blockIdx.x * HASH_BS + threadIdx.x, total = nitems * (size_t)L;
+    const size_t p = t >> 1;
+    if (p >= total) return;                            // whole pairs leave together
+    const bool hi = (t & 1) != 0;
+    const size_t item = p / (size_t)L;
+    const uint32_t nonce = (kappa[item] + (uint32_t)(p % (size_t)L)) & 0xFFFFu;
+    Shake2<17> sp;
+    sp.init(hi);
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const uint64_t v = rhoprime[item * 8 + w];
+        sp.s[w] = hi ? (uint32_t)(v >> 32) : (uint32_t)v;
+    }
+    sp.s[8] = hi ? 0u : (nonce | (0x1Fu << 16));
+    sp.s[16] ^= hi ? 0x80000000u : 0u;
+    __shared__ uint32_t ring[(HASH_BS / 64) * CoeffSink::LDS_DWORDS_PER_WAVE];
+    CoeffSink sink(ring + (threadIdx.x >> 6) * CoeffSink::LDS_DWORDS_PER_WAVE, threadIdx.x & 63, y + p * 256, !hi);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int blk = 0; blk < 5; blk++) {
+        keccak2_f1600(sp.s, hi);
+        uint32_t D[34];                                // the block as stream dwords (same in both lanes of the pair)
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+            const uint32_t own = sp.s[w], par = k2_partner(own);
+            D[2 * w] = hi ? par : own;
+            D[2 * w + 1] = hi ? own : par;
+        }
+#pragma unroll
+        for (int c = 0; c < 256; c++) {
+            const int o = B * c, e = o + B;
+            if (e > BLOCK_BITS * blk && e <= BLOCK_BITS * (blk + 1)) {          // coefficient c ends in this block (static)
+                const int lj = (o >> 5) - 34 * blk, sh = o & 31;                 // local dword of its first bit; -1: previous block
+                const uint32_t lo = lj < 0 ? carry : D[lj < 0 ? 0 : lj];
+                uint32_t f;
+                if (sh + B <= 32) f = (lo >> sh) & MASK;
+                else f = __builtin_amdgcn_alignbit(D[lj + 1], lo, sh) & MASK;
+                const int32_t v = GAMMA1 - (int32_t)f;
+                sink.put(c, v + ((v >> 31) & (int32_t)QU));                      // (the partner lane writes its own, unused column)
+                if ((c & (CoeffSink::CHUNK - 1)) == CoeffSink::CHUNK - 1 && !hi) sink.flush_if_ready(c + 1);
+            }
+        }
+        carry = D[33];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // SampleInBall: c = tau coefficients +-1 from SHAKE256(c~): 8 sign bytes, then for
 // i = 256-tau..255 draw bytes until b <= i; c[i] = c[b]; c[b] = 1 - 2*sign.
@@ -478,8 +537,13 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
     if (total <= (size_t)two_lane_max_sponges.load(std::memory_order_relaxed)) {        // latency-bound: two lanes per sponge
         const int grid = (int)((2 * total + HASH_BS - 1) / HASH_BS);
+#ifdef DIL_EM2_OLD
         if (level == 2) hipLaunchKernelGGL((expand_mask_kernel<18, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
         else hipLaunchKernelGGL((expand_mask_kernel<20, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
+#else
+        if (level == 2) hipLaunchKernelGGL(expand_mask2_kernel<18>, grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
+        else hipLaunchKernelGGL(expand_mask2_kernel<20>, grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
+#endif
         return hipGetLastError();
     }
     const int grid = (int)((total + HASH_BS - 1) / HASH_BS);
