@@ -459,6 +459,14 @@ def main():
                     L.dil_verify_sig_dev(P(vd), P(pk), P(sigd), P(mu), 3, nb, 0, stream)
                 torch.cuda.synchronize()
                 lat[f"verify_sig_batch_{nb}_ms"] = (time.perf_counter() - t0) / reps * 1e3
+            for name, call in (("keygen_batch_1_ms", lambda: L.dil_keygen_dev(P(pk), P(sk), P(seed), 3, 1, stream)),
+                               ("sign_batch_1_ms", lambda: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, 1, 1, 512, stream))):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    call()
+                torch.cuda.synchronize()
+                lat[name] = (time.perf_counter() - t0) / 20 * 1e3
             sec["scheme_level3_wire_format"]["latency"] = lat
         except Exception as e:  # noqa: BLE001
             sec["scheme_level3_wire_format"] = {"error": repr(e)}
