@@ -1,0 +1,25 @@
+# Top-level Makefile -- the same build as `python -c "import __graft_entry__ as g; g.build()"`, for C / C++ users without Python:
+#   make            libdil256.so (HIP kernels + C-ABI, gfx950) and libdil256_ref.so (the reference-identical C++ symbols)
+#   make checkers   the oracle (test infrastructure) and, where /root/reference exists, the compiled reference under oracle/_ref/
+#   make cpp-tests  the C++ mains under tests/cpp/ (linked against the two libraries; they need a GPU to run)
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+CSRC    := dilithium_amd/csrc
+HIP_SRC := $(addprefix $(CSRC)/,kernels.hip pipelines.hip hash_kernels.hip codec_kernels.hip wire_kernels.hip gen_kernels.hip capi.hip scheme.hip multi_gpu.hip)
+HIP_HDR := $(wildcard $(CSRC)/*.hpp) include/dil256.h include/dil256_ref.hpp
+
+all: dilithium_amd/libdil256.so dilithium_amd/libdil256_ref.so
+
+dilithium_amd/libdil256.so: $(HIP_SRC) $(HIP_HDR)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wall $(HIP_SRC) -o $@
+
+dilithium_amd/libdil256_ref.so: $(CSRC)/ref_api.cpp dilithium_amd/libdil256.so include/dil256_ref.hpp
+	$(CXX) -O2 -std=c++17 -shared -fPIC -Wall $< -Ldilithium_amd -ldil256 -Wl,-rpath,'$$ORIGIN' -o $@
+
+checkers:
+	$(MAKE) -C oracle
+
+cpp-tests: all
+	$(MAKE) -C tests/cpp
+
+.PHONY: all checkers cpp-tests
