@@ -78,7 +78,8 @@ int dil_shutdown(void);
  *                                   in the per-stream arena until the next call on that stream overwrites it
  *   "sign_early", "sign_cap", "sign_waste", "aux_overlap", "ntt_blocks_per_cu", "wpi_blocks_per_cu",
  *   "fused_wgs_per_cu"              tuning knobs
- * Unknown name -> hipErrorInvalidValue. */
+ * Unknown name -> hipErrorInvalidValue.  (Options, device queries and error strings are runtime utilities: the reference -- synthesised
+ * logic and a batch-of-one C++ model -- has no counterpart.) */
 int dil_set_option(const char* name, int value);
 int dil_get_option(const char* name, int* value);
 int dil_device_count(int* count);
@@ -172,7 +173,8 @@ int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, vo
 #define DIL_CODEC_Z 4    /* 18|20 b, L polys, gamma1 - z */
 int dil_unpack_dev(int32_t* out, const uint8_t* in, size_t in_stride, size_t in_offset, int kind, int level, size_t batch, void* stream);
 int dil_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const int32_t* in, int kind, int level, size_t batch, void* stream);
-/* hints: omega position bytes + K cumulative counts <-> h [batch][K][256] bytes 0/1; bad[i] = 1 if malformed */
+/* hints: omega position bytes + K cumulative counts <-> h [batch][K][256] bytes 0/1; bad[i] = 1 if malformed
+ * (decoder side usehint.v:92-114, encoder side makehint.v:104-150) */
 int dil_hint_unpack_dev(uint8_t* h, int32_t* bad, const uint8_t* in, size_t in_stride, size_t in_offset, int level, size_t batch, void* stream);
 int dil_hint_pack_dev(uint8_t* out, size_t out_stride, size_t out_offset, const uint8_t* h, int level, size_t batch, void* stream);
 /* ExpandS: s1 [batch][L][256], s2 [batch][K][256] canonical from rho' (64 B at rhoprime + i*stride)   gen_s.v */
@@ -182,7 +184,8 @@ int dil_keygen_dev(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, siz
 size_t dil_pk_bytes(int level);
 size_t dil_sk_bytes(int level);
 size_t dil_sig_bytes(int level);
-/* wire-format verification: verdict[i] = 0 accept; bit0 challenge mismatch, bit1 ||z|| bound, bit2 malformed hint.
+/* wire-format verification (combined_top.v verify mode: VY_* states :1104-1470; stream order of pk / sig in rtl_tb/tb_verify_top.v:58-68):
+ * verdict[i] = 0 accept; bit0 challenge mismatch, bit1 ||z|| bound (norm_check.v:84-105), bit2 malformed hint (usehint.v:92-114).
  * mu [batch][64] = SHAKE256(tr || message) (dil_mu_dev / dil_verify_msg_dev hash the message on the device); shared_pk: one pk for all */
 int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                        int shared_pk, void* stream);
@@ -264,7 +267,7 @@ int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags
                          const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                          const int32_t* t0hat, int level, size_t batch, int shared_key, void* stream);
 
-/* ---- timing helpers (hipEvent on the caller's stream; used by bench.py) ------------------ */
+/* ---- timing helpers (hipEvent on the caller's stream; used by bench.py; runtime utilities without a reference counterpart) ---- */
 int dil_event_create(void** ev);
 int dil_event_destroy(void* ev);
 int dil_event_record(void* ev, void* stream);
