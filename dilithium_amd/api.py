@@ -207,6 +207,30 @@ def sign_phase2(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False):
     return z, h, flags
 
 
+def sign_phase2_early(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False):
+    """phase 2 as the signing loop runs it: stops at an attempt's first failed check (r0 rows -> 2, z rows -> 1, c t0
+    rows -> 4); z, h complete only where flags == 0.  w0 is IN/OUT (holds r0 of the evaluated rows afterwards)."""
+    K, Lv = _kl(level)
+    B = y.numel() // (Lv * N)
+    z = torch.zeros((B, Lv, N), dtype=torch.int32, device=y.device)
+    h = torch.zeros((B, K, N), dtype=torch.uint8, device=y.device)
+    flags = torch.empty((B,), dtype=torch.int32, device=y.device)
+    _lib.check(_lib.load().dil_sign_phase2_early_dev(_dev(z, torch.int32), _dev(h, torch.uint8), _dev(flags, torch.int32),
+                                                     _dev(c, torch.int32), _dev(y, torch.int32), _dev(w0, torch.int32),
+                                                     _dev(w1, torch.uint8), _dev(s1hat, torch.int32), _dev(s2hat, torch.int32),
+                                                     _dev(t0hat, torch.int32), level, B, int(shared_key), _stream()),
+               "dil_sign_phase2_early_dev")
+    return z, h, flags
+
+
+def launch_info(family: str) -> dict:
+    """most recent launch of a persistent kernel family: grid, items per workgroup and step, batch, launches so far"""
+    g, ipb, items, n = C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t()
+    _lib.check(_lib.load().dil_launch_info(family.encode(), C.byref(g), C.byref(ipb), C.byref(items), C.byref(n)), "dil_launch_info")
+    return {"grid": g.value, "items_per_block": ipb.value, "items": items.value, "launches": n.value,
+            "steps": -(-items.value // max(1, g.value * ipb.value))}
+
+
 # ---- row N1: SHAKE-bound samplers on the device (uint8 / int32 CUDA tensors) -----------------------
 def shake256(data, out_bytes):
     """out[i] = SHAKE256(data[i]); data uint8 [B, n] with n % 8 == 0, out_bytes % 8 == 0"""

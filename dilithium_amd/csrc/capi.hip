@@ -4,6 +4,7 @@
 // dilithium-256/ is C++; nothing here is a CPU fallback -- every arithmetic entry
 // point launches a HIP kernel and returns the hipError_t if that is not possible.
 #include "capi_internal.hpp"
+#include "launch_util.hpp"
 
 #include <algorithm>
 #include <mutex>
@@ -542,6 +543,30 @@ int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c
 {
     DIL_ENTER(d, T);
     return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, T, S(stream));
+}
+
+int dil_sign_phase2_early_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, int32_t* w0,
+                              const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
+                              size_t batch, int shared_key, void* stream)
+{
+    DIL_ENTER(d, T);
+    return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, T, S(stream), dil::KeyMap(), w0);
+}
+
+int dil_launch_info(const char* family, int* grid, int* items_per_block, size_t* items, size_t* launches)
+{
+    if (!family) return (int)hipErrorInvalidValue;
+    int n;
+    dil::LaunchRecord* tab = dil::launch_records(&n);
+    for (int i = 0; i < n; i++)
+        if (!strcmp(tab[i].family, family)) {
+            if (grid) *grid = (int)tab[i].grid.load(std::memory_order_relaxed);
+            if (items_per_block) *items_per_block = (int)tab[i].items_per_block.load(std::memory_order_relaxed);
+            if (items) *items = (size_t)tab[i].items.load(std::memory_order_relaxed);
+            if (launches) *launches = (size_t)tab[i].launches.load(std::memory_order_relaxed);
+            return 0;
+        }
+    return (int)hipErrorInvalidValue;
 }
 
 // ---- row N1: samplers ---------------------------------------------------------------------------

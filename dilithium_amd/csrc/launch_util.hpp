@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <atomic>
 #include <mutex>
+#include <stdint.h>
+#include <string.h>
 #include <vector>
 
 namespace dil {
@@ -43,6 +46,37 @@ inline int resident_blocks_per_cu(KernelT kernel, int block_threads, int cap, in
         n = occ_cache(device, key, block_threads, n);
     }
     return n < cap ? n : cap;
+}
+
+// Debug record of the most recent launch of every PERSISTENT kernel family (grid = min(work, resident)): the parity
+// tests read it through dil_launch_info() to assert that a batch was large enough for the kernels' item loops to be
+// re-entered -- the code after the first item (next-item prefetch, loop-carried registers) is otherwise never compared
+// with the oracle.  Three relaxed atomic stores per launch; process-wide (the tests are single-threaded).
+struct LaunchRecord {
+    const char* family;
+    std::atomic<uint32_t> grid{0}, items_per_block{0};
+    std::atomic<uint64_t> items{0}, launches{0};
+};
+inline LaunchRecord* launch_records(int* count)
+{
+    static LaunchRecord tab[] = {{"matvec_wpi"},  {"sign1_wpi"},     {"matvec_shared"},   {"sign1_shared"},       {"keygen_wpi"},
+                                 {"verify_wpi"},  {"verify_shared"}, {"sign2_wpi"},       {"sign2_early_wpi"},    {"verify_wire_wpi"},
+                                 {"verify_wire_shared"}, {"verify_wire_gen"}, {"sign1_packed_wpi"}, {"sign1_packed_shared"}};
+    if (count) *count = (int)(sizeof(tab) / sizeof(tab[0]));
+    return tab;
+}
+inline void note_launch(const char* family, int grid, int items_per_block, size_t items)
+{
+    int n;
+    LaunchRecord* tab = launch_records(&n);
+    for (int i = 0; i < n; i++)
+        if (!strcmp(tab[i].family, family)) {
+            tab[i].grid.store((uint32_t)grid, std::memory_order_relaxed);
+            tab[i].items_per_block.store((uint32_t)items_per_block, std::memory_order_relaxed);
+            tab[i].items.store(items, std::memory_order_relaxed);
+            tab[i].launches.fetch_add(1, std::memory_order_relaxed);
+            return;
+        }
 }
 
 static inline int grid_for(size_t work_blocks, int max_blocks)

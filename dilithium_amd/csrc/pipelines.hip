@@ -844,6 +844,7 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
     if (AF == A_I32 && use_wpi(batch, t) && shared_A) {
         constexpr int NW = SharedNW<LEVEL>::MATVEC;
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
+        note_launch(OUT == OUT_W ? "matvec_shared" : "sign1_shared", g, NW, batch);
         hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
@@ -851,6 +852,7 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
     if (use_wpi(batch, t)) {
         const int g = grid_for((batch + 3) / 4,
                                t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT, AF>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch(OUT == OUT_W ? "matvec_wpi" : "sign1_wpi", g, 4, batch);
         hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT, AF>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, km, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
@@ -892,9 +894,11 @@ static hipError_t launch_keygen_level(uint8_t* pk, size_t pk_stride, uint8_t* sk
 {
     if (a_fmt == A_P24) {
         const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(keygen_wpi_kernel<LEVEL, A_P24>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch("keygen_wpi", g, 4, batch);
         hipLaunchKernelGGL((keygen_wpi_kernel<LEVEL, A_P24>), g, 256, 0, s, pk, pk_stride, sk, sk_stride, sk_t0_offset, A, s1, s2, batch, t.fwd, t.inv_pipe);
     } else {
         const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(keygen_wpi_kernel<LEVEL, A_I32>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch("keygen_wpi", g, 4, batch);
         hipLaunchKernelGGL((keygen_wpi_kernel<LEVEL, A_I32>), g, 256, 0, s, pk, pk_stride, sk, sk_stride, sk_t0_offset, A, s1, s2, batch, t.fwd, t.inv_pipe);
     }
     return hipGetLastError();
@@ -920,9 +924,11 @@ static void launch_verify_wpi(uint8_t* w1, const int32_t* A, const int32_t* z, c
     if (shared_pk) {
         constexpr int NW = SharedNW<LEVEL>::VERIFY;
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
+        note_launch("verify_shared", g, NW, batch);
         hipLaunchKernelGGL((verify_shared_kernel<LEVEL, NW>), g, 64 * NW, 0, s, w1, A, z, c, t1, h, batch, t.fwd, t.inv_pipe);
     } else {
         const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(verify_wpi_kernel<LEVEL>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch("verify_wpi", g, 4, batch);
         hipLaunchKernelGGL((verify_wpi_kernel<LEVEL>), g, 256, 0, s, w1, A, z, c, t1, h, batch, t.fwd, t.inv_pipe);
     }
 }
@@ -966,9 +972,12 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
     if (use_wpi(batch, t) && w0_scratch) {      // the signing loop's early-exit form (w0 is its own scratch, reused for r0)
         if (w0_scratch != w0) return hipErrorInvalidValue;
 #define DIL_S2E(LV)                                                                                                              \
-    hipLaunchKernelGGL(sign2_early_wpi_kernel<LV>,                                                                               \
-                       grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu, t.device)), \
-                       256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe);          \
+    {                                                                                                                            \
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu, t.device)); \
+        note_launch("sign2_early_wpi", g, 4, batch);                                                                             \
+        hipLaunchKernelGGL(sign2_early_wpi_kernel<LV>, g, 256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, \
+                           km, t.fwd, t.inv_pipe);                                                                               \
+    }                                                                                                                            \
     break
         switch (level) {
         case 2: DIL_S2E(2);
@@ -980,12 +989,21 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
         return hipGetLastError();
     }
     if (use_wpi(batch, t)) {
+#define DIL_S2W(LV)                                                                                                              \
+    {                                                                                                                            \
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu, t.device)); \
+        note_launch("sign2_wpi", g, 4, batch);                                                                                   \
+        hipLaunchKernelGGL(sign2_wpi_kernel<LV>, g, 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, \
+                           t.inv_pipe);                                                                                          \
+    }                                                                                                                            \
+    break
         switch (level) {
-        case 2: hipLaunchKernelGGL(sign2_wpi_kernel<2>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<2>, 256, t.wpi_blocks_per_cu, t.device)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
-        case 3: hipLaunchKernelGGL(sign2_wpi_kernel<3>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<3>, 256, t.wpi_blocks_per_cu, t.device)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
-        case 5: hipLaunchKernelGGL(sign2_wpi_kernel<5>, grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<5>, 256, t.wpi_blocks_per_cu, t.device)), 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, t.inv_pipe); break;
+        case 2: DIL_S2W(2);
+        case 3: DIL_S2W(3);
+        case 5: DIL_S2W(5);
         default: return hipErrorInvalidValue;
         }
+#undef DIL_S2W
         return hipGetLastError();
     }
     const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);

@@ -337,16 +337,19 @@ static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const
     if (shared_pk) {
         constexpr int NW = WireNW<LEVEL>::N;
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
+        note_launch("verify_wire_shared", g, NW, batch);
         hipLaunchKernelGGL((verify_wire_shared_kernel<LEVEL, NW>), g, 64 * NW, 0, s, w1p, verdict, A, pk, sig, sig_stride, cbits, batch,
                            t.fwd, t.inv_pipe);
     } else if (a_fmt == A_P24) {
         const int g = grid_for((batch + 3) / 4,
                                t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_P24>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch("verify_wire_wpi", g, 4, batch);
         hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_P24>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
                            t.fwd, t.inv_pipe);
     } else {
         const int g = grid_for((batch + 3) / 4,
                                t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_I32>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch("verify_wire_wpi", g, 4, batch);
         hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_I32>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
                            t.fwd, t.inv_pipe);
     }

@@ -46,6 +46,8 @@ SIGNATURES = {
     "dil_verify_core_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase1_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase2_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_sign_phase2_early_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_launch_info": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(_sz)],
     "dil_shake256_dev": [_vp, _sz, _vp, _sz, _sz, _vp],
     "dil_expand_a_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_expand_mask_dev": [_vp, _vp, _vp, C.c_int, _sz, _vp],

@@ -147,6 +147,20 @@ int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c
                         const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
                         size_t batch, int shared_key, void* stream);
 
+/* Phase 2 as the signing LOOP runs it (dil_sign_dev): an attempt is abandoned at its FIRST failed check, the checks ordered
+ * r0 rows (flag 2), z rows (flag 1), c t0 rows (flag 4, | 8 for too many hints counted so far); z and h are complete only
+ * where flags == 0 (flags & 8 alone: all checks ran, hint count over omega).  w0 is IN/OUT: on return it holds r0 = w0 - c s2
+ * of the rows that were evaluated (FSM2 of combined_top.v:1981-2229 likewise stops at the first failed norm check). */
+int dil_sign_phase2_early_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, int32_t* w0,
+                              const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
+                              size_t batch, int shared_key, void* stream);
+
+/* Debug record of the most recent launch of a persistent kernel family ("verify_wpi", "sign2_wpi", "matvec_wpi", "sign1_wpi",
+ * "keygen_wpi", "sign2_early_wpi", "verify_wire_wpi", "matvec_shared", "sign1_shared", "verify_shared", "verify_wire_shared" ...):
+ * grid (workgroups), items per workgroup and step, batch, launches so far.  A wave re-enters its item loop when
+ * items > grid * items_per_block; the parity tests assert exactly that.  Runtime utility without a reference counterpart. */
+int dil_launch_info(const char* family, int* grid, int* items_per_block, size_t* items, size_t* launches);
+
 /* ---- SHAKE-bound samplers on the device ---------------------------------
  * (round-3 v3.1 conventions, the ones the reference's KAT files obey; all buffers 8-byte aligned)
  * shake256:        out[i] = SHAKE256(in[i]); one input length for the batch; in_bytes, out_bytes % 8 == 0

@@ -611,6 +611,30 @@ void orc_verify_core_batch(int level, const int32_t *A, const int32_t *z, const 
     (void)orc_time_verify_core(level, A, z, c, t1, h, w1, n, shared_pk);
 }
 
+/* batch forms of the sign phases (same per-item functions; the Python side may split a batch over threads) */
+void orc_sign_phase1_batch(int level, const int32_t *A, const int32_t *y, uint8_t *w1, int32_t *w0, size_t n, int shared_key)
+{
+    orc_params p;
+    if (orc_get_params(level, &p)) return;
+    size_t szA = (size_t)p.K * p.L * N, szy = (size_t)p.L * N, szk = (size_t)p.K * N;
+    for (size_t i = 0; i < n; i++)
+        orc_sign_phase1(level, A + (shared_key ? 0 : i * szA), y + i * szy, w1 + i * szk, w0 + i * szk);
+}
+
+void orc_sign_phase2_batch(int level, const int32_t *c, const int32_t *y, const int32_t *w0, const uint8_t *w1,
+                           const int32_t *s1hat, const int32_t *s2hat, const int32_t *t0hat, int32_t *z, uint8_t *h,
+                           int32_t *flags, size_t n, int shared_key)
+{
+    orc_params p;
+    if (orc_get_params(level, &p)) return;
+    size_t szl = (size_t)p.L * N, szk = (size_t)p.K * N;
+    for (size_t i = 0; i < n; i++) {
+        size_t j = shared_key ? 0 : i;
+        flags[i] = orc_sign_phase2(level, c + i * N, y + i * szl, w0 + i * szk, w1 + i * szk, s1hat + j * szl,
+                                   s2hat + j * szk, t0hat + j * szk, z + i * szl, h + i * szk);
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* exhaustive self-checks used by tests/test_oracle_*.py                 */
 /* ------------------------------------------------------------------ */

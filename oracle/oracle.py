@@ -47,6 +47,31 @@ def build_dropin_mains(force: bool = False) -> bool:
     return all(os.path.exists(o) for o in outs)
 
 
+def _chunks(n, threads):
+    """contiguous item ranges for `threads` workers (the C functions are stateless; ctypes drops the GIL)"""
+    threads = max(1, min(int(threads), n))
+    step = -(-n // threads) if n else 0
+    return [(lo, min(lo + step, n)) for lo in range(0, n, step)] if n else []
+
+
+def _run_chunks(fn, n, threads):
+    ch = _chunks(n, threads)
+    if len(ch) <= 1:
+        for lo, hi in ch:
+            fn(lo, hi)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(len(ch)) as ex:
+        list(ex.map(lambda r: fn(*r), ch))
+
+
+def default_threads():
+    try:
+        return max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(32, os.cpu_count() or 1))
+
+
 class Oracle:
     def __init__(self):
         build()
@@ -136,7 +161,12 @@ class Oracle:
         A = np.ascontiguousarray(A, dtype=np.int32)
         n = y.size // (L * N)
         w = np.empty((n, K, N), dtype=np.int32)
-        self.lib.orc_matvec_batch(K, L, _p(A), _p(y), _p(w), C.c_size_t(n), int(shared_A))
+        y = y.reshape(n, L * N)
+        A2 = A.reshape(-1, K * L * N)
+
+        def run(lo, hi):
+            self.lib.orc_matvec_batch(K, L, _p(A2[0 if shared_A else lo:]), _p(y[lo:]), _p(w[lo:]), C.c_size_t(hi - lo), int(shared_A))
+        _run_chunks(run, n, default_threads() if n >= 512 else 1)
         return w
 
     def verify_core(self, level, A, z, c, t1, h, shared_pk=False):
@@ -148,8 +178,14 @@ class Oracle:
         t1 = np.ascontiguousarray(t1, dtype=np.int32)
         h = np.ascontiguousarray(h, dtype=np.uint8)
         w1 = np.empty((n, p.K, N), dtype=np.uint8)
-        self.lib.orc_verify_core_batch(int(level), _p(A), _p(z), _p(c), _p(t1), _p(h, _u8p),
-                                       _p(w1, _u8p), C.c_size_t(n), int(shared_pk))
+        z, c, h = z.reshape(n, -1), c.reshape(n, -1), h.reshape(n, -1)
+        A2, t2 = A.reshape(-1, p.K * p.L * N), t1.reshape(-1, p.K * N)
+
+        def run(lo, hi):
+            k = 0 if shared_pk else lo
+            self.lib.orc_verify_core_batch(int(level), _p(A2[k:]), _p(z[lo:]), _p(c[lo:]), _p(t2[k:]), _p(h[lo:], _u8p),
+                                           _p(w1[lo:], _u8p), C.c_size_t(hi - lo), int(shared_pk))
+        _run_chunks(run, n, default_threads() if n >= 512 else 1)
         return w1
 
     def time_verify_core(self, level, A, z, c, t1, h, shared_pk=False):
@@ -166,9 +202,12 @@ class Oracle:
         n = y.shape[0]
         w1 = np.empty((n, p.K, N), dtype=np.uint8)
         w0 = np.empty((n, p.K, N), dtype=np.int32)
-        for i in range(n):
-            Ai = A[i if A.shape[0] > 1 else 0]
-            self.lib.orc_sign_phase1(int(level), _p(Ai), _p(y[i]), _p(w1[i], _u8p), _p(w0[i]))
+        shared = A.shape[0] == 1
+
+        def run(lo, hi):
+            self.lib.orc_sign_phase1_batch(int(level), _p(A[0 if shared else lo:]), _p(y[lo:]), _p(w1[lo:], _u8p), _p(w0[lo:]),
+                                           C.c_size_t(hi - lo), int(shared))
+        _run_chunks(run, n, default_threads() if n >= 512 else 1)
         return w1, w0
 
     def sign_phase2(self, level, c, y, w0, w1, s1hat, s2hat, t0hat):
@@ -184,11 +223,14 @@ class Oracle:
         z = np.empty((n, p.L, N), dtype=np.int32)
         h = np.empty((n, p.K, N), dtype=np.uint8)
         flags = np.empty(n, dtype=np.int32)
-        for i in range(n):
-            j = i if s1hat.shape[0] > 1 else 0
-            flags[i] = self.lib.orc_sign_phase2(int(level), _p(c[i]), _p(y[i]), _p(w0[i]), _p(w1[i], _u8p),
-                                                _p(s1hat[j]), _p(s2hat[j]), _p(t0hat[j]), _p(z[i]),
-                                                _p(h[i], _u8p))
+        shared = s1hat.shape[0] == 1
+
+        def run(lo, hi):
+            k = 0 if shared else lo
+            self.lib.orc_sign_phase2_batch(int(level), _p(c[lo:]), _p(y[lo:]), _p(w0[lo:]), _p(w1[lo:], _u8p), _p(s1hat[k:]),
+                                           _p(s2hat[k:]), _p(t0hat[k:]), _p(z[lo:]), _p(h[lo:], _u8p), _p(flags[lo:]),
+                                           C.c_size_t(hi - lo), int(shared))
+        _run_chunks(run, n, default_threads() if n >= 512 else 1)
         return z, h, flags
 
     # -- timing helpers (cpu_baseline) --------------------------------------

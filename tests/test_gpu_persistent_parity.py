@@ -1,0 +1,195 @@
+"""GPU parity where the PERSISTENT item loops of the wave-per-item kernels are re-entered.
+
+The `*_wpi` kernels launch grid = min(work, resident workgroups) and every wave walks items it, it + nwaves, ... ; the
+code after a wave's first item -- the software prefetch of the NEXT item's inputs, the loop-carried row registers --
+runs only when batch / 4 exceeds the resident workgroups (768-2048).  The dispatch-size tests (n = 2125 / 2304) never
+get there.  Here every output of every such kernel is compared with the oracle at batches of 8192 and 20000-40000, a key
+per item and one key for the batch, and each test ASSERTS through the library's launch record (dil_launch_info) that the
+loop was re-entered (steps >= 2 at 8192, >= 3 at the large size).
+rtl_src/combined_top.v:1207-1469 (verify), :1850-1933 (mat-vec / FSM1), :1981-2229 (FSM2), :921-1079 (keygen)."""
+import numpy as np
+import pytest
+
+from oracle import dilithium_kat as dk
+from oracle.oracle import N, Q
+from tests.test_gpu_pipelines import KL, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def big_inputs(level, n, seed, nkeys):
+    """verify-core style inputs without the per-item python loops of synth(): A, z (also used as y), c, t1, h"""
+    K, L = KL[level]
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(seed)
+    A = rng.integers(0, Q, (nkeys, K, L, N), dtype=np.int32)
+    z = np.mod(rng.integers(-(p.gamma1 - 1), p.gamma1 + 1, (n, L, N), dtype=np.int32), Q).astype(np.int32)
+    # c: tau coefficients +-1 at distinct positions (argpartition of random keys = a random tau-subset per item)
+    pos = np.argpartition(rng.random((n, N), dtype=np.float32), p.tau, axis=1)[:, :p.tau]
+    c = np.zeros((n, N), np.int32)
+    np.put_along_axis(c, pos, np.where(rng.integers(0, 2, (n, p.tau)) == 1, 1, Q - 1).astype(np.int32), axis=1)
+    t1 = rng.integers(0, 1 << 10, (nkeys, K, N), dtype=np.int32)
+    h = (rng.random((n, K, N), dtype=np.float32) < 0.03).astype(np.uint8)
+    return A, z, c, t1, h
+
+
+def key_material(oracle, level, nkeys, seed):
+    K, L = KL[level]
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(seed)
+    s1h = oracle.ntt(np.mod(rng.integers(-p.eta, p.eta + 1, (nkeys, L, N)), Q).astype(np.int32))
+    s2h = oracle.ntt(np.mod(rng.integers(-p.eta, p.eta + 1, (nkeys, K, N)), Q).astype(np.int32))
+    t0h = oracle.ntt(np.mod(rng.integers(-(1 << 12) + 1, (1 << 12) + 1, (nkeys, K, N)), Q).astype(np.int32))
+    return s1h, s2h, t0h
+
+
+def steps(family, n, at_least):
+    from dilithium_amd import api
+    info = api.launch_info(family)
+    assert info["items"] == n, (family, info)
+    assert info["grid"] * info["items_per_block"] < n and info["steps"] >= at_least, (family, info)
+    return info
+
+
+@pytest.mark.parametrize("level", [2, 5])
+@pytest.mark.parametrize("n,min_steps", [(8192, 2), (20000, 3)])
+def test_verify_wpi_persistent_loop_vs_oracle(gpu, oracle, level, n, min_steps):
+    """verify_wpi_kernel<2|5>, a public key per item: all n x K x 256 outputs (level 3: test_full_config4_batch_all_items,
+    and at 20000 below)"""
+    from dilithium_amd import api
+    A, z, c, t1, h = big_inputs(level, n, 100 * level + n, n)
+    w1 = api.verify_core(dev(gpu, A), dev(gpu, z), dev(gpu, c), dev(gpu, t1), dev(gpu, h, np.uint8), level).cpu().numpy()
+    steps("verify_wpi", n, min_steps)
+    assert (w1 == oracle.verify_core(level, A, z, c, t1, h)).all()
+
+
+def test_verify_wpi_level3_20000_vs_oracle(gpu, oracle):
+    from dilithium_amd import api
+    n = 20000
+    A, z, c, t1, h = big_inputs(3, n, 333, n)
+    w1 = api.verify_core(dev(gpu, A), dev(gpu, z), dev(gpu, c), dev(gpu, t1), dev(gpu, h, np.uint8), 3).cpu().numpy()
+    steps("verify_wpi", n, 3)
+    assert (w1 == oracle.verify_core(3, A, z, c, t1, h)).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("shared,n,min_steps", [(True, 8192, 2), (True, 40000, 3), (False, 8192, 2), (False, 20000, 3)])
+def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, min_steps):
+    """phase 1 (matvec_shared / matvec_wpi <OUT_W1W0>: w1, w0), phase 2 (sign2_wpi_kernel: z, h, flags) and the signing
+    loop's early-exit phase 2 (sign2_early_wpi_kernel through its in/out w0 scratch: first failed check, z / h of the
+    accepted attempts), one key and a key per item, every attempt of the batch"""
+    from dilithium_amd import api
+    nk = 1 if shared else n
+    A, y, c, _, _ = big_inputs(level, n, 7000 + 10 * level + n + shared, nk)
+    s1h, s2h, t0h = key_material(oracle, level, nk, 11 * level + n)
+    # phase 1
+    w1, w0 = api.sign_phase1(dev(gpu, A), dev(gpu, y), level, shared_key=shared)
+    steps("sign1_shared" if shared else "sign1_wpi", n, min_steps)
+    ow1, ow0 = oracle.sign_phase1(level, A, y)
+    assert (w1.cpu().numpy() == ow1).all() and (w0.cpu().numpy() == ow0).all()
+    del A
+    # phase 2, every check of every attempt
+    dc, dy, dw0, dw1 = dev(gpu, c), dev(gpu, y), dev(gpu, ow0), dev(gpu, ow1, np.uint8)
+    ds1, ds2, dt0 = dev(gpu, s1h), dev(gpu, s2h), dev(gpu, t0h)
+    z, h, fl = api.sign_phase2(dc, dy, dw0, dw1, ds1, ds2, dt0, level, shared_key=shared)
+    steps("sign2_wpi", n, min_steps)
+    oz, oh, ofl = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
+    assert (fl.cpu().numpy() == ofl).all()
+    assert (z.cpu().numpy() == oz).all() and (h.cpu().numpy() == oh).all()
+    acc = ofl == 0
+    assert acc.any() and (~acc).any()
+    # phase 2 as the signing loop runs it: stop at the first failed check (r0 -> 2, z -> 1, c t0 -> 4 [| 8])
+    w0s = dw0.clone()
+    ze, he, fle = api.sign_phase2_early(dc, dy, w0s, dw1, ds1, ds2, dt0, level, shared_key=shared)
+    steps("sign2_early_wpi", n, min_steps)
+    fle = fle.cpu().numpy()
+    r0f, zf, ctf = (ofl & 2) != 0, (ofl & 1) != 0, (ofl & 4) != 0
+    assert (fle[r0f] == 2).all()
+    assert (fle[~r0f & zf] == 1).all()
+    m4 = ~r0f & ~zf & ctf
+    assert ((fle[m4] & ~8) == 4).all()
+    rest = ~r0f & ~zf & ~ctf
+    assert (fle[rest] == ofl[rest]).all()                  # 0, or 8 (all checks passed, too many hints)
+    assert (ze.cpu().numpy()[acc] == oz[acc]).all() and (he.cpu().numpy()[acc] == oh[acc]).all()
+    # the scratch holds r0 = w0 - c s2 for every row that was evaluated: all K rows of the attempts that got past stage (A)
+    K = KL[level][0]
+    if (~r0f).any():
+        i = int(np.flatnonzero(~r0f)[-1])
+        cs2 = oracle.invntt(oracle.pointwise(np.broadcast_to(oracle.ntt(c[i]), (K, N)), s2h[0 if shared else i]))
+        assert (w0s[i].cpu().numpy() == np.mod(ow0[i].astype(np.int64) - cs2, Q)).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("n,min_steps", [(8192, 2), (20000, 3)])
+def test_matvec_wpi_persistent_loop_vs_oracle(gpu, oracle, level, n, min_steps):
+    """matvec_wpi_kernel<K, L, LEVEL, OUT_W> (a matrix per item), every output"""
+    from dilithium_amd import api
+    K, L = KL[level]
+    A, y, *_ = big_inputs(level, n, 5000 + level + n, n)
+    w = api.matvec(dev(gpu, A), dev(gpu, y), level).cpu().numpy()
+    steps("matvec_wpi", n, min_steps)
+    assert (w == oracle.matvec(K, L, A, y)).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_keygen_wpi_persistent_loop(gpu, oracle, level):
+    """keygen_wpi_kernel at 20000 keys: t1 2^13 + t0 == A s1 + s2 with the mat-vec recomputed by the ORACLE for EVERY key,
+    and (pk, sk) byte-identical to the host KAT harness on 1024 keys spread over every step of the persistent loop"""
+    from dilithium_amd import api
+    from tests.test_gpu_codecs import cu
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(60 + level)
+    n = 20000
+    seed = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    pk, sk = api.keygen(cu(gpu, seed), level)
+    info = steps("keygen_wpi", n, 3)
+    sb = 32 * p.eta_bits
+    t1 = api.unpack(pk, api.CODEC_T1, level, 32).long()
+    t0 = api.unpack(sk, api.CODEC_T0, level, 96 + (p.L + p.K) * sb).long()
+    s1 = api.unpack(sk, api.CODEC_S1, level, 96)
+    s2 = api.unpack(sk, api.CODEC_S2, level, 96 + p.L * sb).long()
+    A = api.expand_a(pk[:, :32].contiguous(), level)
+    w = gpu.from_numpy(oracle.matvec(p.K, p.L, A.cpu().numpy(), s1.cpu().numpy())).cuda().long()
+    assert bool((((t1 << 13) + t0 - w - s2) % dk.Q == 0).all())
+    del A, w
+    eng = dk.OracleEngine(oracle)
+    pkh, skh = pk.cpu().numpy(), sk.cpu().numpy()
+    per_step = info["grid"] * info["items_per_block"]
+    sample = set(rng.choice(n, 1000, replace=False).tolist()) | {0, n - 1, per_step - 1, per_step, 2 * per_step - 1, 2 * per_step}
+    sample |= set(range(n - 18, n))
+    for i in sorted(sample):
+        kg = dk.keygen(level, seed[i].tobytes(), eng)
+        assert pkh[i].tobytes() == kg["rho"] + kg["t1_packed"], i
+        assert skh[i].tobytes() == kg["rho"] + kg["key"] + kg["tr"] + dk.pack_eta(p, kg["s1"]) + dk.pack_eta(p, kg["s2"]) + \
+            dk.pack_t0(p, kg["t0"]), i
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_verify_wire_wpi_persistent_loop(gpu, oracle, level):
+    """verify_wire_wpi_kernel (packed z / t1 / hints in, packed w1 out) at 20000 (key, signature) pairs: keys and signatures
+    from the device keygen / signing loop, the kernel's packed w1 against the ORACLE's verify core fed with host-decoded
+    fields, for every item"""
+    from dilithium_amd import api
+    from tests.test_gpu_codecs import cu
+    p = dk.PARAMS[level]
+    K, L = KL[level]
+    rng = np.random.default_rng(80 + level)
+    n = 20000
+    seed = cu(gpu, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    mu = cu(gpu, rng.integers(0, 256, (n, 64), dtype=np.uint8))
+    pk, sk = api.keygen(seed, level)
+    sig, _ = api.sign(sk, mu, level)
+    A = api.expand_a(pk[:, :32].contiguous(), level)
+    w1p, verdict = api.verify_wire_core(A, pk, sig, level)
+    steps("verify_wire_wpi", n, 3)
+    assert int(verdict.abs().sum()) == 0
+    zb = L * 32 * p.z_bits
+    z = api.unpack(sig, api.CODEC_Z, level, 32)
+    t1 = api.unpack(pk, api.CODEC_T1, level, 32)
+    h, bad = api.hint_unpack(sig, level, 32 + zb)
+    assert int(bad.sum()) == 0
+    c = api.sample_in_ball(sig[:, :32].contiguous(), level)
+    ow1 = oracle.verify_core(level, A.cpu().numpy(), z.cpu().numpy(), c.cpu().numpy(), t1.cpu().numpy(), h.cpu().numpy())
+    want = api.pack_w1(cu(gpu, ow1), level)
+    assert gpu.equal(w1p.view(-1), want.view(-1))
+    assert (api.verify_sig(pk, sig, mu, level) == 0).all()
