@@ -11,7 +11,7 @@ HIP_HDR := $(wildcard $(CSRC)/*.hpp) include/dil256.h include/dil256_ref.hpp
 all: dilithium_amd/libdil256.so dilithium_amd/libdil256_ref.so
 
 dilithium_amd/libdil256.so: $(HIP_SRC) $(HIP_HDR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wall $(HIP_SRC) -o $@
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wall -pthread $(HIP_SRC) -o $@
 
 dilithium_amd/libdil256_ref.so: $(CSRC)/ref_api.cpp dilithium_amd/libdil256.so include/dil256_ref.hpp
 	$(CXX) -O2 -std=c++17 -shared -fPIC -Wall $< -Ldilithium_amd -ldil256 -Wl,-rpath,'$$ORIGIN' -o $@

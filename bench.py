@@ -441,8 +441,8 @@ def main():
             offs = (torch.arange(VBATCH, device="cuda", dtype=torch.int64) * 64).contiguous()
             lens = torch.full((VBATCH,), 64, dtype=torch.int32, device="cuda")
             sig_m = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
-            sm_ms, _ = timed(lambda i: L.dil_sign_msg_dev(P(sig_m), P(att), P(sk), P(blob), P(offs), P(lens), 3, VBATCH, 1, 512, stream))
-            vm_ms, _ = timed(lambda i: L.dil_verify_msg_dev(P(vd), P(pk), P(sig_m), P(blob), P(offs), P(lens), 3, VBATCH, 1, stream))
+            sm_ms, _ = timed(lambda i: L.dil_sign_msg_dev(P(sig_m), P(att), P(sk), P(blob), blob.numel(), P(offs), P(lens), 3, VBATCH, 1, 512, stream))
+            vm_ms, _ = timed(lambda i: L.dil_verify_msg_dev(P(vd), P(pk), P(sig_m), P(blob), blob.numel(), P(offs), P(lens), 3, VBATCH, 1, stream))
             ok = ok and int(vd.abs().sum()) == 0
             per_s = lambda ms: VBATCH / (ms * 1e-3)  # noqa: E731
             sec["scheme_level3_wire_format"] = {

@@ -13,9 +13,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdil256.so")
 REF_LIB = os.path.join(PKG, "libdil256_ref.so")     # reference-identical C++ signatures (include/dil256_ref.hpp)
 SOURCES = ["kernels.hip", "pipelines.hip", "hash_kernels.hip", "codec_kernels.hip", "wire_kernels.hip", "gen_kernels.hip", "capi.hip", "scheme.hip", "multi_gpu.hip"]
-HEADERS = ["capi_internal.hpp", "modarith.hpp", "ntt_core.hpp", "kernels.hpp", "device_common.hpp", "pipeline_common.hpp", "launch_util.hpp", "keccak.hpp", "wire_common.hpp", "sampler_bodies.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
+HEADERS = ["variants.hpp", "capi_internal.hpp", "modarith.hpp", "ntt_core.hpp", "kernels.hpp", "device_common.hpp", "pipeline_common.hpp", "launch_util.hpp", "keccak.hpp", "wire_common.hpp", "sampler_bodies.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
            os.path.join("..", "..", "include", "dil256_ref.hpp")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-pthread"]
 
 
 def _stale() -> bool:

@@ -431,26 +431,34 @@ def pack_messages(msgs, device="cuda"):
     lens = np.array([len(m) for m in msgs], dtype=np.int32)
     offs = np.zeros(len(msgs), dtype=np.int64)
     offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
-    blob = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8).copy()
+    blob = np.frombuffer(b"".join(msgs), dtype=np.uint8).copy()          # may be empty: the library takes (NULL, 0)
     return torch.from_numpy(blob).to(device), torch.from_numpy(offs).to(device), torch.from_numpy(lens).to(device)
 
 
-def mu(tr, blob, offsets, lengths):
-    """mu uint8 [B,64] = SHAKE256(tr_i || M_i); tr uint8 [B,32] or [1,32] (one tr for the batch)"""
+def _blob(blob):
+    return (C.c_void_p(blob.data_ptr()) if blob.numel() else None), blob.numel()
+
+
+def mu(tr, blob, offsets, lengths, bad=None):
+    """mu uint8 [B,64] = SHAKE256(tr_i || M_i); tr uint8 [B,32] or [1,32] (one tr for the batch); bad (optional int32 [B]):
+    1 where (offset, length) leaves the blob (that item is hashed as an empty message)"""
     B = lengths.shape[0]
-    out = torch.empty((B, 64), dtype=torch.uint8, device=blob.device)
+    out = torch.empty((B, 64), dtype=torch.uint8, device=lengths.device)
     stride = 0 if tr.shape[0] == 1 and B > 1 else tr.stride(0)
-    _lib.check(_lib.load().dil_mu_dev(_dev(out, torch.uint8), C.c_void_p(tr.data_ptr()), stride, _dev(blob, torch.uint8),
-                                      _dev(offsets, torch.int64), _dev(lengths, torch.int32), B, _stream()), "dil_mu_dev")
+    bp, bn = _blob(blob)
+    _lib.check(_lib.load().dil_mu_dev(_dev(out, torch.uint8), C.c_void_p(tr.data_ptr()), stride, bp, bn,
+                                      _dev(offsets, torch.int64), _dev(lengths, torch.int32),
+                                      None if bad is None else _dev(bad, torch.int32), B, _stream()), "dil_mu_dev")
     return out
 
 
 def sign_msg(sk, blob, offsets, lengths, level, shared_sk=False, max_attempts=512):
     """deterministic signing of ragged messages: (sig uint8 [B,sig_bytes], attempts int32 [B])"""
     B = lengths.shape[0]
-    sig = torch.empty((B, sig_bytes(level)), dtype=torch.uint8, device=blob.device)
-    att = torch.empty((B,), dtype=torch.int32, device=blob.device)
-    _lib.check(_lib.load().dil_sign_msg_dev(_dev(sig, torch.uint8), _dev(att, torch.int32), _dev(sk, torch.uint8), _dev(blob, torch.uint8),
+    sig = torch.empty((B, sig_bytes(level)), dtype=torch.uint8, device=sk.device)
+    att = torch.empty((B,), dtype=torch.int32, device=sk.device)
+    bp, bn = _blob(blob)
+    _lib.check(_lib.load().dil_sign_msg_dev(_dev(sig, torch.uint8), _dev(att, torch.int32), _dev(sk, torch.uint8), bp, bn,
                                             _dev(offsets, torch.int64), _dev(lengths, torch.int32), level, B, int(shared_sk),
                                             max_attempts, _stream()), "dil_sign_msg_dev")
     return sig, att
@@ -460,8 +468,9 @@ def verify_msg(pk, sig, blob, offsets, lengths, level, shared_pk=False):
     """verification of (pk, M, sig): verdict int32 [B], 0 = accept"""
     B = sig.shape[0]
     verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
+    bp, bn = _blob(blob)
     _lib.check(_lib.load().dil_verify_msg_dev(_dev(verdict, torch.int32), _dev(pk, torch.uint8), _dev(sig, torch.uint8),
-                                              _dev(blob, torch.uint8), _dev(offsets, torch.int64), _dev(lengths, torch.int32),
+                                              bp, bn, _dev(offsets, torch.int64), _dev(lengths, torch.int32),
                                               level, B, int(shared_pk), _stream()), "dil_verify_msg_dev")
     return verdict
 

@@ -380,6 +380,7 @@ int dil_num_cus(void)
 const char* dil_error_string(int code)
 {
     if (code == DIL_ERR_UNFINISHED) return "signing did not finish within max_attempts";
+    if (code == DIL_ERR_RCCL) return "RCCL error (dil_multi_last_error has the text)";
     return hipGetErrorString((hipError_t)code);
 }
 

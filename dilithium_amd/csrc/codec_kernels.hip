@@ -352,6 +352,16 @@ __global__ __launch_bounds__(256) void or_flag_kernel(int32_t* __restrict__ verd
     if (i < n && flag[i]) verdict[i] |= bit;
 }
 
+// dil_sign_msg_dev: an item whose message reference left the blob gets no signature (zero bytes, attempts = -1); one wave per item
+__global__ __launch_bounds__(256) void sign_void_bad_kernel(uint8_t* __restrict__ sig, size_t sig_bytes, int32_t* __restrict__ attempts,
+                                                            const int32_t* __restrict__ bad, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n || !bad[i]) return;
+    for (size_t b = threadIdx.x & 63; b < sig_bytes; b += 64) sig[i * sig_bytes + b] = 0;
+    if ((threadIdx.x & 63) == 0 && attempts) attempts[i] = -1;
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
@@ -365,6 +375,13 @@ hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(or_flag_kernel, (int)((n + 255) / 256), 256, 0, s, verdict, flag, bit, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sign_void_bad(uint8_t* sig, size_t sig_bytes, int32_t* attempts, const int32_t* bad, size_t n, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(sign_void_bad_kernel, (int)((n + 3) / 4), 256, 0, s, sig, sig_bytes, attempts, bad, n);
     return hipGetLastError();
 }
 

@@ -26,9 +26,6 @@
 
 namespace dil {
 
-#ifndef DIL_GEN_ABL
-#define DIL_GEN_ABL 0      // ablations of phase 2 for profiling: 1 plain stores, 2 no accumulate, 3 no LDS at all, 4 permutations only
-#endif
 
 template <int LEVEL>
 struct Gen {
@@ -64,11 +61,7 @@ struct GenGroup {
             idx[e] = min(cnt, 255);
         }
         cnt -= mask[e];
-#if DIL_GEN_ABL == 3          // ablation: no z^ read either
-        z[e] = (int32_t)(v[e] ^ 0x1234567);
-#else
         z[e] = (int32_t)zb[idx[e] * ZS];
-#endif
     }
     __device__ __forceinline__ void pick(const uint64_t (&s)[25], int g, uint32_t dead, const uint32_t* zb, int& cnt)
     {
@@ -88,13 +81,7 @@ struct GenGroup {
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const int32_t p = mont_red64((int64_t)(int32_t)v[e] * z[e]) & mask[e];
-#if DIL_GEN_ABL == 1          // ablation: plain store instead of the atomic add
-            wb[idx[e] * WR] = (uint32_t)p;
-#elif DIL_GEN_ABL == 2 || DIL_GEN_ABL == 3   // ablation: no accumulate at all (the product still has a consumer)
-            if (p == 0x7fffffff) wb[0] = 1;
-#else
             __hip_atomic_fetch_add(reinterpret_cast<int32_t*>(wb + idx[e] * WR), p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
         }
     }
 };
@@ -102,11 +89,6 @@ struct GenGroup {
 template <bool CLAMP, int ZS, int WR>
 __device__ __forceinline__ void gen_block(const uint64_t (&s)[25], uint32_t dead, const uint32_t* zb, uint32_t* wb, int& cnt)
 {
-#if DIL_GEN_ABL == 4
-    cnt += 52;
-    if (s[0] == 0x123456789ull) wb[0] = 1;
-    return;
-#endif
     GenGroup<CLAMP, ZS> grp[2];
     grp[0].pick(s, 0, dead, zb, cnt);
 #pragma unroll
@@ -208,10 +190,6 @@ __global__ __launch_bounds__(64) void verify_wire_gen_kernel(
         const uint32_t* zb = zl + tt * L + jj;
         uint32_t* wb = wl + tt * K + ii;
         int cnt = live ? 0 : 256;
-#if DIL_GEN_ABL == 5          // ablation: no phase 2 at all
-        cnt = 256;
-        if (s[0] == 0x123456789ull) wb[0] = 1;
-#else
 #pragma unroll 1
         for (int blk = 0; blk < 4; blk++) {
             keccak_f1600(s);
@@ -221,7 +199,6 @@ __global__ __launch_bounds__(64) void verify_wire_gen_kernel(
             keccak_f1600(s);
             gen_block<true, ZS, WR>(s, dead, zb, wb, cnt);
         } while (__any(cnt < 256));
-#endif
     }
     __syncthreads();
 

@@ -308,8 +308,8 @@ __device__ __forceinline__ uint64_t ld_u64u(const uint8_t* p)
     return v;
 }
 __global__ __launch_bounds__(HASH_BS) void mu_kernel(uint64_t* __restrict__ mu, const uint8_t* __restrict__ tr, size_t tr_stride,
-                                                     const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ lengths, size_t batch)
+                                                     const uint8_t* __restrict__ msgs, size_t msgs_bytes, const uint64_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ lengths, int32_t* __restrict__ bad, size_t batch)
 {
     const size_t i = (size_t)blockIdx.x * HASH_BS + threadIdx.x;
     const bool live = i < batch;
@@ -321,8 +321,15 @@ __global__ __launch_bounds__(HASH_BS) void mu_kernel(uint64_t* __restrict__ mu, 
         const uint64_t* t = reinterpret_cast<const uint64_t*>(tr + i * tr_stride);
 #pragma unroll
         for (int w = 0; w < 4; w++) sp.s[w] = t[w];
-        mp = msgs + offsets[i];
-        rem = lengths[i];
+        // an item whose (offset, length) leaves the blob is never read: it is hashed as an EMPTY message and flagged
+        const uint64_t off = offsets[i];
+        const uint32_t len = lengths[i];
+        const bool inside = off <= msgs_bytes && len <= msgs_bytes - off;
+        if (inside) {
+            mp = msgs + off;
+            rem = len;
+        }
+        if (bad) bad[i] = inside ? 0 : 1;
     }
     bool padded = !live, finished = !live;
     uint64_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -360,12 +367,12 @@ __global__ __launch_bounds__(HASH_BS) void mu_kernel(uint64_t* __restrict__ mu, 
     }
 }
 
-hipError_t launch_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, const uint64_t* offsets,
-                     const uint32_t* lengths, size_t batch, hipStream_t s)
+hipError_t launch_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
+                     const uint32_t* lengths, int32_t* bad, size_t batch, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
     hipLaunchKernelGGL(mu_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint64_t*>(mu), tr, tr_stride, msgs,
-                       offsets, lengths, batch);
+                       msgs_bytes, offsets, lengths, bad, batch);
     return hipGetLastError();
 }
 

@@ -372,11 +372,7 @@ struct CoeffSink {
                 v.y = (int32_t)ring[(base + 4 * q + 1) * 64];
                 v.z = (int32_t)ring[(base + 4 * q + 2) * 64];
                 v.w = (int32_t)ring[(base + 4 * q + 3) * 64];
-#if defined(DIL_EA_ABL) && DIL_EA_ABL == 3
-                if (v.x == 0x7fffffff) *reinterpret_cast<int4*>(dst + flushed + 4 * q) = v;   // ablation: (almost) never stores
-#else
                 *reinterpret_cast<int4*>(dst + flushed + 4 * q) = v;
-#endif
             }
             flushed += CHUNK;
         }
@@ -436,19 +432,7 @@ struct CoeffSinkWaveT {
                     v.y = (int32_t)wave_ring[(base + 4 * q + 1) * 64 + p];
                     v.z = (int32_t)wave_ring[(base + 4 * q + 2) * 64 + p];
                     v.w = (int32_t)wave_ring[(base + 4 * q + 3) * 64 + p];
-#if defined(DIL_EA_ABL) && DIL_EA_ABL == 4
-                    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x7fffffff) *reinterpret_cast<int4*>(wave_dst + p * 256 + flushed + 4 * q) = v;   // ablation: all LDS reads, (almost) no stores
-#elif defined(DIL_EA_ABL) && DIL_EA_ABL == 5
-                    if (p < live_polys) *reinterpret_cast<int4*>(wave_dst + (p & 3) * 256 + flushed + 4 * q) = v;   // ablation: all stores, 4 KiB footprint per wave (L2-resident)
-#elif defined(DIL_EA_NT)
-                    if (p < live_polys) {
-                        int32_t* d_ = wave_dst + p * 256 + flushed + 4 * q;
-                        __builtin_nontemporal_store(v.x, d_); __builtin_nontemporal_store(v.y, d_ + 1);
-                        __builtin_nontemporal_store(v.z, d_ + 2); __builtin_nontemporal_store(v.w, d_ + 3);
-                    }
-#else
                     if (p < live_polys) put4(wave_dst + p * POLY_DW, flushed + 4 * q, v);
-#endif
                 }
                 flushed += CHUNK;
             } else if (__any(cnt - flushed > RING - 8)) {

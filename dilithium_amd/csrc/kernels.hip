@@ -26,13 +26,8 @@ namespace dil {
 
 // cache-policy A/B hooks of the standalone transforms (scripts/ab_verify.py --kind ntt): the strided 256-byte-per-instruction
 // accesses (forward loads, inverse stores) can be built with the default policy instead of non-temporal
-#ifdef DIL_NTT_STRIDED_PLAIN
-__device__ __forceinline__ int32_t ld_s(const int32_t* p) { return *p; }
-__device__ __forceinline__ void st_s(int32_t* p, int32_t v) { *p = v; }
-#else
 __device__ __forceinline__ int32_t ld_s(const int32_t* p) { return ld_nt(p); }
 __device__ __forceinline__ void st_s(int32_t* p, int32_t v) { st_nt(p, v); }
-#endif
 
 // ---------------------------------------------------------------------------------------
 // address translation of the hardware model's `bram` (address_encoder_decoder.cpp:34-55)

@@ -79,8 +79,11 @@ hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nit
 // expect (may be nullptr): 32 bytes per item at expect + i * expect_stride, any alignment (c~ read in place from a signature)
 hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,
                                  const uint8_t* expect, size_t batch, hipStream_t s, size_t expect_stride = 32);
-hipError_t launch_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, const uint64_t* offsets,
-                     const uint32_t* lengths, size_t batch, hipStream_t s);
+// bad (nullable): bad[i] = 1 where (offsets[i], lengths[i]) leaves the blob of msgs_bytes bytes -- such an item is hashed as an empty message
+hipError_t launch_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
+                     const uint32_t* lengths, int32_t* bad, size_t batch, hipStream_t s);
+// signing of items whose message reference was bad: attempts[i] = -1, signature bytes zero
+hipError_t launch_sign_void_bad(uint8_t* sig, size_t sig_bytes, int32_t* attempts, const int32_t* bad, size_t n, hipStream_t s);
 hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t batch, hipStream_t s);
 
 // ---- wire-format fused verify (wire_kernels.hip): packed z / t1 / hints / c in, packed w1 + verdict bits 2|4 out ----

@@ -181,6 +181,74 @@ struct X10Lds {
 
 __device__ __forceinline__ void LaneMasks::operator()(int32_t (&r)[4]) const { xchg_10(r, *this); }
 
+// All three exchanges through LDS (XAllLds): the VALU-bound pipelines (sign phase 2: 84 % VALU-busy, profiles/r03a_sign_pmc.txt)
+// spend 28 % of a transform's issue cycles on the exchanges (4 permlane swaps, 16 DPP moves, 8 v_bfi = ~138 of ~500 cycles);
+// through a 1 KiB per-wave buffer each one is 4 ds_write_b32 + 1 ds_read_b128 (about 20 LDS-pipe cycles, MI355X_MICROARCH.md
+// LDS table) and no VALU work at all.  Exchange at lane bit-pair position S (0, 2 or 4): lane (hi, b, lo) register m afterwards
+// holds what lane (hi, m, lo) register b held.  The writer lane (field value bw) stores its register j to the dword the reader
+// lane (field value j) finds at offset bw of its 16-byte slot:  dword = 4 * slot(lane with field <- j) + bw, and every lane reads
+// ONE ds_read_b128 from slot(own lane).  slot() xor-swizzles the field with the other lane bits so that the b128 read (served in
+// four irregular groups of 16 lanes, bank = dword mod 64) is conflict-free and each ds_write_b32 is at most 2-way (which costs
+// nothing: a 4-byte store is bound by its VGPR transfer, not by the LDS array).
+template <int S>
+__device__ __forceinline__ uint32_t xslot(uint32_t lane, uint32_t field)
+{
+    if (S == 4) {                                   // lane = 16 b + lo4: slot = 4 lo4 + (b ^ g(lo4 >> 2)), g = {0, 2, 3, 1}
+        const uint32_t lo4 = lane & 15, g = (0x78u >> (2 * (lo4 >> 2))) & 3u;      // 0b01'11'10'00
+        return 4 * lo4 + (field ^ g);
+    }
+    if (S == 2) {                                   // lane = 16 h + 4 b + lo: slot = 16 h + 4 lo + (b ^ lo)
+        const uint32_t h = lane >> 4, lo = lane & 3;
+        return 16 * h + 4 * lo + (field ^ lo);
+    }
+    const uint32_t q = lane >> 2;                   // lane = 4 q + b: slot = 4 q + (b ^ (q & 3))
+    return 4 * q + (field ^ (q & 3));
+}
+template <int S>
+struct XLdsAt {
+    uint32_t* wr[4];          // where this lane's register j goes
+    const uint32_t* rd;       // this lane's 16-byte slot
+    __device__ __forceinline__ void init(uint32_t* wave_buf /* 256 dwords */, int lane)
+    {
+        const uint32_t l = (uint32_t)lane, bw = (l >> S) & 3u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) wr[j] = wave_buf + 4 * xslot<S>(l, j) + bw;
+        rd = wave_buf + 4 * xslot<S>(l, bw);
+    }
+    __device__ __forceinline__ void operator()(int32_t (&r)[4]) const
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++) *wr[j] = (uint32_t)r[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same-wave LDS accesses execute in order
+        const int4 v = *reinterpret_cast<const int4*>(rd);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+    }
+};
+struct XAllLds {
+    XLdsAt<4> e54;
+    XLdsAt<2> e32;
+    XLdsAt<0> e10;
+    __device__ __forceinline__ XAllLds(uint32_t* wave_buf /* 256 dwords */, int lane)
+    {
+        e54.init(wave_buf, lane);
+        e32.init(wave_buf, lane);
+        e10.init(wave_buf, lane);
+    }
+    __device__ __forceinline__ void x54(int32_t (&r)[4]) const { e54(r); }
+    __device__ __forceinline__ void x32(int32_t (&r)[4]) const { e32(r); }
+    __device__ __forceinline__ void operator()(int32_t (&r)[4]) const { e10(r); }
+};
+// (5:4) and (3:2) of a policy that only provides the (1:0) exchange stay in registers
+template <class X>
+__device__ __forceinline__ auto do_x54(const X& x, int32_t (&r)[4], int) -> decltype(x.x54(r), void()) { x.x54(r); }
+template <class X>
+__device__ __forceinline__ void do_x54(const X&, int32_t (&r)[4], long) { xchg_54(r); }
+template <class X>
+__device__ __forceinline__ auto do_x32(const X& x, int32_t (&r)[4], int) -> decltype(x.x32(r), void()) { x.x32(r); }
+template <class X>
+__device__ __forceinline__ void do_x32(const X&, int32_t (&r)[4], long) { xchg_32(r); }
+
 // one forward radix-2x2 pass on the lane's 4-tuple (ref_ntt2x2.cpp:57-79 / butterfly2x2.v)
 __device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
 {
@@ -203,11 +271,11 @@ __device__ __forceinline__ void ntt_fwd_core(int32_t (&r)[4], const TW& tw, cons
     const Tw8 t1 = tw.template get<1>();
     DIL_TW_FENCE();
     fwd_pass(r, t0);
-    xchg_54(r);
+    do_x54(x10, r, 0);
     const Tw8 t2 = tw.template get<2>();
     DIL_TW_FENCE();
     fwd_pass(r, t1);
-    xchg_32(r);
+    do_x32(x10, r, 0);
     const Tw8 t3 = tw.template get<3>();
     DIL_TW_FENCE();
     fwd_pass(r, t2);
@@ -243,11 +311,11 @@ __device__ __forceinline__ void ntt_inv_core(int32_t (&r)[4], const TW& tw, cons
     const Tw8 t2 = tw.template get<2>();
     DIL_TW_FENCE();
     inv_pass<false>(r, t1);
-    xchg_32(r);
+    do_x32(x10, r, 0);
     const Tw8 t3 = tw.template get<3>();
     DIL_TW_FENCE();
     inv_pass<false>(r, t2);
-    xchg_54(r);
+    do_x54(x10, r, 0);
     inv_pass<true>(r, t3);
 }
 

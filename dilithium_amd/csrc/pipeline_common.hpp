@@ -148,11 +148,7 @@ __device__ __forceinline__ void store_row_u8(uint8_t* __restrict__ out_row, cons
     uint8_t* sc = reinterpret_cast<uint8_t*>(scratch);
 #pragma unroll
     for (int m = 0; m < 4; m++) sc[lane + 64 * m] = (uint8_t)v[m];
-#ifdef DIL_ABL_W1_NT
-    __builtin_nontemporal_store(scratch[lane], reinterpret_cast<uint32_t*>(out_row) + lane);
-#else
     reinterpret_cast<uint32_t*>(out_row)[lane] = scratch[lane];
-#endif
 }
 __device__ __forceinline__ uint32_t load_row_u8(const uint8_t* __restrict__ row, int lane)   // issue early, unpack late
 {
@@ -258,9 +254,8 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
 template <bool NT = true>
 __device__ __forceinline__ void load_strided(int32_t (&r)[4], const int32_t* __restrict__ a, int lane)
 {
-#if defined(DIL_ABL_NOSMALL)
-#pragma unroll
-    for (int m = 0; m < 4; m++) r[m] = lane * 17 + m;            // ablation: no time-domain loads at all
+#ifdef DIL_LOAD_STRIDED_HOOK       // variant builds only (variants.hpp)
+    DIL_LOAD_STRIDED_HOOK(r, a, lane);
 #else
 #pragma unroll
     for (int m = 0; m < 4; m++) r[m] = NT ? ld_nt(a + lane + 64 * m) : a[lane + 64 * m];
@@ -276,8 +271,8 @@ struct ARow<L, A_I32> {
     // stream = true: this row is read once (per-item A): non-temporal; false: shared A, keep it cached
     __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane, bool stream)
     {
-#ifdef DIL_ABL_A_PLAIN
-        stream = false;                                          // ablation: default cache policy for the matrix stream
+#ifdef DIL_AROW_STREAM_HOOK        // variant builds only (variants.hpp)
+        stream = DIL_AROW_STREAM_HOOK(stream);
 #endif
         if (stream) {
 #pragma unroll

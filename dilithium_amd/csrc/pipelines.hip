@@ -367,20 +367,13 @@ __global__ __launch_bounds__(256) void keygen_wpi_kernel(
     }
 }
 
-// ablation hooks of verify_wpi_kernel (scripts/ab_verify.py; never defined in the shipped build)
-#ifdef DIL_ABL_NONTT
-#define VW_FWD(r, tw, x) ((void)0)
-#define VW_INV(r, tw, x) ((void)0)
-#else
+// Hook points of the A/B builds (csrc/variants.hpp through scripts/build_variant.py -DDIL_VARIANT_BUILD ...): the shipped
+// build compiles exactly these defaults.
+#ifndef VW_FWD
 #define VW_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
 #define VW_INV(r, tw, x) ntt_inv_core(r, tw, x)
 #endif
-#ifdef DIL_ABL_NOALOAD
-#define VW_ALOAD(Ar, p, lane, st)                                                    \
-    do {                                                                             \
-        for (int l_ = 0; l_ < L; l_++) Ar.v[l_] = make_int4(lane + l_, lane * 3, 7 * l_ + 1, lane ^ l_); \
-    } while (0)
-#else
+#ifndef VW_ALOAD
 #define VW_ALOAD(Ar, p, lane, st) Ar.load(p, lane, st)
 #endif
 // waves per SIMD the register allocator aims for: 4 at level 2 (118 VGPRs), 3 at levels 3 / 5 (138 / 168 VGPRs; forcing 4
@@ -418,12 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
         const uint8_t* hit = h + it * K * 256;
         // row 0 operands fly under the z-phase
         ARow<L> Ar;
-#ifdef DIL_ABL_AROWMAJOR     // ablation: read the matrix as if it were laid out [k][item][l] (row k of ALL items contiguous)
-#define VW_AROW(k) (A + ((size_t)(k) * batch + it) * (size_t)L * 256)
-#else
-#define VW_AROW(k) (Ait + (size_t)(k) * L * 256)
-#endif
-        VW_ALOAD(Ar, VW_AROW(0), lane, true);
+        VW_ALOAD(Ar, Ait, lane, true);
         int32_t tn[4];
         uint32_t hn;
         load_strided<false>(tn, t1it, lane);
@@ -454,7 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
             for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
             unpack_row_u8(hb, hn, sc, lane);
             if (k + 1 < K) {
-                VW_ALOAD(Ar, VW_AROW(k + 1), lane, true);
+                VW_ALOAD(Ar, Ait + (size_t)(k + 1) * L * 256, lane, true);
                 load_strided<false>(tn, t1it + (k + 1) * 256, lane);
                 hn = load_row_u8(hit + (k + 1) * 256, lane);
             }

@@ -66,9 +66,6 @@ __device__ __forceinline__ void expand_a_body(int32_t* __restrict__ A, const uin
 // (v < q) as sign-bit arithmetic: a rejected candidate is simply overwritten by the next one -- no compare, no divergent
 // branch, no VCC (56 candidates per rate block; VCC-form selects cost ~22 cycles each on gfx950).  The first four blocks
 // cannot reach 256 coefficients (4 x 56 = 224), so only later blocks pay for the `cnt < 256` clamp.
-#ifndef DIL_EA_ABL
-#define DIL_EA_ABL 0          // ablations: 1 = no ring / global stores, 2 = permutations only
-#endif
 template <bool CLAMP, int RING>
 __device__ __forceinline__ void emit23b(uint32_t v, uint32_t& val, uint32_t& slot, int& cnt)
 {
@@ -81,10 +78,6 @@ __device__ __forceinline__ void emit23b(uint32_t v, uint32_t& val, uint32_t& slo
 template <bool CLAMP, class EaSink>
 __device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink, int& cnt)
 {
-#if DIL_EA_ABL == 2
-    cnt += 52;
-    return;
-#endif
 #pragma unroll
     for (int g = 0; g < 7; g++) {
         const uint64_t w0 = sp.s[3 * g], w1 = sp.s[3 * g + 1], w2 = sp.s[3 * g + 2];
@@ -99,7 +92,6 @@ __device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink
         emit23b<CLAMP, EaSink::RING>((uint32_t)((w1 >> 56) | (w2 << 8)), val[5], slot[5], cnt);
         emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 16), val[6], slot[6], cnt);
         emit23b<CLAMP, EaSink::RING>((uint32_t)(w2 >> 40), val[7], slot[7], cnt);
-#if DIL_EA_ABL != 1
         uint32_t* at[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) at[e] = sink.ring + slot[e];
@@ -107,10 +99,7 @@ __device__ __forceinline__ void expand_a_block(const Shake<21>& sp, EaSink& sink
 #pragma unroll
         for (int e = 0; e < 8; e++) *at[e] = val[e];
         __builtin_amdgcn_sched_barrier(0);
-#endif
-#if DIL_EA_ABL == 0 || DIL_EA_ABL == 3 || DIL_EA_ABL == 4 || DIL_EA_ABL == 5
-        sink.flush_if_ready(cnt);           // (ablation 6: ring writes, no flush; 4: flush reads, no stores; 5: stores into 4 KiB per wave)
-#endif
+        sink.flush_if_ready(cnt);
     }
 }
 // body of expand_a_fast_kernel<P24> (hash_kernels.hip) for workgroup `block`; `ring`: CoeffSinkWaveT<P24>::LDS_DWORDS_PER_WAVE dwords
@@ -147,9 +136,6 @@ __device__ __forceinline__ void expand_a_fast_body(int32_t* __restrict__ A, cons
         keccak_f1600(sp.s);
         expand_a_block<true>(sp, sink, cnt);
     } while (__any(cnt < 256));
-#if DIL_EA_ABL != 0            // ablation builds: keep the sponge and the counters observable (without this hipcc deletes most of the kernel)
-    if (cnt != 256 || sp.s[0] == 0x0123456789abcdefull) A[p & 1023] = cnt;
-#endif
 }
 
 

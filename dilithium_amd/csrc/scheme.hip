@@ -26,13 +26,15 @@ Arena* ArenaPool::acquire(hipStream_t s)
     std::lock_guard<std::mutex> lk(mu);
     Arena *free_slot = nullptr, *lru = nullptr;
     for (Arena& a : slots) {
+        if (a.in_use) {
+            if (a.stream == s) return nullptr;      // this stream's arena is busy (or being regrown): the call spills
+            continue;
+        }
         if (a.base && a.stream == s) {
-            if (a.in_use) return nullptr;
             a.in_use = true;
             a.last_use = ++tick;
             return &a;
         }
-        if (a.in_use) continue;
         if (!a.base && !free_slot) free_slot = &a;
         if (a.base && (!lru || a.last_use < lru->last_use)) lru = &a;
     }
@@ -50,22 +52,37 @@ Arena* ArenaPool::acquire(hipStream_t s)
 }
 int ArenaPool::release(Arena* a, size_t wanted)
 {
+    // The slot is ours alone while in_use is set (acquire() skips it), but other threads READ every slot's base / stream under
+    // `mu`: the regrow happens on locals and base / size are published together with in_use = false under the mutex.
+    // (hipFree waits for the work that still uses the old block; it runs outside the lock so that it stalls nobody else's acquire.)
     int rc = 0;
-    if (wanted > a->size) {       // grow for next time; hipFree waits for the work that still uses the old block
-        if (a->base) (void)hipFree(a->base);
-        a->base = nullptr;
-        a->size = 0;
+    char* base = a->base;
+    size_t size = a->size;
+    const bool regrow = wanted > size;
+    if (regrow) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            a->base = nullptr;        // nobody may match this slot by stream while its block is being replaced
+            a->size = 0;
+        }
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        size = 0;
         const size_t sz = wanted + wanted / 8;
-        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&a->base), sz);
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), sz);
         if (e == hipSuccess) {
-            a->size = sz;
+            size = sz;
         } else {                  // reported to the caller (StreamScratch::close): the next call would spill everything
             (void)hipGetLastError();
-            a->base = nullptr;
+            base = nullptr;
             rc = (int)e;
         }
     }
     std::lock_guard<std::mutex> lk(mu);
+    if (regrow) {
+        a->base = base;
+        a->size = size;
+    }
     a->in_use = false;
     return rc;
 }
@@ -250,6 +267,16 @@ struct AuxFork {
     AuxFork(Device& d, hipStream_t m) : dv(d), lk(d.aux.mu, std::try_to_lock), main(m)
     {
         on = dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed) && lk.owns_lock() && dv.aux.ensure();
+    }
+    // defer = true: an inert object (never locks, never forks) -- the caller already owns the helper stream through another AuxFork
+    AuxFork(Device& d, hipStream_t m, bool defer) : dv(d), lk(d.aux.mu, std::defer_lock), main(m)
+    {
+        if (!defer) {
+            (void)lk.try_lock();
+            on = dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed) && lk.owns_lock() && dv.aux.ensure();
+        } else {
+            on = false;
+        }
     }
     // `sponges`: lanes of the lane-per-sponge work going to the helper.  Only latency-bound work (less than about one
     // wave per SIMD) gains from running beside the main stream; throughput-bound work just pays the fork/join.
@@ -509,7 +536,11 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         // Many keys: the smaller job goes to the helper stream, under the larger one.  (Tried: SampleInBall riding in the
         // first workgroups of the throughput ExpandA's launch -- level 2 +8 %, level 3 -1.5 %, level 5 +2.5 % at 8192 keys,
         // -3 % at 65536 keys at every level: not kept.)
-        AuxFork ax(dv, s);
+        // (the helper stream's owner is whoever holds dv.aux.mu: a caller that already forked on it -- dil_verify_msg_dev, whose mu
+        //  chain was joined above -- hands its AuxFork down; constructing a second one on this thread would try_lock a mutex the
+        //  thread owns, which is undefined behaviour and, on glibc, silently turned the overlap off)
+        AuxFork own_ax(dv, s, /*defer=*/mu_pending != nullptr);
+        AuxFork& ax = mu_pending ? *mu_pending : own_ax;
         const size_t a_sponges = nk * p.K * p.L;
         hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;
         hipStream_t sc = a_sponges <= batch ? s : ax.fork(batch);
@@ -533,7 +564,8 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
     uint8_t* w1 = ws.take<uint8_t>(batch * p.K * 256);
     uint8_t* w1p = ws.take<uint8_t>(batch * w1b);
     if (ws.rc) return ws.rc;
-    AuxFork ax(dv, s);
+    AuxFork own_ax(dv, s, /*defer=*/mu_pending != nullptr);
+    AuxFork& ax = mu_pending ? *mu_pending : own_ax;
     {   // public-key side (helper stream when it is latency-bound): A = ExpandA(rho), t1
         hipStream_t a = ax.fork(nk * p.K * p.L);
         DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, a));
@@ -739,30 +771,30 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
 // What the reference's top level absorbs itself (rtl_src/expandmask_ext.v:131-185; bus order mlen, tr, m in
 // rtl_tb/tb_sign_top.v:57-69 and tb_verify_top.v:58-68).
 namespace {
-int check_msgs(const uint8_t* msgs, const uint64_t* offsets, const uint32_t* lengths)
+int check_msgs(const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets, const uint32_t* lengths)
 {
-    if (!msgs || !offsets || !lengths) return (int)hipErrorInvalidValue;
+    if ((!msgs && msgs_bytes) || !offsets || !lengths) return (int)hipErrorInvalidValue;      // msgs == NULL: an empty blob (every message empty)
     if ((reinterpret_cast<uintptr_t>(offsets) & 7) || (reinterpret_cast<uintptr_t>(lengths) & 3)) return (int)hipErrorInvalidValue;
     return 0;
 }
 }  // namespace
 
-int dil_mu_dev(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, const uint64_t* offsets, const uint32_t* lengths,
-               size_t batch, void* stream)
+int dil_mu_dev(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
+               const uint32_t* lengths, int32_t* bad, size_t batch, void* stream)
 {
     int rc;
-    if ((rc = check_msgs(msgs, offsets, lengths))) return rc;
+    if ((rc = check_msgs(msgs, msgs_bytes, offsets, lengths))) return rc;
     if ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(tr) | tr_stride) & 7) return (int)hipErrorInvalidValue;
     DIL_ENTER(dv, T);
-    return (int)dil::launch_mu(mu, tr, tr_stride, msgs, offsets, lengths, batch, S(stream));
+    return (int)dil::launch_mu(mu, tr, tr_stride, msgs, msgs_bytes, offsets, lengths, bad, batch, S(stream));
 }
 
-int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* msgs, const uint64_t* offsets,
+int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
                      const uint32_t* lengths, int level, size_t batch, int shared_sk, int max_attempts, void* stream)
 {
     LevelPar p;
     int rc;
-    if ((rc = level_par(level, &p)) || (rc = check_msgs(msgs, offsets, lengths))) return rc;
+    if ((rc = level_par(level, &p)) || (rc = check_msgs(msgs, msgs_bytes, offsets, lengths))) return rc;
     DIL_ENTER(dv, T);
     if (batch == 0) return 0;
     if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
@@ -770,18 +802,24 @@ int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const u
     hipStream_t s = S(stream);
     StreamScratch ws(dv, s);
     uint8_t* mu = ws.take<uint8_t>(batch * 64);
+    int32_t* bad = ws.take<int32_t>(batch);
     if (ws.rc) return ws.rc;
     // tr sits at byte 64 of the secret key (rho | key | tr | ...)
-    DIL_TRY(dil::launch_mu(mu, sk + 64, (shared_sk || batch == 1) ? 0 : dil_sk_bytes(level), msgs, offsets, lengths, batch, s));
-    return ws.close(sign_core(dv, T, ws, sig, attempts, sk, mu, level, p, batch, shared_sk, max_attempts, s));
+    DIL_TRY(dil::launch_mu(mu, sk + 64, (shared_sk || batch == 1) ? 0 : dil_sk_bytes(level), msgs, msgs_bytes, offsets, lengths, bad, batch, s));
+    rc = sign_core(dv, T, ws, sig, attempts, sk, mu, level, p, batch, shared_sk, max_attempts, s);
+    if (rc == 0 || rc == DIL_ERR_UNFINISHED) {        // items whose message reference left the blob: no signature, attempts = -1
+        const hipError_t e = dil::launch_sign_void_bad(sig, dil_sig_bytes(level), attempts, bad, batch, s);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    return ws.close(rc);
 }
 
-int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* offsets,
+int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
                        const uint32_t* lengths, int level, size_t batch, int shared_pk, void* stream)
 {
     LevelPar p;
     int rc;
-    if ((rc = level_par(level, &p)) || (rc = check_msgs(msgs, offsets, lengths))) return rc;
+    if ((rc = level_par(level, &p)) || (rc = check_msgs(msgs, msgs_bytes, offsets, lengths))) return rc;
     DIL_ENTER(dv, T);
     if (batch == 0) return 0;
     if (reinterpret_cast<uintptr_t>(pk) & 7) return (int)hipErrorInvalidValue;
@@ -790,6 +828,7 @@ int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     const size_t nk = shared_pk ? 1 : batch, pkb = dil_pk_bytes(level);
     uint8_t* tr = ws.take<uint8_t>(nk * 32);
     uint8_t* mu = ws.take<uint8_t>(batch * 64);
+    int32_t* bad = ws.take<int32_t>(batch);
     if (ws.rc) return ws.rc;
     // tr = SHAKE256(pk, 32) (pk length is a multiple of 8 at every level), then mu = SHAKE256(tr || M, 64): with few keys a
     // latency-bound chain (15 + permutations in a row) that nothing needs before the challenge hash at the very end -- it runs
@@ -797,8 +836,10 @@ int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
     AuxFork ax(dv, s);
     hipStream_t h = nk * p.K * p.L <= dil::EA_TWO_LANE_MAX ? ax.fork(nk) : s;
     DIL_TRY(dil::launch_shake256(reinterpret_cast<uint64_t*>(tr), 32, reinterpret_cast<const uint64_t*>(pk), (int)pkb, nk, h));
-    DIL_TRY(dil::launch_mu(mu, tr, shared_pk ? 0 : 32, msgs, offsets, lengths, batch, h));
-    return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s, nullptr, &ax));
+    DIL_TRY(dil::launch_mu(mu, tr, shared_pk ? 0 : 32, msgs, msgs_bytes, offsets, lengths, bad, batch, h));
+    if ((rc = verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s, nullptr, &ax))) return rc;
+    // (verify_sig_core joined the helper stream before the challenge hash, its last launch on `s`: bad[] is complete here)
+    return ws.close((int)dil::launch_or_flag(verdict, bad, 8, batch, T, s));
 }
 
 // ---- host-buffer forms of the whole operations (H2D -> device call -> D2H on the null stream) --------

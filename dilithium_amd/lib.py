@@ -66,9 +66,9 @@ SIGNATURES = {
     "dil_verify_sig_expanded_dev": [_vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_verify_wire_core_dev": [_vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
-    "dil_mu_dev": [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp],
-    "dil_sign_msg_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
-    "dil_verify_msg_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_mu_dev": [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _sz, _vp],
+    "dil_sign_msg_dev": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
+    "dil_verify_msg_dev": [_vp, _vp, _vp, _vp, _sz, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_keygen_host": [_vp, _vp, _vp, C.c_int, _sz],
     "dil_sign_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int],
     "dil_verify_sig_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int],
@@ -77,6 +77,14 @@ SIGNATURES = {
     "dil_keygen_multi_host": [_vp, _vp, _vp, C.c_int, _sz, C.c_int],
     "dil_sign_multi_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, C.c_int],
     "dil_verify_sig_multi_host": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int],
+    "dil_multi_init": [C.c_int],
+    "dil_multi_shutdown": [],
+    "dil_multi_last_error": [],
+    "dil_gather_slabs_multi_dev": [_vp, _sz, _sz, C.c_int, C.c_int],
+    "dil_ntt_multi_dev": [_vp, _sz, C.c_int, C.c_int, C.c_int],
+    "dil_sign_multi_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, C.c_int, C.c_int],
+    "dil_verify_sig_multi_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, C.c_int],
+    "dil_sign_phases_multi_dev": [_vp] * 11 + [C.c_int, _sz, C.c_int, C.c_int, C.c_int],
     "dil_verify_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_attempt_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_event_create": [C.POINTER(_vp)],
@@ -85,7 +93,7 @@ SIGNATURES = {
     "dil_event_elapsed_ms": [C.POINTER(C.c_float), _vp, _vp],
     "dil_stream_sync": [_vp],
 }
-_RESTYPE = {"dil_error_string": C.c_char_p, "dil_host_twiddle_tables": None, "dil_host_zetas": None,
+_RESTYPE = {"dil_error_string": C.c_char_p, "dil_multi_last_error": C.c_char_p, "dil_host_twiddle_tables": None, "dil_host_zetas": None,
             "dil_shard_range": None, "dil_pk_bytes": C.c_size_t, "dil_sk_bytes": C.c_size_t, "dil_sig_bytes": C.c_size_t}
 
 _lib = None

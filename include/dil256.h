@@ -30,7 +30,7 @@
  *   switching devices between calls.  Calls are thread-safe; concurrent composite calls (dil_keygen / dil_sign /
  *   dil_verify_sig ...) on ONE stream are not ordered against each other's scratch -- use a stream per thread,
  *   as with any stream-ordered API.  The *_host transform entry points of one device serialise on a lock of
- *   their own (they share staging buffers); dil_*_multi_host (below) spreads a host batch over every GPU.
+ *   their own (they share staging buffers); dil_*_multi_host / dil_*_multi_dev (below) spread a batch over every GPU.
  */
 #ifndef DIL256_H
 #define DIL256_H
@@ -232,16 +232,19 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
 
 /* ---- messages in, not digests: mu = SHAKE256(tr || M, 64) on the device --------------------------------------------------
  * The reference's top level absorbs (mlen, tr, m) itself (rtl_src/expandmask_ext.v:131-185; bus order rtl_tb/tb_sign_top.v:57-69,
- * tb_verify_top.v:58-68; its KAT messages are 33 ... 3300 bytes).  Messages are RAGGED: one byte blob `msgs` plus, per item,
- * offsets[i] (uint64, byte offset into the blob) and lengths[i] (uint32); any alignment, zero length allowed.
+ * tb_verify_top.v:58-68; its KAT messages are 33 ... 3300 bytes).  Messages are RAGGED: one byte blob `msgs` of `msgs_bytes` bytes plus,
+ * per item, offsets[i] (uint64, byte offset into the blob) and lengths[i] (uint32); any alignment, zero length allowed; msgs may be
+ * NULL when msgs_bytes == 0 (every message empty).  An item whose (offset, length) leaves the blob is never read past the blob: it is
+ * hashed as an empty message and FLAGGED -- dil_mu_dev: bad[i] = 1 (bad may be NULL); dil_sign_msg_dev: attempts[i] = -1 and a zeroed
+ * signature; dil_verify_msg_dev: verdict bit3 (value 8).
  * dil_mu_dev:         mu[i] (64 B, 8-byte aligned) from tr at tr + i * tr_stride (32 B, 8-byte aligned; stride 0 = one tr)
  * dil_sign_msg_dev:   dil_sign_dev on (sk, M): tr is read from the secret key
  * dil_verify_msg_dev: dil_verify_sig_dev on (pk, M, sig): tr = SHAKE256(pk) is computed on the device first */
-int dil_mu_dev(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, const uint64_t* offsets, const uint32_t* lengths,
-               size_t batch, void* stream);
-int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* msgs, const uint64_t* offsets,
+int dil_mu_dev(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
+               const uint32_t* lengths, int32_t* bad, size_t batch, void* stream);
+int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
                      const uint32_t* lengths, int level, size_t batch, int shared_sk, int max_attempts, void* stream);
-int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, const uint64_t* offsets,
+int dil_verify_msg_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
                        const uint32_t* lengths, int level, size_t batch, int shared_pk, void* stream);
 
 /* host-buffer forms of the three whole operations (what the reference's test benches tb_keygen_top.v / tb_sign_top.v /
@@ -252,9 +255,10 @@ int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint
 int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                         int shared_pk);
 
-/* ---- all GPUs of the node from one C++ process: contiguous slices [g*B/G, (g+1)*B/G) of a HOST batch, one host
- * thread per device running the single-device host-pointer entry point on its slice; ndev <= 0 = every visible device.
- * dil_shard_range gives the slice of `rank` (sizes differ by at most one item; same rule as dilithium_amd/sharding.py). */
+/* ---- all GPUs of the node from one C++ process: contiguous slices [g*B/G, (g+1)*B/G) of a batch, one host thread per
+ * device running the single-device entry point on its slice; ndev <= 0 = every visible device.  dil_shard_range gives the slice of
+ * `rank` (sizes differ by at most one item; same rule as dilithium_amd/sharding.py).
+ * HOST buffers (dil_*_multi_host): every thread's D2H copy lands in the caller's array -- no collective. */
 void dil_shard_range(size_t n_items, int rank, int world, size_t* lo, size_t* hi);
 int dil_ntt_multi_host(int32_t* polys, size_t batch, int inverse, int ndev);
 int dil_keygen_multi_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, size_t batch, int ndev);
@@ -262,6 +266,31 @@ int dil_sign_multi_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, cons
                         int max_attempts, int ndev);
 int dil_verify_sig_multi_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level, size_t batch,
                               int shared_pk, int ndev);
+/* DEVICE-resident data (dil_*_multi_dev): the ONE exchange of the design is an RCCL collective over xGMI of the result slabs.
+ *   inputs  in[g]:  device g's SLICE, items [lo_g, hi_g) of dil_shard_range(batch, g, ndev), in device g's memory (one key for the
+ *                   batch: a copy per device)
+ *   outputs out[g]: a FULL-size array [batch][...] in device g's memory; device g writes its slab in place at item lo_g, then
+ *                   gather_root < 0: all-gather -- every out[g] complete (ncclAllGather; ragged slices: one ncclBroadcast per slab in
+ *                   one group);  gather_root = r: only out[r] complete (grouped ncclSend / ncclRecv)
+ * dil_multi_init builds the communicators (ncclCommInitAll over devices 0 .. ndev-1) and one stream per device, cached until ndev
+ * changes or dil_multi_shutdown; the calls below do it on first use.  They are synchronous (every device's stream is drained) and
+ * not re-entrant.  RCCL is bound with dlopen at first use: failures return DIL_ERR_RCCL (text: dil_multi_last_error). */
+#define DIL_ERR_RCCL (-3)
+int dil_multi_init(int ndev);
+int dil_multi_shutdown(void);
+const char* dil_multi_last_error(void);
+int dil_gather_slabs_multi_dev(void* const* bufs, size_t item_bytes, size_t batch, int gather_root, int ndev);
+int dil_ntt_multi_dev(int32_t* const* polys /* in/out: full-size, slab in place */, size_t batch, int inverse, int gather_root, int ndev);
+int dil_sign_multi_dev(uint8_t* const* sig, int32_t* const* attempts /* or NULL */, const uint8_t* const* sk, const uint8_t* const* mu,
+                       int level, size_t batch, int shared_sk, int max_attempts, int gather_root, int ndev);
+int dil_verify_sig_multi_dev(int32_t* const* verdict, const uint8_t* const* pk, const uint8_t* const* sig, const uint8_t* const* mu, int level,
+                             size_t batch, int shared_pk, int gather_root, int ndev);
+/* BASELINE configs[4]: sign inner loop (phase 1 + phase 2, combined_top.v:1830-2229) on every device's slice of the attempts, then the
+ * gather of the (z, h, flags) slabs.  w1_scratch / w0_scratch [g]: [slice][K][256] bytes / int32 on device g. */
+int dil_sign_phases_multi_dev(int32_t* const* z, uint8_t* const* h, int32_t* const* flags, const int32_t* const* A, const int32_t* const* y,
+                              const int32_t* const* c, const int32_t* const* s1hat, const int32_t* const* s2hat, const int32_t* const* t0hat,
+                              uint8_t* const* w1_scratch, int32_t* const* w0_scratch, int level, size_t batch, int shared_key, int gather_root,
+                              int ndev);
 
 /* ---- SURVEY 8(f) row N3 (first step): whole verify / sign-attempt sequences as ONE call --------
  * Everything between the wire-format codecs runs on the device, on `stream`, with no host round trip;

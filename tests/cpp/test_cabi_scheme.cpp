@@ -66,8 +66,8 @@ int main(int argc, char** argv)
     CK(hipMemcpy(d_sk, sk.data(), skb, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_pk, pk.data(), pkb, hipMemcpyHostToDevice));
     // sign (sk, M) and verify (pk, M, sig) on the caller's stream
-    CK(dil_sign_msg_dev(d_sig, d_att, d_sk, d_blob, d_offs, d_lens, level, n, /*shared_sk*/ 1, 512, st));
-    CK(dil_verify_msg_dev(d_verdict, d_pk, d_sig, d_blob, d_offs, d_lens, level, n, /*shared_pk*/ 1, st));
+    CK(dil_sign_msg_dev(d_sig, d_att, d_sk, d_blob, blob.size(), d_offs, d_lens, level, n, /*shared_sk*/ 1, 512, st));
+    CK(dil_verify_msg_dev(d_verdict, d_pk, d_sig, d_blob, blob.size(), d_offs, d_lens, level, n, /*shared_pk*/ 1, st));
     std::vector<int32_t> verdict(n), att(n);
     std::vector<uint8_t> sig(n * sgb), mu(n * 64);
     CK(hipStreamSynchronize(st));
@@ -77,7 +77,7 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < n; i++)
         if (verdict[i] != 0 || att[i] < 1) return printf("message %zu: verdict %d attempts %d\nERROR\n", i, verdict[i], att[i]), 1;
     // ---- the same signatures from the digest path: mu on the device, then the host-buffer multi-GPU layer -------
-    CK(dil_mu_dev(d_mu, d_sk + 64, 0, d_blob, d_offs, d_lens, n, st));
+    CK(dil_mu_dev(d_mu, d_sk + 64, 0, d_blob, blob.size(), d_offs, d_lens, /*bad*/ nullptr, n, st));
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(mu.data(), d_mu, n * 64, hipMemcpyDeviceToHost));
     std::vector<uint8_t> sig2(n * sgb);
@@ -92,7 +92,7 @@ int main(int argc, char** argv)
     sig2[2 * sgb + 40] ^= 4;
     CK(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_sig, sig2.data(), n * sgb, hipMemcpyHostToDevice));
-    CK(dil_verify_msg_dev(d_verdict, d_pk, d_sig, d_blob, d_offs, d_lens, level, n, 1, st));
+    CK(dil_verify_msg_dev(d_verdict, d_pk, d_sig, d_blob, blob.size(), d_offs, d_lens, level, n, 1, st));
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(verdict.data(), d_verdict, n * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; i++) {
@@ -104,7 +104,7 @@ int main(int argc, char** argv)
     CK(dil_set_option("zeroize", 1));
     CK(dil_get_option("zeroize", &v));
     if (v != 1 || dil_set_option("no_such_option", 1) == 0) return printf("options\nERROR\n"), 1;
-    CK(dil_sign_msg_dev(d_sig, d_att, d_sk, d_blob, d_offs, d_lens, level, n, 1, 512, st));      // with scratch wiping
+    CK(dil_sign_msg_dev(d_sig, d_att, d_sk, d_blob, blob.size(), d_offs, d_lens, level, n, 1, 512, st));      // with scratch wiping
     CK(hipStreamSynchronize(st));
     CK(dil_set_option("zeroize", 0));
     CK(dil_shutdown());

@@ -71,3 +71,65 @@ def test_shared_key_messages(gpu, level, kat_msgs):
     assert (sig == ref).all()
     assert sig[0].cpu().numpy().tobytes() == k["ctilde"][0].tobytes() + k["z"][0].tobytes() + k["h"][0].tobytes()
     assert int(api.verify_msg(cu(gpu, pk[:1]), sig, blob, offs, lens, level, shared_pk=True).abs().sum()) == 0
+
+
+def test_message_reference_outside_the_blob_is_flagged_not_read(gpu, kat_msgs):
+    """an item whose (offset, length) leaves the blob is never read past it: mu flags it (and hashes an empty message),
+    sign_msg voids it (attempts -1, zero signature), verify_msg rejects it with bit 3; the other items are untouched.  An
+    all-empty batch may pass (NULL, 0) as its blob."""
+    from dilithium_amd import api
+    level = 3
+    k, pk, sk, _ = kat_wire(level)
+    msgs = [bytes([i]) * (10 + i) for i in range(8)]
+    blob, offs, lens = api.pack_messages(msgs)
+    good_sig, good_att = api.sign_msg(cu(gpu, sk[:1]), blob, offs, lens, level, shared_sk=True)
+    o2, l2 = offs.clone(), lens.clone()
+    o2[2] = blob.numel() - 3          # runs 3 + ... past the end
+    l2[5] = 1 << 30                   # absurd length
+    o2[6] = (1 << 62)                 # absurd offset (offset + length would wrap)
+    bad = gpu.full((8,), -7, dtype=gpu.int32, device="cuda")
+    mu = api.mu(cu(gpu, k["tr"][:1]), blob, o2, l2, bad=bad).cpu().numpy()
+    assert bad.cpu().numpy().tolist() == [0, 0, 1, 0, 0, 1, 1, 0]
+    empty = hashlib.shake_256(k["tr"][0].tobytes()).digest(64)
+    for i in range(8):
+        want = empty if i in (2, 5, 6) else hashlib.shake_256(k["tr"][0].tobytes() + msgs[i]).digest(64)
+        assert mu[i].tobytes() == want, i
+    sig, att = api.sign_msg(cu(gpu, sk[:1]), blob, o2, l2, level, shared_sk=True)
+    att = att.cpu().numpy()
+    for i in range(8):
+        if i in (2, 5, 6):
+            assert att[i] == -1 and int(sig[i].sum()) == 0
+        else:
+            assert att[i] == int(good_att[i]) and gpu.equal(sig[i], good_sig[i])
+    v = api.verify_msg(cu(gpu, pk[:1]), good_sig, blob, o2, l2, level, shared_pk=True).cpu().numpy()
+    assert [int(x) & 8 for x in v] == [0, 0, 8, 0, 0, 8, 8, 0] and all(v[i] == 0 for i in (0, 1, 3, 4, 7))
+    # every message empty: no blob at all
+    eb, eo, el = api.pack_messages([b""] * 5)
+    assert eb.numel() == 0
+    s5, a5 = api.sign_msg(cu(gpu, sk[:1]), eb, eo, el, level, shared_sk=True)
+    mu0 = np.frombuffer(empty, dtype=np.uint8)[None].repeat(5, 0)
+    ref, _ = api.sign(cu(gpu, sk[:1]), cu(gpu, mu0), level, shared_sk=True)
+    assert gpu.equal(s5, ref) and (a5 > 0).all()
+    assert int(api.verify_msg(cu(gpu, pk[:1]), s5, eb, eo, el, level, shared_pk=True).abs().sum()) == 0
+
+
+def test_verify_msg_many_keys_uses_the_helper_stream_once(gpu):
+    """dil_verify_msg_dev with more keys than the few-keys path takes (> 32768 A-polynomials): the call hands ITS helper-stream
+    fork down to the verification instead of try-locking the helper's mutex a second time on the same thread; verdicts equal
+    those of verify_sig on host-hashed mu, tampered items rejected"""
+    from dilithium_amd import api
+    level, n = 3, 1400                       # 1400 x 30 = 42000 polynomials of A
+    rng = np.random.default_rng(31)
+    seed = cu(gpu, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    pk, sk = api.keygen(seed, level)
+    msgs = [rng.integers(0, 256, int(rng.integers(0, 120)), dtype=np.uint8).tobytes() for _ in range(n)]
+    blob, offs, lens = api.pack_messages(msgs)
+    sig, _ = api.sign_msg(sk, blob, offs, lens, level)
+    bad = sig.clone()
+    bad[7, 100] ^= 1
+    bad[1399, 5] ^= 64
+    v = api.verify_msg(pk, bad, blob, offs, lens, level).cpu().numpy()
+    assert set(np.nonzero(v)[0]) == {7, 1399}
+    tr = api.shake256(pk, 32)
+    mu = api.mu(tr, blob, offs, lens)
+    assert (api.verify_sig(pk, bad, mu, level).cpu().numpy() == v).all()

@@ -3,7 +3,8 @@
 The `*_wpi` kernels launch grid = min(work, resident workgroups) and every wave walks items it, it + nwaves, ... ; the
 code after a wave's first item -- the software prefetch of the NEXT item's inputs, the loop-carried row registers --
 runs only when batch / 4 exceeds the resident workgroups (768-2048).  The dispatch-size tests (n = 2125 / 2304) never
-get there.  Here every output of every such kernel is compared with the oracle at batches of 8192 and 20000-40000, a key
+get there.  Here every output of every such kernel is compared with the oracle at batches of 8192 / 9216 (the lightest kernels
+keep 2048 workgroups = 8192 waves resident, so 8192 items would be ONE step for them) and 20000-40000, a key
 per item and one key for the batch, and each test ASSERTS through the library's launch record (dil_launch_info) that the
 loop was re-entered (steps >= 2 at 8192, >= 3 at the large size).
 rtl_src/combined_top.v:1207-1469 (verify), :1850-1933 (mat-vec / FSM1), :1981-2229 (FSM2), :921-1079 (keygen)."""
@@ -73,7 +74,7 @@ def test_verify_wpi_level3_20000_vs_oracle(gpu, oracle):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
-@pytest.mark.parametrize("shared,n,min_steps", [(True, 8192, 2), (True, 40000, 3), (False, 8192, 2), (False, 20000, 3)])
+@pytest.mark.parametrize("shared,n,min_steps", [(True, 9216, 2), (True, 40000, 3), (False, 9216, 2), (False, 20000, 3)])
 def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, min_steps):
     """phase 1 (matvec_shared / matvec_wpi <OUT_W1W0>: w1, w0), phase 2 (sign2_wpi_kernel: z, h, flags) and the signing
     loop's early-exit phase 2 (sign2_early_wpi_kernel through its in/out w0 scratch: first failed check, z / h of the
