@@ -68,6 +68,26 @@ def cpu_baseline(sample_polys=4096, target_s=10.0):
                       f"1 thread of {os.cpu_count()} host CPUs"}
 
 
+def cpu_quota():
+    """(effective CPUs the container may use, source): the cgroup CPU quota when there is one -- sched_getaffinity / nproc report
+    the VISIBLE hardware threads, which a CPU-limited lease cannot all run at once"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            return float(q) / float(per), "cgroup v2 cpu.max"
+        return None, "cgroup v2 cpu.max = max (no quota)"
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                     # cgroup v1
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per, "cgroup v1 cpu.cfs_quota_us"
+        return None, "cgroup v1: no quota"
+    except Exception:
+        return None, "no cgroup CPU controller visible"
+
+
 def cpu_baseline_all_threads(per_poly_s, target_s=5.0, sample_polys=1024):
     """the same reference ntt()+invntt() on every host hardware thread at once (the reference itself is single-threaded;
     SURVEY 8(d) asks for both figures).  ctypes drops the GIL during the foreign call, so plain threads run in parallel."""
@@ -102,7 +122,13 @@ def cpu_baseline_all_threads(per_poly_s, target_s=5.0, sample_polys=1024):
         t.join()
     dt = time.perf_counter() - t0
     n = sum(done)
-    return {"value": n / dt, "unit": "NTT/s", "cores": nthreads,
+    quota, qsrc = cpu_quota()
+    one_thread = 1.0 / per_poly_s
+    return {"value": n / dt, "unit": "NTT/s", "threads": nthreads,
+            "cores": round(quota, 2) if quota else nthreads,
+            "cores_note": f"threads started = visible hardware threads = {nthreads}; CPU quota of this container: "
+                          f"{'%.2f CPUs' % quota if quota else 'none'} ({qsrc}); measured parallel speed-up over one thread "
+                          f"{n / dt / one_thread:.1f}x -- `cores` is the quota when there is one",
             "sample": f"{nthreads} threads, each alternating {chunk} x ntt / {chunk} x invntt over {sample_polys} polynomials "
                       f"until {target_s:.0f} s had passed = {n} transforms in {dt:.1f} s"}
 
@@ -157,6 +183,10 @@ def main():
                     help="HIP streams the steps alternate over (step i runs on stream i %% S; a batch always stays on one "
                          "stream).  2 keeps a second launch in flight, which fills the dispatch gap and the ramp/tail of "
                          "every kernel: +15 %% over one stream")
+    ap.add_argument("--region-ms", type=float, default=50.0,
+                    help="a timed region of the headline is a whole number of K-step groups at least this long")
+    ap.add_argument("--regions", type=int, default=7, help="timed regions of the headline (at least)")
+    ap.add_argument("--total-ms", type=float, default=400.0, help="the headline's regions add up to at least this much")
     ap.add_argument("--min-ms", type=float, default=25.0,
                     help="every secondary leg is timed for at least this long, whatever --steps says")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -191,20 +221,22 @@ def main():
 
     def timed(fn, st=None, min_ms=None):
         """average milliseconds per call of fn() (direct C-ABI launches on stream `st`): HIP events around a region that is
-        at least min_ms long -- the repeat count comes from a calibration pass, not from --steps"""
+        at least min_ms long -- the repeat count comes from a calibration pass, not from --steps.  Returns (ms per call,
+        calls in the measured region)."""
         st = stream if st is None else st
         min_ms = args.min_ms if min_ms is None else min_ms
         e0, e1 = ev(), ev()
-        reps, rc = 4, 0
+        reps, used, rc = 4, 4, 0
         for _ in range(3):                       # warm-up, then calibrate, then the measured region
             L.dil_event_record(e0, st)
             for i in range(reps):
                 rc |= fn(i)
             L.dil_event_record(e1, st)
+            used = reps
             per = max(elapsed(e0, e1) / reps, 1e-4)
             reps = max(10, int(min_ms / per) + 1)
         dlib.check(rc, "timed launches")
-        return per, reps
+        return per, used
 
     # ---- inputs, resident in HBM ------------------------------------------------------------
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -225,25 +257,41 @@ def main():
         return L.dil_ntt_dev(p, BATCH, st) | L.dil_invntt_dev(p, BATCH, st)
 
     def region(k, fixed=None, one=False):
-        """EXACTLY k steps, bracketed by one HIP event pair per stream; returns (wall seconds, per-stream event ms)"""
-        ns = 1 if one else NS
-        e0 = [ev() for _ in range(ns)]
-        e1 = [ev() for _ in range(ns)]
+        """EXACTLY k steps between barrier + synchronize on both sides, host clock; no events inside (an event record between two
+        launches costs several microseconds of GPU idle time -- at 26 us per kernel a 10 % perturbation).  Returns this rank's
+        wall seconds."""
         sharding.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rc = 0
-        for j in range(ns):
-            rc |= L.dil_event_record(e0[j], hstreams[j])
         for i in range(k):
             rc |= step(i, fixed, one)
-        for j in range(ns):
-            rc |= L.dil_event_record(e1[j], hstreams[j])
         torch.cuda.synchronize()
         sharding.barrier()
         wall = time.perf_counter() - t0
         dlib.check(rc, "timed NTT launches")
-        return sharding.max_over_ranks(wall), [elapsed(a, b) for a, b in zip(e0, e1)]
+        return wall
+
+    def measure(k, fixed=None, one=False, min_region_ms=None, min_total_ms=None, min_regions=None):
+        """Robust at any --steps: a timed region is M back-to-back groups of K steps (M = what makes it >= --region-ms long, so the
+        ~30 us a synchronised region loses to the first launch's ramp and the last one's drain stays below 0.1 %), and R >= --regions
+        such regions are timed (>= --total-ms in all).  Returns per-step seconds: median / min / max over the regions (each the MAX
+        over ranks), M, R."""
+        min_region_ms = args.region_ms if min_region_ms is None else min_region_ms
+        min_total_ms = args.total_ms if min_total_ms is None else min_total_ms
+        min_regions = args.regions if min_regions is None else min_regions
+        probe = max(region(k, fixed, one), 1e-6)                                         # calibration (also a warm region)
+        m = max(1, int(np.ceil(min_region_ms * 1e-3 / probe)))
+        m = int(sharding.max_over_ranks(float(m)))                                       # same M on every rank
+        r = max(min_regions, int(np.ceil(min_total_ms / max(min_region_ms, probe * m * 1e3))))
+        walls = torch.tensor([region(m * k, fixed, one) for _ in range(r)], dtype=torch.float64)
+        if world > 1:
+            w = walls.cuda()
+            torch.distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
+            walls = w.cpu()
+        per_step = (walls / (m * k)).numpy()
+        return {"median": float(np.median(per_step)), "min": float(per_step.min()), "max": float(per_step.max()), "groups_per_region": m,
+                "regions": r}
 
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:      # untimed clock/power warm-up
@@ -254,37 +302,61 @@ def main():
         step(i)
     torch.cuda.synchronize()
     K = args.steps
-    # Timed region: no events inside (an event record between two launches costs several microseconds of GPU idle
-    # time -- the marker packet drains the pipeline -- which at 26 us per kernel is a 10 % perturbation).
-    dt, ev_ms = region(K)
+    hd = measure(K)
     assert torch.equal(bufs[0][:64], check), "fwd+inv round trip is not the identity"
-    value = world * K * 2 * BATCH / dt
-    region_ms = max(ev_ms)
-    overlapped_gbs = NTT_BYTES * BATCH * 2 * K / (region_ms * 1e-3) / 1e9    # aggregate over the timed region (NS launches overlap)
+    step_s = hd["median"]
+    value = world * 2 * BATCH / step_s
+    overlapped_gbs = NTT_BYTES * BATCH * 2 / step_s / 1e9          # the SAME clock as `value`: all launches' bytes / elapsed time
 
-    # the SAME K steps on ONE stream: the per-kernel roofline (no overlap between launches; each launch's share of the
-    # region includes its ~2 us dispatch gap, so this is a lower bound of what rocprofv3 reports per kernel)
-    one_dt, one_ev = region(K, one=True)
-    one_stream_value = world * K * 2 * BATCH / one_dt
-    launch_ms = one_ev[0] / (2 * K)
+    # the same steps on ONE stream: the per-kernel roofline (no overlap between launches; each launch's share of the region
+    # includes its ~2 us dispatch gap, so this is a lower bound of what rocprofv3 reports per kernel)
+    one = measure(K, one=True, min_total_ms=args.total_ms / 2, min_regions=max(3, args.regions // 2))
+    one_stream_value = world * 2 * BATCH / one["median"]
+    launch_ms = one["median"] / 2 * 1e3
     kernel_gbs = NTT_BYTES * BATCH / (launch_ms * 1e-3) / 1e9
+
+    # what the transforms' access pattern reaches on THIS box without any arithmetic: the same launch shape, loads and stores
+    # (csrc/kernels.hip ntt_traffic_kernel), on scratch copies of the rotating batches, one stream, same clock
+    scratch = [torch.randint(0, 8380417, (BATCH, 256), dtype=torch.int32, device="cuda", generator=g) for _ in range(R)]
+    sptr = [P(b) for b in scratch]
+
+    def traffic_region(k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = 0
+        for i in range(k):
+            rc |= L.dil_ntt_traffic_dev(sptr[i % R], BATCH, 0, hstreams[0]) | L.dil_ntt_traffic_dev(sptr[i % R], BATCH, 1, hstreams[0])
+        torch.cuda.synchronize()
+        dlib.check(rc, "traffic-only launches")
+        return (time.perf_counter() - t0) / (2 * k)
+    traffic_region(8)
+    kk = max(8, int(0.05 / max(traffic_region(8), 1e-6) / 2))
+    ach_s = float(np.median([traffic_region(kk) for _ in range(5)]))
+    achievable_gbs = NTT_BYTES * BATCH / ach_s / 1e9
+    del scratch
 
     # LLC-resident variant (the same NS batches every step: 64 MiB each, inside the 256 MiB Infinity Cache) for context
     for i in range(8):
         step(i, fixed=0)
     torch.cuda.synchronize()
-    llc_dt, _ = region(K, fixed=0)
-    llc_value = world * K * 2 * BATCH / llc_dt
+    llc = measure(K, fixed=0, min_total_ms=args.total_ms / 4, min_regions=3)
+    llc_value = world * 2 * BATCH / llc["median"]
 
     traffic = pmc_traffic("ntt_fwd_kernel")
     out = {
         "metric": "ntt256_transforms_per_sec", "value": value, "unit": "NTT/s", "n_gpus": world, "steps": K,
-        "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batched forward+inverse NTT, n=256, q=8380417, "
                                "batch=65536 polynomials per GPU; step = 1 fwd launch + 1 inv launch",
                    "batch_per_gpu": BATCH, "rotating_resident_batches": R, "streams": NS,
                    "parallelism": f"shard x{world}", "bytes_per_transform": NTT_BYTES},
+        "timing": {"clock": "host perf_counter around barrier + torch.cuda.synchronize() on both sides, MAX over ranks per region",
+                   "steps_per_timed_region": hd["groups_per_region"] * K, "regions": hd["regions"],
+                   "ms_per_step_median": hd["median"] * 1e3, "ms_per_step_min": hd["min"] * 1e3, "ms_per_step_max": hd["max"] * 1e3,
+                   "value_min": world * 2 * BATCH / hd["max"], "value_max": world * 2 * BATCH / hd["min"],
+                   "note": "a timed region is a whole number of K-step groups, long enough (--region-ms) that the result does not "
+                           "depend on --steps; value / ms_per_step are the MEDIAN region"},
         "roofline": {"bound": "hbm",
                      "kernel": "ntt_fwd_kernel<LAYOUT_POLY> / ntt_inv_kernel<LAYOUT_POLY> (alternating launches, identical "
                                "algorithmic bytes)",
@@ -292,13 +364,21 @@ def main():
                      "avg_launch_ms": launch_ms, "algorithmic_bytes_per_launch": NTT_BYTES * BATCH,
                      "achieved_overlapped": overlapped_gbs, "frac_overlapped": overlapped_gbs / HBM_PEAK_GBS,
                      "concurrent_launches_overlapped": NS,
+                     "achievable": achievable_gbs, "achievable_frac_of_peak": achievable_gbs / HBM_PEAK_GBS,
+                     "frac_of_achievable": kernel_gbs / achievable_gbs,
+                     "achievable_source": "measured in this run: ntt_traffic_kernel = the transforms' loads and stores (same grid, same "
+                                          "prefetch, strided 256-B dword accesses on one side and 1-KiB dwordx4 rows on the other) with NO "
+                                          "arithmetic, forward + inverse pattern alternating on one stream over the same rotating batches",
                      "traffic": traffic,
+                     "traffic_level": "L2 <-> memory-fabric bytes (TCC FETCH_SIZE x 2 x 1024 B + WRITE_SIZE x 1024 B, the gfx950 correction of "
+                                      "MI355X_MICROARCH.md); the counter cannot tell Infinity-Cache hits from HBM accesses -- the steps rotate over "
+                                      "512 MiB of batches (twice the 256 MiB Infinity Cache), which makes them HBM reads for this kernel",
                      "traffic_source": "profiles/pmc_summary.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                        "this kernel (bytes per launch; not re-measured in this run)" if traffic else None,
-                     "timing": "achieved / frac = algorithmic bytes per launch / avg_launch_ms, the per-launch share of K steps "
-                               "(2K launches) on ONE stream between two HIP events; achieved_overlapped / frac_overlapped = all "
-                               "launches' bytes / the elapsed time of the timed region behind `value`, in which "
-                               "`concurrent_launches_overlapped` launches are in flight"},
+                     "timing": "every figure on the host clock of `value` (barrier + synchronize on both sides of a region): achieved / frac "
+                               "= algorithmic bytes per launch / avg_launch_ms, the per-launch share of regions on ONE stream (median of "
+                               f"{one['regions']} regions); achieved_overlapped / frac_overlapped = bytes per step / ms_per_step of `value`, "
+                               "with `concurrent_launches_overlapped` launches in flight"},
         "llc_resident_value": llc_value,
         "one_stream_value": one_stream_value,
     }

@@ -520,6 +520,12 @@ int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int ma
     });
 }
 
+int dil_ntt_traffic_dev(int32_t* polys, size_t batch, int inverse, void* stream)
+{
+    DIL_ENTER(d, T);
+    return (int)dil::launch_ntt_traffic(inverse != 0, polys, batch, T, S(stream));
+}
+
 // ---- fused pipelines ---------------------------------------------------------------------------
 int dil_matvec_dev(int32_t* w, const int32_t* A, const int32_t* y, int level, size_t batch, int shared_A, void* stream)
 {

@@ -192,6 +192,44 @@ __global__ __launch_bounds__(256) void pointwise_kernel(int32_t* c, const int32_
     }
 }
 
+// The transforms' memory traffic WITHOUT the arithmetic (bench.py `roofline.achievable`): the same persistent grid, the same
+// prefetch distance, the same instructions to memory -- forward: four strided 256-byte dword loads, one 1-KiB dwordx4 store per
+// wave and polynomial; inverse: mirrored -- so that the bench line carries, beside the 8 TB/s spec, what this access pattern
+// reaches on the box it runs on.  Scrambles the buffer (a lane's four strided values leave as one row); scratch data only.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void ntt_traffic_kernel(int32_t* __restrict__ polys, size_t batch)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    if (wave >= batch) return;
+    if (!INVERSE) {
+        int32_t nxt[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) nxt[m] = ld_s(polys + wave * 256 + lane + 64 * m);
+        for (size_t p = wave; p < batch; p += nwaves) {
+            const int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+            const size_t pn = p + nwaves;
+            if (pn < batch) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) nxt[m] = ld_s(polys + pn * 256 + lane + 64 * m);
+            }
+            st_nt4(polys + p * 256 + 4 * lane, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+        }
+    } else {
+        int4 nx = ld_nt4(polys + wave * 256 + 4 * lane);
+        for (size_t p = wave; p < batch; p += nwaves) {
+            const int4 r = nx;
+            const size_t pn = p + nwaves;
+            if (pn < batch) nx = ld_nt4(polys + pn * 256 + 4 * lane);
+            st_s(polys + p * 256 + lane, r.x);
+            st_s(polys + p * 256 + lane + 64, r.y);
+            st_s(polys + p * 256 + lane + 128, r.z);
+            st_s(polys + p * 256 + lane + 192, r.w);
+        }
+    }
+}
+
 // ntt2x2_mul on `bram` (ntt2x2_mul.cpp:33-59): ram[map(l)][k] *= mul_ram[l][k]; one thread per row
 __global__ __launch_bounds__(256) void bram_mul_kernel(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping)
 {
@@ -227,6 +265,15 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
         if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_POLY>, grid, 256, 0, s, polys, batch, tab, mapping);
         else hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_BRAM>, grid, 256, 0, s, polys, batch, tab, mapping);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_traffic(bool inverse, int32_t* polys, size_t batch, const Tables& t, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    const int grid = grid_for((batch + 3) / 4, t.num_cus * t.ntt_blocks_per_cu);      // the transforms' own launch shape
+    if (inverse) hipLaunchKernelGGL(ntt_traffic_kernel<true>, grid, 256, 0, s, polys, batch);
+    else hipLaunchKernelGGL(ntt_traffic_kernel<false>, grid, 256, 0, s, polys, batch);
     return hipGetLastError();
 }
 

@@ -36,6 +36,8 @@ struct Tables {
 };
 
 hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, size_t batch, const Tables& t, hipStream_t s);
+// the transforms' loads and stores without the arithmetic (bench.py roofline.achievable); scrambles `polys`
+hipError_t launch_ntt_traffic(bool inverse, int32_t* polys, size_t batch, const Tables& t, hipStream_t s);
 hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t* b, const int32_t* acc, size_t batch,
                             const Tables& t, hipStream_t s);
 hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dil_host_zetas": [_i32p],
     "dil_ntt_dev": [_vp, _sz, _vp],
     "dil_invntt_dev": [_vp, _sz, _vp],
+    "dil_ntt_traffic_dev": [_vp, _sz, C.c_int, _vp],
     "dil_ntt_host": [_i32p, _sz],
     "dil_invntt_host": [_i32p, _sz],
     "dil_pointwise_dev": [_vp, _vp, _vp, _sz, _vp],

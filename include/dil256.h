@@ -96,6 +96,9 @@ void dil_host_zetas(int32_t* zetas /*256*/);
  * dil_invntt_* == invntt() / invntt2x2_ref()  (ref_ntt.cpp:59-87, ref_ntt2x2.cpp:100-145) */
 int dil_ntt_dev(int32_t* polys, size_t batch, void* stream);
 int dil_invntt_dev(int32_t* polys, size_t batch, void* stream);
+/* measurement helper (bench.py `roofline.achievable`): the loads and stores of dil_ntt_dev (inverse = 0) / dil_invntt_dev (1) with the
+ * same launch shape and NO arithmetic -- what this access pattern reaches on the box.  SCRAMBLES polys: scratch data only. */
+int dil_ntt_traffic_dev(int32_t* polys, size_t batch, int inverse, void* stream);
 int dil_ntt_host(int32_t* polys, size_t batch);
 int dil_invntt_host(int32_t* polys, size_t batch);
 
