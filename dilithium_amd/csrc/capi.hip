@@ -38,6 +38,7 @@ const OptName* option_table(int* n)
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
         {"gen_a", "DIL_GEN_A", &cfg.gen_a},
+        {"verify_chunks", "DIL_VERIFY_CHUNKS", &cfg.verify_chunks},
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
         {"two_lane_max_sponges", "DIL_TWO_LANE_MAX", &dil::two_lane_max_sponges},
@@ -155,8 +156,11 @@ bool AuxStream::ensure()
 {
     if (s) return true;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; return false; }
-    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+    for (hipEvent_t& e : chunk_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         destroy();
         return false;
     }
@@ -166,8 +170,13 @@ void AuxStream::destroy()
 {
     if (fork) (void)hipEventDestroy(fork);
     if (join) (void)hipEventDestroy(join);
+    for (hipEvent_t& e : chunk_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
     if (s) (void)hipStreamDestroy(s);
-    s = nullptr;
+    if (s2) (void)hipStreamDestroy(s2);
+    s = s2 = nullptr;
     fork = join = nullptr;
 }
 }  // namespace rt

@@ -36,6 +36,10 @@ struct Config {
     std::atomic<int> fuse_keygen{1};       // DIL_FUSE_KEYGEN: 0 = keygen's mat-vec, Power2Round and t1 / t0 packing as separate kernels
     std::atomic<int> a24{1};               // DIL_A24: 0 = the composite calls keep per-item matrices as int32 in HBM (1: 24-bit packed)
     std::atomic<int> gen_a{0};             // DIL_GEN_A: 1 = wire-format verify with a key per signature samples A inside the verifying kernel
+    std::atomic<int> verify_chunks{1};     // DIL_VERIFY_CHUNKS: wire-format verify, a key per signature: > 1 = ExpandA / fused kernel / challenge hash
+                                           // pipelined over this many chunks on three streams.  Built and measured in round 3, SLOWER at every
+                                           // level and size (level 3, 8192: 286 us one pass, 389 / 442 / 641 us with 2 / 4 / 8 chunks; 65536: 1.81
+                                           // vs 1.95-2.01 ms; profiles/r03f_verify_chunks.txt) -- default 1 = one pass
 };
 extern Config cfg;
 std::atomic<int>* option_slot(const char* name);     // nullptr: unknown option
@@ -59,10 +63,13 @@ struct ArenaPool {
 };
 
 // helper stream of the composite calls: latency-bound independent parts run beside the caller's stream
+constexpr int AUX_MAX_CHUNKS = 8;
 struct AuxStream {
     std::mutex mu;
     hipStream_t s = nullptr;
+    hipStream_t s2 = nullptr;                                  // second helper: the chunk pipelines' third lane (scheme.hip)
     hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t chunk_ev[2 * AUX_MAX_CHUNKS + 1] = {};          // per chunk: producer done, consumer done; + the last lane's end
     bool ensure();
     void destroy();
 };

@@ -542,12 +542,48 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         AuxFork own_ax(dv, s, /*defer=*/mu_pending != nullptr);
         AuxFork& ax = mu_pending ? *mu_pending : own_ax;
         const size_t a_sponges = nk * p.K * p.L;
-        hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;
-        hipStream_t sc = a_sponges <= batch ? s : ax.fork(batch);
         // (int32 matrix here: the fused verify kernel is not bound by the A stream -- with 24-bit packed A it runs 64.7 vs
         //  63.1 us and ExpandA's 48-byte pieces cost 8 us more than its 64-byte ones; profiles/r02_a24.txt.  The format
         //  parameter stays for A/B runs: option a24 = 2 forces the packed form here too.)
         const int a_fmt = (!shared_pk && dil::rt::cfg.a24.load(std::memory_order_relaxed) == 2) ? matrix_format(nk, p.K, p.L) : dil::A_I32;
+        // Option verify_chunks > 1 (OFF by default): three lanes over chunks of the batch -- ExpandA of chunk i + 1 on one helper
+        // stream, the fused kernel of chunk i on the caller's, the challenge hash of chunk i - 1 on a second helper (the reference
+        // streams A in while z decodes, combined_top.v:1149-1207).  On paper ExpandA (Keccak-VALU-bound, 170 us per 8192 level-3
+        // keys) hides the HBM-bound fused kernel (59 us) and all but the last latency-bound hash (51 us): 283 -> ~230 us.  Measured
+        // (profiles/r03f_verify_chunks.txt): 286 us in one pass, 389 / 442 / 641 us with 2 / 4 / 8 chunks, and no gain at 65536
+        // either -- a cross-stream dependency costs ~15-20 us, the throughput-form ExpandA of a quarter batch is one wave per SIMD
+        // (70-80 % of its rate), and both kernels want the same VALUs.  The one-pass sequence below stays the default.
+        int chunks = dil::rt::cfg.verify_chunks.load(std::memory_order_relaxed);
+        chunks = std::min<int>(std::min<int>(chunks, dil::rt::AUX_MAX_CHUNKS), (int)(batch / 1024));
+        if (!shared_pk && chunks >= 2 && ax.on) {
+            dil::rt::AuxStream& xs = dv.aux;
+            hipStream_t s_ea = xs.s, s_hash = xs.s2;
+            DIL_TRY(hipEventRecord(xs.fork, s));                          // both helper lanes start after whatever is already on `s`
+            DIL_TRY(hipStreamWaitEvent(s_ea, xs.fork, 0));
+            DIL_TRY(hipStreamWaitEvent(s_hash, xs.fork, 0));
+            DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));      // latency-bound, beside the first ExpandA
+            const size_t per = (batch + chunks - 1) / chunks;
+            int nch = 0;
+            for (size_t off = 0; off < batch; off += per, nch++) {
+                const size_t cnt = std::min(per, batch - off);
+                int32_t* Ac = A + off * (size_t)(p.K * p.L) * (a_fmt == dil::A_P24 ? 192 : 256);
+                hipEvent_t ea_done = xs.chunk_ev[2 * nch], v_done = xs.chunk_ev[2 * nch + 1];
+                DIL_TRY(dil::launch_expand_a(Ac, pk + off * pkb, pkb, level, cnt, s_ea, a_fmt));
+                DIL_TRY(hipEventRecord(ea_done, s_ea));
+                DIL_TRY(hipStreamWaitEvent(s, ea_done, 0));
+                DIL_TRY(dil::launch_verify_wire(level, w1p + off * w1b, verdict + off, Ac, pk + off * pkb, pkb, sig + off * sgb, sgb, cbits + off * 64,
+                                                cnt, 0, T, s, a_fmt));
+                DIL_TRY(hipEventRecord(v_done, s));
+                DIL_TRY(hipStreamWaitEvent(s_hash, v_done, 0));
+                DIL_TRY(dil::launch_challenge_hash(nullptr, verdict + off, mu + off * 64, w1p + off * w1b, level, sig + off * sgb, cnt, s_hash, sgb));
+            }
+            hipEvent_t all_done = xs.chunk_ev[2 * dil::rt::AUX_MAX_CHUNKS];
+            DIL_TRY(hipEventRecord(all_done, s_hash));
+            DIL_TRY(hipStreamWaitEvent(s, all_done, 0));                  // (s_ea is joined through the last chunk's ea_done)
+            return 0;
+        }
+        hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;
+        hipStream_t sc = a_sponges <= batch ? s : ax.fork(batch);
         DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, sa, a_fmt));
         DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, sc));
         if ((rc = ax.join())) return rc;
