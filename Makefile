@@ -18,8 +18,17 @@ dilithium_amd/libdil256_ref.so: $(CSRC)/ref_api.cpp dilithium_amd/libdil256.so i
 
 checkers:
 	$(MAKE) -C oracle
+ifeq ($(SAN),1)
+	$(MAKE) -C oracle san
+endif
+
+# AddressSanitizer + UBSan over the CPU side: the oracle, the drop-in's host code (ref_api.cpp) and the HOST code of the runtime
+# (capi.hip, scheme.hip arenas / options, multi_gpu.hip) -- two passes, one per sanitizer runtime (gcc's for the C / C++ files,
+# clang's for the hipcc-compiled ones); logs under profiles/.   make sanitize
+sanitize:
+	bash scripts/san_check.sh
 
 cpp-tests: all
 	$(MAKE) -C tests/cpp
 
-.PHONY: all checkers cpp-tests
+.PHONY: all checkers cpp-tests sanitize

@@ -11,7 +11,9 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdil256.so")
-REF_LIB = os.path.join(PKG, "libdil256_ref.so")     # reference-identical C++ signatures (include/dil256_ref.hpp)
+# reference-identical C++ signatures (include/dil256_ref.hpp); DIL_REF_LIB_PATH: another build of it (scripts/san_check.sh)
+REF_LIB_BUILT = os.path.join(PKG, "libdil256_ref.so")                      # what build_ref() writes
+REF_LIB = os.environ.get("DIL_REF_LIB_PATH", REF_LIB_BUILT)              # what the tests load
 SOURCES = ["kernels.hip", "pipelines.hip", "hash_kernels.hip", "codec_kernels.hip", "wire_kernels.hip", "gen_kernels.hip", "capi.hip", "scheme.hip", "multi_gpu.hip"]
 HEADERS = ["variants.hpp", "capi_internal.hpp", "modarith.hpp", "ntt_core.hpp", "kernels.hpp", "device_common.hpp", "pipeline_common.hpp", "launch_util.hpp", "keccak.hpp", "wire_common.hpp", "sampler_bodies.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
            os.path.join("..", "..", "include", "dil256_ref.hpp")]
@@ -28,7 +30,7 @@ def _stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
-        if not os.path.exists(REF_LIB):
+        if not os.path.exists(REF_LIB_BUILT):
             build_ref(verbose)
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -46,11 +48,11 @@ def build_ref(verbose: bool = False) -> str:
     """libdil256_ref.so: host-only C++ (no device code), links against libdil256.so next to it"""
     cxx = shutil.which("g++") or shutil.which("hipcc")
     cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", os.path.join(CSRC, "ref_api.cpp"),
-           "-L" + PKG, "-ldil256", "-Wl,-rpath,$ORIGIN", "-o", REF_LIB]
+           "-L" + PKG, "-ldil256", "-Wl,-rpath,$ORIGIN", "-o", REF_LIB_BUILT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return REF_LIB
+    return REF_LIB_BUILT
 
 
 if __name__ == "__main__":

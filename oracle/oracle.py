@@ -75,7 +75,8 @@ def default_threads():
 class Oracle:
     def __init__(self):
         build()
-        self.lib = C.CDLL(os.path.join(HERE, "liboracle.so"))
+        # DIL_ORACLE_PATH: another build of the same source (the sanitizer build of scripts/san_check.sh)
+        self.lib = C.CDLL(os.environ.get("DIL_ORACLE_PATH", os.path.join(HERE, "liboracle.so")))
         L = self.lib
         L.orc_init()
         L.orc_zetas.restype = _i32p
