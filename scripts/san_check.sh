@@ -22,7 +22,7 @@ g++ $SANFLAGS -std=c++17 -shared -fPIC -Wall dilithium_amd/csrc/ref_api.cpp -Ldi
     -o $SAN/libdil256_ref.so >> $LOG 2>&1 || { say "ref_api san build FAILED"; exit 1; }
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" DIL_ORACLE_PATH=$SAN/liboracle.so DIL_REF_LIB_PATH=$SAN/libdil256_ref.so \
     python -m pytest tests/test_oracle.py tests/test_kat_oracle.py tests/test_ref_dropin.py tests/test_model_and_cabi.py tests/test_bench_cpu_legs.py \
-    -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -15 | tee -a $LOG
+    -q -m "not gpu" -p no:cacheprovider 2>&1 | grep -v "^gold:\|^test:\|^t Error" | tail -15 | tee -a $LOG
 P1=${PIPESTATUS[0]}
 
 say "== pass 2: hipcc host code with clang's -fsanitize=address,undefined: libdil256.so (capi / scheme / multi_gpu host paths)"
