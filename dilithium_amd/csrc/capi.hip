@@ -39,6 +39,8 @@ const OptName* option_table(int* n)
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
         {"gen_a", "DIL_GEN_A", &cfg.gen_a},
         {"verify_chunks", "DIL_VERIFY_CHUNKS", &cfg.verify_chunks},
+        {"packed_y", "DIL_PACKED_Y", &cfg.packed_y},
+        {"sign_overlap", "DIL_SIGN_OVERLAP", &cfg.sign_overlap},
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
         {"two_lane_max_sponges", "DIL_TWO_LANE_MAX", &dil::two_lane_max_sponges},

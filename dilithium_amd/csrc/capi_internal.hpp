@@ -36,6 +36,11 @@ struct Config {
     std::atomic<int> fuse_keygen{1};       // DIL_FUSE_KEYGEN: 0 = keygen's mat-vec, Power2Round and t1 / t0 packing as separate kernels
     std::atomic<int> a24{1};               // DIL_A24: 0 = the composite calls keep per-item matrices as int32 in HBM (1: 24-bit packed)
     std::atomic<int> gen_a{0};             // DIL_GEN_A: 1 = wire-format verify with a key per signature samples A inside the verifying kernel
+    std::atomic<int> sign_overlap{0};      // DIL_SIGN_OVERLAP: 1 = large signing rounds run hash + SampleInBall of one half of the entries on the helper
+                                           // stream beside the other half's polynomial kernels.  Built and measured in round 3: SLOWER (level 3, 8192
+                                           // messages: 1.42 -> 1.77 ms; level 5: 1.59 -> 2.07 ms; profiles/r03j_sign_overlap.txt) -- a cross-stream
+                                           // dependency costs ~20 us and a round needs four.  Default 0.
+    std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
     std::atomic<int> verify_chunks{1};     // DIL_VERIFY_CHUNKS: wire-format verify, a key per signature: > 1 = ExpandA / fused kernel / challenge hash
                                            // pipelined over this many chunks on three streams.  Built and measured in round 3, SLOWER at every
                                            // level and size (level 3, 8192: 286 us one pass, 389 / 442 / 641 us with 2 / 4 / 8 chunks; 65536: 1.81

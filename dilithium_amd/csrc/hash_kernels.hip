@@ -113,11 +113,7 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
     // sponge form always takes the wave-synchronous transposed flush: whole 64-byte segments per store instruction
     // instead of a 16-byte piece per lane.
     const size_t first = (size_t)blockIdx.x * HASH_BS;
-#ifdef DIL_EM_LANESINK          // A/B: the per-lane flush in the lane-per-sponge form too
-    constexpr bool LS = true;
-#else
     constexpr bool LS = TWO;
-#endif
     typename std::conditional<LS, CoeffSink, CoeffSinkWave>::type sink = make_sink<LS>(ring, y, p, first, total, wr && (TWO || t < total));
     uint64_t buf = 0;
     int nbits = 0, cnt = 0;          // wave-uniform
@@ -149,6 +145,54 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
             if (wr) sink.flush_if_ready(cnt);  // <= 4 coefficients per 64-bit word
         }
     }
+}
+
+// ExpandMask WITHOUT the unpacking: ExpandMask has no rejection, so the B-bit packed form of y (gamma1 - y, the layout of z on
+// the wire: decoder.v:89-143) IS the first 32 B bytes of the SHAKE256 stream (expandmask_ext.v:98, sampler_y_ext.v).  The signing
+// loop's large rounds keep y in that form -- 640 (576) bytes per polynomial instead of 1 KiB of int32, no per-coefficient
+// extraction here -- and the consumers (sign phase 1 / phase 2, pipelines.hip) unpack in their load stage the way the verify
+// kernels read z.  One lane per sponge; each rate block leaves through an LDS transpose so that 17 consecutive lanes write one
+// polynomial's contiguous 136 bytes (a lane's own stream would be 8 bytes per instruction at a 640-byte stride).
+template <int B>
+__global__ __launch_bounds__(HASH_BS) void expand_mask_raw_kernel(uint8_t* __restrict__ yp, const uint64_t* __restrict__ rhoprime,
+                                                                  const uint32_t* __restrict__ kappa, int L, size_t nitems)
+{
+    constexpr int POLYB = 32 * B, QW = POLYB / 8, NBLK = (QW + 16) / 17, LASTW = QW - 17 * (NBLK - 1);   // 80 (72) qwords, 5 blocks, 12 (4) in the last
+    static_assert(HASH_BS == 64, "one wave per workgroup");
+    const int lane = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * 64, total = nitems * (size_t)L;
+    size_t p = first + lane;
+    if (p >= total) p = total - 1;                   // lanes past the end run along (they help store) but own nothing
+    const int live = (int)(total - first < 64 ? total - first : 64);
+    const size_t item = p / (size_t)L;
+    const uint32_t nonce = (kappa[item] + (uint32_t)(p % (size_t)L)) & 0xFFFFu;
+    Shake<17> sp;
+    sp.init();
+#pragma unroll
+    for (int w = 0; w < 8; w++) sp.s[w] = rhoprime[item * 8 + w];
+    sp.s[8] = (uint64_t)nonce | (0x1Full << 16);
+    sp.s[16] ^= 0x8000000000000000ull;
+    __shared__ uint64_t ring[17 * 65];               // [word][lane], rows padded to 65 qwords: conflict-free both ways
+    uint8_t* wave_dst = yp + first * POLYB;
+    auto flush = [&](int blk, auto nw_c) {
+        constexpr int NW = decltype(nw_c)::value;
+#pragma unroll
+        for (int w = 0; w < NW; w++) ring[w * 65 + lane] = sp.s[w];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            const int i = lane + 64 * j, pl = i / NW, w = i - pl * NW;
+            if (pl < live) *reinterpret_cast<uint64_t*>(wave_dst + (size_t)pl * POLYB + 136 * blk + 8 * w) = ring[w * 65 + pl];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK - 1; blk++) {
+        keccak_f1600(sp.s);
+        flush(blk, std::integral_constant<int, 17>());
+    }
+    keccak_f1600(sp.s);
+    flush(NBLK - 1, std::integral_constant<int, LASTW>());
 }
 
 // Two-lane form of ExpandMask for few entries (the narrow late rounds of the signing loop, single signatures): a lone wave
@@ -544,18 +588,27 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
     if (total <= (size_t)two_lane_max_sponges.load(std::memory_order_relaxed)) {        // latency-bound: two lanes per sponge
         const int grid = (int)((2 * total + HASH_BS - 1) / HASH_BS);
-#ifdef DIL_EM2_OLD
-        if (level == 2) hipLaunchKernelGGL((expand_mask_kernel<18, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
-        else hipLaunchKernelGGL((expand_mask_kernel<20, true>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
-#else
         if (level == 2) hipLaunchKernelGGL(expand_mask2_kernel<18>, grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
         else hipLaunchKernelGGL(expand_mask2_kernel<20>, grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
-#endif
         return hipGetLastError();
     }
     const int grid = (int)((total + HASH_BS - 1) / HASH_BS);
     if (level == 2) hipLaunchKernelGGL((expand_mask_kernel<18, false>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
     else hipLaunchKernelGGL((expand_mask_kernel<20, false>), grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s)
+{
+    if (nitems == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    if (reinterpret_cast<uintptr_t>(yp) & 7) return hipErrorInvalidValue;
+    const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    const size_t total = nitems * (size_t)L;
+    const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
+    const int grid = (int)((total + HASH_BS - 1) / HASH_BS);
+    if (level == 2) hipLaunchKernelGGL(expand_mask_raw_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
+    else hipLaunchKernelGGL(expand_mask_raw_kernel<20>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
     return hipGetLastError();
 }
 

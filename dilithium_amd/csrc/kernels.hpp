@@ -22,6 +22,10 @@ enum { OUT_W = 0, OUT_W1W0 = 1 };
 // calls' internal one for a matrix per item -- coefficients are < 2^23, so they travel as 3 bytes: [K][L][768 bytes], a
 // quarter less write traffic for ExpandA and read traffic for the wave-per-item kernels, which are HBM-bound on exactly that stream.
 enum { A_I32 = 0, A_P24 = 1 };
+// y of the signing loop in HBM.  Y_I32: [L][256] int32 canonical (the public form).  Y_PACKED: the B-bit packed SHAKE256 stream
+// ExpandMask squeezes (gamma1 - y; B = 18 | 20, 576 | 640 bytes per polynomial, the wire layout of z) -- internal to dil_sign_*:
+// ExpandMask has no rejection, so its packed output IS the stream, and phase 1 / phase 2 unpack in their load stage.
+enum { Y_I32 = 0, Y_PACKED = 1 };
 
 struct Tables {
     const uint32_t* fwd = nullptr;   // device, [4][64][8]
@@ -56,7 +60,9 @@ struct KeyMap {
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
                          size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km = KeyMap(),
                          uint8_t* w1_packed = nullptr,    // OUT_W1W0 only: w1 also written packed (4 | 6 bits), [batch][K * 128|192]
-                         int a_fmt = A_I32);              // A_P24: a matrix per key in packed form (never with shared_A)
+                         int a_fmt = A_I32,               // A_P24: a matrix per key in packed form (never with shared_A)
+                         int y_fmt = Y_I32);              // Y_PACKED (OUT_W1W0, wave-per-item / shared-key shapes only): y is ExpandMask's raw stream
+bool fused_wpi_shape(size_t batch, const Tables& t);      // the wave-per-item / shared-key kernels serve this batch size
 // keygen: t = A s1 + s2, Power2Round, t1 -> pk (10 bit), 2^12 - t0 -> sk (13 bit) in one wave-per-key kernel (pipelines.hip)
 bool keygen_fused_available(size_t batch, const Tables& t);
 hipError_t launch_keygen_matvec(int level, uint8_t* pk, size_t pk_stride, uint8_t* sk, size_t sk_stride, size_t sk_t0_offset,
@@ -67,7 +73,8 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
                         const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km = KeyMap(),
-                        int32_t* w0_scratch = nullptr);   // == w0: rejected attempts stop at their first failed check
+                        int32_t* w0_scratch = nullptr,    // == w0: rejected attempts stop at their first failed check
+                        int y_fmt = Y_I32);
 
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
@@ -76,6 +83,8 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
 hipError_t launch_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int32_t* s1, int32_t* s2, const uint8_t* rhoprime,
                              size_t rp_stride, int level, int eta, size_t nkeys, hipStream_t s);
 hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
+// y as the raw B-bit stream (Y_PACKED), lane per sponge: the signing loop's large rounds
+hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s);
 hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s);
 // expect (may be nullptr): 32 bytes per item at expect + i * expect_stride, any alignment (c~ read in place from a signature)

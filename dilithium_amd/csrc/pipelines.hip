@@ -4,6 +4,7 @@
 // Two shapes: workgroup-per-item (small batches, low latency) and wave-per-item (large batches).
 #include "launch_util.hpp"
 #include "pipeline_common.hpp"
+#include "wire_common.hpp"
 
 namespace dil {
 
@@ -219,16 +220,51 @@ struct RawPolys {
     }
 };
 
+// Time-domain y of the signing loop in either of its two HBM forms (kernels.hpp Y_I32 / Y_PACKED): int32 [L][256] canonical, or
+// the B-bit packed SHAKE256 stream ExpandMask squeezes (expand_mask_raw_kernel: gamma1 - y, 32 B bytes per polynomial), read the
+// way the verify kernels read z.  raw() issues the loads of one polynomial (4 dwords per lane either way), value() turns them
+// into the lane's coefficients lane + 64 m -- canonical (Y_I32) or centred in [-gamma1, gamma1] (Y_PACKED); both are valid
+// transform inputs and valid addends of z = y + c s1.
+template <int LEVEL, int YF>
+struct YSrc;
+template <int LEVEL>
+struct YSrc<LEVEL, Y_I32> {
+    static constexpr size_t POLY = 1024;             // bytes per polynomial
+    __device__ __forceinline__ explicit YSrc(int) {}
+    __device__ __forceinline__ void raw(int32_t (&r)[4], const int32_t* __restrict__ base, size_t poly, int lane) const
+    {
+        load_strided(r, base + poly * 256, lane);
+    }
+    __device__ __forceinline__ void value(int32_t (&)[4]) const {}
+};
+template <int LEVEL>
+struct YSrc<LEVEL, Y_PACKED> {
+    static constexpr int B = Wire<LEVEL>::ZBITS;
+    static constexpr size_t POLY = 32 * B;
+    PackedLane<B> pl;
+    __device__ __forceinline__ explicit YSrc(int lane) : pl(lane) {}
+    __device__ __forceinline__ void raw(int32_t (&r)[4], const int32_t* __restrict__ base, size_t poly, int) const
+    {
+        uint32_t u[4];
+        pl.load(u, reinterpret_cast<const uint8_t*>(base) + poly * POLY);
+#pragma unroll
+        for (int m = 0; m < 4; m++) r[m] = (int32_t)u[m];
+    }
+    __device__ __forceinline__ void value(int32_t (&r)[4]) const
+    {
+        uint32_t u[4] = {(uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]}, f[4];
+        pl.fields(f, u);
+#pragma unroll
+        for (int m = 0; m < 4; m++) r[m] = Par<LEVEL>::GAMMA1 - (int32_t)f[m];
+    }
+};
+
 #define DIL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef DIL_MV_XOUT
-#define DIL_MV_XOUT 0     // 1: mat-vec rows leave as one dwordx4 store per lane after an LDS transpose -- measured neutral
-                          // (74.6 vs 74.5 us level 3, 138.1 vs 134.3 us sign1 level 5), so the four strided dword stores stay
-#endif
 
 // mat-vec / sign phase 1, wave-per-item.  Per item: issue row-0 loads | L forward NTTs on registers
 // loaded during the PREVIOUS item's row phase, y^ -> this wave's LDS slice | issue the NEXT item's y
 // loads | K rows: MAC from LDS, prefetch row k+1, INTT, (Decompose), store.
-template <int K, int L, int LEVEL, int OUT, int AF>
+template <int K, int L, int LEVEL, int OUT, int AF, int YF>
 __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
@@ -245,8 +281,13 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     uint32_t* yl = lds + 2 * TW_TABLE_DWORDS + wv * (L * 256);
     const size_t nwaves = (size_t)gridDim.x * 4;
     size_t it = (size_t)blockIdx.x * 4 + wv;
+    const YSrc<LEVEL, YF> ys(lane);
     RawPolys<L> yr;
-    if (it < batch) yr.load(y + it * L * 256, lane);
+    auto load_y = [&](size_t i) {
+#pragma unroll
+        for (int l = 0; l < L; l++) ys.raw(yr.v[l], y, i * L + l, lane);
+    };
+    if (it < batch) load_y(it);
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
         constexpr int PD = ARow<L, AF>::PD;
@@ -255,12 +296,13 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
         Ar.load(Ait, lane, !shared_A && km.S == 1);
 #pragma unroll
         for (int l = 0; l < L; l++) {
+            ys.value(yr.v[l]);
             ntt_fwd_core(yr.v[l], twf, lm);
             *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
         }
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
-        if (itn < batch) yr.load(y + itn * L * 256, lane);
+        if (itn < batch) load_y(itn);
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, yl, lane);
@@ -269,7 +311,7 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
             DIL_SCHED_FENCE();
             ntt_inv_core(r, twi, lm);
             DIL_SCHED_FENCE();
-            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, (DIL_MV_XOUT != 0 && XP::DW != 0) ? xb : nullptr);
+            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, nullptr);
         }
     }
 }
@@ -464,7 +506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
     }
 }
 
-template <int LEVEL>
+template <int LEVEL, int YF>
 __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
     const int32_t* __restrict__ c, const int32_t* __restrict__ y, const int32_t* __restrict__ w0,
@@ -481,6 +523,7 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
     const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
     uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
+    const YSrc<LEVEL, YF> ys(lane);
     const size_t nwaves = (size_t)gridDim.x * 4;
     for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
         const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
@@ -495,10 +538,11 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
             const int4 s = sn;
             const size_t o = (it * L + l) * 256;
             int32_t yv[4];
-            load_strided(yv, y + o, lane);
+            ys.raw(yv, y, it * L + l, lane);
             if (l + 1 < L) sn = *reinterpret_cast<const int4*>(s1 + (l + 1) * 256 + 4 * lane);
             int32_t r[4] = {mont_mul(ch[0], s.x), mont_mul(ch[1], s.y), mont_mul(ch[2], s.z), mont_mul(ch[3], s.w)};
             ntt_inv_core(r, twi, lm);
+            ys.value(yv);
             bool rej = false;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -546,7 +590,7 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
 // failure (2 / 1 / 4, | 8 for too many hints); z and h are complete only when flags == 0, which is all the loop
 // reads.  r0 is parked in the attempt's own w0 scratch between (A) and (C).  Expected inverse transforms per level-5
 // attempt: ~10 instead of 23.
-template <int LEVEL>
+template <int LEVEL, int YF>
 __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
     const int32_t* __restrict__ c, const int32_t* __restrict__ y, int32_t* __restrict__ w0,
@@ -563,6 +607,7 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
     const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
     uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
+    const YSrc<LEVEL, YF> ys(lane);
     const size_t nwaves = (size_t)gridDim.x * 4;
     for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
         const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
@@ -603,10 +648,11 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
                 const int4 sv = kn;
                 const size_t o = (it * L + l) * 256;
                 int32_t yv[4];
-                load_strided(yv, y + o, lane);
+                ys.raw(yv, y, it * L + l, lane);
                 if (l + 1 < L) kn = *reinterpret_cast<const int4*>(s1 + (l + 1) * 256 + 4 * lane);
                 int32_t r[4] = {mont_mul(ch[0], sv.x), mont_mul(ch[1], sv.y), mont_mul(ch[2], sv.z), mont_mul(ch[3], sv.w)};
                 ntt_inv_core(r, twi, lm);
+                ys.value(yv);
                 bool rej = false;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
@@ -684,41 +730,59 @@ __device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a
     }
 }
 
-template <int K, int L, int LEVEL, int OUT, int NW>
+// y^ stays in REGISTERS here (4 L VGPRs): a lane multiplies the four coefficients it produced itself, so the vector needs no
+// LDS slice -- that slice (L KiB per wave) was what capped the workgroup at 12 waves = 3 per SIMD at level 5, and three waves per
+// SIMD issue no more than two (scripts/tune_xchg.hip, profiles/r03c_tune_xchg.txt: 785 / 785 / 689 cycles per transform at 2 / 3 /
+// 4 waves).  Now 16 waves = 4 per SIMD at every level, no ds_write of y^ and half the ds_read_b128 of the multiply-accumulate.
+template <int K, int L, int LEVEL, int OUT, int NW, int YF>
 __global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch,
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
-    // (1:0) exchange in registers: both MAC operands come from LDS here, the LDS pipe is the busy one (measured: the LDS
-    // form costs 12 % in this kernel and gains 1-2 % in the HBM-streaming ones, profiles/r02_fused_ab.txt)
+    // (1:0) exchange in registers: the LDS pipe serves A and the twiddles here (measured: the LDS form costs 12 % in this kernel
+    // and gains 1-2 % in the HBM-streaming ones, profiles/r02_fused_ab.txt)
     using XP = X10Pick<false>;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + NW * L) * 256 + NW * 64 + NW * XP::DW];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + K * L * 256 + NW * 64 + NW * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
     stage_polys(Al, A, K * L);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const typename XP::type lm(Al + (K * L + NW * L) * 256 + NW * 64 + wv * XP::DW, lane);
-    uint32_t* yl = Al + K * L * 256 + wv * (L * 256);
-    uint32_t* sc = Al + (K * L + NW * L) * 256 + wv * 64;   // byte-plane scratch
+    const typename XP::type lm(Al + K * L * 256 + NW * 64 + wv * XP::DW, lane);
+    uint32_t* sc = Al + K * L * 256 + wv * 64;   // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * NW;
     size_t it = (size_t)blockIdx.x * NW + wv;
+    const YSrc<LEVEL, YF> ys(lane);
     RawPolys<L> yr;
-    if (it < batch) yr.load(y + it * L * 256, lane);
+    auto load_y = [&](size_t i) {
+#pragma unroll
+        for (int l = 0; l < L; l++) ys.raw(yr.v[l], y, i * L + l, lane);
+    };
+    if (it < batch) load_y(it);
     __syncthreads();                               // tables + key staged (the only barrier)
     for (; it < batch; it += nwaves) {
+        int32_t yh[L][4];
 #pragma unroll
         for (int l = 0; l < L; l++) {
-            ntt_fwd_core(yr.v[l], twf, lm);
-            *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
+#pragma unroll
+            for (int m = 0; m < 4; m++) yh[l][m] = yr.v[l][m];
+            ys.value(yh[l]);
+            ntt_fwd_core(yh[l], twf, lm);
         }
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
-        if (itn < batch) yr.load(y + itn * L * 256, lane);
+        if (itn < batch) load_y(itn);
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
-            mac_row_lds<L>(acc, Al + k * L * 256, yl, lane);
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int4 a = *reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane);
+                acc[0] += (int64_t)a.x * yh[l][0];
+                acc[1] += (int64_t)a.y * yh[l][1];
+                acc[2] += (int64_t)a.z * yh[l][2];
+                acc[3] += (int64_t)a.w * yh[l][3];
+            }
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
             ntt_inv_core(r, twi, lm);
@@ -807,9 +871,13 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
 
 // LDS budget (160 KiB): tables 16 KiB + key + NW * L KiB of per-wave vector slices
 template <int LEVEL> struct SharedNW;
-template <> struct SharedNW<2> { static constexpr int MATVEC = 16, VERIFY = 16; };   // 16+16(+4)+64  = 96 / 100 KiB
-template <> struct SharedNW<3> { static constexpr int MATVEC = 16, VERIFY = 16; };   // 16+30(+6)+80  = 126 / 132 KiB
-template <> struct SharedNW<5> { static constexpr int MATVEC = 12, VERIFY = 11; };   // 16+56(+8)+84/77 = 156 / 157 KiB
+// (mat-vec: y^ lives in registers, the workgroup is 16 waves at every level: 16 + K L + 4 KiB)
+#ifndef DIL_MVS_NW
+#define DIL_MVS_NW 16
+#endif
+template <> struct SharedNW<2> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = 16; };   // verify: 16+16+4+64 = 100 KiB
+template <> struct SharedNW<3> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = 16; };   // verify: 16+30+6+80 = 132 KiB
+template <> struct SharedNW<5> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = 11; };   // verify: 16+56+8+77 = 157 KiB
 
 // ---------------------------------------------------------------------------------------
 // launchers
@@ -823,25 +891,26 @@ static inline bool use_wpi(size_t batch, const Tables& t)
     return batch >= (size_t)t.num_cus * 8;
 }
 
-template <int LEVEL, int OUT, int AF>
+template <int LEVEL, int OUT, int AF, int YF>
 static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y,
                                       size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    if (YF == Y_PACKED && !use_wpi(batch, t)) return hipErrorInvalidValue;       // packed y: wave-per-item / shared-key shapes only
     if (AF == A_P24 && shared_A) return hipErrorInvalidValue;      // the shared-key kernels keep A in LDS: nothing to save
     if (AF == A_I32 && use_wpi(batch, t) && shared_A) {
         constexpr int NW = SharedNW<LEVEL>::MATVEC;
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
         note_launch(OUT == OUT_W ? "matvec_shared" : "sign1_shared", g, NW, batch);
-        hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, t.fwd,
+        hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW, YF>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
     }
     if (use_wpi(batch, t)) {
         const int g = grid_for((batch + 3) / 4,
-                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT, AF>, 256, t.wpi_blocks_per_cu, t.device));
+                               t.num_cus * resident_blocks_per_cu(matvec_wpi_kernel<K, L, LEVEL, OUT, AF, YF>, 256, t.wpi_blocks_per_cu, t.device));
         note_launch(OUT == OUT_W ? "matvec_wpi" : "sign1_wpi", g, 4, batch);
-        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT, AF>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, km, t.fwd,
+        hipLaunchKernelGGL((matvec_wpi_kernel<K, L, LEVEL, OUT, AF, YF>), g, 256, 0, s, w, w1, w0, A, y, batch, shared_A, km, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
     }
@@ -853,13 +922,15 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
 
 hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32_t* w0, const int32_t* A,
                          const int32_t* y, size_t batch, int shared_A, const Tables& t, hipStream_t s, KeyMap km, uint8_t* w1_packed,
-                         int a_fmt)
+                         int a_fmt, int y_fmt)
 {
     if (batch == 0) return hipSuccess;
     if (out_mode != OUT_W) w = reinterpret_cast<int32_t*>(w1_packed);      // the kernels' w slot carries packed w1 in this mode
-#define DIL_MV2(LV, AF)                                                                                       \
-    return out_mode == OUT_W ? launch_matvec_level<LV, OUT_W, AF>(w, w1, w0, A, y, batch, shared_A, t, s, km) \
-                             : launch_matvec_level<LV, OUT_W1W0, AF>(w, w1, w0, A, y, batch, shared_A, t, s, km)
+    if (y_fmt == Y_PACKED && out_mode == OUT_W) return hipErrorInvalidValue;   // packed y exists only inside the signing loop (phase 1)
+#define DIL_MV2(LV, AF)                                                                                                      \
+    return out_mode == OUT_W    ? launch_matvec_level<LV, OUT_W, AF, Y_I32>(w, w1, w0, A, y, batch, shared_A, t, s, km)          \
+           : y_fmt == Y_PACKED ? launch_matvec_level<LV, OUT_W1W0, AF, Y_PACKED>(w, w1, w0, A, y, batch, shared_A, t, s, km)   \
+                               : launch_matvec_level<LV, OUT_W1W0, AF, Y_I32>(w, w1, w0, A, y, batch, shared_A, t, s, km)
 #define DIL_MV(LV)                      \
     if (a_fmt == A_P24) DIL_MV2(LV, A_P24); \
     DIL_MV2(LV, A_I32)
@@ -873,6 +944,8 @@ hipError_t launch_matvec(int level, int out_mode, int32_t* w, uint8_t* w1, int32
 #undef DIL_MV2
 }
 
+// the wave-per-item / shared-key shapes serve this batch (keygen's fused output stage, the signing loop's packed y)
+bool fused_wpi_shape(size_t batch, const Tables& t) { return use_wpi(batch, t); }
 // keygen's fused mat-vec + Power2Round + t1 / t0 packing; false: this batch is served by the unfused kernels instead
 bool keygen_fused_available(size_t batch, const Tables& t) { return use_wpi(batch, t); }
 
@@ -954,18 +1027,22 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
                         const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km,
-                        int32_t* w0_scratch)
+                        int32_t* w0_scratch, int y_fmt)
 {
     if (batch == 0) return hipSuccess;
+    if (y_fmt == Y_PACKED && !use_wpi(batch, t)) return hipErrorInvalidValue;      // packed y: wave-per-item shapes only
     if (use_wpi(batch, t) && w0_scratch) {      // the signing loop's early-exit form (w0 is its own scratch, reused for r0)
         if (w0_scratch != w0) return hipErrorInvalidValue;
-#define DIL_S2E(LV)                                                                                                              \
+#define DIL_S2E2(LV, YF)                                                                                                         \
     {                                                                                                                            \
-        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu, t.device)); \
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV, YF>, 256, t.wpi_blocks_per_cu, t.device)); \
         note_launch("sign2_early_wpi", g, 4, batch);                                                                             \
-        hipLaunchKernelGGL(sign2_early_wpi_kernel<LV>, g, 256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, \
+        hipLaunchKernelGGL((sign2_early_wpi_kernel<LV, YF>), g, 256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, \
                            km, t.fwd, t.inv_pipe);                                                                               \
-    }                                                                                                                            \
+    }
+#define DIL_S2E(LV)                              \
+    if (y_fmt == Y_PACKED) DIL_S2E2(LV, Y_PACKED) \
+    else DIL_S2E2(LV, Y_I32)                      \
     break
         switch (level) {
         case 2: DIL_S2E(2);
@@ -974,16 +1051,20 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
         default: return hipErrorInvalidValue;
         }
 #undef DIL_S2E
+#undef DIL_S2E2
         return hipGetLastError();
     }
     if (use_wpi(batch, t)) {
-#define DIL_S2W(LV)                                                                                                              \
+#define DIL_S2W2(LV, YF)                                                                                                         \
     {                                                                                                                            \
-        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<LV>, 256, t.wpi_blocks_per_cu, t.device)); \
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<LV, YF>, 256, t.wpi_blocks_per_cu, t.device)); \
         note_launch("sign2_wpi", g, 4, batch);                                                                                   \
-        hipLaunchKernelGGL(sign2_wpi_kernel<LV>, g, 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, \
+        hipLaunchKernelGGL((sign2_wpi_kernel<LV, YF>), g, 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, \
                            t.inv_pipe);                                                                                          \
-    }                                                                                                                            \
+    }
+#define DIL_S2W(LV)                              \
+    if (y_fmt == Y_PACKED) DIL_S2W2(LV, Y_PACKED) \
+    else DIL_S2W2(LV, Y_I32)                      \
     break
         switch (level) {
         case 2: DIL_S2W(2);
@@ -992,6 +1073,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
         default: return hipErrorInvalidValue;
         }
 #undef DIL_S2W
+#undef DIL_S2W2
         return hipGetLastError();
     }
     const int grid = grid_for(batch, t.num_cus * t.fused_wgs_per_cu);

@@ -211,6 +211,7 @@ namespace {
 struct AttemptScratch {
     int32_t* y; uint8_t* w1; int32_t* w0; uint8_t* w1p; int32_t* c;
     int a_fmt = dil::A_I32;      // format of the matrix the attempts multiply by (kernels.hpp)
+    bool packed_y = false;       // the signing loop: y stays ExpandMask's raw stream in rounds large enough for the wave-per-item kernels
     int alloc(StreamScratch& ws, int level, int K, int L, size_t batch)
     {
         y = ws.take<int32_t>(batch * L * 256);
@@ -227,35 +228,6 @@ inline int matrix_format(size_t nkeys, int K, int L)
 {
     return (nkeys > 1 && nkeys * (size_t)(K * L) > dil::EA_TWO_LANE_MAX && dil::rt::cfg.a24.load(std::memory_order_relaxed)) ? dil::A_P24 : dil::A_I32;
 }
-int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
-                      const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
-                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
-                      int phases = 3, bool early_exit = false)
-{
-    if (phases & 1) DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
-    if (!(phases & 2)) return 0;
-    // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt));
-    DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
-    DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
-    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
-                              early_exit ? t.w0 : nullptr));
-    return 0;
-}
-
-// The same attempt over entries [off, off + cnt) of the per-entry arrays (per-key arrays are addressed through km)
-int sign_attempt_range(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
-                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
-                       const int32_t* t0hat, int level, int K, int L, size_t off, size_t cnt, int shared_key, hipStream_t s, dil::KeyMap km,
-                       int phases = 3, bool early_exit = false)
-{
-    AttemptScratch u = t;
-    u.y += off * L * 256; u.w1 += off * K * 256; u.w0 += off * K * 256; u.w1p += off * K * (level == 2 ? 192 : 128); u.c += off * 256;
-    km.base += (uint32_t)off;
-    return sign_attempt_impl(T, u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
-                             rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases, early_exit);
-}
-
 // Run an independent part of a composite call on the helper stream (if nobody else is using it): fork() returns the
 // stream to launch that part on -- the helper, ordered after everything already on `main`, or `main` itself -- and
 // join() makes `main` wait for it.
@@ -300,6 +272,85 @@ struct AuxFork {
     }
     ~AuxFork() { (void)join(); }
 };
+int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+                      const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                      const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
+                      int phases = 3, bool early_exit = false)
+{
+    // y: int32, or -- the loop's large rounds -- the raw B-bit SHAKE256 stream, unpacked by phase 1 / phase 2 as they load it
+    // (below `two_lane_max_sponges` polynomials ExpandMask is latency-bound and its two-lane form -- int32 output -- is the faster one)
+    int Kq, Lq;
+    (void)level_kl(level, &Kq, &Lq);
+    const int y_fmt = (t.packed_y && phases == 3 && dil::fused_wpi_shape(batch, T) &&
+                       batch * (size_t)Lq > (size_t)dil::two_lane_max_sponges.load(std::memory_order_relaxed)) ? dil::Y_PACKED : dil::Y_I32;
+    if (phases & 1) {
+        if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, batch, s));
+        else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
+    }
+    if (!(phases & 2)) return 0;
+    // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt, y_fmt));
+    DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
+    DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
+                              early_exit ? t.w0 : nullptr, y_fmt));
+    return 0;
+}
+
+// The same attempt over entries [off, off + cnt) of the per-entry arrays (per-key arrays are addressed through km)
+int sign_attempt_range(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
+                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
+                       const int32_t* t0hat, int level, int K, int L, size_t off, size_t cnt, int shared_key, hipStream_t s, dil::KeyMap km,
+                       int phases = 3, bool early_exit = false)
+{
+    AttemptScratch u = t;
+    u.packed_y = t.packed_y && off == 0;         // (a packed stream is addressed from entry 0: split rounds keep int32)
+    u.y += off * L * 256; u.w1 += off * K * 256; u.w0 += off * K * 256; u.w1p += off * K * (level == 2 ? 192 : 128); u.c += off * 256;
+    km.base += (uint32_t)off;
+    return sign_attempt_impl(T, u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
+                             rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases, early_exit);
+}
+
+
+// One round of the signing loop with its two latency-bound kernels (challenge hash: a chain of 7-9 permutations per entry;
+// SampleInBall: a serial loop per entry -- together 85 of a round's 455 us at level 3, during which the chip is ~85 % idle)
+// overlapped with polynomial work: the entries are cut in two halves, the caller's stream runs phase 1 of half A, phase 1 of half
+// B, phase 2 of A, phase 2 of B, the helper stream runs hash + SampleInBall of A beside phase 1 of B and those of B beside phase 2
+// of A.  (The FPGA overlaps the same way: operator 0 computes the next w while operator 1 judges the current attempt,
+// combined_top.v:1831,1853-1854,2016,2500 `fsm1_even`.)  ax must own the helper stream (ax.on).
+int sign_attempt_overlapped(Device& dv, const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags,
+                            const int32_t* A, const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat,
+                            const int32_t* s2hat, const int32_t* t0hat, int level, int K, int L, size_t E, int shared_key, hipStream_t s,
+                            dil::KeyMap km, bool early_exit)
+{
+    const int y_fmt = (t.packed_y && E * (size_t)L > (size_t)dil::two_lane_max_sponges.load(std::memory_order_relaxed)) ? dil::Y_PACKED : dil::Y_I32;
+    const size_t ypoly = y_fmt == dil::Y_PACKED ? (size_t)(level == 2 ? 576 : 640) : 1024, w1pb = (size_t)K * (level == 2 ? 192 : 128);
+    dil::rt::AuxStream& xs = dv.aux;
+    hipStream_t hs = xs.s;
+    if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, E, s));
+    else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, E, s));
+    const size_t half = E / 2;
+    const size_t off[2] = {0, half}, cnt[2] = {half, E - half};
+    auto ybase = [&](int i) { return reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(t.y) + off[i] * (size_t)L * ypoly); };
+    dil::KeyMap kmh[2] = {km, km};
+    kmh[1].base += (uint32_t)half;
+    for (int i = 0; i < 2; i++) {          // phase 1 of both halves on the caller's stream; each hands over to the helper as it ends
+        DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1 + off[i] * K * 256, t.w0 + off[i] * K * 256, A, ybase(i), cnt[i], shared_key,
+                                   T, s, kmh[i], t.w1p + off[i] * w1pb, t.a_fmt, y_fmt));
+        DIL_TRY(hipEventRecord(xs.chunk_ev[i], s));
+        DIL_TRY(hipStreamWaitEvent(hs, xs.chunk_ev[i], 0));
+        DIL_TRY(dil::launch_challenge_hash(ctilde + off[i] * 32, nullptr, mu + off[i] * 64, t.w1p + off[i] * w1pb, level, nullptr, cnt[i], hs));
+        DIL_TRY(dil::launch_sample_in_ball(t.c + off[i] * 256, ctilde + off[i] * 32, level, cnt[i], hs));
+        DIL_TRY(hipEventRecord(xs.chunk_ev[2 + i], hs));
+    }
+    for (int i = 0; i < 2; i++) {
+        DIL_TRY(hipStreamWaitEvent(s, xs.chunk_ev[2 + i], 0));
+        int32_t* w0i = t.w0 + off[i] * K * 256;
+        DIL_TRY(dil::launch_sign2(level, z + off[i] * L * 256, h + off[i] * K * 256, flags + off[i], t.c + off[i] * 256, ybase(i), w0i,
+                                  t.w1 + off[i] * K * 256, s1hat, s2hat, t0hat, cnt[i], shared_key, T, s, kmh[i], early_exit ? w0i : nullptr, y_fmt));
+    }
+    return 0;
+}
 }  // namespace
 
 int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
@@ -718,11 +769,13 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         // counters cleared -- and, when the keys are few, A = ExpandA(rho) by the same launch's first workgroups (latency-bound,
         // two lanes per sponge).  Many keys: the throughput ExpandA first, on the same stream.
         att.a_fmt = matrix_format(nk, p.K, p.L);
+        att.packed_y = dil::rt::cfg.packed_y.load(std::memory_order_relaxed) != 0;
         const bool few = nk * p.K * p.L <= dil::EA_TWO_LANE_MAX;            // (then the matrix format is int32)
         if (!few) DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s, att.a_fmt));
         DIL_TRY(dil::launch_sign_setup(level, A, few, s1h, s2h, t0h, sk, nk, rp, attempts, mu, sk_stride, batch, T, s));
     }
 
+    AuxFork overlap(dv, s, /*defer=*/dil::rt::cfg.sign_overlap.load(std::memory_order_relaxed) == 0);
     struct EventGuard {
         hipEvent_t ev = nullptr;
         ~EventGuard() { if (ev) (void)hipEventDestroy(ev); }
@@ -763,8 +816,12 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
             DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
             DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
         }
-        if ((rc = sign_attempt_range(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, 0, E, shared_sk, s, keys, 3,
-                                     sign_early)))
+        // large rounds: the latency-bound hash kernels of one half of the entries run beside the polynomial kernels of the other
+        if (overlap.on && E >= 2 * 4096 && dil::fused_wpi_shape(E / 2, T)) {
+            if ((rc = sign_attempt_overlapped(dv, T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, E, shared_sk, s, keys, sign_early)))
+                return rc;
+        } else if ((rc = sign_attempt_range(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, 0, E, shared_sk, s, keys, 3,
+                                            sign_early)))
             return rc;
         // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
         DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s));
