@@ -473,8 +473,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
             zr.load(z + itn * L * 256, lane);
             load_strided<false>(cr, c + itn * 256, lane);
         }
-        // (a second row buffer -- two matrix rows in flight per wave -- was tried again in round 2: 150-168 VGPRs with
-        //  spills at level 5 and no gain; the HBM stream is throughput-, not latency-limited)
+        // (more matrix rows in flight per wave were tried in rounds 2 and 3: a ring of 2 / 3 row buffers at 2, 3 and 4 waves per
+        //  SIMD is within noise of this form at levels 3 and 5 -- 61.5-61.9 us vs 61.5 -- and slower at level 2 and with three
+        //  rows (level 5: 150 us, spills); two waves per SIMD lose 10 % whatever the depth: profiles/r03k_ab_vw.txt)
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, zl, lane);
