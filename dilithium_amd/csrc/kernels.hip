@@ -39,6 +39,15 @@ __device__ __forceinline__ int resolve_row(int mapping, int addr)
     return addr;
 }
 
+// exchange policy of the standalone transforms (A/B hook: -DDIL_NTT_XPOL=2 = all three exchanges through LDS)
+#if defined(DIL_NTT_XPOL) && DIL_NTT_XPOL == 2
+#define DIL_NTT_XDECL(name)                                                        \
+    __shared__ __attribute__((aligned(16))) uint32_t name##_buf[4 * 256];          \
+    const XAllLds name(name##_buf + (threadIdx.x >> 6) * 256, lane)
+#else
+#define DIL_NTT_XDECL(name) const LaneMasks& name = lm
+#endif
+
 // LAYOUT = LAYOUT_POLY : plain data_t[256] in reference order (ref_ntt.h API)
 // LAYOUT = LAYOUT_BRAM : `bram` rows behind `mapping`; the transform leaves its output rows at
 //                        the model's post-transform permutation (ntt2x2_test.cpp:55,76,129-132)
@@ -87,6 +96,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
     const int out_off = fwd_out_row_off<LAYOUT>(lane, mapping);
     TwRegs tw;
     const LaneMasks lm(lane);
+    DIL_NTT_XDECL(xp);
     if (LAYOUT == LAYOUT_BRAM && mapping == MAP_AFTER_INVNTT) {
         // this mapping puts the lane's 4 inputs at 16 (lane>>2) + 4 m + (lane&3): 16-byte pieces 64 B apart for every
         // load instruction.  Read the wave's 1 KiB with one dwordx4 per lane instead and transpose inside each quad.
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
             const size_t pn = p + nwaves;
             if (pn < batch) nx = ld_nt4(polys + pn * 256 + 4 * lane);
             xchg_10(r, lm);
-            ntt_fwd_core(r, tw, lm);
+            ntt_fwd_core(r, tw, xp);
             st_nt4(polys + p * 256 + out_off, canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
         }
         return;
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
 #pragma unroll
             for (int m = 0; m < 4; m++) nxt[m] = ld_s(polys + pn * 256 + off[m]);
         }
-        ntt_fwd_core(r, tw, lm);
+        ntt_fwd_core(r, tw, xp);
         st_nt4(polys + p * 256 + out_off, canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
     }
 }
@@ -135,11 +145,12 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ poly
     TwRegs tw;
     tw.load(tw_tab, lane);
     const LaneMasks lm(lane);
+    DIL_NTT_XDECL(xp);
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
         const size_t pn = p + nwaves;
         if (pn < batch) nxt = ld_nt4(polys + pn * 256 + in_off);
-        ntt_inv_core(r, tw, lm);
+        ntt_inv_core(r, tw, xp);
         if (LAYOUT == LAYOUT_BRAM && mapping == MAP_NATURAL) {
             // outputs of this (op, mapping) land at 16 (lane>>2) + 4 m + (lane&3): transpose inside each quad and
             // write the wave's 1 KiB as one dwordx4 per lane instead of four 16-byte-granular scatters

@@ -507,6 +507,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
     }
 }
 
+// Phase 2 is VALU-bound (84 % VALU-busy at 7 waves per SIMD, profiles/r03a_sign_pmc.txt) and uses almost no LDS: all three
+// exchanges of its transforms go through a 1-KiB per-wave LDS buffer (ntt_core.hpp XAllLds) instead of permlane / DPP / v_bfi --
+// measured -10 % at every level (level 5, one key, 8192 attempts: 78.2 -> 69.5 us; profiles/r03l_ab_s2.txt).  The gain needs
+// occupancy: at 2-3 waves per SIMD the LDS round trips are exposed and the register form wins (profiles/r03c_tune_xchg.txt).
+struct S2X {
+    using type = XAllLds;
+    static constexpr int DW = 256;
+};
 template <int LEVEL, int YF>
 __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
     const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    using XP = X10Pick<false>;       // neutral here (measured); keep the LDS footprint small
+    using XP = S2X;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
     const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    using XP = X10Pick<false>;       // neutral here (measured); keep the LDS footprint small
+    using XP = S2X;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
@@ -741,9 +749,10 @@ __global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch,
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
-    // (1:0) exchange in registers: the LDS pipe serves A and the twiddles here (measured: the LDS form costs 12 % in this kernel
-    // and gains 1-2 % in the HBM-streaming ones, profiles/r02_fused_ab.txt)
-    using XP = X10Pick<false>;
+    // All three exchanges through LDS (S2X = XAllLds), as in phase 2: with y^ in registers the LDS pipe serves only A and the
+    // twiddles, and at 4 waves per SIMD the exchange-free transforms win 3-6 % (level 5 sign phase 1: 51.1 -> 48.0 us).  The (1:0)
+    // exchange ALONE through LDS (one ds_write_b128 + four ds_read_b32) costs 20 % here: profiles/r03m_ab_x.txt.
+    using XP = S2X;
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + K * L * 256 + NW * 64 + NW * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
@@ -794,7 +803,9 @@ __global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
 }
 
 // verify, shared public key: A and t1^ = NTT(t1 2^13) live in LDS; t1^ is computed once per
-// workgroup by its first K waves (VY_NTT_T1, combined_top.v:1259) -- cheaper than a second launch
+// workgroup by its first K waves (VY_NTT_T1, combined_top.v:1259) -- cheaper than a second launch.
+// z^ stays in registers (a lane multiplies the coefficients it transformed itself), as y^ in matvec_shared_kernel: no per-wave
+// LDS slice, 16 waves per workgroup at every level (level 5 was 11), and all three exchanges through LDS.
 template <int LEVEL, int NW>
 __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
     uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
@@ -802,53 +813,71 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    using XP = X10Pick<false>;       // both MAC operands come from LDS here: the LDS pipe is the busy one, keep the exchange in registers
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K + NW * L) * 256 + NW * 64 + NW * XP::DW];
+    using XP = S2X;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K) * 256 + NW * 64 + NW * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
     uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
     uint32_t* Tl = Al + K * L * 256;
     stage_polys(Al, A, K * L);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const typename XP::type lm(Tl + (K + NW * L) * 256 + NW * 64 + wv * XP::DW, lane);
-    uint32_t* zl = Tl + K * 256 + wv * (L * 256);
-    uint32_t* sc = Tl + (K + NW * L) * 256 + wv * 64;        // byte-plane scratch
+    const typename XP::type lm(Tl + K * 256 + NW * 64 + wv * XP::DW, lane);
+    uint32_t* sc = Tl + K * 256 + wv * 64;        // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * NW;
     size_t it = (size_t)blockIdx.x * NW + wv;
-    RawPolys<L, false> zr;
+    // the next item's z is prefetched a whole row phase ahead where the registers allow it (levels 2, 3); at level 5 that second
+    // copy (28 VGPRs) would spill under the 128-register cap of a 16-wave workgroup, so z is loaded where it is used -- four
+    // waves per SIMD cover the latency
+    constexpr bool PFZ = L <= 5;
+    RawPolys<PFZ ? L : 1, false> zr;
     int32_t cr[4] = {0, 0, 0, 0};
     if (it < batch) {
-        zr.load(z + it * L * 256, lane);
+        if (PFZ) zr.load(z + it * L * 256, lane);
         load_strided<false>(cr, c + it * 256, lane);
     }
     __syncthreads();                               // tables + A staged
-    if (wv < K) {                                  // t1_k * 2^13 (decoder.v:96-100) -> NTT -> LDS, lazy residues
+    for (int k = wv; k < K; k += NW) {             // t1_k * 2^13 (decoder.v:96-100) -> NTT -> LDS, lazy residues
         int32_t th[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) th[m] = (t1[wv * 256 + lane + 64 * m] & 0x3FF) << 13;
+        for (int m = 0; m < 4; m++) th[m] = (t1[k * 256 + lane + 64 * m] & 0x3FF) << 13;
         ntt_fwd_core(th, twf, lm);
-        *reinterpret_cast<int4*>(Tl + wv * 256 + 4 * lane) = make_int4(th[0], th[1], th[2], th[3]);
+        *reinterpret_cast<int4*>(Tl + k * 256 + 4 * lane) = make_int4(th[0], th[1], th[2], th[3]);
     }
     __syncthreads();
     for (; it < batch; it += nwaves) {
         const uint8_t* hit = h + it * K * 256;
         uint32_t hn = load_row_u8(hit, lane);
+        int32_t zh[L][4];
+        if (!PFZ) {
+#pragma unroll
+            for (int l = 0; l < L; l++) load_strided<false>(zh[l], z + (it * L + l) * 256, lane);
+        }
 #pragma unroll
         for (int l = 0; l < L; l++) {
-            ntt_fwd_core(zr.v[l], twf, lm);
-            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zr.v[l][0], zr.v[l][1], zr.v[l][2], zr.v[l][3]);
+            if (PFZ) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) zh[l][m] = zr.v[l][m];
+            }
+            ntt_fwd_core(zh[l], twf, lm);
         }
         int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
         ntt_fwd_core(ch, twf, lm);
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) {
-            zr.load(z + itn * L * 256, lane);
+            if (PFZ) zr.load(z + itn * L * 256, lane);
             load_strided<false>(cr, c + itn * 256, lane);
         }
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
-            mac_row_lds<L>(acc, Al + k * L * 256, zl, lane);
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int4 a = *reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane);
+                acc[0] += (int64_t)a.x * zh[l][0];
+                acc[1] += (int64_t)a.y * zh[l][1];
+                acc[2] += (int64_t)a.z * zh[l][2];
+                acc[3] += (int64_t)a.w * zh[l][3];
+            }
             const int4 th = *reinterpret_cast<const int4*>(Tl + k * 256 + 4 * lane);
             acc[0] -= (int64_t)ch[0] * th.x;
             acc[1] -= (int64_t)ch[1] * th.y;
@@ -872,13 +901,13 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
 
 // LDS budget (160 KiB): tables 16 KiB + key + NW * L KiB of per-wave vector slices
 template <int LEVEL> struct SharedNW;
-// (mat-vec: y^ lives in registers, the workgroup is 16 waves at every level: 16 + K L + 4 KiB)
+// (y^ / z^ live in registers, the workgroup is 16 waves at every level: tables 16 + key K L (+ K) + 16 x 1.25 KiB)
 #ifndef DIL_MVS_NW
 #define DIL_MVS_NW 16
 #endif
-template <> struct SharedNW<2> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = 16; };   // verify: 16+16+4+64 = 100 KiB
-template <> struct SharedNW<3> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = 16; };   // verify: 16+30+6+80 = 132 KiB
-template <> struct SharedNW<5> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = 11; };   // verify: 16+56+8+77 = 157 KiB
+template <> struct SharedNW<2> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = DIL_MVS_NW; };
+template <> struct SharedNW<3> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = DIL_MVS_NW; };
+template <> struct SharedNW<5> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = DIL_MVS_NW; };   // 16 + 56 + 8 + 16 x 1.25 = 100 KiB
 
 // ---------------------------------------------------------------------------------------
 // launchers

@@ -18,6 +18,19 @@
 namespace dil {
 
 #define DIL_SCHED_FENCE_W() __builtin_amdgcn_sched_barrier(0)
+// shape of verify_wire_shared_kernel per level: waves per workgroup, exchange policy (all through LDS, or in registers where
+// the 15 LDS addresses would push a 16-wave workgroup past its 128 registers), prefetch of the next item's packed z
+#ifndef DIL_VWS_SHAPE
+#define DIL_VWS_SHAPE 0
+#endif
+template <int LEVEL> struct WireSh;
+#if DIL_VWS_SHAPE == 0
+template <> struct WireSh<2> { static constexpr int NW = 16; static constexpr bool PFZ = false; using X = XAllLds; };   // 124 VGPRs
+template <> struct WireSh<3> { static constexpr int NW = 16; static constexpr bool PFZ = false; using X = X10Dpp; };    // 122 VGPRs
+template <> struct WireSh<5> { static constexpr int NW = 12; static constexpr bool PFZ = false; using X = XAllLds; };   // 12 waves: up to 168 VGPRs
+#else        // A/B: every level at 12 waves with prefetch and LDS exchanges
+template <int LEVEL> struct WireSh { static constexpr int NW = 12; static constexpr bool PFZ = true; using X = XAllLds; };
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // distinct public keys: wave per item, A streamed from HBM (expanded by expand_a_kernel), everything else packed
@@ -128,8 +141,10 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using W = Wire<LEVEL>;
-    using XP = X10Pick<false>;       // LDS-resident key: exchange in registers (see matvec_shared_kernel)
-    constexpr int WAVE_DW = L * 256 + 64 + 64 + XP::DW;
+    // z^ in registers (a lane multiplies the coefficients it transformed itself), all three exchanges through LDS, 16 waves per
+    // workgroup at every level -- as verify_shared_kernel / matvec_shared_kernel (pipelines.hip)
+    constexpr int XDW = 256;
+    constexpr int WAVE_DW = 64 + 64 + XDW;           // byte scratch | hint bitmap | exchange buffer
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K) * 256 + NW * WAVE_DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
@@ -138,18 +153,20 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
     for (int i = threadIdx.x; i < K * L * 64; i += blockDim.x)
         reinterpret_cast<uint4*>(Al)[i] = reinterpret_cast<const uint4*>(A)[i];
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    uint32_t* zl = Tl + K * 256 + wv * WAVE_DW;
-    uint32_t* sc = zl + L * 256;
+    uint32_t* sc = Tl + K * 256 + wv * WAVE_DW;
     uint32_t* bm = sc + 64;
-    const typename XP::type lm(bm + 64, lane);
+    const typename WireSh<LEVEL>::X lm(bm + 64, lane);
     const PackedLane<W::ZBITS> plz(lane);
     const size_t nwaves = (size_t)gridDim.x * NW;
     size_t it = (size_t)blockIdx.x * NW + wv;
+    // packed z (4 dwords per polynomial and lane) is prefetched one item ahead where the registers allow it; at level 5 the
+    // second copy would spill under the 128-register cap of a 16-wave workgroup and z is loaded where it is decoded
+    constexpr bool PFZ = WireSh<LEVEL>::PFZ;
     RawZ<LEVEL> zr;
     uint32_t cb = 0, hb0 = 0, hb1 = 0;
     auto load_item = [&](size_t i) {
         const uint8_t* sg = sig + i * sig_stride;
-        zr.load(sg + 32, plz);
+        if (PFZ) zr.load(sg + 32, plz);
         cb = cbits[i * 64 + lane];
         hb0 = (lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + lane] : 0;          // (61 hint bytes at level 3: never read past the signature)
         hb1 = (64 + lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + 64 + lane] : 0;
@@ -171,12 +188,12 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
     for (; it < batch; it += nwaves) {
         const bool bad = hints_to_bitmap<LEVEL>(bm, sc, hb0, hb1, lane);
         int32_t zmax = 0;
+        int32_t zh[L][4];
+        if (!PFZ) zr.load(sig + it * sig_stride + 32, plz);
 #pragma unroll
         for (int l = 0; l < L; l++) {
-            int32_t r[4];
-            decode_z<LEVEL>(r, zr.v[l], plz, zmax);
-            ntt_fwd_core(r, twf, lm);
-            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+            decode_z<LEVEL>(zh[l], zr.v[l], plz, zmax);
+            ntt_fwd_core(zh[l], twf, lm);
         }
         int32_t ch[4];
         decode_c(ch, cb);
@@ -191,11 +208,10 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
 #pragma unroll
             for (int l = 0; l < L; l++) {
                 const int4 a = *reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane);
-                const int4 z = *reinterpret_cast<const int4*>(zl + l * 256 + 4 * lane);
-                acc[0] += (int64_t)a.x * z.x;
-                acc[1] += (int64_t)a.y * z.y;
-                acc[2] += (int64_t)a.z * z.z;
-                acc[3] += (int64_t)a.w * z.w;
+                acc[0] += (int64_t)a.x * zh[l][0];
+                acc[1] += (int64_t)a.y * zh[l][1];
+                acc[2] += (int64_t)a.z * zh[l][2];
+                acc[3] += (int64_t)a.w * zh[l][3];
             }
             const int4 th = *reinterpret_cast<const int4*>(Tl + k * 256 + 4 * lane);
             acc[0] -= (int64_t)ch[0] * th.x;
@@ -216,11 +232,8 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
     }
 }
 
-// LDS budget (160 KiB): tables 16 + A K*L + t1^ K + NW * (L KiB + 0.5)
-template <int LEVEL> struct WireNW;
-template <> struct WireNW<2> { static constexpr int N = 16; };   // 16 + 16 + 4 + 72   = 108 KiB
-template <> struct WireNW<3> { static constexpr int N = 16; };   // 16 + 30 + 6 + 88   = 140 KiB
-template <> struct WireNW<5> { static constexpr int N = 10; };   // 16 + 56 + 8 + 75   = 155 KiB
+// LDS budget (160 KiB): tables 16 + A K*L + t1^ K + NW * 1.5 KiB
+template <int LEVEL> struct WireNW { static constexpr int N = WireSh<LEVEL>::NW; };   // level 5: 16 + 56 + 8 + 18 = 98 KiB
 
 // ---------------------------------------------------------------------------------------------------------
 // SampleInBall (gen_c.v:163-196,318-339) into the compact per-lane form the kernels above consume:
