@@ -45,10 +45,18 @@ def key_material(oracle, level, nkeys, seed):
 
 
 def steps(family, n, at_least):
+    """the family's last launch covered n items with a grid smaller than the work: every wave re-entered its item loop"""
+    import os
     from dilithium_amd import api
     info = api.launch_info(family)
     assert info["items"] == n, (family, info)
     assert info["grid"] * info["items_per_block"] < n and info["steps"] >= at_least, (family, info)
+    log = os.environ.get("DIL_STEPS_LOG")          # scripts/gpu_round.sh: profiles/r03_pytest_kernel_coverage.txt
+    if log:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+        with open(log, "a") as f:
+            f.write(f"{family:20s} items {n:6d}  grid {info['grid']:5d} x {info['items_per_block']:2d} items/step = "
+                    f"{info['grid'] * info['items_per_block']:6d} < {n:6d}  -> {info['steps']} steps per wave   [{test}]\n")
     return info
 
 
