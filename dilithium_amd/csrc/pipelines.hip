@@ -261,6 +261,18 @@ struct YSrc<LEVEL, Y_PACKED> {
 
 #define DIL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Matrix rows in flight per wave in the per-item-matrix kernels: with ONE row buffer the loads of row k + 1 are issued only after
+// the multiply-accumulate of row k has drained the registers, and fly under one INTT; with a ring of two the stream has a whole
+// row phase more to land -- mat-vec / sign phase 1 with a matrix per item: level 3 75.5 -> 63.0 us, level 5 134 -> 111 us,
+// BASELINE configs[2] (level 2, 4096 items) 20.2 -> 18.0 us; four rows are no better (profiles/r03q_ab_mr.txt).  (The fused
+// VERIFY kernels did not gain from the same ring -- profiles/r03k_ab_vw.txt; the wire-format one spills with it at level 5,
+// 128 -> 191 us, profiles/r03r_rows_keygen_wire.txt -- and keep one buffer.)
+#ifndef DIL_MV_ROWS
+#define DIL_MV_ROWS(K) 2
+#endif
+#ifndef DIL_KG_ROWS
+#define DIL_KG_ROWS(K) 1          // keygen's fused kernel (24-bit packed matrix): two rows in flight change nothing (profiles/r03r_rows_keygen_wire.txt)
+#endif
 // mat-vec / sign phase 1, wave-per-item.  Per item: issue row-0 loads | L forward NTTs on registers
 // loaded during the PREVIOUS item's row phase, y^ -> this wave's LDS slice | issue the NEXT item's y
 // loads | K rows: MAC from LDS, prefetch row k+1, INTT, (Decompose), store.
@@ -291,9 +303,11 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
         constexpr int PD = ARow<L, AF>::PD;
+        constexpr int NR = DIL_MV_ROWS(K);           // matrix rows in flight per wave
         const int32_t* Ait = A + (shared_A ? 0 : km.key(it) * K) * (size_t)L * PD;
-        ARow<L, AF> Ar;
-        Ar.load(Ait, lane, !shared_A && km.S == 1);
+        ARow<L, AF> Ar[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) Ar[j].load(Ait + (size_t)j * L * PD, lane, !shared_A && km.S == 1);
 #pragma unroll
         for (int l = 0; l < L; l++) {
             ys.value(yr.v[l]);
@@ -303,10 +317,12 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) load_y(itn);
+#pragma unroll(NR > 1 ? K : 1)
         for (int k = 0; k < K; k++) {
+            const int slot = NR > 1 ? k % NR : 0;
             int64_t acc[4] = {0, 0, 0, 0};
-            mac_row<L>(acc, Ar, yl, lane);
-            if (k + 1 < K) Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, !shared_A && km.S == 1);
+            mac_row<L>(acc, Ar[slot], yl, lane);
+            if (k + NR < K) Ar[slot].load(Ait + (size_t)(k + NR) * L * PD, lane, !shared_A && km.S == 1);
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
             ntt_inv_core(r, twi, lm);
@@ -364,10 +380,14 @@ __global__ __launch_bounds__(256) void keygen_wpi_kernel(
     for (; it < batch; it += nwaves) {
         const int32_t* Ait = A + it * (size_t)(K * L) * PD;
         const int32_t* s2it = s2 + it * (size_t)K * 256;
-        ARow<L, AF> Ar;
-        Ar.load(Ait, lane, true);
-        int32_t e[4];
-        load_strided(e, s2it, lane);
+        constexpr int NR = DIL_KG_ROWS(K);
+        ARow<L, AF> Ar[NR];
+        int32_t e[NR][4];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            Ar[j].load(Ait + (size_t)j * L * PD, lane, true);
+            load_strided(e[j], s2it + j * 256, lane);
+        }
 #pragma unroll
         for (int l = 0; l < L; l++) {
             ntt_fwd_core(yr.v[l], twf, lm);
@@ -376,13 +396,15 @@ __global__ __launch_bounds__(256) void keygen_wpi_kernel(
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) yr.load(s1 + itn * L * 256, lane);
+#pragma unroll(NR > 1 ? K : 1)
         for (int k = 0; k < K; k++) {
+            const int slot = NR > 1 ? k % NR : 0;
             int64_t acc[4] = {0, 0, 0, 0};
-            mac_row<L>(acc, Ar, yl, lane);
-            int32_t e2[4] = {e[0], e[1], e[2], e[3]};
-            if (k + 1 < K) {
-                Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, true);
-                load_strided(e, s2it + (k + 1) * 256, lane);
+            mac_row<L>(acc, Ar[slot], yl, lane);
+            int32_t e2[4] = {e[slot][0], e[slot][1], e[slot][2], e[slot][3]};
+            if (k + NR < K) {
+                Ar[slot].load(Ait + (size_t)(k + NR) * L * PD, lane, true);
+                load_strided(e[slot], s2it + (k + NR) * 256, lane);
             }
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
