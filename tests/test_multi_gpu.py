@@ -153,3 +153,14 @@ def test_cpp_multi_dev_bad_arguments(gpu):
     assert L_.dil_ntt_multi_dev(_ptrs([t]), 4, 0, 5, 1) != 0            # root beyond the devices
     dlib.check(L_.dil_ntt_multi_dev(_ptrs([t]), 0, 0, -1, 1))           # empty batch
     assert L_.dil_multi_last_error() is not None
+
+
+@pytest.mark.gpu
+def test_cpp_host_program_on_every_gpu(gpu):
+    """tests/cpp/test_multi_dev.cpp: a C++ host (HIP runtime + include/dil256.h only) driving every visible GPU through
+    dil_*_multi_dev -- ragged NTT batch all-gathered and gathered to a root, a signing batch sharded / gathered / verified,
+    all identical to the single-device calls"""
+    from tests.test_ref_dropin import _build, CPP
+    _build()
+    out = subprocess.run([os.path.join(CPP, "test_multi_dev")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
