@@ -153,7 +153,8 @@ int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c
 /* Phase 2 as the signing LOOP runs it (dil_sign_dev): an attempt is abandoned at its FIRST failed check, the checks ordered
  * r0 rows (flag 2), z rows (flag 1), c t0 rows (flag 4, | 8 for too many hints counted so far); z and h are complete only
  * where flags == 0 (flags & 8 alone: all checks ran, hint count over omega).  w0 is IN/OUT: on return it holds r0 = w0 - c s2
- * of the rows that were evaluated (FSM2 of combined_top.v:1981-2229 likewise stops at the first failed norm check). */
+ * of the rows that were evaluated (FSM2 of combined_top.v:1981-2229 likewise stops at the first failed norm check).  Batches below the
+ * wave-per-item threshold (8 x #CUs items, option fused_mode) run the full phase 2 instead: every flag bit, w0 untouched. */
 int dil_sign_phase2_early_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, int32_t* w0,
                               const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
                               size_t batch, int shared_key, void* stream);

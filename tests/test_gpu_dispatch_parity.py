@@ -216,3 +216,19 @@ def test_options_api(gpu):
     api.set_option("zeroize", 1)
     assert api.get_option("zeroize") == 1
     api.set_option("zeroize", 0)
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_sign_phase2_early_small_batch_runs_the_full_phase2(gpu, oracle, level):
+    """dil_sign_phase2_early_dev below the wave-per-item threshold: the workgroup-per-item kernel evaluates every check (all flag
+    bits, z and h of every attempt) and leaves w0 alone"""
+    from dilithium_amd import api
+    n = 97
+    A, y, c, s1h, s2h, t0h = sign_inputs(oracle, level, n, 8800 + level, 1)
+    ow1, ow0 = oracle.sign_phase1(level, A, y)
+    w0 = dev(gpu, ow0)
+    z, h, fl = api.sign_phase2_early(dev(gpu, c), dev(gpu, y), w0, dev(gpu, ow1, np.uint8), dev(gpu, s1h), dev(gpu, s2h), dev(gpu, t0h),
+                                     level, shared_key=True)
+    oz, oh, ofl = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
+    assert (fl.cpu().numpy() == ofl).all() and (z.cpu().numpy() == oz).all() and (h.cpu().numpy() == oh).all()
+    assert (w0.cpu().numpy() == ow0).all()
