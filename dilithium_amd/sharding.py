@@ -50,28 +50,31 @@ def max_over_ranks(x: float, device=None) -> float:
 
 
 def gather_slabs(local: torch.Tensor, n_items: int | None = None) -> torch.Tensor:
-    """Final gather: concatenate every rank's result slab along dim 0, in rank order.
+    """Final gather: every rank's result slab, concatenated along dim 0 in rank order, on every rank.
 
-    Slabs may be ragged by one item (shard_range); they are padded to the largest slab for the
-    fixed-size collective and trimmed afterwards.  Single process: returns `local`."""
+    Equal slabs: ONE all_gather_into_tensor straight into the result (no staging copy).  Slabs ragged by one item
+    (shard_range): each rank places its slab at its offset of the result and the slabs are exchanged in place as one
+    broadcast per rank (all-gather-v; the same scheme as csrc/multi_gpu.hip) -- no padding, no torch.cat.
+    Single process: returns `local`."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     if n_items is None:
         cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         n_items = int(cnt.item())
     sizes = [shard_range(n_items, r, world) for r in range(world)]
-    big = max(hi - lo for lo, hi in sizes)
-    pad = local
-    if local.shape[0] < big:
-        pad = torch.zeros((big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[: local.shape[0]] = local
-    out = torch.empty((world * big,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous())
-    if all(hi - lo == big for lo, hi in sizes):
+    lo, hi = sizes[rank]
+    assert local.shape[0] == hi - lo, "slab size does not match this rank's slice"
+    out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if all(h - l == hi - lo for l, h in sizes):
+        dist.all_gather_into_tensor(out, local.contiguous())
         return out
-    return torch.cat([out[r * big: r * big + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    out[lo:hi] = local
+    works = [dist.broadcast(out[l:h], src=r, async_op=True) for r, (l, h) in enumerate(sizes) if h > l]
+    for w in works:
+        w.wait()
+    return out
 
 
 def run_sharded(fn, n_items: int, *batched: torch.Tensor, gather: bool = True):
