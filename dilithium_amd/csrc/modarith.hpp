@@ -71,6 +71,17 @@ __device__ __forceinline__ uint32_t canon_any(int32_t x)
     return canon_small(x - k * Q);
 }
 
+// (-2q, 2q) -> [0, q) by unsigned minima: x + 2q in (0, 4q), then min(t, t - 2q), min(t, t - q) (a subtraction that wraps is never the
+// minimum).  add + 2 x (sub + v_min_u32): 16 issue cycles against canon_any's 20, for sums / differences of two residues in (-q, q).
+__device__ __forceinline__ uint32_t canon_pm2q(int32_t x)
+{
+    uint32_t t = (uint32_t)x + 2u * (uint32_t)Q;
+    t = min(t, t - 2u * (uint32_t)Q);
+    return min(t, t - (uint32_t)Q);
+}
+// [0, 2q) -> [0, q)
+__device__ __forceinline__ uint32_t canon_2q(uint32_t x) { return min(x, x - (uint32_t)Q); }
+
 // the constant 2^32 mod q in table form (wt = 2^64 mod q centred): mont_tw(mont_mul(a, b), R2_WT, R2_WQ) == a * b mod q
 constexpr int32_t R2_WT = 2365951;
 constexpr uint32_t R2_WQ = 2145647103u;        // R2_WT * q^-1 mod 2^32   (checked in tests/test_model_and_cabi.py)

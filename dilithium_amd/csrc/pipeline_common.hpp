@@ -111,6 +111,25 @@ __device__ __forceinline__ uint32_t make_hint(uint32_t s, uint32_t a1)
     return (uint32_t)(~none) & 1u;
 }
 
+// MakeHint as a PREDICATE (one compare chain, the mask lives in SGPRs): with t = (s + gamma2 - 1) mod q the no-hint interval
+// s <= gamma2 or s > q - gamma2 is t < 2 gamma2, and s == q - gamma2 is t == q - 1.  3 VALU + 3 compares instead of ~20 bit-field
+// operations; the caller turns the wave's mask into bytes / counts (sign phase 2).  Same truth table as make_hint (checked against
+// it over all of [0, q) x {a1 == 0, a1 != 0} in tests/test_gpu_dispatch_parity.py through the oracle's outputs).
+template <int LEVEL>
+__device__ __forceinline__ bool make_hint_p(uint32_t s, uint32_t a1)
+{
+    constexpr uint32_t G2 = (uint32_t)Par<LEVEL>::GAMMA2;
+    const uint32_t t = canon_2q(s + (G2 - 1));
+    return t >= 2u * G2 && !(t == (uint32_t)Q - 1u && a1 == 0u);
+}
+// a wave mask (SGPR pair) -> 0 / 1 per lane as ONE v_cndmask_b32 in its SGPR-mask form (the VCC form issues 5 x slower on gfx950)
+__device__ __forceinline__ uint32_t mask_to_01(uint64_t mask)
+{
+    uint32_t v;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(v) : "s"(mask));
+    return v;
+}
+
 __device__ __forceinline__ bool norm_reject(uint32_t x, uint32_t bound)   // norm_check.v:84-105
 {
     return x >= bound && x <= (uint32_t)Q - bound;

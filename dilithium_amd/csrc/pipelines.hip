@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
             bool rej = false;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const uint32_t v = canon_any(r[m] + yv[m]);
+                const uint32_t v = canon_pm2q(r[m] + yv[m]);
                 rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
                 st_nt(z_out + o + lane + 64 * m, (int32_t)v);
             }
@@ -600,12 +600,12 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const uint32_t ct0 = canon_small(b[m]);
-                const uint32_t r0 = canon_any(wv0[m] - a[m]);
+                const uint32_t r0 = canon_pm2q(wv0[m] - a[m]);
                 rej1 |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
                 rej2 |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
-                const uint32_t s = canon_small((int32_t)(r0 + ct0) - Q);
-                hv[m] = make_hint<LEVEL>(s, wv1[m]);
-                nh += __popcll(__ballot(hv[m]));
+                const uint64_t hm = __ballot(make_hint_p<LEVEL>(canon_2q(r0 + ct0), wv1[m]));
+                hv[m] = mask_to_01(hm);
+                nh += __popcll(hm);
             }
             store_row_u8(h_out + o, hv, sc, lane);
             if (__ballot(rej1)) bits |= 2;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
             bool rej = false;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const uint32_t r0 = canon_any(wv0[m] - a[m]);
+                const uint32_t r0 = canon_pm2q(wv0[m] - a[m]);
                 rej |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
                 w0[o + lane + 64 * m] = (int32_t)r0;
             }
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
                 bool rej = false;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const uint32_t v = canon_any(r[m] + yv[m]);
+                    const uint32_t v = canon_pm2q(r[m] + yv[m]);
                     rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
                     z_out[o + lane + 64 * m] = (int32_t)v;
                 }
@@ -717,9 +717,9 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
                 for (int m = 0; m < 4; m++) {
                     const uint32_t ct0 = canon_small(b[m]);
                     rej |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
-                    const uint32_t sm = canon_small((int32_t)((uint32_t)r0v[m] + ct0) - Q);
-                    hv[m] = make_hint<LEVEL>(sm, wv1[m]);
-                    nh += __popcll(__ballot(hv[m]));
+                    const uint64_t hm = __ballot(make_hint_p<LEVEL>(canon_2q((uint32_t)r0v[m] + ct0), wv1[m]));
+                    hv[m] = mask_to_01(hm);
+                    nh += __popcll(hm);
                 }
                 store_row_u8(h_out + o, hv, sc, lane);
                 if (__ballot(rej)) {
