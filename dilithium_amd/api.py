@@ -269,6 +269,18 @@ def sample_in_ball(ctilde, level):
     return c
 
 
+def challenge(mu, w1_packed, level):
+    """(c~ uint8 [B,32], c int32 [B,256]) from mu uint8 [B,64] and the packed w1 (pack_w1) -- one launch (gen_c.v is one module)"""
+    K, _ = _kl(level)
+    B = mu.shape[0]
+    assert mu.shape == (B, 64) and w1_packed.shape == (B, K * (192 if level == 2 else 128))
+    ct = torch.empty((B, 32), dtype=torch.uint8, device=mu.device)
+    c = torch.empty((B, N), dtype=torch.int32, device=mu.device)
+    _lib.check(_lib.load().dil_challenge_dev(_dev(ct, torch.uint8), _dev(c, torch.int32), _dev(mu, torch.uint8), _dev(w1_packed, torch.uint8),
+                                             level, B, _stream()), "dil_challenge_dev")
+    return ct, c
+
+
 def pack_w1(w1, level):
     """[B,K,256] uint8 -> [B, K*128] (levels 3/5) or [B, K*192] (level 2) uint8"""
     K, _ = _kl(level)

@@ -40,6 +40,7 @@ const OptName* option_table(int* n)
         {"gen_a", "DIL_GEN_A", &cfg.gen_a},
         {"verify_chunks", "DIL_VERIFY_CHUNKS", &cfg.verify_chunks},
         {"packed_y", "DIL_PACKED_Y", &cfg.packed_y},
+        {"fuse_challenge", "DIL_FUSE_CHALLENGE", &cfg.fuse_challenge},
         {"sign_overlap", "DIL_SIGN_OVERLAP", &cfg.sign_overlap},
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
@@ -609,6 +610,13 @@ int dil_sample_in_ball_dev(int32_t* c, const uint8_t* ctilde, int level, size_t 
 {
     DIL_ENTER(d, T);
     return (int)dil::launch_sample_in_ball(c, ctilde, level, batch, S(stream));
+}
+int dil_challenge_dev(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1_packed, int level, size_t batch, void* stream)
+{
+    DIL_ENTER(d, T);
+    if ((reinterpret_cast<uintptr_t>(ctilde) | reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(w1_packed)) & 7)
+        return (int)hipErrorInvalidValue;
+    return (int)dil::launch_challenge_sample(ctilde, c, mu, w1_packed, level, batch, S(stream));
 }
 int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, void* stream)
 {

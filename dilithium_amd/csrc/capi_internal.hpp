@@ -40,6 +40,7 @@ struct Config {
                                            // stream beside the other half's polynomial kernels.  Built and measured in round 3: SLOWER (level 3, 8192
                                            // messages: 1.42 -> 1.77 ms; level 5: 1.59 -> 2.07 ms; profiles/r03j_sign_overlap.txt) -- a cross-stream
                                            // dependency costs ~20 us and a round needs four.  Default 0.
+    std::atomic<int> fuse_challenge{1};    // DIL_FUSE_CHALLENGE: 1 = the signing loop hashes c~ and samples c in ONE launch (0: challenge hash, then SampleInBall)
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
     std::atomic<int> verify_chunks{1};     // DIL_VERIFY_CHUNKS: wire-format verify, a key per signature: > 1 = ExpandA / fused kernel / challenge hash
                                            // pipelined over this many chunks on three streams.  Built and measured in round 3, SLOWER at every

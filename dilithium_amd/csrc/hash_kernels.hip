@@ -492,6 +492,69 @@ __global__ __launch_bounds__(HASH_BS) void challenge_hash2_kernel(uint32_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The signing loop's challenge as ONE unit, as gen_c.v is one module (absorb mu || w1: gen_c.v:163-196; sample c: :318-339):
+// c~ = SHAKE256(mu || w1_packed) is written out (it is a signature field) AND stays in the sponge's registers as the input
+// block of SampleInBall's own SHAKE256(c~) -- no second launch, no c~ round trip.  TWO: two lanes per sponge (32 signatures
+// per one-wave workgroup) for rounds that would leave the SIMDs under-occupied, else one sponge per lane (64 signatures).
+// ---------------------------------------------------------------------------------------
+template <bool TWO>
+__global__ __launch_bounds__(64) void challenge_sample_kernel(uint32_t* __restrict__ ctilde_out, int32_t* __restrict__ c_out,
+                                                              const uint32_t* __restrict__ mu, const uint32_t* __restrict__ w1p, int w1_words,
+                                                              int tau, size_t batch)
+{
+    constexpr int ITEMS = TWO ? 32 : 64;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[SibLds<ITEMS>::BYTES];
+    int8_t* cl = reinterpret_cast<int8_t*>(lds);
+    uint32_t* rb = reinterpret_cast<uint32_t*>(lds + SibLds<ITEMS>::CL_BYTES);
+    const int lane = threadIdx.x, col = TWO ? lane >> 1 : lane;
+    const size_t base = (size_t)blockIdx.x * ITEMS, item = base + col;
+    const bool live = item < batch;
+    const size_t ii = live ? item : batch - 1;               // a dead column hashes a valid entry again and stores nothing
+    sib_clear(cl, SibLds<ITEMS>::CL_BYTES);
+    if (TWO) {
+        const int hi = lane & 1;
+        Shake2<17> sp;
+        sp.init(hi);
+#pragma unroll
+        for (int w = 0; w < 8; w++) sp.s[w] = mu[ii * 16 + 2 * w + hi];
+        const int fill = sp.template absorb<8>(w1p + ii * (size_t)w1_words * 2, w1_words);
+        sp.finish_words(fill);
+        if (live) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) ctilde_out[item * 8 + 2 * w + hi] = sp.s[w];
+        }
+        // SampleInBall's sponge: the 32 digest bytes are its whole message and already sit in words 0..3
+#pragma unroll
+        for (int w = 4; w < 25; w++) sp.s[w] = 0;
+        sp.s[4] = hi ? 0u : 0x1Fu;
+        sp.s[16] = hi ? 0x80000000u : 0u;
+        keccak2_f1600(sp.s, sp.hi);
+        __syncthreads();                                     // cl cleared by all lanes before any lane writes its column
+        sib_sample<ITEMS>(SibTwoLane{sp}, col, live ? tau : 0, cl, rb);
+    } else {
+        const uint64_t* mu64 = reinterpret_cast<const uint64_t*>(mu);
+        Shake<17> sp;
+        sp.init();
+#pragma unroll
+        for (int t = 0; t < 8; t++) sp.s[t] = mu64[ii * 8 + t];
+        const int fill = sp.template absorb<8>(reinterpret_cast<const uint64_t*>(w1p) + ii * (size_t)w1_words, w1_words);
+        sp.finish_words(fill);
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) reinterpret_cast<uint64_t*>(ctilde_out)[item * 4 + t] = sp.s[t];
+        }
+#pragma unroll
+        for (int w = 4; w < 25; w++) sp.s[w] = 0;
+        sp.s[4] = 0x1Full;
+        sp.s[16] = 0x8000000000000000ull;
+        keccak_f1600(sp.s);
+        __syncthreads();
+        sib_sample<ITEMS>(SibOneLane{sp}, col, live ? tau : 0, cl, rb);
+    }
+    sib_store_poly<ITEMS>(c_out, batch, base, cl);
+}
+
 // one sponge per lane fills the chip from about one wave per SIMD; below that the two-lane form is faster
 static inline bool few_sponges(size_t batch) { return batch < 65536; }
 
@@ -511,6 +574,21 @@ hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t
     hipLaunchKernelGGL(challenge_hash_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint64_t*>(out32), verdict,
                        reinterpret_cast<const uint64_t*>(mu), reinterpret_cast<const uint64_t*>(w1p), words,
                        expect, expect_stride, batch);
+    return hipGetLastError();
+}
+
+hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1p, int level, size_t batch, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
+    const int words = K * (level == 2 ? 192 : 128) / 8, tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    if (few_sponges(batch))
+        hipLaunchKernelGGL(challenge_sample_kernel<true>, (int)((batch + 31) / 32), 64, 0, s, reinterpret_cast<uint32_t*>(ctilde), c,
+                           reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words, tau, batch);
+    else
+        hipLaunchKernelGGL(challenge_sample_kernel<false>, (int)((batch + 63) / 64), 64, 0, s, reinterpret_cast<uint32_t*>(ctilde), c,
+                           reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words, tau, batch);
     return hipGetLastError();
 }
 

@@ -86,6 +86,8 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
 // y as the raw B-bit stream (Y_PACKED), lane per sponge: the signing loop's large rounds
 hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s);
+// the signing loop's challenge in one launch: c~ = H(mu || w1_packed) -> ctilde (32 B per entry) AND c = SampleInBall(c~) -> c (int32 [256] per entry)
+hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1p, int level, size_t batch, hipStream_t s);
 hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s);
 // expect (may be nullptr): 32 bytes per item at expect + i * expect_stride, any alignment (c~ read in place from a signature)
 hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,

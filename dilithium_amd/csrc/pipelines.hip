@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) load_y(itn);
-#pragma unroll(NR > 1 ? K : 1)
+        constexpr int ROW_UNROLL = NR > 1 ? K : 1;           // the ring's slot index must be static
+#pragma unroll ROW_UNROLL
         for (int k = 0; k < K; k++) {
             const int slot = NR > 1 ? k % NR : 0;
             int64_t acc[4] = {0, 0, 0, 0};
@@ -396,7 +397,8 @@ __global__ __launch_bounds__(256) void keygen_wpi_kernel(
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) yr.load(s1 + itn * L * 256, lane);
-#pragma unroll(NR > 1 ? K : 1)
+        constexpr int ROW_UNROLL = NR > 1 ? K : 1;           // the ring's slot index must be static
+#pragma unroll ROW_UNROLL
         for (int k = 0; k < K; k++) {
             const int slot = NR > 1 ? k % NR : 0;
             int64_t acc[4] = {0, 0, 0, 0};

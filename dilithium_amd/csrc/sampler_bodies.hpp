@@ -217,16 +217,81 @@ struct SibLds {
     static constexpr int CL_BYTES = 256 * PITCH, RB_DWORDS = 34 * ITEMS, BYTES = CL_BYTES + 4 * RB_DWORDS;
 };
 
+// The sponge behind the sampling loop, in either form of keccak.hpp: how its rate block reaches rb, and the 64 sign bits.
+struct SibOneLane {                               // one sponge per lane
+    Shake<17>& sp;
+    template <int ITEMS>
+    __device__ __forceinline__ void spill(uint32_t* rb, int col) const
+    {
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+            rb[(2 * w) * ITEMS + col] = (uint32_t)sp.s[w];
+            rb[(2 * w + 1) * ITEMS + col] = (uint32_t)(sp.s[w] >> 32);
+        }
+    }
+    __device__ __forceinline__ uint64_t signs() const { return sp.s[0]; }
+    __device__ __forceinline__ void permute() { keccak_f1600(sp.s); }
+};
+struct SibTwoLane {                               // two lanes per sponge: each lane spills its own half of every word, both lanes of
+    Shake2<17>& sp;                               // a pair then run the same loop on the same LDS cells with the same values
+    template <int ITEMS>
+    __device__ __forceinline__ void spill(uint32_t* rb, int col) const
+    {
+#pragma unroll
+        for (int w = 0; w < 17; w++) rb[(2 * w + (sp.hi ? 1 : 0)) * ITEMS + col] = sp.s[w];
+    }
+    __device__ __forceinline__ uint64_t signs() const
+    {
+        const uint32_t own = sp.s[0], par = k2_partner(own);
+        return sp.hi ? (((uint64_t)own << 32) | par) : (((uint64_t)par << 32) | own);
+    }
+    __device__ __forceinline__ void permute() { keccak2_f1600(sp.s, sp.hi); }
+};
+
+__device__ __forceinline__ void sib_clear(int8_t* cl, int cl_bytes)
+{
+    for (int k = threadIdx.x; k < cl_bytes / 16; k += 64) reinterpret_cast<uint4*>(cl)[k] = make_uint4(0, 0, 0, 0);
+}
+
+// The sampling loop: `sq` is the sponge of column `col` after its first squeeze permutation; cl must be clear (and the clear
+// visible: __syncthreads between sib_clear and this).  tau = 0 for a column without a signature.
+template <int ITEMS, class SQ>
+__device__ __forceinline__ void sib_sample(SQ sq, int col, int tau, int8_t* cl, uint32_t* rb)
+{
+    constexpr int PITCH = SibLds<ITEMS>::PITCH;
+    uint64_t signs = sq.signs();
+    sq.template spill<ITEMS>(rb, col);
+    // Every lane consumes ONE byte per step (so the read position is wave-uniform and the loop is flat): the byte is either
+    // taken for the lane's current i or skipped.  The wave runs max-over-lanes(bytes consumed) ~ tau + 12 steps, where a loop
+    // over i with an inner rejection loop runs sum-over-i(max-over-lanes(tries)) ~ 2.7 tau.
+    int pos = 8, i = 256 - tau;
+    while (__any(i < 256)) {
+        if (pos == 136) {
+            sq.permute();
+            sq.template spill<ITEMS>(rb, col);
+            pos = 0;
+        }
+        const int b = (int)((rb[(pos >> 2) * ITEMS + col] >> (8 * (pos & 3))) & 255u);
+        pos++;
+        if (i < 256 && b <= i) {
+            cl[i * PITCH + col] = cl[b * PITCH + col];
+            cl[b * PITCH + col] = (int8_t)(1 - 2 * (int)(signs & 1));
+            signs >>= 1;
+            i++;
+        }
+    }
+    __syncthreads();
+}
+
 // fills cl for the workgroup's signatures (item = base + (lane & (ITEMS - 1)); c~ at ctilde + item * ct_stride, any alignment)
 template <int ITEMS>
 __device__ __forceinline__ void sample_in_ball_core(const uint8_t* __restrict__ ctilde, size_t ct_stride, int tau, size_t nitems, size_t base,
                                                     int8_t* cl, uint32_t* rb)
 {
-    constexpr int PITCH = SibLds<ITEMS>::PITCH;
     const int lane = threadIdx.x, col = lane & (ITEMS - 1);
     const size_t item = base + col;
     const bool live = item < nitems;
-    for (int k = lane; k < SibLds<ITEMS>::CL_BYTES / 16; k += 64) reinterpret_cast<uint4*>(cl)[k] = make_uint4(0, 0, 0, 0);
+    sib_clear(cl, SibLds<ITEMS>::CL_BYTES);
     Shake<17> sp;
     sp.init();
     if (live) {
@@ -243,35 +308,7 @@ __device__ __forceinline__ void sample_in_ball_core(const uint8_t* __restrict__ 
     sp.s[16] ^= 0x8000000000000000ull;
     keccak_f1600(sp.s);
     __syncthreads();                              // cl cleared by all lanes before any lane writes its column
-    uint64_t signs = sp.s[0];
-    auto spill = [&]() {
-#pragma unroll
-        for (int w = 0; w < 17; w++) {
-            rb[(2 * w) * ITEMS + col] = (uint32_t)sp.s[w];
-            rb[(2 * w + 1) * ITEMS + col] = (uint32_t)(sp.s[w] >> 32);
-        }
-    };
-    spill();
-    // Every lane consumes ONE byte per step (so the read position is wave-uniform and the loop is flat): the byte is either
-    // taken for the lane's current i or skipped.  The wave runs max-over-lanes(bytes consumed) ~ tau + 12 steps, where a loop
-    // over i with an inner rejection loop runs sum-over-i(max-over-lanes(tries)) ~ 2.7 tau.
-    int pos = 8, i = 256 - tau;
-    while (__any(i < 256)) {
-        if (pos == 136) {
-            keccak_f1600(sp.s);
-            spill();
-            pos = 0;
-        }
-        const int b = (int)((rb[(pos >> 2) * ITEMS + col] >> (8 * (pos & 3))) & 255u);
-        pos++;
-        if (i < 256 && b <= i) {
-            cl[i * PITCH + col] = cl[b * PITCH + col];
-            cl[b * PITCH + col] = (int8_t)(1 - 2 * (int)(signs & 1));
-            signs >>= 1;
-            i++;
-        }
-    }
-    __syncthreads();
+    sib_sample<ITEMS>(SibOneLane{sp}, col, tau, cl, rb);
 }
 
 // output stage, compact form (wire_kernels.hip decode_c): cbits[item][lane] bit m = c[lane + 64 m] != 0, bit 4 + m = its sign
@@ -306,13 +343,10 @@ __device__ __forceinline__ void sample_in_ball_bits_body(uint32_t* __restrict__ 
 
 // output stage, polynomial form (the signing loop): c[item][256] int32, canonical (+1 -> 1, -1 -> q - 1)
 template <int ITEMS>
-__device__ __forceinline__ void sample_in_ball_poly_body(int32_t* __restrict__ c_out, const uint8_t* __restrict__ ctilde, size_t ct_stride,
-                                                         int tau, size_t nitems, unsigned block, int8_t* cl, uint32_t* rb)
+__device__ __forceinline__ void sib_store_poly(int32_t* __restrict__ c_out, size_t nitems, size_t base, const int8_t* cl)
 {
     constexpr int PITCH = SibLds<ITEMS>::PITCH;
     const int lane = threadIdx.x;
-    const size_t base = (size_t)block * ITEMS;
-    sample_in_ball_core<ITEMS>(ctilde, ct_stride, tau, nitems, base, cl, rb);
     for (int t0 = 0; t0 < ITEMS; t0 += 4) {
         if (base + t0 >= nitems) break;
         uint32_t d[4];
@@ -329,6 +363,14 @@ __device__ __forceinline__ void sample_in_ball_poly_body(int32_t* __restrict__ c
             }
         }
     }
+}
+template <int ITEMS>
+__device__ __forceinline__ void sample_in_ball_poly_body(int32_t* __restrict__ c_out, const uint8_t* __restrict__ ctilde, size_t ct_stride,
+                                                         int tau, size_t nitems, unsigned block, int8_t* cl, uint32_t* rb)
+{
+    const size_t base = (size_t)block * ITEMS;
+    sample_in_ball_core<ITEMS>(ctilde, ct_stride, tau, nitems, base, cl, rb);
+    sib_store_poly<ITEMS>(c_out, nitems, base, cl);
 }
 
 }  // namespace dil

@@ -211,6 +211,7 @@ namespace {
 struct AttemptScratch {
     int32_t* y; uint8_t* w1; int32_t* w0; uint8_t* w1p; int32_t* c;
     int a_fmt = dil::A_I32;      // format of the matrix the attempts multiply by (kernels.hpp)
+    bool fuse_challenge = true;  // c~ and c by one launch (hash_kernels.hip challenge_sample_kernel)
     bool packed_y = false;       // the signing loop: y stays ExpandMask's raw stream in rounds large enough for the wave-per-item kernels
     int alloc(StreamScratch& ws, int level, int K, int L, size_t batch)
     {
@@ -290,8 +291,12 @@ int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ct
     if (!(phases & 2)) return 0;
     // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
     DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt, y_fmt));
-    DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
-    DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
+    if (t.fuse_challenge) {
+        DIL_TRY(dil::launch_challenge_sample(ctilde, t.c, mu, t.w1p, level, batch, s));
+    } else {
+        DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
+        DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
+    }
     DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
                               early_exit ? t.w0 : nullptr, y_fmt));
     return 0;
@@ -339,8 +344,12 @@ int sign_attempt_overlapped(Device& dv, const dil::Tables& T, const AttemptScrat
                                    T, s, kmh[i], t.w1p + off[i] * w1pb, t.a_fmt, y_fmt));
         DIL_TRY(hipEventRecord(xs.chunk_ev[i], s));
         DIL_TRY(hipStreamWaitEvent(hs, xs.chunk_ev[i], 0));
-        DIL_TRY(dil::launch_challenge_hash(ctilde + off[i] * 32, nullptr, mu + off[i] * 64, t.w1p + off[i] * w1pb, level, nullptr, cnt[i], hs));
-        DIL_TRY(dil::launch_sample_in_ball(t.c + off[i] * 256, ctilde + off[i] * 32, level, cnt[i], hs));
+        if (t.fuse_challenge) {
+            DIL_TRY(dil::launch_challenge_sample(ctilde + off[i] * 32, t.c + off[i] * 256, mu + off[i] * 64, t.w1p + off[i] * w1pb, level, cnt[i], hs));
+        } else {
+            DIL_TRY(dil::launch_challenge_hash(ctilde + off[i] * 32, nullptr, mu + off[i] * 64, t.w1p + off[i] * w1pb, level, nullptr, cnt[i], hs));
+            DIL_TRY(dil::launch_sample_in_ball(t.c + off[i] * 256, ctilde + off[i] * 32, level, cnt[i], hs));
+        }
         DIL_TRY(hipEventRecord(xs.chunk_ev[2 + i], hs));
     }
     for (int i = 0; i < 2; i++) {
@@ -364,6 +373,7 @@ int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags
     hipStream_t s = S(stream);
     StreamScratch ws(dv, s);
     AttemptScratch t;
+    t.fuse_challenge = dil::rt::cfg.fuse_challenge.load(std::memory_order_relaxed) != 0;
     if ((rc = t.alloc(ws, level, K, L, batch))) return rc;
     return ws.close(sign_attempt_impl(T, t, ctilde, z, h, flags, A, mu, rhoprime, kappa, s1hat, s2hat, t0hat, level, batch, shared_key, s));
 }
@@ -770,6 +780,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         // two lanes per sponge).  Many keys: the throughput ExpandA first, on the same stream.
         att.a_fmt = matrix_format(nk, p.K, p.L);
         att.packed_y = dil::rt::cfg.packed_y.load(std::memory_order_relaxed) != 0;
+        att.fuse_challenge = dil::rt::cfg.fuse_challenge.load(std::memory_order_relaxed) != 0;
         const bool few = nk * p.K * p.L <= dil::EA_TWO_LANE_MAX;            // (then the matrix format is int32)
         if (!few) DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s, att.a_fmt));
         DIL_TRY(dil::launch_sign_setup(level, A, few, s1h, s2h, t0h, sk, nk, rp, attempts, mu, sk_stride, batch, T, s));

@@ -53,6 +53,7 @@ SIGNATURES = {
     "dil_expand_a_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_expand_mask_dev": [_vp, _vp, _vp, C.c_int, _sz, _vp],
     "dil_sample_in_ball_dev": [_vp, _vp, C.c_int, _sz, _vp],
+    "dil_challenge_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, _vp],
     "dil_pack_w1_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_unpack_dev": [_vp, _vp, _sz, _sz, C.c_int, C.c_int, _sz, _vp],
     "dil_pack_dev": [_vp, _sz, _sz, _vp, C.c_int, C.c_int, _sz, _vp],

@@ -172,11 +172,15 @@ int dil_launch_info(const char* family, int* grid, int* items_per_block, size_t*
  * expand_mask:     y[i][l] from rho'[i] (64 B), nonce kappa[i] + l; canonical [0,q)
  *                                                          expandmask_ext.v:98, sampler_y_ext.v, rejection_y.v
  * sample_in_ball:  c[i] (+-1 as 1 / q-1) from c~[i] (32 B) gen_c.v:163-196,318-339
- * pack_w1:         [K][256] bytes -> 4-bit (levels 3/5) or 6-bit (level 2) stream   encoder.v:96-133 */
+ * pack_w1:         [K][256] bytes -> 4-bit (levels 3/5) or 6-bit (level 2) stream   encoder.v:96-133
+ * challenge:       the signing loop's challenge as the ONE unit gen_c.v is: c~[i] = SHAKE256(mu[i] (64 B) || w1_packed[i]
+ *                  (K * 128 B; level 2: K * 192 B), 32) -> ctilde, and c[i] = SampleInBall(c~[i]) -> c, in one launch with
+ *                  c~ never leaving the sponge's registers in between               gen_c.v:163-196 (absorb), :318-339 (sample) */
 int dil_shake256_dev(uint8_t* out, size_t out_bytes, const uint8_t* in, size_t in_bytes, size_t batch, void* stream);
 int dil_expand_a_dev(int32_t* A, const uint8_t* rho, int level, size_t batch, void* stream);
 int dil_expand_mask_dev(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t batch, void* stream);
 int dil_sample_in_ball_dev(int32_t* c, const uint8_t* ctilde, int level, size_t batch, void* stream);
+int dil_challenge_dev(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1_packed, int level, size_t batch, void* stream);
 int dil_pack_w1_dev(uint8_t* out, const uint8_t* w1, int level, size_t batch, void* stream);
 
 /* ---- wire-format codecs, ExpandS, keygen ------------------------------

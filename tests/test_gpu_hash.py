@@ -109,6 +109,33 @@ def test_sample_in_ball_vs_host_sampler(gpu, level):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("n", [1, 31, 33, 200, 70001])
+def test_challenge_one_launch_vs_hashlib_and_host_sampler(gpu, level, n):
+    """c~ = H(mu || w1_packed) and c = SampleInBall(c~) from ONE launch (gen_c.v:163-196,318-339 is one module): against hashlib
+    + the KAT harness's sampler, and against the library's own two-launch form.  n = 31 / 33: a partial workgroup of the
+    two-lanes-per-sponge form (32 signatures per workgroup); n = 70001: the lane-per-sponge form (64 per workgroup, ragged tail)"""
+    from dilithium_amd import api
+    p = dk.PARAMS[level]
+    rng = np.random.default_rng(40 + level + n)
+    wb = p.K * (192 if level == 2 else 128)
+    mu = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    w1p = rng.integers(0, 256, (n, wb), dtype=np.uint8)
+    ct, c = api.challenge(cu(gpu, mu), cu(gpu, w1p), level)
+    pick = range(n) if n <= 200 else [0, 1, 63, 64, 65, 4095, 4096, n // 2, n - 66, n - 65, n - 64, n - 2, n - 1]
+    cth, ch = ct.cpu().numpy(), c.cpu().numpy()
+    for i in pick:
+        want = hashlib.shake_256(mu[i].tobytes() + w1p[i].tobytes()).digest(32)
+        assert cth[i].tobytes() == want, i
+        assert (ch[i] == dk.canon(dk.sample_in_ball(p, want))).all(), i
+    assert ((ch != 0).sum(axis=1) == p.tau).all()
+    # every entry against the two-launch form (the challenge hash is reached through shake256 on the concatenated input)
+    cat = gpu.cat([cu(gpu, mu), cu(gpu, w1p)], dim=1).contiguous()
+    ct2 = api.shake256(cat, 32)
+    assert gpu.equal(ct, ct2)
+    assert gpu.equal(c, api.sample_in_ball(ct2, level))
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
 def test_pack_w1_vs_host_codec(gpu, level):
     from dilithium_amd import api
     p = dk.PARAMS[level]
