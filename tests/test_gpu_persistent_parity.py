@@ -51,7 +51,7 @@ def steps(family, n, at_least):
     info = api.launch_info(family)
     assert info["items"] == n, (family, info)
     assert info["grid"] * info["items_per_block"] < n and info["steps"] >= at_least, (family, info)
-    log = os.environ.get("DIL_STEPS_LOG")          # scripts/gpu_round.sh: profiles/r03_pytest_kernel_coverage.txt
+    log = os.environ.get("DIL_STEPS_LOG")          # scripts/gpu_r03.sh: profiles/r03_pytest_kernel_coverage.txt
     if log:
         test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
         with open(log, "a") as f:
