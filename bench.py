@@ -203,8 +203,9 @@ def main():
     rank, world, local = sharding.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local)
-    api.init(local)
+    dev = sharding.local_device(local)
+    torch.cuda.set_device(dev)
+    api.init(dev)
     L = dlib.load()
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
@@ -284,6 +285,7 @@ def main():
         m = max(1, int(np.ceil(min_region_ms * 1e-3 / probe)))
         m = int(sharding.max_over_ranks(float(m)))                                       # same M on every rank
         r = max(min_regions, int(np.ceil(min_total_ms / max(min_region_ms, probe * m * 1e3))))
+        r = int(sharding.max_over_ranks(float(r)))                                       # a region holds barriers: same R on every rank too
         walls = torch.tensor([region(m * k, fixed, one) for _ in range(r)], dtype=torch.float64)
         if world > 1:
             w = walls.cuda()

@@ -106,7 +106,8 @@ struct Rccl {
 };
 
 struct Multi {
-    std::mutex mu;
+    std::mutex call_mu;                 // one *_multi_dev call (compute on the devices' streams + its collectives) at a time
+    std::mutex mu;                      // the state below
     Rccl rccl;
     int G = 0;
     std::vector<ncclComm_t> comm;
@@ -192,17 +193,27 @@ int gather_slabs(void* const* bufs, size_t item_bytes, size_t batch, int root, i
     if (G > 1 && batch > 0 && item_bytes > 0) {
         const bool equal = batch % (size_t)G == 0;
         DIL_NCCL(m.rccl.GroupStart(), "ncclGroupStart");
+        ncclResult_t bad = ncclSuccess;                  // first failure inside the group; the group is closed either way
+        const char* bad_what = "";
+#define DIL_IN_GROUP(call, what)                                  \
+    do {                                                          \
+        const ncclResult_t r__ = bad == ncclSuccess ? (call) : bad; \
+        if (r__ != ncclSuccess && bad == ncclSuccess) {           \
+            bad = r__;                                            \
+            bad_what = what;                                      \
+        }                                                         \
+    } while (0)
         for (int g = 0; g < G; g++) {
             char* mine = static_cast<char*>(bufs[g]);
             if (root < 0 && equal) {                     // in-place all-gather: the send slab sits at its own offset of the receive array
                 const size_t cnt = batch / (size_t)G * item_bytes;
-                DIL_NCCL(m.rccl.AllGather(mine + (size_t)g * cnt, mine, cnt, ncclUint8, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclAllGather");
+                DIL_IN_GROUP(m.rccl.AllGather(mine + (size_t)g * cnt, mine, cnt, ncclUint8, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclAllGather");
             } else if (root < 0) {                       // ragged by one item: all-gather-v = one broadcast per slab, all in ONE group
                 for (int r = 0; r < G; r++) {
                     size_t lo, hi;
                     dil_shard_range(batch, r, G, &lo, &hi);
                     if (hi > lo)
-                        DIL_NCCL(m.rccl.Broadcast(mine + lo * item_bytes, mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, r,
+                        DIL_IN_GROUP(m.rccl.Broadcast(mine + lo * item_bytes, mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, r,
                                                   m.comm[(size_t)g], m.stream[(size_t)g]), "ncclBroadcast");
                 }
             } else if (g == root) {                      // gather to one root: it receives every other slab ...
@@ -210,16 +221,19 @@ int gather_slabs(void* const* bufs, size_t item_bytes, size_t batch, int root, i
                     size_t lo, hi;
                     dil_shard_range(batch, r, G, &lo, &hi);
                     if (r != root && hi > lo)
-                        DIL_NCCL(m.rccl.Recv(mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, r, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclRecv");
+                        DIL_IN_GROUP(m.rccl.Recv(mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, r, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclRecv");
                 }
             } else {                                     // ... and every other device sends its own
                 size_t lo, hi;
                 dil_shard_range(batch, g, G, &lo, &hi);
                 if (hi > lo)
-                    DIL_NCCL(m.rccl.Send(mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, root, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclSend");
+                    DIL_IN_GROUP(m.rccl.Send(mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, root, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclSend");
             }
         }
-        DIL_NCCL(m.rccl.GroupEnd(), "ncclGroupEnd");
+#undef DIL_IN_GROUP
+        const ncclResult_t ge = m.rccl.GroupEnd();
+        if (bad != ncclSuccess) return rccl_fail(bad, bad_what);
+        if (ge != ncclSuccess) return rccl_fail(ge, "ncclGroupEnd");
     } else if (G == 1 && batch > 0 && item_bytes > 0) {
         // one device: the slab IS the array; still one (trivial) RCCL collective so that the path is the one a node runs
         DIL_NCCL(m.rccl.AllGather(bufs[0], bufs[0], batch * item_bytes, ncclUint8, m.comm[0], m.stream[0]), "ncclAllGather");
@@ -245,12 +259,14 @@ const char* dil_multi_last_error(void) { return g_multi.last_error; }
 
 int dil_multi_init(int ndev)
 {
+    std::lock_guard<std::mutex> call(g_multi.call_mu);
     int G;
     return multi_ensure(ndev, &G);
 }
 
 int dil_multi_shutdown(void)
 {
+    std::lock_guard<std::mutex> call(g_multi.call_mu);
     std::lock_guard<std::mutex> lk(g_multi.mu);
     multi_teardown_locked();
     return 0;
@@ -258,6 +274,7 @@ int dil_multi_shutdown(void)
 
 int dil_gather_slabs_multi_dev(void* const* bufs, size_t item_bytes, size_t batch, int gather_root, int ndev)
 {
+    std::lock_guard<std::mutex> call(g_multi.call_mu);
     int G, rc;
     if (!bufs) return (int)hipErrorInvalidValue;
     if ((rc = multi_ensure(ndev, &G))) return rc;
@@ -266,6 +283,7 @@ int dil_gather_slabs_multi_dev(void* const* bufs, size_t item_bytes, size_t batc
 
 int dil_ntt_multi_dev(int32_t* const* polys, size_t batch, int inverse, int gather_root, int ndev)
 {
+    std::lock_guard<std::mutex> call(g_multi.call_mu);
     int G, rc;
     if (!polys) return (int)hipErrorInvalidValue;
     if ((rc = multi_ensure(ndev, &G))) return rc;
@@ -280,6 +298,7 @@ int dil_ntt_multi_dev(int32_t* const* polys, size_t batch, int inverse, int gath
 int dil_sign_multi_dev(uint8_t* const* sig, int32_t* const* attempts, const uint8_t* const* sk, const uint8_t* const* mu, int level,
                        size_t batch, int shared_sk, int max_attempts, int gather_root, int ndev)
 {
+    std::lock_guard<std::mutex> call(g_multi.call_mu);
     const size_t sgb = dil_sig_bytes(level);
     int G, rc;
     if (!sgb || !sig || !sk || !mu) return (int)hipErrorInvalidValue;
@@ -305,6 +324,7 @@ int dil_sign_multi_dev(uint8_t* const* sig, int32_t* const* attempts, const uint
 int dil_verify_sig_multi_dev(int32_t* const* verdict, const uint8_t* const* pk, const uint8_t* const* sig, const uint8_t* const* mu, int level,
                              size_t batch, int shared_pk, int gather_root, int ndev)
 {
+    std::lock_guard<std::mutex> call(g_multi.call_mu);
     int G, rc;
     if (!dil_pk_bytes(level) || !verdict || !pk || !sig || !mu) return (int)hipErrorInvalidValue;
     if ((rc = multi_ensure(ndev, &G))) return rc;
@@ -323,6 +343,7 @@ int dil_sign_phases_multi_dev(int32_t* const* z, uint8_t* const* h, int32_t* con
                               uint8_t* const* w1_scratch, int32_t* const* w0_scratch, int level, size_t batch, int shared_key, int gather_root,
                               int ndev)
 {
+    std::lock_guard<std::mutex> call(g_multi.call_mu);
     int G, rc;
     const int K = level == 2 ? 4 : level == 3 ? 6 : level == 5 ? 8 : 0, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     if (!K || !z || !h || !flags || !A || !y || !c || !s1hat || !s2hat || !t0hat || !w1_scratch || !w0_scratch) return (int)hipErrorInvalidValue;

@@ -28,12 +28,20 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:                      # DIL_DIST_BACKEND=gloo: a multi-rank rehearsal on a box with fewer GPUs than ranks
+            backend = os.environ.get("DIL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def local_device(local_rank: int) -> int:
+    """the GPU of this rank: its local rank -- except in a gloo rehearsal on a box with fewer GPUs than ranks, where ranks share"""
+    n = torch.cuda.device_count()
+    if n and local_rank >= n and dist.is_initialized() and dist.get_backend() == "gloo":
+        return local_rank % n
+    return local_rank
 
 
 def barrier() -> None:

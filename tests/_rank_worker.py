@@ -1,6 +1,7 @@
 """One rank of a multi-process run of the sharded path (launched by tests/test_multi_gpu.py through torch.distributed.run):
 slices a seeded batch with sharding.run_sharded, computes the level-5 sign inner loop (phase 1 + 2) and a forward NTT on its
-slice -- with the HIP kernels on cuda:LOCAL_RANK (--compute hip, backend nccl = RCCL) or with the oracle on the CPU
+slice -- with the HIP kernels on cuda:LOCAL_RANK (--compute hip, backend nccl = RCCL; or gloo with the ranks sharing a GPU when
+DIL_DIST_BACKEND=gloo: the one-GPU rehearsal of the same code) or with the oracle on the CPU
 (--compute oracle, backend gloo: exercises this script itself where there is no GPU) -- gathers the (z, h, flag) slabs and the
 transformed polynomials, and rank 0 compares EVERYTHING with the oracle's unsharded result.  Exit code 0 = identical."""
 import argparse
@@ -23,7 +24,8 @@ def main():
     ap.add_argument("--level", type=int, default=5)
     a = ap.parse_args()
     hip = a.compute == "hip"
-    rank, world, local = sharding.init_distributed("nccl" if hip else "gloo")
+    # hip: nccl (= RCCL), or -- DIL_DIST_BACKEND=gloo -- a rehearsal in which the ranks share the GPUs that are there
+    rank, world, local = sharding.init_distributed(None if hip else "gloo")
     o = Oracle()
     level, n = a.level, a.items
     p = dk.PARAMS[level]
@@ -40,8 +42,9 @@ def main():
     polys = splitmix64_polys(n, seed=5)
     if hip:
         from dilithium_amd import api
-        torch.cuda.set_device(local)
-        api.init(local)
+        dev = sharding.local_device(local)
+        torch.cuda.set_device(dev)
+        api.init(dev)
         d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
         dA, ds1, ds2, dt0 = d(A), d(s1h), d(s2h), d(t0h)
 

@@ -28,10 +28,12 @@ def _free_port():
     return p
 
 
-def _launch_ranks(world, compute, items):
+def _launch_ranks(world, compute, items, backend=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rank_worker.py"), "--compute", compute, "--items", str(items)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    if backend:
+        env["DIL_DIST_BACKEND"] = backend
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
 
 
@@ -58,6 +60,36 @@ def test_nccl_ranks_hip_compute_vs_oracle(world):
         pytest.skip(f"needs {world} GPUs")
     r = _launch_ranks(world, "hip", 8192 * world + 3)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_hip_compute_vs_oracle(world):
+    """the same worker, HIP compute on every rank's slice under sharding.run_sharded at world size > 1 on a ONE-GPU box: the ranks
+    share the GPU and exchange their slabs over gloo (DIL_DIST_BACKEND=gloo) -- everything of the multi-rank path except RCCL
+    itself (which the test above runs when the GPUs are there); ragged split, every output vs the oracle"""
+    if _ngpu() < 1:
+        pytest.skip("needs a GPU")
+    r = _launch_ranks(world, "hip", 4096 * world + 1, backend="gloo")
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """bench.py --gpus 2 as the driver launches it, the two ranks sharing the GPU over gloo: every rank reaches every barrier /
+    max-over-ranks the same number of times (a mismatch hangs -> timeout), rank 0 prints ONE JSON line with the contract's keys"""
+    import json
+    if _ngpu() < 1:
+        pytest.skip("needs a GPU")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DIL_DIST_BACKEND="gloo")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["secondary"]["configs4_sharded"]["gathered_signatures_verify"] is True
 
 
 def _ptrs(tensors):
