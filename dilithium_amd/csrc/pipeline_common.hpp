@@ -135,6 +135,38 @@ __device__ __forceinline__ bool norm_reject(uint32_t x, uint32_t bound)   // nor
     return x >= bound && x <= (uint32_t)Q - bound;
 }
 
+// Two SMALL products from one inverse transform.  c has tau coefficients +-1 and the secret vectors are tiny (|s| <= eta), so
+// |c s1|, |c s2| <= beta = tau eta <= 196 while a residue mod q has 23 bits: by linearity INTT(c^ o (s1^ + 2^11 s2^)) =
+// c s1 + 2^11 c s2, and both parts are read off the one result exactly -- sign phase 2 needs 1 + 2 K transforms instead of
+// 1 + L + 2 K (level 5: 17 for 24).  Exact while |c s1|, |c s2| <= 1023 (|x + 2^11 y| <= 1023 + 2^11 * 1023 < q / 2): every
+// polynomial a secret-key BYTE STRING can decode to qualifies at every level (worst case: level 3's 4-bit fields give
+// |s| <= 11, tau = 49: 539), not only well-formed keys; the low-level entry points state the bound (include/dil256.h).
+// (c t0 reaches 2^18 and has no partner.)  The reference computes the products one by one (combined_top.v:1994-2229); the
+// results are the same integers.
+struct SmallPair {
+    static constexpr int BITS = 11, HALF = 1 << (BITS - 1);
+    static constexpr int32_t SHIFT_R = (int32_t)((1ull << (32 + BITS)) % (uint64_t)Q);     // 2^11 in Montgomery form: mont_mul(x, SHIFT_R) = 2^11 x
+    static constexpr int32_t OFF = HALF + (HALF << BITS);                                  // makes both digits non-negative
+    // c^ s1^ + (2^11 c^) s2^, Montgomery-reduced: |ch s1| < 9 q^2, |cp s2| < q^2 -- far below mont_red64's 2^31 q
+    __device__ __forceinline__ static int32_t mul(int32_t ch, int32_t s1, int32_t cp, int32_t s2)
+    {
+        return mont_red64((int64_t)ch * s1 + (int64_t)cp * s2);
+    }
+    // one key for the whole launch: its L rows s1^[l] + 2^11 s2^[l] (canonical), formed once per workgroup into LDS
+    template <int L>
+    __device__ __forceinline__ static void stage_key(int32_t* dst, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat)
+    {
+        for (int i = threadIdx.x; i < L * 256; i += blockDim.x) dst[i] = (int32_t)canon_pm2q(s1hat[i] + mont_mul(s2hat[i], SHIFT_R));
+    }
+    // r in (-q, q), r == x + 2^11 y (mod q) with |x|, |y| < 2^10  ->  x, y
+    __device__ __forceinline__ static void split(int32_t r, int32_t& x, int32_t& y)
+    {
+        const uint32_t t = canon_pm2q(r + OFF);            // (x + 2^10) + 2^11 (y + 2^10) in [0, 2^22): its own canonical residue
+        x = (int32_t)(t & ((1u << BITS) - 1)) - HALF;
+        y = (int32_t)(t >> BITS) - HALF;
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // Fused pipelines.  One workgroup per item (signature / verification), one wave per
 // polynomial row; NTT-domain vectors shared through LDS as LAZY signed residues (no

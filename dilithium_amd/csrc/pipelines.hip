@@ -539,8 +539,14 @@ struct S2X {
     using type = XAllLds;
     static constexpr int DW = 256;
 };
-template <int LEVEL, int YF>
-__global__ __launch_bounds__(256) void sign2_wpi_kernel(
+// Five waves per SIMD (<= 96 VGPRs): the per-item-key form of the paired rows wants 105-113 registers, and at four waves per SIMD it
+// loses more to exposed latency than the saved transforms give back (level 5, 8192 attempts: 77.7 us at four waves, 69.1 at five
+// with 2-10 spilled registers; the unpaired kernel: 74.0; profiles/r03_small_pair.txt).  The one-key form fits without help.
+#ifndef DIL_S2_ATTR
+#define DIL_S2_ATTR __attribute__((amdgpu_waves_per_eu(5)))
+#endif
+template <int LEVEL, int YF, bool SH>      // SH: one key for the batch -- its s1^ + 2^11 s2^ rows are formed once per workgroup, in LDS
+__global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
     const int32_t* __restrict__ c, const int32_t* __restrict__ y, const int32_t* __restrict__ w0,
     const uint8_t* __restrict__ w1, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
@@ -549,10 +555,13 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using XP = S2X;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW];
+    constexpr int PAIR_AT = 2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (SH ? L * 256 : 0)];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
+    if (SH) SmallPair::stage_key<L>(reinterpret_cast<int32_t*>(lds + PAIR_AT), s1hat, s2hat);
     __syncthreads();
+    const int32_t* s12 = reinterpret_cast<const int32_t*>(lds + PAIR_AT);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
     const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
     uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
@@ -562,42 +571,57 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
         const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
         const int32_t* s2 = s2hat + (shared_key ? 0 : km.key(it) * K) * 256;
         const int32_t* t0 = t0hat + (shared_key ? 0 : km.key(it) * K) * 256;
-        int32_t ch[4];
+        int32_t ch[4], cp[4];
         load_strided(ch, c + it * 256, lane);
-        int4 sn = *reinterpret_cast<const int4*>(s1 + 4 * lane);
+        int4 n1 = make_int4(0, 0, 0, 0), n2 = n1;
+        if (!SH || L < K) n2 = *reinterpret_cast<const int4*>(s2 + (SH ? L : 0) * 256 + 4 * lane);   // SH: s2's own rows matter from row L on
+        if (!SH) n1 = *reinterpret_cast<const int4*>(s1 + 4 * lane);
         ntt_fwd_core(ch, twf, lm);
-        uint32_t bits = 0, nh = 0;
-        for (int l = 0; l < L; l++) {
-            const int4 s = sn;
-            const size_t o = (it * L + l) * 256;
-            int32_t yv[4];
-            ys.raw(yv, y, it * L + l, lane);
-            if (l + 1 < L) sn = *reinterpret_cast<const int4*>(s1 + (l + 1) * 256 + 4 * lane);
-            int32_t r[4] = {mont_mul(ch[0], s.x), mont_mul(ch[1], s.y), mont_mul(ch[2], s.z), mont_mul(ch[3], s.w)};
-            ntt_inv_core(r, twi, lm);
-            ys.value(yv);
-            bool rej = false;
+        if (!SH) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const uint32_t v = canon_pm2q(r[m] + yv[m]);
-                rej |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
-                st_nt(z_out + o + lane + 64 * m, (int32_t)v);
-            }
-            if (__ballot(rej)) bits |= 1;
+            for (int m = 0; m < 4; m++) cp[m] = mont_mul(ch[m], SmallPair::SHIFT_R);      // c^ * 2^11
         }
+        uint32_t bits = 0, nh = 0;
+        // Row k: c s1[k] and c s2[k] from ONE inverse transform (SmallPair: both products are tiny, so c^ o (s1^ + 2^11 s2^) carries
+        // them side by side in one residue), c t0[k] from a second -- 1 + 2 K transforms per attempt instead of 1 + L + 2 K.
         for (int k = 0; k < K; k++) {
-            const int4 a2 = *reinterpret_cast<const int4*>(s2 + k * 256 + 4 * lane);
-            const int4 b0 = *reinterpret_cast<const int4*>(t0 + k * 256 + 4 * lane);
-            const size_t o = (it * K + k) * 256;
-            int32_t wv0[4];
+            const bool pair = k < L;
+            const int4 a1 = n1, a2 = n2, b0 = *reinterpret_cast<const int4*>(t0 + k * 256 + 4 * lane);      // (t0's row: used after the first transform)
+            const size_t o = (it * K + k) * 256, oz = (it * L + k) * 256;
+            int32_t wv0[4], yv[4];
             uint32_t wv1[4], hv[4];
             load_strided(wv0, w0 + o, lane);
             const uint32_t w1p = load_row_u8(w1 + o, lane);
-            int32_t a[4] = {mont_mul(ch[0], a2.x), mont_mul(ch[1], a2.y), mont_mul(ch[2], a2.z), mont_mul(ch[3], a2.w)};
-            int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
+            if (pair) ys.raw(yv, y, it * L + k, lane);
+            if (k + 1 < K) {
+                if (!SH && k + 1 < L) n1 = *reinterpret_cast<const int4*>(s1 + (k + 1) * 256 + 4 * lane);
+                if (!SH || k + 1 > L) n2 = *reinterpret_cast<const int4*>(s2 + (k + 1) * 256 + 4 * lane);
+            }
+            int32_t a[4];
+            if (pair && SH) {
+                const int4 p = *reinterpret_cast<const int4*>(s12 + k * 256 + 4 * lane);
+                a[0] = mont_mul(ch[0], p.x); a[1] = mont_mul(ch[1], p.y); a[2] = mont_mul(ch[2], p.z); a[3] = mont_mul(ch[3], p.w);
+            } else if (pair) {
+                a[0] = SmallPair::mul(ch[0], a1.x, cp[0], a2.x); a[1] = SmallPair::mul(ch[1], a1.y, cp[1], a2.y);
+                a[2] = SmallPair::mul(ch[2], a1.z, cp[2], a2.z); a[3] = SmallPair::mul(ch[3], a1.w, cp[3], a2.w);
+            } else {
+                a[0] = mont_mul(ch[0], a2.x); a[1] = mont_mul(ch[1], a2.y); a[2] = mont_mul(ch[2], a2.z); a[3] = mont_mul(ch[3], a2.w);
+            }
             ntt_inv_core(a, twi, lm);
+            int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
             ntt_inv_core(b, twi, lm);
-            bool rej1 = false, rej2 = false;
+            bool rej0 = false, rej1 = false, rej2 = false;
+            if (pair) {
+                ys.value(yv);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    int32_t cs1;
+                    SmallPair::split(a[m], cs1, a[m]);                       // a[m] := c s2, as the lone rows have it
+                    const uint32_t v = canon_pm2q(yv[m] + cs1);
+                    rej0 |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
+                    st_nt(z_out + oz + lane + 64 * m, (int32_t)v);
+                }
+            }
             unpack_row_u8(wv1, w1p, sc, lane);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -610,6 +634,7 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
                 nh += __popcll(hm);
             }
             store_row_u8(h_out + o, hv, sc, lane);
+            if (__ballot(rej0)) bits |= 1;
             if (__ballot(rej1)) bits |= 2;
             if (__ballot(rej2)) bits |= 4;
         }
@@ -618,13 +643,15 @@ __global__ __launch_bounds__(256) void sign2_wpi_kernel(
 }
 
 // Sign phase 2 for the signing LOOP (dil_sign_dev): same arithmetic, but an attempt is abandoned at its first failed
-// check, and the checks run in the order that rejects most per transform spent: (A) r0 = w0 - c s2 row by row
-// (fails 61 % of level-5 attempts), (B) z = y + c s1 (34 %), (C) c t0 and the hints.  flags reports only that first
-// failure (2 / 1 / 4, | 8 for too many hints); z and h are complete only when flags == 0, which is all the loop
-// reads.  r0 is parked in the attempt's own w0 scratch between (A) and (C).  Expected inverse transforms per level-5
-// attempt: ~10 instead of 23.
-template <int LEVEL, int YF>
-__global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
+// check; flags reports only that first failure (2: an r0 row, 1: a z row, 4: a c t0 row, | 8 for too many hints); z and h are
+// complete only when flags == 0, which is all the loop reads.  r0 is parked in the attempt's own w0 scratch until (C).
+//   one key (SH):   rows k = 0 .. K-1 in turn: r0[k] = w0[k] - c s2[k], then z[k] = y[k] + c s1[k] for k < L -- one inverse
+//                   transform per row gives both (SmallPair, the key's paired rows staged in LDS) -- then (C) c t0 and the hints.
+//   a key per item: (A) all r0 rows (61 % of level-5 attempts fail one), (B) all z rows (34 %), (C): every key row is HBM traffic
+//                   of its own there, so the rows that reject most go first and nothing is paired.
+// Expected inverse transforms per level-5 attempt: ~6 (one key) / ~10 (a key per item) instead of 16 / 23 for the full kernels.
+template <int LEVEL, int YF, bool SH>
+__global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
     const int32_t* __restrict__ c, const int32_t* __restrict__ y, int32_t* __restrict__ w0,
     const uint8_t* __restrict__ w1, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
@@ -633,10 +660,13 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using XP = S2X;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW];
+    constexpr int PAIR_AT = 2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (SH ? L * 256 : 0)];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     stage_tables(lds, fwd_tab, inv_tab);
+    if (SH) SmallPair::stage_key<L>(reinterpret_cast<int32_t*>(lds + PAIR_AT), s1hat, s2hat);
     __syncthreads();
+    const int32_t* s12 = reinterpret_cast<const int32_t*>(lds + PAIR_AT);
     const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
     const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
     uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
@@ -648,9 +678,60 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
         const int32_t* t0 = t0hat + (shared_key ? 0 : km.key(it) * K) * 256;
         int32_t ch[4];
         load_strided(ch, c + it * 256, lane);
-        int4 kn = *reinterpret_cast<const int4*>(s2 + 4 * lane);
+        int4 kn = make_int4(0, 0, 0, 0);
+        if (SH && L < K) kn = *reinterpret_cast<const int4*>(s2 + L * 256 + 4 * lane);         // one key: s2's own rows matter from row L on
+        if (!SH) kn = *reinterpret_cast<const int4*>(s2 + 4 * lane);
         ntt_fwd_core(ch, twf, lm);
         uint32_t bits = 0, nh = 0;
+        if constexpr (SH) {
+        // (A + B) row k: r0[k] = w0[k] - c s2[k] and, for k < L, z[k] = y[k] + c s1[k] -- both products from ONE inverse transform
+        // (SmallPair), r0 checked before z
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            const bool pair = k < L;
+            const int4 a2 = kn;
+            const size_t o = (it * K + k) * 256, oz = (it * L + k) * 256;
+            int32_t wv0[4], yv[4];
+            load_strided(wv0, w0 + o, lane);
+            if (pair) ys.raw(yv, y, it * L + k, lane);
+            if (k + 1 < K && k + 1 > L) kn = *reinterpret_cast<const int4*>(s2 + (k + 1) * 256 + 4 * lane);
+            int32_t a[4];
+            if (pair) {
+                const int4 p = *reinterpret_cast<const int4*>(s12 + k * 256 + 4 * lane);
+                a[0] = mont_mul(ch[0], p.x); a[1] = mont_mul(ch[1], p.y); a[2] = mont_mul(ch[2], p.z); a[3] = mont_mul(ch[3], p.w);
+            } else {
+                a[0] = mont_mul(ch[0], a2.x); a[1] = mont_mul(ch[1], a2.y); a[2] = mont_mul(ch[2], a2.z); a[3] = mont_mul(ch[3], a2.w);
+            }
+            ntt_inv_core(a, twi, lm);
+            bool rej = false, rejz = false;
+            if (pair) {
+                ys.value(yv);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    int32_t cs1;
+                    SmallPair::split(a[m], cs1, a[m]);
+                    const uint32_t v = canon_pm2q(yv[m] + cs1);
+                    rejz |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
+                    z_out[oz + lane + 64 * m] = (int32_t)v;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t r0 = canon_pm2q(wv0[m] - a[m]);
+                rej |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
+                w0[o + lane + 64 * m] = (int32_t)r0;
+            }
+            if (__ballot(rej)) {
+                bits = 2;
+                break;
+            }
+            if (__ballot(rejz)) {
+                bits = 1;
+                break;
+            }
+        }
+        } else {
+        // a key per item: every row of s1^ / s2^ is HBM traffic of its own, so the rows that reject most go first and nothing is paired
         // (A) r0 rows
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
@@ -698,6 +779,7 @@ __global__ __launch_bounds__(256) void sign2_early_wpi_kernel(
                     break;
                 }
             }
+        }
         }
         // (C) c t0 rows and the hints
         if (!bits) {
@@ -1087,16 +1169,18 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
     if (y_fmt == Y_PACKED && !use_wpi(batch, t)) return hipErrorInvalidValue;      // packed y: wave-per-item shapes only
     if (use_wpi(batch, t) && w0_scratch) {      // the signing loop's early-exit form (w0 is its own scratch, reused for r0)
         if (w0_scratch != w0) return hipErrorInvalidValue;
-#define DIL_S2E2(LV, YF)                                                                                                         \
+#define DIL_S2E2(LV, YF, SH)                                                                                                     \
     {                                                                                                                            \
-        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV, YF>, 256, t.wpi_blocks_per_cu, t.device)); \
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_early_wpi_kernel<LV, YF, SH>, 256, t.wpi_blocks_per_cu, t.device)); \
         note_launch("sign2_early_wpi", g, 4, batch);                                                                             \
-        hipLaunchKernelGGL((sign2_early_wpi_kernel<LV, YF>), g, 256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, \
+        hipLaunchKernelGGL((sign2_early_wpi_kernel<LV, YF, SH>), g, 256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, \
                            km, t.fwd, t.inv_pipe);                                                                               \
     }
-#define DIL_S2E(LV)                              \
-    if (y_fmt == Y_PACKED) DIL_S2E2(LV, Y_PACKED) \
-    else DIL_S2E2(LV, Y_I32)                      \
+#define DIL_S2E(LV)                                                \
+    if (y_fmt == Y_PACKED && shared_key) DIL_S2E2(LV, Y_PACKED, true) \
+    else if (y_fmt == Y_PACKED) DIL_S2E2(LV, Y_PACKED, false)      \
+    else if (shared_key) DIL_S2E2(LV, Y_I32, true)                 \
+    else DIL_S2E2(LV, Y_I32, false)                                \
     break
         switch (level) {
         case 2: DIL_S2E(2);
@@ -1109,16 +1193,18 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
         return hipGetLastError();
     }
     if (use_wpi(batch, t)) {
-#define DIL_S2W2(LV, YF)                                                                                                         \
+#define DIL_S2W2(LV, YF, SH)                                                                                                     \
     {                                                                                                                            \
-        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<LV, YF>, 256, t.wpi_blocks_per_cu, t.device)); \
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<LV, YF, SH>, 256, t.wpi_blocks_per_cu, t.device)); \
         note_launch("sign2_wpi", g, 4, batch);                                                                                   \
-        hipLaunchKernelGGL((sign2_wpi_kernel<LV, YF>), g, 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, \
+        hipLaunchKernelGGL((sign2_wpi_kernel<LV, YF, SH>), g, 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, \
                            t.inv_pipe);                                                                                          \
     }
-#define DIL_S2W(LV)                              \
-    if (y_fmt == Y_PACKED) DIL_S2W2(LV, Y_PACKED) \
-    else DIL_S2W2(LV, Y_I32)                      \
+#define DIL_S2W(LV)                                                \
+    if (y_fmt == Y_PACKED && shared_key) DIL_S2W2(LV, Y_PACKED, true) \
+    else if (y_fmt == Y_PACKED) DIL_S2W2(LV, Y_PACKED, false)      \
+    else if (shared_key) DIL_S2W2(LV, Y_I32, true)                 \
+    else DIL_S2W2(LV, Y_I32, false)                                \
     break
         switch (level) {
         case 2: DIL_S2W(2);

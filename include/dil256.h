@@ -143,18 +143,24 @@ int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const i
  * phase 2 (FSM2): z = y + c*s1, r0 = w0 - c*s2, ct0 = c*t0, h = MakeHint(r0 + ct0, w1);
  *   flags[i]: bit0 ||z|| >= gamma1-beta, bit1 ||r0|| >= gamma2-beta, bit2 ||ct0|| >= gamma2,
  *   bit3 #hints > omega  (norm_check.v:84-105, makehint.v:98-99,176-177); 0 = accept.
- * s1hat [batch|1][L][256], s2hat / t0hat [batch|1][K][256]: NTT domain, canonical. */
+ * s1hat [batch|1][L][256], s2hat / t0hat [batch|1][K][256]: NTT domain, canonical.
+ * Precondition of phase 2: ||c s1||_inf, ||c s2||_inf <= 1023 -- true for every challenge (tau coefficients +-1) with every s1, s2 a
+ * secret-key byte string can decode to (|s| <= 11 at worst), the only inputs the scheme produces.  The wave-per-item kernels read
+ * c s1[k] and c s2[k] off ONE inverse transform of c^ o (s1^[k] + 2^11 s2^[k]) (1 + 2 K transforms per attempt instead of
+ * 1 + L + 2 K); outside the bound the two would overlap.  Results inside it are the reference's integers, bit for bit. */
 int dil_sign_phase1_dev(uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y, int level, size_t batch,
                         int shared_key, void* stream);
 int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, const int32_t* w0,
                         const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
                         size_t batch, int shared_key, void* stream);
 
-/* Phase 2 as the signing LOOP runs it (dil_sign_dev): an attempt is abandoned at its FIRST failed check, the checks ordered
- * r0 rows (flag 2), z rows (flag 1), c t0 rows (flag 4, | 8 for too many hints counted so far); z and h are complete only
- * where flags == 0 (flags & 8 alone: all checks ran, hint count over omega).  w0 is IN/OUT: on return it holds r0 = w0 - c s2
- * of the rows that were evaluated (FSM2 of combined_top.v:1981-2229 likewise stops at the first failed norm check).  Batches below the
- * wave-per-item threshold (8 x #CUs items, option fused_mode) run the full phase 2 instead: every flag bit, w0 untouched. */
+/* Phase 2 as the signing LOOP runs it (dil_sign_dev): an attempt is abandoned at its FIRST failed check; flags != 0 iff the attempt is
+ * rejected and names that first check: 2 an r0 row, 1 a z row, 4 a c t0 row (| 8 for too many hints counted so far; 8 alone: all checks
+ * ran, hint count over omega).  Order of evaluation: shared_key: rows k = 0 .. K-1 in turn, r0[k] before z[k] (one transform yields
+ * both, see below); a key per item: all r0 rows, then all z rows; then the c t0 rows.  z and h are complete only where flags == 0.
+ * w0 is IN/OUT: on return it holds r0 = w0 - c s2 of the rows that were evaluated.  (The reference's FSM2, combined_top.v:1981-2229,
+ * evaluates every check and tests `reject_mh || norm_rejected` at the end, :2218; stopping early is this runtime's.)  Batches below
+ * the wave-per-item threshold (8 x #CUs items, option fused_mode) run the full phase 2 instead: every flag bit, w0 untouched. */
 int dil_sign_phase2_early_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, int32_t* w0,
                               const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
                               size_t batch, int shared_key, void* stream);

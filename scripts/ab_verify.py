@@ -59,6 +59,19 @@ for path in a.libs:
     assert L_.dil_init(0) == 0
     libs.append((os.path.basename(path), L_))
 E = libs[0][1]
+if a.kind == "sign2":
+    # phase 2 needs a REAL challenge and key: c = SampleInBall(c~) (tau coefficients +-1), s1 / s2 with |coefficients| <= eta, t0 below 2^12 --
+    # the kernel reads c s1 and c s2 off one transform, which is exact for such inputs only (pipeline_common.hpp SmallPair)
+    E.dil_sample_in_ball_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    eta = {2: 2, 3: 4, 5: 2}[a.level]
+    small = lambda lim, *sh: (torch.randint(-lim, lim + 1, sh, dtype=torch.int64, device="cuda", generator=g) % Q).to(torch.int32)  # noqa: E731
+    s1h, s2h, t0h = small(eta, nk, L, 256), small(eta, nk, K, 256), small(4095, nk, K, 256)
+    for t in (s1h, s2h, t0h):
+        assert E.dil_ntt_dev(p(t), t.numel() // 256, None) == 0
+    for st in sets:
+        ct = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        assert E.dil_sample_in_ball_dev(p(st[2]), p(ct), a.level, n, None) == 0
+    torch.cuda.synchronize()
 e0, e1 = C.c_void_p(), C.c_void_p()
 E.dil_event_create(C.byref(e0))
 E.dil_event_create(C.byref(e1))

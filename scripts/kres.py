@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """kernel resource usage of a .hip file from hipcc's -Rpass-analysis remarks: VGPRs, AGPRs, spills, LDS, occupancy
-usage: scripts/kres.py dilithium_amd/csrc/pipelines.hip [substring]"""
+usage: scripts/kres.py dilithium_amd/csrc/pipelines.hip [substring] [-DFLAG ...]"""
 import re
 import subprocess
 import sys
 
 f = sys.argv[1]
-filt = sys.argv[2] if len(sys.argv) > 2 else ""
+extra = [x for x in sys.argv[2:] if x.startswith("-D")]
+rest = [x for x in sys.argv[2:] if not x.startswith("-D")]
+filt = rest[0] if rest else ""
 out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only",
-                      "-Rpass-analysis=kernel-resource-usage", f, "-o", "/tmp/kres.o"], capture_output=True, text=True).stderr
+                      "-Rpass-analysis=kernel-resource-usage", *extra, f, "-o", "/tmp/kres.o"], capture_output=True, text=True).stderr
 cur = None
 rows = []
 for line in out.splitlines():

@@ -107,24 +107,45 @@ def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, mi
     assert (z.cpu().numpy() == oz).all() and (h.cpu().numpy() == oh).all()
     acc = ofl == 0
     assert acc.any() and (~acc).any()
-    # phase 2 as the signing loop runs it: stop at the first failed check (r0 -> 2, z -> 1, c t0 -> 4 [| 8])
+    # phase 2 as the signing loop runs it: stop at the FIRST failed check (include/dil256.h: one key -- rows in turn, r0[k] (-> 2) then
+    # z[k] (-> 1); a key per item -- all r0 rows, then all z rows); then the c t0 rows (-> 4 [| 8]).  The expectation is rebuilt row
+    # by row from the oracle's z and c s2.
     w0s = dw0.clone()
     ze, he, fle = api.sign_phase2_early(dc, dy, w0s, dw1, ds1, ds2, dt0, level, shared_key=shared)
     steps("sign2_early_wpi", n, min_steps)
     fle = fle.cpu().numpy()
+    K, L = KL[level]
+    p = dk.PARAMS[level]
+    cen = lambda a: np.where(a > Q // 2, a - Q, a)  # noqa: E731
+    first_r0 = np.full(n, 99)
+    first_z = np.full(n, 99)
+    for lo in range(0, n, 4096):
+        hi = min(n, lo + 4096)
+        chat = oracle.ntt(c[lo:hi])[:, None, :].repeat(K, axis=1)
+        s2 = np.broadcast_to(s2h[0], (hi - lo, K, N)) if shared else s2h[lo:hi]
+        cs2 = oracle.invntt(oracle.pointwise(np.ascontiguousarray(chat), np.ascontiguousarray(s2)))
+        r0 = np.mod(ow0[lo:hi].astype(np.int64) - cs2, Q)
+        bad_r0 = np.abs(cen(r0)).max(axis=2) >= p.gamma2 - p.beta                      # [items, K]
+        bad_z = np.abs(cen(oz[lo:hi].astype(np.int64))).max(axis=2) >= p.gamma1 - p.beta    # [items, L]
+        first_r0[lo:hi] = np.where(bad_r0.any(axis=1), bad_r0.argmax(axis=1), 99)
+        first_z[lo:hi] = np.where(bad_z.any(axis=1), bad_z.argmax(axis=1), 99)
     r0f, zf, ctf = (ofl & 2) != 0, (ofl & 1) != 0, (ofl & 4) != 0
-    assert (fle[r0f] == 2).all()
-    assert (fle[~r0f & zf] == 1).all()
-    m4 = ~r0f & ~zf & ctf
+    assert ((first_r0 < 99) == r0f).all() and ((first_z < 99) == zf).all()             # the rebuilt rows agree with the oracle's flags
+    if shared:
+        want = np.where(first_r0 <= first_z, 2, 1)         # one key: rows in turn, r0[k] before z[k] (both from one transform)
+    else:
+        want = np.where(first_r0 < 99, 2, 1)               # a key per item: all r0 rows, then all z rows
+    early = r0f | zf
+    assert (fle[early] == want[early]).all()
+    m4 = ~early & ctf
     assert ((fle[m4] & ~8) == 4).all()
-    rest = ~r0f & ~zf & ~ctf
+    rest = ~early & ~ctf
     assert (fle[rest] == ofl[rest]).all()                  # 0, or 8 (all checks passed, too many hints)
     assert (ze.cpu().numpy()[acc] == oz[acc]).all() and (he.cpu().numpy()[acc] == oh[acc]).all()
-    # the scratch holds r0 = w0 - c s2 for every row that was evaluated: all K rows of the attempts that got past stage (A)
-    K = KL[level][0]
-    if (~r0f).any():
-        i = int(np.flatnonzero(~r0f)[-1])
-        cs2 = oracle.invntt(oracle.pointwise(np.broadcast_to(oracle.ntt(c[i]), (K, N)), s2h[0 if shared else i]))
+    # the scratch holds r0 = w0 - c s2 for every row that was evaluated: all K rows of an attempt that reached stage (C)
+    if (~early).any():
+        i = int(np.flatnonzero(~early)[-1])
+        cs2 = oracle.invntt(oracle.pointwise(np.broadcast_to(oracle.ntt(c[i]), (K, N)).copy(), np.ascontiguousarray(s2h[0 if shared else i])))
         assert (w0s[i].cpu().numpy() == np.mod(ow0[i].astype(np.int64) - cs2, Q)).all()
 
 
