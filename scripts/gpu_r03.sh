@@ -74,4 +74,21 @@ if has signpmc; then      # counter evidence for the sign path: sign2_wpi_kernel
   for d in $OUT/${TAG}_spmc*/; do python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py $d/p_results.db | grep -E "sign2_wpi|matvec_shared|kernel " | grep -v "at::" | cut -c1-190; done > $OUT/${TAG}_sign_pmc.txt 2>&1
   rm -rf $OUT/${TAG}_spmc*/
   cat $OUT/${TAG}_sign_pmc.txt | head -50
+  python - "$OUT/${TAG}_sign_pmc.txt" "$OUT/${TAG}_pmc_summary.json" <<'PY'     # VALU instructions per attempt -> the summary bench.py reads
+import json, re, sys
+txt, js = sys.argv[1], sys.argv[2]
+v = {}
+for line in open(txt):
+    m = re.search(r"(sign2_wpi_kernel|matvec_shared_kernel)<.*SQ_INSTS_VALU\s+([0-9.]+)", line)
+    if m:
+        v["phase2" if m.group(1).startswith("sign2") else "phase1"] = float(m.group(2)) / 8192
+try:
+    d = json.load(open(js))
+except Exception:
+    d = {}
+if len(v) == 2:
+    d["sign_valu_insts_per_attempt"] = dict(v, source="SQ_INSTS_VALU of matvec_shared_kernel<8,7,5,OUT_W1W0,16> / sign2_wpi_kernel<5> over 8192 attempts")
+    json.dump(d, open(js, "w"), indent=1)
+    print("sign VALU per attempt:", v)
+PY
 fi
