@@ -557,7 +557,9 @@ def main():
             per_s = lambda ms: VBATCH / (ms * 1e-3)  # noqa: E731
             sec["scheme_level3_wire_format"] = {
                 "note": "pk/sk/sig bytes in HBM -> bytes in HBM; SHAKE, samplers, codecs, rejection loop all on the device; "
-                        "verification reads the packed fields inside the fused kernel (no int32 temporaries)",
+                        "verification reads the packed fields inside the fused kernel (no int32 temporaries).  Rates are whole calls "
+                        "timed with HIP events around back-to-back calls on one stream; the sign rates are therefore HOST-INCLUSIVE: "
+                        "dil_sign_dev synchronises the stream once per rejection round (an 8-byte count read back, ~10 us per round)",
                 "keygen_per_s": per_s(kg_ms), "sign_shared_key_per_s": per_s(sg_ms), "sign_distinct_keys_per_s": per_s(sgd_ms),
                 "verify_shared_pk_per_s": per_s(vf_ms), "verify_distinct_pk_per_s": per_s(vfd_ms),
                 "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "sample_in_ball_bits_kernel + "
