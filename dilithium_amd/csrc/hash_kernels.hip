@@ -195,6 +195,56 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_raw_kernel(uint8_t* __res
     flush(NBLK - 1, std::integral_constant<int, LASTW>());
 }
 
+// The raw stream from TWO lanes per sponge, for rounds too narrow to fill the chip with one sponge per lane (a lone wave pays ~5
+// cycles per dependent instruction: 8 us per permutation here against 9.1): 32 polynomials per one-wave workgroup, lane 2i the even
+// dwords of sponge i's stream, lane 2i + 1 the odd ones; each rate block leaves through an LDS transpose as 34 consecutive dwords
+// per polynomial.  The narrow late rounds of the signing loop were 76 us of int32 extraction (expand_mask2_kernel); this is ~45.
+template <int B>
+__global__ __launch_bounds__(HASH_BS) void expand_mask_raw2_kernel(uint8_t* __restrict__ yp, const uint64_t* __restrict__ rhoprime,
+                                                                   const uint32_t* __restrict__ kappa, int L, size_t nitems)
+{
+    constexpr int POLYB = 32 * B, DW = POLYB / 4, NBLK = (DW + 33) / 34, LASTD = DW - 34 * (NBLK - 1);   // 160 (144) dwords, 5 blocks, 24 (8) in the last
+    static_assert(HASH_BS == 64, "one wave per workgroup");
+    const int lane = threadIdx.x, col = lane >> 1;
+    const bool hi = (lane & 1) != 0;
+    const size_t first = (size_t)blockIdx.x * 32, total = nitems * (size_t)L;
+    size_t p = first + col;
+    if (p >= total) p = total - 1;                   // pairs past the end run along (they help store) but own nothing
+    const int live = (int)(total - first < 32 ? total - first : 32);
+    const size_t item = p / (size_t)L;
+    const uint32_t nonce = (kappa[item] + (uint32_t)(p % (size_t)L)) & 0xFFFFu;
+    Shake2<17> sp;
+    sp.init(hi);
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const uint64_t v = rhoprime[item * 8 + w];
+        sp.s[w] = hi ? (uint32_t)(v >> 32) : (uint32_t)v;
+    }
+    sp.s[8] = hi ? 0u : (nonce | (0x1Fu << 16));
+    sp.s[16] ^= hi ? 0x80000000u : 0u;
+    __shared__ uint32_t ring[34 * 33];               // [stream dword][sponge], rows padded to 33 dwords: conflict-free both ways
+    uint8_t* wave_dst = yp + first * POLYB;
+    auto flush = [&](int blk, auto nd_c) {
+        constexpr int ND = decltype(nd_c)::value;    // stream dwords of this block that belong to the polynomial (even)
+#pragma unroll
+        for (int w = 0; w < ND / 2; w++) ring[(2 * w + (hi ? 1 : 0)) * 33 + col] = sp.s[w];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < (32 * ND + 63) / 64; j++) {
+            const int i = lane + 64 * j, pl = i / ND, d = i - pl * ND;
+            if (pl < live) *reinterpret_cast<uint32_t*>(wave_dst + (size_t)pl * POLYB + 136 * blk + 4 * d) = ring[d * 33 + pl];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    };
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK - 1; blk++) {
+        keccak2_f1600(sp.s, hi);
+        flush(blk, std::integral_constant<int, 34>());
+    }
+    keccak2_f1600(sp.s, hi);
+    flush(NBLK - 1, std::integral_constant<int, LASTD>());
+}
+
 // Two-lane form of ExpandMask for few entries (the narrow late rounds of the signing loop, single signatures): a lone wave
 // pays ~5 cycles per dependent instruction, so the extraction is unrolled at compile time -- nothing in it depends on the data.
 // Lane 2i holds the even dwords of sponge i's output stream, lane 2i + 1 the odd ones; after each permutation both lanes fetch
@@ -684,6 +734,12 @@ hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const
     const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t total = nitems * (size_t)L;
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
+    if (total <= (size_t)two_lane_max_sponges.load(std::memory_order_relaxed)) {        // latency-bound: two lanes per sponge
+        const int grid = (int)((total + 31) / 32);
+        if (level == 2) hipLaunchKernelGGL(expand_mask_raw2_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
+        else hipLaunchKernelGGL(expand_mask_raw2_kernel<20>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
+        return hipGetLastError();
+    }
     const int grid = (int)((total + HASH_BS - 1) / HASH_BS);
     if (level == 2) hipLaunchKernelGGL(expand_mask_raw_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
     else hipLaunchKernelGGL(expand_mask_raw_kernel<20>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);

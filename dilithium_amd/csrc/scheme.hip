@@ -278,12 +278,9 @@ int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ct
                       const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
                       int phases = 3, bool early_exit = false)
 {
-    // y: int32, or -- the loop's large rounds -- the raw B-bit SHAKE256 stream, unpacked by phase 1 / phase 2 as they load it
-    // (below `two_lane_max_sponges` polynomials ExpandMask is latency-bound and its two-lane form -- int32 output -- is the faster one)
-    int Kq, Lq;
-    (void)level_kl(level, &Kq, &Lq);
-    const int y_fmt = (t.packed_y && phases == 3 && dil::fused_wpi_shape(batch, T) &&
-                       batch * (size_t)Lq > (size_t)dil::two_lane_max_sponges.load(std::memory_order_relaxed)) ? dil::Y_PACKED : dil::Y_I32;
+    // y: int32, or -- every round wide enough for the wave-per-item kernels -- the raw B-bit SHAKE256 stream, unpacked by phase 1 /
+    // phase 2 as they load it (ExpandMask picks one or two lanes per sponge by the round's width either way)
+    const int y_fmt = (t.packed_y && phases == 3 && dil::fused_wpi_shape(batch, T)) ? dil::Y_PACKED : dil::Y_I32;
     if (phases & 1) {
         if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, batch, s));
         else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
@@ -328,7 +325,7 @@ int sign_attempt_overlapped(Device& dv, const dil::Tables& T, const AttemptScrat
                             const int32_t* s2hat, const int32_t* t0hat, int level, int K, int L, size_t E, int shared_key, hipStream_t s,
                             dil::KeyMap km, bool early_exit)
 {
-    const int y_fmt = (t.packed_y && E * (size_t)L > (size_t)dil::two_lane_max_sponges.load(std::memory_order_relaxed)) ? dil::Y_PACKED : dil::Y_I32;
+    const int y_fmt = t.packed_y ? dil::Y_PACKED : dil::Y_I32;
     const size_t ypoly = y_fmt == dil::Y_PACKED ? (size_t)(level == 2 ? 576 : 640) : 1024, w1pb = (size_t)K * (level == 2 ? 192 : 128);
     dil::rt::AuxStream& xs = dv.aux;
     hipStream_t hs = xs.s;

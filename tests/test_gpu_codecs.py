@@ -494,6 +494,29 @@ def test_concurrent_calls_on_two_streams(gpu, kat_msgs):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("n", [700, 3000, 9000])
+def test_sign_options_give_identical_signatures(gpu, level, n):
+    """the signing loop's alternative code paths against each other on the same messages: y as int32 vs ExpandMask's raw stream (the
+    one- and the two-lanes-per-sponge writers: wide and narrow rounds), the challenge as one launch vs two, early-exit phase 2 vs full"""
+    from dilithium_amd import api
+    g = gpu.Generator(device="cuda").manual_seed(31 * level + n)
+    seed = gpu.randint(0, 256, (1, 32), dtype=gpu.uint8, device="cuda", generator=g)
+    mu = gpu.randint(0, 256, (n, 64), dtype=gpu.uint8, device="cuda", generator=g)
+    pk, sk = api.keygen(seed, level)
+    ref, ref_att = api.sign(sk, mu, level, shared_sk=True)
+    assert int(api.verify_sig(pk, ref, mu, level, shared_pk=True).abs().sum()) == 0
+    try:
+        for opt in ("packed_y", "fuse_challenge", "sign_early"):
+            api.set_option(opt, 0)
+            sig, att = api.sign(sk, mu, level, shared_sk=True)
+            api.set_option(opt, 1)
+            assert gpu.equal(sig, ref) and gpu.equal(att, ref_att), opt
+    finally:
+        for opt in ("packed_y", "fuse_challenge", "sign_early"):
+            api.set_option(opt, 1)
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
 def test_full_size_roundtrip_keygen_sign_verify(gpu, level):
     """BASELINE config sizes (8192 per GPU), size-independent property: fresh keys -> signatures -> all verify; a
     signature never verifies under its neighbour's key; signing is deterministic"""
