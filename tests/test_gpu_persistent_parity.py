@@ -150,6 +150,46 @@ def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, mi
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("shared", [True, False])
+def test_sign_phase2_paired_rows_at_the_edge_of_what_key_bytes_decode_to(gpu, oracle, level, shared):
+    """Phase 2 reads c s1[k] and c s2[k] off ONE inverse transform (pipeline_common.hpp SmallPair), exact while both stay within
+    +-1023.  A secret key's eta-bit fields decode to eta - v for ANY field value v -- [-11, 4] at level 3, [-5, 2] at levels 2 / 5 --
+    so malformed key bytes give larger |s| than a well-formed key (|s| <= eta) and are the worst case the scheme can present:
+    tau * 11 = 539 at level 3.  Keys drawn from that full decoder range, with the extremes forced into every row; every z, h
+    and flag vs the oracle, both key forms, at a batch where the persistent loop re-enters."""
+    from dilithium_amd import api
+    n = 9216
+    nk = 1 if shared else n
+    K, L = KL[level]
+    lo, hi = (-11, 4) if level == 3 else (-5, 2)
+    A, y, c, _, _ = big_inputs(level, n, 9100 + level + shared, nk)
+    rng = np.random.default_rng(77 + level)
+    s1 = rng.integers(lo, hi + 1, (nk, L, N))
+    s2 = rng.integers(lo, hi + 1, (nk, K, N))
+    s1[:, :, :128] = lo                                  # a run of the extreme value in every row, and challenges whose tau
+    s2[:, :, 100:228] = lo                               # coefficients are +1 (-1) side by side: |c s| = tau |lo|, as large as it can get
+    tau = dk.PARAMS[level].tau
+    for i in range(8):
+        c[i] = 0
+        c[i, 7 * i:7 * i + tau] = 1 if i % 2 == 0 else Q - 1
+    s1h = oracle.ntt(np.mod(s1, Q).astype(np.int32))
+    s2h = oracle.ntt(np.mod(s2, Q).astype(np.int32))
+    t0h = oracle.ntt(np.mod(rng.integers(-(1 << 12) + 1, (1 << 12) + 1, (nk, K, N)), Q).astype(np.int32))
+    ow1, ow0 = oracle.sign_phase1(level, A, y)
+    del A
+    z, h, fl = api.sign_phase2(dev(gpu, c), dev(gpu, y), dev(gpu, ow0), dev(gpu, ow1, np.uint8), dev(gpu, s1h), dev(gpu, s2h), dev(gpu, t0h),
+                               level, shared_key=shared)
+    steps("sign2_wpi", n, 2)
+    oz, oh, ofl = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
+    assert (fl.cpu().numpy() == ofl).all()
+    assert (z.cpu().numpy() == oz).all() and (h.cpu().numpy() == oh).all()
+    # the products really are larger than a well-formed key's beta (so this is not the ordinary case again) and inside the bound
+    cs = oracle.invntt(oracle.pointwise(np.broadcast_to(oracle.ntt(c[:1]), (L, N)).copy(), np.ascontiguousarray(s1h[0])))
+    big = np.abs(np.where(cs > Q // 2, cs.astype(np.int64) - Q, cs)).max()
+    assert big == tau * -lo and dk.PARAMS[level].beta < big <= 1023
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
 @pytest.mark.parametrize("n,min_steps", [(8192, 2), (20000, 3)])
 def test_matvec_wpi_persistent_loop_vs_oracle(gpu, oracle, level, n, min_steps):
     """matvec_wpi_kernel<K, L, LEVEL, OUT_W> (a matrix per item), every output"""
