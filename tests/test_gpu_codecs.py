@@ -456,6 +456,14 @@ def test_scheme_entry_points_edge_cases(gpu):
     mu0 = gpu.zeros((1, 64), dtype=gpu.uint8, device="cuda")
     verdict = gpu.zeros(1, dtype=gpu.int32, device="cuda")
     assert L.dil_verify_sig_dev(verdict.data_ptr(), buf.data_ptr() + 1, sg.data_ptr(), mu0.data_ptr(), 3, 1, 0, None) != 0
+    # the one-launch challenge: empty batch is a no-op, unknown level and a misaligned mu are refused
+    ct = gpu.zeros((2, 32), dtype=gpu.uint8, device="cuda")
+    cc = gpu.zeros((2, 256), dtype=gpu.int32, device="cuda")
+    w1p = gpu.zeros((2, 6 * 128 + 8), dtype=gpu.uint8, device="cuda")
+    mu2 = gpu.zeros((2 * 64 + 8,), dtype=gpu.uint8, device="cuda")
+    assert L.dil_challenge_dev(ct.data_ptr(), cc.data_ptr(), mu2.data_ptr(), w1p.data_ptr(), 3, 0, None) == 0
+    assert L.dil_challenge_dev(ct.data_ptr(), cc.data_ptr(), mu2.data_ptr(), w1p.data_ptr(), 4, 2, None) != 0
+    assert L.dil_challenge_dev(ct.data_ptr(), cc.data_ptr(), mu2.data_ptr() + 4, w1p.data_ptr(), 3, 2, None) != 0
 
 
 def test_concurrent_calls_on_two_streams(gpu, kat_msgs):
