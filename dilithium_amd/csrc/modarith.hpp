@@ -43,6 +43,24 @@ __device__ __forceinline__ int32_t sgn(int32_t x)
     return m;
 }
 
+#ifdef DIL_BFLY64     // variant builds only (A/B, profiles/r04*): the constant product through two 64-bit multiply-adds
+// y * w = hi32(p - m q) with p = y wt (v_mad_i64_i32), m = lo32(p) q^-1 (v_mul_lo_u32), p - m q (v_mad_i64_i32): no wq operand
+__device__ __forceinline__ int64_t mad64(int32_t a, int32_t b, int64_t c)
+{
+    int64_t d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+__device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t)
+{
+    int64_t p;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(y), "v"(wt) : "vcc");
+    const int32_t m = (int32_t)((uint32_t)p * QINV);
+    return (int32_t)(mad64(m, -Q, p) >> 32);
+}
+#define DIL_MONT_TW_DEFINED
+#endif
+#ifndef DIL_MONT_TW_DEFINED
 // y * w for a table constant w = (wt, wq):  wt = centred(w * 2^32 mod q), wq = wt * q^-1 mod 2^32.
 // Any int32 y; |result| < q (|y * wt| < 2^31 * q/2).      v_mul_lo_u32, 2 x v_mul_hi_i32, v_sub
 __device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
@@ -51,6 +69,7 @@ __device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
     return mulhi_i32(y, wt) - mulhi_i32(m, Q);
 }
 
+#endif
 // p * 2^-32 mod q for |p| < 2^31 * q;  |result| < q.
 __device__ __forceinline__ int32_t mont_red64(int64_t p)
 {

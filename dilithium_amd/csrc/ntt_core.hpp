@@ -70,6 +70,63 @@ struct TwLds {
     __device__ __forceinline__ Tw8 get() const { return load_tw8(tab + PASS * TW_PASS_STRIDE, lane); }
 };
 
+// LDS, compact (round 4): a pass's twiddles depend on lane >> s only -- forward pass p on lane >> (6 - 2p), inverse pass p on
+// lane >> 2p -- so the [pass][half][lane][4] image holds 1 + 4 + 16 + 64 distinct 32-byte entries per direction, not 4 x 64.
+// The compact table keeps exactly those: the wave-uniform pass (forward 0, inverse 3) rides in SGPRs as the scalar operand of its
+// multiplies (no LDS read at all), the 4- and 16-entry passes are broadcast reads (lanes of one entry read the same 16 bytes:
+// no bank conflict), the 64-entry pass is lane-linear as before.  2 x 2688 B instead of 2 x 8 KiB of LDS per workgroup -- what
+// lets a second 16-wave workgroup of the shared-key kernels fit a CU (pipelines.hip) -- and 6 instead of 8 ds_read_b128 per transform.
+struct TwU {
+    uint32_t v[8];        // same slots as Tw8, wave-uniform
+};
+constexpr int TWC_P4 = 0, TWC_P16 = 32, TWC_P64 = 160;     // dword offsets of the 4-, 16- and 64-entry passes: [half][entry][4]
+constexpr int TWC_DWORDS = 672;                             // per direction
+template <bool FWD>
+struct TwLdsC {
+    const uint32_t* tab;   // LDS, this direction's compact table
+    int lane;
+    TwU u;                 // the uniform pass
+    // global_tab: the full [pass][half][lane][4] image of this direction (kernel argument -> scalar loads)
+    __device__ __forceinline__ TwLdsC(const uint32_t* lds_tab, const uint32_t* __restrict__ global_tab, int lane_) : tab(lds_tab), lane(lane_)
+    {
+        const uint32_t* g = global_tab + (FWD ? 0 : 3 * TW_PASS_STRIDE);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u.v[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)g[i]);
+            u.v[4 + i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)g[256 + i]);
+        }
+    }
+    template <int PASS>
+    __device__ __forceinline__ auto get() const
+    {
+        if constexpr (PASS == (FWD ? 0 : 3)) {
+            return u;
+        } else {
+            constexpr int E = FWD ? (PASS == 1 ? 4 : PASS == 2 ? 16 : 64) : (PASS == 0 ? 64 : PASS == 1 ? 16 : 4);
+            constexpr int OFF = E == 4 ? TWC_P4 : E == 16 ? TWC_P16 : TWC_P64;
+            const int e = E == 64 ? lane : E == 16 ? lane >> 2 : lane >> 4;
+            const uint4 a = *reinterpret_cast<const uint4*>(tab + OFF + 4 * e);
+            const uint4 b = *reinterpret_cast<const uint4*>(tab + OFF + 4 * E + 4 * e);
+            Tw8 t;
+            t.v[0] = a.x; t.v[1] = a.y; t.v[2] = a.z; t.v[3] = a.w;
+            t.v[4] = b.x; t.v[5] = b.y; t.v[6] = b.z; t.v[7] = b.w;
+            return t;
+        }
+    }
+};
+// one 16-byte granule of the compact table (g in [0, 168)) <- the full image: which (pass, half, lane) it is
+template <bool FWD>
+__device__ __forceinline__ int twc_source_granule(int g)
+{
+    int e_log, h, e;           // entries = 1 << e_log
+    if (g < 8) { e_log = 2; h = g >> 2; e = g & 3; }
+    else if (g < 40) { e_log = 4; h = (g - 8) >> 4; e = (g - 8) & 15; }
+    else { e_log = 6; h = (g - 40) >> 6; e = (g - 40) & 63; }
+    const int pass = FWD ? e_log / 2 : 3 - e_log / 2;
+    const int lane = e << (6 - e_log);
+    return pass * (TW_PASS_STRIDE / 4) + h * 64 + lane;
+}
+
 // cross-lane 4x4 transposes -----------------------------------------------------------
 // 2x2 step on a register pair (X = index bit 0, Y = index bit 1) against one lane bit:
 //   X[lanes with bit = 1]  <->  Y[partner lanes with bit = 0]
@@ -183,46 +240,77 @@ __device__ __forceinline__ void LaneMasks::operator()(int32_t (&r)[4]) const { x
 
 // All three exchanges through LDS (XAllLds): the VALU-bound pipelines (sign phase 2: 84 % VALU-busy, profiles/r03a_sign_pmc.txt)
 // spend 28 % of a transform's issue cycles on the exchanges (4 permlane swaps, 16 DPP moves, 8 v_bfi = ~138 of ~500 cycles);
-// through a 1 KiB per-wave buffer each one is 4 ds_write_b32 + 1 ds_read_b128 (about 20 LDS-pipe cycles, MI355X_MICROARCH.md
-// LDS table) and no VALU work at all.  Exchange at lane bit-pair position S (0, 2 or 4): lane (hi, b, lo) register m afterwards
-// holds what lane (hi, m, lo) register b held.  The writer lane (field value bw) stores its register j to the dword the reader
-// lane (field value j) finds at offset bw of its 16-byte slot:  dword = 4 * slot(lane with field <- j) + bw, and every lane reads
-// ONE ds_read_b128 from slot(own lane).  slot() xor-swizzles the field with the other lane bits so that the b128 read (served in
-// four irregular groups of 16 lanes, bank = dword mod 64) is conflict-free and each ds_write_b32 is at most 2-way (which costs
-// nothing: a 4-byte store is bound by its VGPR transfer, not by the LDS array).
+// through a 1 KiB per-wave buffer each one is 4 ds_write_b32 + 1 ds_read_b128 (about 20 LDS-pipe cycles) and no VALU work at
+// all.  Exchange at lane bit-pair position S (0, 2 or 4): lane (hi, b, lo) register m afterwards holds what lane (hi, m, lo)
+// register b held.  The writer lane (field value bw) stores its register j to the dword the reader lane (field value j) finds at
+// offset bw of its 16-byte slot:  dword = 4 * slot(lane with field <- j) + bw, and every lane reads its own slot.
+// Bank arithmetic (MI355X_MICROARCH.md, LDS table): a ds_write_b32 is served in two groups of 32 lanes against 32 banks of 4 bytes,
+// a ds_read_b128 in four irregular groups of 16 lanes and a ds_read_b64 in two groups of 32, both against 64 banks.  Round 3's
+// slot maps were derived for 64 write banks and measured 2-way on every store (SQ_LDS_BANK_CONFLICT = 77-84 % of the LDS
+// instruction cycles of the sign kernels, profiles/r03z_sign_pmc.txt).  These are conflict-free on both sides:
+//   S = 2  lane = (l5, l4, b, lo):  slot = 32 l5 + 16 b1 + 8 b0 + 4 l4 + lo        store bank = 4 (4 l4 + lo) + bw
+//   S = 0  lane = (q, b), q = 4 bit: slot = 32 q3 + 16 b0 + 8 b1 + ((q & 7) ^ b0)  store bank = 4 ((q & 7) ^ j0) + bw
+//   S = 4  lane = (b, lo4): the 32 lanes of a store group hold only two values of bw, so one 16-byte slot per reader can use at
+//          most half the banks.  The reader's four dwords are therefore split over two 8-byte halves in two planes -- writers
+//          with bw < 2 fill plane 0, the others plane 1, dword = 128 plane + 2 reader_lane + (bw & 1), store bank = 2 lo4 + bw,
+//          -- and read back as two ds_read_b64 (the same 4 LDS cycles as one ds_read_b128).
+#ifndef DIL_XS4
+#define DIL_XS4 1
+#endif
+#ifndef DIL_XS2
+#define DIL_XS2 1
+#endif
+#ifndef DIL_XS0
+#define DIL_XS0 1
+#endif
 template <int S>
 __device__ __forceinline__ uint32_t xslot(uint32_t lane, uint32_t field)
 {
-    if (S == 4) {                                   // lane = 16 b + lo4: slot = 4 lo4 + (b ^ g(lo4 >> 2)), g = {0, 2, 3, 1}
-        const uint32_t lo4 = lane & 15, g = (0x78u >> (2 * (lo4 >> 2))) & 3u;      // 0b01'11'10'00
+    if (S == 4) {                                   // (round-3 map; the round-4 form of S = 4 has two planes, see XLdsAt)
+        const uint32_t lo4 = lane & 15, g = (0x78u >> (2 * (lo4 >> 2))) & 3u;
         return 4 * lo4 + (field ^ g);
     }
-    if (S == 2) {                                   // lane = 16 h + 4 b + lo: slot = 16 h + 4 lo + (b ^ lo)
+    if (S == 2) {
+        if (DIL_XS2) return 32 * (lane >> 5) + 16 * (field >> 1) + 8 * (field & 1) + 4 * ((lane >> 4) & 1) + (lane & 3);
         const uint32_t h = lane >> 4, lo = lane & 3;
         return 16 * h + 4 * lo + (field ^ lo);
     }
-    const uint32_t q = lane >> 2;                   // lane = 4 q + b: slot = 4 q + (b ^ (q & 3))
+    const uint32_t q = lane >> 2;
+    if (DIL_XS0) return 32 * (q >> 3) + 16 * (field & 1) + 8 * (field >> 1) + ((q & 7) ^ (field & 1));
     return 4 * q + (field ^ (q & 3));
 }
 template <int S>
 struct XLdsAt {
+    static constexpr bool TWO_PLANES = S == 4 && DIL_XS4;
     uint32_t* wr[4];          // where this lane's register j goes
-    const uint32_t* rd;       // this lane's 16-byte slot
+    const uint32_t* rd;       // this lane's 16-byte slot (two planes: its 8 bytes of plane 0; plane 1 is 128 dwords on)
     __device__ __forceinline__ void init(uint32_t* wave_buf /* 256 dwords */, int lane)
     {
         const uint32_t l = (uint32_t)lane, bw = (l >> S) & 3u;
+        if constexpr (TWO_PLANES) {
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++) wr[j] = wave_buf + 4 * xslot<S>(l, j) + bw;
-        rd = wave_buf + 4 * xslot<S>(l, bw);
+            for (uint32_t j = 0; j < 4; j++) wr[j] = wave_buf + 128 * (bw >> 1) + 2 * (16 * j + (l & 15u)) + (bw & 1u);
+            rd = wave_buf + 2 * l;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) wr[j] = wave_buf + 4 * xslot<S>(l, j) + bw;
+            rd = wave_buf + 4 * xslot<S>(l, bw);
+        }
     }
     __device__ __forceinline__ void operator()(int32_t (&r)[4]) const
     {
 #pragma unroll
         for (int j = 0; j < 4; j++) *wr[j] = (uint32_t)r[j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same-wave LDS accesses execute in order
-        const int4 v = *reinterpret_cast<const int4*>(rd);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        if constexpr (TWO_PLANES) {
+            const int2 a = *reinterpret_cast<const int2*>(rd), b = *reinterpret_cast<const int2*>(rd + 128);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+        } else {
+            const int4 v = *reinterpret_cast<const int4*>(rd);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        }
     }
 };
 struct XAllLds {
@@ -258,6 +346,28 @@ __device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
     ct_bfly(r[2], r[3], (int32_t)t.v[4], t.v[5]);
 }
 
+// the same pass with wave-uniform twiddles as the SCALAR operand of the multiplies (TwLdsC: forward pass 0)
+__device__ __forceinline__ int32_t mont_tw_s(int32_t y, uint32_t wt, uint32_t wq)
+{
+    int32_t m, h;
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"(y), "s"(wq));
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(h) : "v"(y), "s"(wt));
+    return h - mulhi_i32(m, Q);
+}
+__device__ __forceinline__ void ct_bfly_s(int32_t& x, int32_t& y, uint32_t wt, uint32_t wq)
+{
+    const int32_t t = mont_tw_s(y, wt, wq);
+    y = x - t;
+    x = x + t;
+}
+__device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const TwU& t)
+{
+    ct_bfly_s(r[0], r[2], t.v[0], t.v[1]);
+    ct_bfly_s(r[1], r[3], t.v[0], t.v[1]);
+    ct_bfly_s(r[0], r[1], t.v[2], t.v[3]);
+    ct_bfly_s(r[2], r[3], t.v[4], t.v[5]);
+}
+
 // Forward NTT.  In: r[m] = a[lane + 64 m], any int32 with |a| < 2^31 - 6q.
 // Out: r[m] = lazy residue (|.| < |in| + 6q) of ntt(a)[4 lane + m]; canon_any() to leave the chip.
 // Twiddles are fetched ONE PASS AHEAD and pinned there with a scheduling fence: with
@@ -267,16 +377,16 @@ __device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
 template <class TW, class X10>
 __device__ __forceinline__ void ntt_fwd_core(int32_t (&r)[4], const TW& tw, const X10& x10)
 {
-    const Tw8 t0 = tw.template get<0>();
-    const Tw8 t1 = tw.template get<1>();
+    const auto t0 = tw.template get<0>();
+    const auto t1 = tw.template get<1>();
     DIL_TW_FENCE();
     fwd_pass(r, t0);
     do_x54(x10, r, 0);
-    const Tw8 t2 = tw.template get<2>();
+    const auto t2 = tw.template get<2>();
     DIL_TW_FENCE();
     fwd_pass(r, t1);
     do_x32(x10, r, 0);
-    const Tw8 t3 = tw.template get<3>();
+    const auto t3 = tw.template get<3>();
     DIL_TW_FENCE();
     fwd_pass(r, t2);
     x10(r);
@@ -298,25 +408,135 @@ __device__ __forceinline__ void inv_pass(int32_t (&r)[4], const Tw8& t)
     }
 }
 
+__device__ __forceinline__ void gs_bfly_s(int32_t& x, int32_t& y, uint32_t wt, uint32_t wq)
+{
+    const int32_t d = x - y;
+    x = x + y;
+    y = mont_tw_s(d, wt, wq);
+}
+// The last inverse pass (wave-uniform twiddles).  Its two extra products are not only the 256^-1: the x outputs of Gentleman-Sande
+// butterflies are plain sums, r[0] has grown to 256 q by now, and the multiplication by f is also its reduction into (-q, q) --
+// which is why f cannot simply be folded into an operand of the preceding pointwise product (tried in round 4: r[0] would need a
+// reduction of the same cost).
+template <bool LAST>
+__device__ __forceinline__ void inv_pass(int32_t (&r)[4], const TwU& t)
+{
+    static_assert(LAST, "the wave-uniform inverse pass is the last");
+    gs_bfly_s(r[0], r[1], t.v[0], t.v[1]);
+    gs_bfly_s(r[2], r[3], t.v[2], t.v[3]);
+    gs_bfly_s(r[0], r[2], t.v[4], t.v[5]);
+    gs_bfly_s(r[1], r[3], t.v[4], t.v[5]);
+    r[0] = mont_tw_s(r[0], t.v[6], t.v[7]);
+    r[1] = mont_tw_s(r[1], t.v[6], t.v[7]);
+}
+
 // Inverse NTT.  In: r[m] = a[4 lane + m] with |a| < q.  Out: r[m] in (-q, q) congruent to
 // invntt(a)[lane + 64 m] (the 256^-1 of ref_ntt.cpp:83-86 included); canon_small() for [0, q).
 template <class TW, class X10>
 __device__ __forceinline__ void ntt_inv_core(int32_t (&r)[4], const TW& tw, const X10& x10)
 {
-    const Tw8 t0 = tw.template get<0>();
-    const Tw8 t1 = tw.template get<1>();
+    const auto t0 = tw.template get<0>();
+    const auto t1 = tw.template get<1>();
     DIL_TW_FENCE();
     inv_pass<false>(r, t0);
     x10(r);
-    const Tw8 t2 = tw.template get<2>();
+    const auto t2 = tw.template get<2>();
     DIL_TW_FENCE();
     inv_pass<false>(r, t1);
     do_x32(x10, r, 0);
-    const Tw8 t3 = tw.template get<3>();
+    const auto t3 = tw.template get<3>();
     DIL_TW_FENCE();
     inv_pass<false>(r, t2);
     do_x54(x10, r, 0);
     inv_pass<true>(r, t3);
+}
+
+// Two transforms side by side on one wave (round 4).  A wave alone exposes every LDS round trip of a transform -- the twiddle
+// reads and, with the exchanges through LDS, three write -> read turnarounds -- and the VALU-bound pipelines run at 4-6 waves per
+// SIMD, too few to cover them (SQ_WAIT_INST_ANY 36 % of the sign kernels' wave cycles, profiles/r03z_sign_pmc.txt).  Two
+// independent polynomials per pass give the scheduler a second dependency chain: b's butterflies run under a's exchange and vice
+// versa, and ONE set of twiddle reads serves both (half the ds_read_b128 per transform).  The two exchanges of a pass go through the
+// SAME 1-KiB buffer back to back: a wave's LDS instructions execute in order, so b's stores cannot overtake a's read.
+template <class TW, class X10>
+__device__ __forceinline__ void ntt_fwd_core2(int32_t (&a)[4], int32_t (&b)[4], const TW& tw, const X10& x10)
+{
+    const auto t0 = tw.template get<0>();
+    const auto t1 = tw.template get<1>();
+    DIL_TW_FENCE();
+    fwd_pass(a, t0);
+    do_x54(x10, a, 0);
+    fwd_pass(b, t0);
+    do_x54(x10, b, 0);
+    const auto t2 = tw.template get<2>();
+    DIL_TW_FENCE();
+    fwd_pass(a, t1);
+    do_x32(x10, a, 0);
+    fwd_pass(b, t1);
+    do_x32(x10, b, 0);
+    const auto t3 = tw.template get<3>();
+    DIL_TW_FENCE();
+    fwd_pass(a, t2);
+    x10(a);
+    fwd_pass(b, t2);
+    x10(b);
+    fwd_pass(a, t3);
+    fwd_pass(b, t3);
+}
+template <class TW, class X10>
+__device__ __forceinline__ void ntt_inv_core2(int32_t (&a)[4], int32_t (&b)[4], const TW& tw, const X10& x10)
+{
+    const auto t0 = tw.template get<0>();
+    const auto t1 = tw.template get<1>();
+    DIL_TW_FENCE();
+    inv_pass<false>(a, t0);
+    x10(a);
+    inv_pass<false>(b, t0);
+    x10(b);
+    const auto t2 = tw.template get<2>();
+    DIL_TW_FENCE();
+    inv_pass<false>(a, t1);
+    do_x32(x10, a, 0);
+    inv_pass<false>(b, t1);
+    do_x32(x10, b, 0);
+    const auto t3 = tw.template get<3>();
+    DIL_TW_FENCE();
+    inv_pass<false>(a, t2);
+    do_x54(x10, a, 0);
+    inv_pass<false>(b, t2);
+    do_x54(x10, b, 0);
+    inv_pass<true>(a, t3);
+    inv_pass<true>(b, t3);
+}
+
+// N forward transforms side by side (the L polynomials of a vector that lives in registers anyway): one set of twiddle reads for
+// all of them, N independent dependency chains per pass
+template <int N, class TW, class X10>
+__device__ __forceinline__ void ntt_fwd_coreN(int32_t (&v)[N][4], const TW& tw, const X10& x10)
+{
+    const auto t0 = tw.template get<0>();
+    const auto t1 = tw.template get<1>();
+    DIL_TW_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        fwd_pass(v[i], t0);
+        do_x54(x10, v[i], 0);
+    }
+    const auto t2 = tw.template get<2>();
+    DIL_TW_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        fwd_pass(v[i], t1);
+        do_x32(x10, v[i], 0);
+    }
+    const auto t3 = tw.template get<3>();
+    DIL_TW_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        fwd_pass(v[i], t2);
+        x10(v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) fwd_pass(v[i], t3);
 }
 
 }  // namespace dil

@@ -190,6 +190,38 @@ __device__ __forceinline__ void stage_tables(uint32_t* lds, const uint32_t* __re
     }
 }
 
+// Twiddle tables of a pipeline kernel: the full [pass][half][lane][4] images (16 KiB) or the compact ones (ntt_core.hpp TwLdsC,
+// 5.25 KiB, the wave-uniform pass in SGPRs).  PipeTables<C>::DWORDS of LDS at `lds`, stage() before the kernel's first barrier.
+template <bool COMPACT>
+struct PipeTables;
+template <>
+struct PipeTables<false> {
+    static constexpr int DWORDS = 2 * TW_TABLE_DWORDS;
+    using Fwd = TwLds;
+    using Inv = TwLds;
+    __device__ __forceinline__ static void stage(uint32_t* lds, const uint32_t* __restrict__ f, const uint32_t* __restrict__ i) { stage_tables(lds, f, i); }
+    __device__ __forceinline__ static Fwd fwd(const uint32_t* lds, const uint32_t* __restrict__, int lane) { return TwLds{lds, lane}; }
+    __device__ __forceinline__ static Inv inv(const uint32_t* lds, const uint32_t* __restrict__, int lane) { return TwLds{lds + TW_TABLE_DWORDS, lane}; }
+};
+template <>
+struct PipeTables<true> {
+    static constexpr int DWORDS = 2 * TWC_DWORDS;
+    using Fwd = TwLdsC<true>;
+    using Inv = TwLdsC<false>;
+    __device__ __forceinline__ static void stage(uint32_t* lds, const uint32_t* __restrict__ f, const uint32_t* __restrict__ i)
+    {
+        for (int g = threadIdx.x; g < TWC_DWORDS / 4; g += blockDim.x) {
+            reinterpret_cast<uint4*>(lds)[g] = reinterpret_cast<const uint4*>(f)[twc_source_granule<true>(g)];
+            reinterpret_cast<uint4*>(lds + TWC_DWORDS)[g] = reinterpret_cast<const uint4*>(i)[twc_source_granule<false>(g)];
+        }
+    }
+    __device__ __forceinline__ static Fwd fwd(const uint32_t* lds, const uint32_t* __restrict__ f, int lane) { return Fwd(lds, f, lane); }
+    __device__ __forceinline__ static Inv inv(const uint32_t* lds, const uint32_t* __restrict__ i, int lane) { return Inv(lds + TWC_DWORDS, i, lane); }
+};
+#ifndef DIL_TWC
+#define DIL_TWC 1
+#endif
+
 // Byte planes (h, w1) move as whole dwords: 64 lanes x 4 bytes = one coalesced 256-B row per
 // instruction.  global_store_byte / global_load_ubyte of 64-byte runs measured 2x the whole
 // kernel's time (profiles/r01_fused_ablation.txt), so the re-layout between the INTT's strided
@@ -258,6 +290,67 @@ __device__ __forceinline__ void store_row_w1_packed(uint8_t* __restrict__ out_ro
     }
 }
 
+// Decompose for sign phase 1's outputs: w1 = HighBits(a) and w0 = LowBits(a) AS A RESIDUE in [0, q) (DECOMP, combined_top.v:1946).
+// LowBits is a - a1 * 2 gamma2 centred into (-gamma2, gamma2]; its residue is that difference plus q where negative -- the
+// centring step of decompose() and the way back cancel (the a1 = 16 | 44 -> 0 wrap leaves a itself, which is its own residue):
+// four instructions fewer per coefficient.  Identical to decompose() + canonicalisation over all of [0, q) (checked in
+// tests/test_model_and_cabi.py through the oracle).
+template <int LEVEL>
+__device__ __forceinline__ void decompose_w0res(uint32_t a, uint32_t& a1, uint32_t& w0)
+{
+    uint32_t t = (a + 127) >> 7;
+    if (LEVEL == 2) {
+        t = (t * 11275u + (1u << 23)) >> 24;
+        t ^= (uint32_t)sgn((int32_t)(43 - t)) & t;
+    } else {
+        t = (t * 1025u + (1u << 21)) >> 22;
+        t &= 15;
+    }
+    const int32_t r = (int32_t)a - (int32_t)t * (2 * Par<LEVEL>::GAMMA2);
+    a1 = t;
+    w0 = (uint32_t)(r + (sgn(r) & Q));
+}
+
+// Sign phase 1's output stage with ONE transposition (round 4).  The INTT leaves coefficient lane + 64 m in register m; w0
+// (int32 row), w1 (byte row) and w1 packed (4 | 6 bits) all want natural order.  Round 3 moved each plane through a byte scratch
+// of its own (8 ds_write_b8 -- four lanes per dword, serialised by the LDS -- three reads, and w0 as four 256-byte strided stores):
+// 22 % of the shared-key phase-1 kernel (profiles/r04a_ab_mvsabl.txt).  w0 < 2^23 and w1 < 2^6 share a dword: four
+// conflict-free ds_write_b32 + one ds_read_b128 give every lane coefficients 4 lane .. 4 lane + 3 of both, w0 leaves as ONE 1-KiB
+// dwordx4 store, the w1 bytes as two v_perm_b32 + one 256-byte store, and the packed row is put together across neighbouring lanes
+// with one DPP move (encoder.v:96-133: 8 coefficients per dword at 4 bits, 16 per three dwords at 6).
+template <int LEVEL>
+__device__ __forceinline__ void emit_w1w0_row_t(uint8_t* __restrict__ w1p_row, uint8_t* __restrict__ w1_row, int32_t* __restrict__ w0_row,
+                                                const int32_t (&r)[4], uint32_t* xb, int lane)
+{
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        uint32_t a1, w0;
+        decompose_w0res<LEVEL>(canon_small(r[m]), a1, w0);
+        xb[lane + 64 * m] = w0 | (a1 << 24);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const uint4 q = *reinterpret_cast<const uint4*>(xb + 4 * lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    st_nt4(w0_row + 4 * lane, q.x & 0xFFFFFFu, q.y & 0xFFFFFFu, q.z & 0xFFFFFFu, q.w & 0xFFFFFFu);
+    // bytes 3 of (q.x, q.y, q.z, q.w) -> one dword (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c = 0)
+    const uint32_t b = __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0703u) | __builtin_amdgcn_perm(q.w, q.z, 0x07030c0cu);
+    reinterpret_cast<uint32_t*>(w1_row)[lane] = b;
+    if (w1p_row) {
+        if (W1Pack<LEVEL>::BITS == 4) {
+            uint32_t n = (b | (b >> 4)) & 0x00FF00FFu;
+            n = (n | (n >> 8)) & 0xFFFFu;                                       // this lane's 4 nibbles
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)n, 0xB1, 0xF, 0xF, true);      // lane ^ 1's
+            if (!(lane & 1)) reinterpret_cast<uint32_t*>(w1p_row)[lane >> 1] = n | (nb << 16);
+        } else {
+            const uint32_t c = (b & 0x3Fu) | ((b >> 2) & 0xFC0u) | ((b >> 4) & 0x3F000u) | ((b >> 6) & 0xFC0000u);   // 4 x 6 bits
+            const uint32_t cn = (uint32_t)__builtin_amdgcn_mov_dpp((int)c, 0xF9, 0xF, 0xF, true);   // quad_perm [1,2,3,3]: the next lane of the quad
+            const uint32_t t = (uint32_t)lane & 3u;                              // 4 lanes = 96 bits = 3 dwords, written by lanes t = 0 .. 2
+            const uint32_t d = (c >> (8 * t)) | (cn << (24 - 8 * t));
+            if (t < 3) reinterpret_cast<uint32_t*>(w1p_row)[3 * (lane >> 2) + t] = d;
+        }
+    }
+}
+
 // Output stage of one mat-vec row: r[] = INTT output (|r| < q, strided order) ->
 //   OUT_W   : w row, canonical int32             (matvec)
 //   OUT_W1W0: w1 = HighBits as bytes, w0 = LowBits as residue in [0,q)  (sign phase 1, DECOMP :1946); if w_out is not
@@ -267,9 +360,14 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
                                                 int32_t* __restrict__ w0_out, size_t o, const int32_t (&r)[4],
                                                 uint32_t* scratch, int lane, uint32_t* xbuf = nullptr)
 {
-    // xbuf (optional, compile-time null or not after inlining): a 1 KiB per-wave LDS buffer through which the int32 row is
-    // turned from the INTT's strided order (lane + 64 m) into row order (4 lane + j), so that it leaves as ONE 1-KiB
-    // dwordx4 store per wave instead of four 256-byte dword stores
+    // xbuf (optional, compile-time null or not after inlining): a 1 KiB per-wave LDS buffer through which the row is turned from
+    // the INTT's strided order (lane + 64 m) into row order (4 lane + j): OUT_W leaves as ONE 1-KiB dwordx4 store per wave
+    // instead of four 256-byte dword stores, OUT_W1W0 takes the one-transposition stage above
+    if (OUT != OUT_W && xbuf) {
+        emit_w1w0_row_t<LEVEL>(w_out ? reinterpret_cast<uint8_t*>(w_out) + (o >> 8) * W1Pack<LEVEL>::ROW_BYTES : nullptr, w1_out + o,
+                               w0_out + o, r, xbuf, lane);
+        return;
+    }
     uint32_t wb[4], ov[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
@@ -277,9 +375,7 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
         if (OUT == OUT_W) {
             ov[m] = v;
         } else {
-            int32_t a0;
-            decompose<LEVEL>(v, wb[m], a0);
-            ov[m] = (uint32_t)(a0 + (sgn(a0) & Q));
+            decompose_w0res<LEVEL>(v, wb[m], ov[m]);
         }
     }
     if (OUT != OUT_W && w_out)       // sign phase 1: w1 ALSO leaves packed (the challenge hash's input) -- no pack_w1 launch

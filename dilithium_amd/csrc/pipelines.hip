@@ -542,6 +542,9 @@ struct S2X {
 // Five waves per SIMD (<= 96 VGPRs): the per-item-key form of the paired rows wants 105-113 registers, and at four waves per SIMD it
 // loses more to exposed latency than the saved transforms give back (level 5, 8192 attempts: 77.7 us at four waves, 69.1 at five
 // with 2-10 spilled registers; the unpaired kernel: 74.0; profiles/r03_small_pair.txt).  The one-key form fits without help.
+#ifndef DIL_S2_DUAL
+#define DIL_S2_DUAL 1
+#endif
 #ifndef DIL_S2_ATTR
 #define DIL_S2_ATTR __attribute__((amdgpu_waves_per_eu(5)))
 #endif
@@ -555,16 +558,18 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using XP = S2X;
-    constexpr int PAIR_AT = 2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW;
+    using PT = PipeTables<DIL_TWC>;
+    constexpr int PAIR_AT = PT::DWORDS + 4 * 64 + 4 * XP::DW;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (SH ? L * 256 : 0)];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
+    PT::stage(lds, fwd_tab, inv_tab);
     if (SH) SmallPair::stage_key<L>(reinterpret_cast<int32_t*>(lds + PAIR_AT), s1hat, s2hat);
     __syncthreads();
     const int32_t* s12 = reinterpret_cast<const int32_t*>(lds + PAIR_AT);
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
+    const typename XP::type lm(lds + PT::DWORDS + 4 * 64 + wv * XP::DW, lane);
+    uint32_t* sc = lds + PT::DWORDS + wv * 64;   // byte-plane scratch
     const YSrc<LEVEL, YF> ys(lane);
     const size_t nwaves = (size_t)gridDim.x * 4;
     for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
@@ -607,9 +612,13 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
             } else {
                 a[0] = mont_mul(ch[0], a2.x); a[1] = mont_mul(ch[1], a2.y); a[2] = mont_mul(ch[2], a2.z); a[3] = mont_mul(ch[3], a2.w);
             }
-            ntt_inv_core(a, twi, lm);
             int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
+#if DIL_S2_DUAL
+            ntt_inv_core2(a, b, twi, lm);           // the row's two transforms side by side (ntt_core.hpp)
+#else
+            ntt_inv_core(a, twi, lm);
             ntt_inv_core(b, twi, lm);
+#endif
             bool rej0 = false, rej1 = false, rej2 = false;
             if (pair) {
                 ys.value(yv);
@@ -660,16 +669,18 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using XP = S2X;
-    constexpr int PAIR_AT = 2 * TW_TABLE_DWORDS + 4 * 64 + 4 * XP::DW;
+    using PT = PipeTables<DIL_TWC>;
+    constexpr int PAIR_AT = PT::DWORDS + 4 * 64 + 4 * XP::DW;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (SH ? L * 256 : 0)];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
+    PT::stage(lds, fwd_tab, inv_tab);
     if (SH) SmallPair::stage_key<L>(reinterpret_cast<int32_t*>(lds + PAIR_AT), s1hat, s2hat);
     __syncthreads();
     const int32_t* s12 = reinterpret_cast<const int32_t*>(lds + PAIR_AT);
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * 64 + wv * XP::DW, lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + wv * 64;   // byte-plane scratch
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
+    const typename XP::type lm(lds + PT::DWORDS + 4 * 64 + wv * XP::DW, lane);
+    uint32_t* sc = lds + PT::DWORDS + wv * 64;   // byte-plane scratch
     const YSrc<LEVEL, YF> ys(lane);
     const size_t nwaves = (size_t)gridDim.x * 4;
     for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
@@ -849,8 +860,42 @@ __device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a
 // LDS slice -- that slice (L KiB per wave) was what capped the workgroup at 12 waves = 3 per SIMD at level 5, and three waves per
 // SIMD issue no more than two (scripts/tune_xchg.hip, profiles/r03c_tune_xchg.txt: 785 / 785 / 689 cycles per transform at 2 / 3 /
 // 4 waves).  Now 16 waves = 4 per SIMD at every level, no ds_write of y^ and half the ds_read_b128 of the multiply-accumulate.
+#ifndef DIL_MVS_XEMIT
+#define DIL_MVS_XEMIT 1         // output rows through one LDS transposition (pipeline_common.hpp emit_w1w0_row_t)
+#endif
+#if DIL_MVS_XEMIT
+#define MVS_XB xb
+#else
+#define MVS_XB nullptr
+#endif
+#ifndef MVS_FWD         // hook points of the A/B builds (variants.hpp)
+#define MVS_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
+#define MVS_INV(r, tw, x) ntt_inv_core(r, tw, x)
+#endif
+#ifndef DIL_MVS_PFY
+#define DIL_MVS_PFY(L) ((L) <= 5)
+#endif
+#ifndef MVS_FWDN
+#define MVS_FWDN(v, tw, x) ntt_fwd_coreN<L>(v, tw, x)
+#endif
+#ifndef MVS_FWD2
+#define MVS_FWD2(a, b, tw, x) ntt_fwd_core2(a, b, tw, x)
+#define MVS_INV2(a, b, tw, x) ntt_inv_core2(a, b, tw, x)
+#endif
+#ifndef DIL_MVS_DUAL
+#define DIL_MVS_DUAL 2          // 1: two polynomials per transform pass (ntt_core.hpp ntt_*_core2); 2: and all L forward transforms at once
+#endif
+#ifndef MVS_AREAD
+#define MVS_AREAD(p) (*reinterpret_cast<const int4*>(p))
+#endif
+#ifndef MVS_EMIT
+#define MVS_EMIT(call, w0, o, r, lane) call
+#endif
+#ifndef DIL_MVS_WGS
+#define DIL_MVS_WGS 1          // 16-wave workgroups per CU the shared-key kernels are built for (8 waves per SIMD need <= 64 VGPRs)
+#endif
 template <int K, int L, int LEVEL, int OUT, int NW, int YF>
-__global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS_WGS * NW / 4))) void matvec_shared_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
     const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch,
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
@@ -858,42 +903,92 @@ __global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
     // All three exchanges through LDS (S2X = XAllLds), as in phase 2: with y^ in registers the LDS pipe serves only A and the
     // twiddles, and at 4 waves per SIMD the exchange-free transforms win 3-6 % (level 5 sign phase 1: 51.1 -> 48.0 us).  The (1:0)
     // exchange ALONE through LDS (one ds_write_b128 + four ds_read_b32) costs 20 % here: profiles/r03m_ab_x.txt.
+    // Round 4: compact twiddle tables (5.25 KiB) and the byte-plane scratch aliased onto the wave's exchange buffer (both are
+    // wave-private and used in turn): level 5 is 5.25 + 56 + 16 = 77.25 KiB per workgroup, so TWO 16-wave workgroups share a CU.
     using XP = S2X;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + K * L * 256 + NW * 64 + NW * XP::DW];
+    using PT = PipeTables<DIL_TWC>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + K * L * 256 + NW * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
-    uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
+    PT::stage(lds, fwd_tab, inv_tab);
+    uint32_t* Al = lds + PT::DWORDS;
     stage_polys(Al, A, K * L);
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const typename XP::type lm(Al + K * L * 256 + NW * 64 + wv * XP::DW, lane);
-    uint32_t* sc = Al + K * L * 256 + wv * 64;   // byte-plane scratch
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
+    uint32_t* xb = Al + K * L * 256 + wv * XP::DW;
+    const typename XP::type lm(xb, lane);
+    uint32_t* sc = xb;                            // byte-plane scratch (64 dwords) = the head of the exchange buffer
     const size_t nwaves = (size_t)gridDim.x * NW;
     size_t it = (size_t)blockIdx.x * NW + wv;
     const YSrc<LEVEL, YF> ys(lane);
-    RawPolys<L> yr;
+    // the next item's y is prefetched a whole row phase ahead where the registers allow it; at level 5 that second copy (28 VGPRs)
+    // does not fit beside seven transforms in flight under the 128-register cap: y is loaded where it is used
+    constexpr bool PFY = DIL_MVS_PFY(L);
+    RawPolys<PFY ? L : 1> yr;
     auto load_y = [&](size_t i) {
 #pragma unroll
-        for (int l = 0; l < L; l++) ys.raw(yr.v[l], y, i * L + l, lane);
+        for (int l = 0; l < (PFY ? L : 0); l++) ys.raw(yr.v[l], y, i * L + l, lane);
     };
     if (it < batch) load_y(it);
     __syncthreads();                               // tables + key staged (the only barrier)
     for (; it < batch; it += nwaves) {
         int32_t yh[L][4];
+        if (!PFY) {
+#pragma unroll
+            for (int l = 0; l < L; l++) ys.raw(yh[l], y, it * L + l, lane);
+        }
 #pragma unroll
         for (int l = 0; l < L; l++) {
+            if (PFY) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) yh[l][m] = yr.v[l][m];
+                for (int m = 0; m < 4; m++) yh[l][m] = yr.v[l][m];
+            }
             ys.value(yh[l]);
-            ntt_fwd_core(yh[l], twf, lm);
         }
+#if DIL_MVS_DUAL == 2
+        MVS_FWDN(yh, twf, lm);
+#elif DIL_MVS_DUAL
+#pragma unroll
+        for (int l = 0; l + 1 < L; l += 2) MVS_FWD2(yh[l], yh[l + 1], twf, lm);
+        if (L & 1) MVS_FWD(yh[L - 1], twf, lm);
+#else
+#pragma unroll
+        for (int l = 0; l < L; l++) MVS_FWD(yh[l], twf, lm);
+#endif
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) load_y(itn);
+#if DIL_MVS_DUAL
+        static_assert(K % 2 == 0, "rows are processed in pairs");
+        for (int k = 0; k < K; k += 2) {
+            int64_t acc[4] = {0, 0, 0, 0}, acd[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int4 a = MVS_AREAD(Al + (k * L + l) * 256 + 4 * lane);
+                const int4 d = MVS_AREAD(Al + ((k + 1) * L + l) * 256 + 4 * lane);
+                acc[0] += (int64_t)a.x * yh[l][0];
+                acc[1] += (int64_t)a.y * yh[l][1];
+                acc[2] += (int64_t)a.z * yh[l][2];
+                acc[3] += (int64_t)a.w * yh[l][3];
+                acd[0] += (int64_t)d.x * yh[l][0];
+                acd[1] += (int64_t)d.y * yh[l][1];
+                acd[2] += (int64_t)d.z * yh[l][2];
+                acd[3] += (int64_t)d.w * yh[l][3];
+            }
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            int32_t rd[4] = {mont_red64(acd[0]), mont_red64(acd[1]), mont_red64(acd[2]), mont_red64(acd[3])};
+            DIL_SCHED_FENCE();
+            MVS_INV2(r, rd, twi, lm);
+            DIL_SCHED_FENCE();
+            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, MVS_XB)), w0_out, (it * K + k) * 256, r, lane);
+            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k + 1) * 256, rd, sc, lane, MVS_XB)), w0_out, (it * K + k + 1) * 256, rd, lane);
+        }
+        if (false)
+#endif
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int l = 0; l < L; l++) {
-                const int4 a = *reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane);
+                const int4 a = MVS_AREAD(Al + (k * L + l) * 256 + 4 * lane);
                 acc[0] += (int64_t)a.x * yh[l][0];
                 acc[1] += (int64_t)a.y * yh[l][1];
                 acc[2] += (int64_t)a.z * yh[l][2];
@@ -901,9 +996,9 @@ __global__ __launch_bounds__(64 * NW) void matvec_shared_kernel(
             }
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
-            ntt_inv_core(r, twi, lm);
+            MVS_INV(r, twi, lm);
             DIL_SCHED_FENCE();
-            emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane);
+            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, MVS_XB)), w0_out, (it * K + k) * 256, r, lane);
         }
     }
 }
@@ -920,13 +1015,15 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using XP = S2X;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K) * 256 + NW * 64 + NW * XP::DW];
+    using PT = PipeTables<DIL_TWC>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + (K * L + K) * 256 + NW * 64 + NW * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
-    uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
+    PT::stage(lds, fwd_tab, inv_tab);
+    uint32_t* Al = lds + PT::DWORDS;
     uint32_t* Tl = Al + K * L * 256;
     stage_polys(Al, A, K * L);
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
     const typename XP::type lm(Tl + K * 256 + NW * 64 + wv * XP::DW, lane);
     uint32_t* sc = Tl + K * 256 + wv * 64;        // byte-plane scratch
     const size_t nwaves = (size_t)gridDim.x * NW;
@@ -1036,7 +1133,8 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
     if (AF == A_P24 && shared_A) return hipErrorInvalidValue;      // the shared-key kernels keep A in LDS: nothing to save
     if (AF == A_I32 && use_wpi(batch, t) && shared_A) {
         constexpr int NW = SharedNW<LEVEL>::MATVEC;
-        const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
+        const int g = grid_for((batch + NW - 1) / NW,
+                               t.num_cus * resident_blocks_per_cu(matvec_shared_kernel<K, L, LEVEL, OUT, NW, YF>, 64 * NW, DIL_MVS_WGS, t.device));
         note_launch(OUT == OUT_W ? "matvec_shared" : "sign1_shared", g, NW, batch);
         hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW, YF>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, t.fwd,
                            t.inv_pipe);

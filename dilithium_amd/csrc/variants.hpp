@@ -31,3 +31,31 @@
 #ifdef DIL_ABL_A_PLAIN
 #define DIL_AROW_STREAM_HOOK(stream) (false)
 #endif
+
+// round 4: the shared-key mat-vec / sign phase 1 kernel taken apart (profiles/r04_mvs_ablation.txt)
+//   DIL_ABL_MVS_NONTT   no forward / inverse transforms      DIL_ABL_MVS_NOINV / NOFWD: only one of them removed
+//   DIL_ABL_MVS_NOAREAD the matrix operand from lane arithmetic instead of LDS
+//   DIL_ABL_MVS_NOEMIT  the output stage replaced by one dword store per lane and row
+#if defined(DIL_ABL_MVS_NONTT) || defined(DIL_ABL_MVS_NOFWD) || defined(DIL_ABL_MVS_NOINV)
+#if defined(DIL_ABL_MVS_NONTT) || defined(DIL_ABL_MVS_NOFWD)
+#define MVS_FWD(r, tw, x) ((void)0)
+#define MVS_FWD2(a, b, tw, x) ((void)0)
+#define MVS_FWDN(v, tw, x) ((void)0)
+#else
+#define MVS_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
+#define MVS_FWD2(a, b, tw, x) ntt_fwd_core2(a, b, tw, x)
+#endif
+#if defined(DIL_ABL_MVS_NONTT) || defined(DIL_ABL_MVS_NOINV)
+#define MVS_INV(r, tw, x) ((void)0)
+#define MVS_INV2(a, b, tw, x) ((void)0)
+#else
+#define MVS_INV(r, tw, x) ntt_inv_core(r, tw, x)
+#define MVS_INV2(a, b, tw, x) ntt_inv_core2(a, b, tw, x)
+#endif
+#endif
+#ifdef DIL_ABL_MVS_NOAREAD
+#define MVS_AREAD(p) make_int4(lane + l, lane * 3 + k, 7 * l + 1, lane ^ k)
+#endif
+#ifdef DIL_ABL_MVS_NOEMIT
+#define MVS_EMIT(call, w0, o, r, lane) st_nt(w0 + (o) + lane, r[0] ^ r[1] ^ r[2] ^ r[3])
+#endif
