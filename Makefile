@@ -5,7 +5,7 @@
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 CSRC    := dilithium_amd/csrc
-HIP_SRC := $(addprefix $(CSRC)/,kernels.hip pipelines.hip hash_kernels.hip codec_kernels.hip wire_kernels.hip gen_kernels.hip capi.hip scheme.hip multi_gpu.hip)
+HIP_SRC := $(addprefix $(CSRC)/,kernels.hip pipelines.hip hash_kernels.hip codec_kernels.hip wire_kernels.hip capi.hip scheme.hip multi_gpu.hip)
 HIP_HDR := $(wildcard $(CSRC)/*.hpp) include/dil256.h include/dil256_ref.hpp
 
 all: dilithium_amd/libdil256.so dilithium_amd/libdil256_ref.so

@@ -480,10 +480,10 @@ def main():
 
             def attempt(i):
                 return L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream) | \
-                    L.dil_sign_phase2_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1, stream)
+                    L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1, 0, stream)
             a_ms, _ = timed(attempt)
             p1_ms, _ = timed(lambda i: L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream))
-            p2_ms, _ = timed(lambda i: L.dil_sign_phase2_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1,
+            p2_ms, _ = timed(lambda i: L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1,
                                                              stream))
             sv = pmc_sign_valu()
             sec["other_configs"] = {
@@ -642,8 +642,8 @@ def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
         f = torch.empty((n,), dtype=torch.int32, device="cuda")
 
         def one(i):
-            return L.dil_sign_phase1_dev(P(w1), P(w0), P(A5), P(ys), 5, n, 1, stream) | \
-                L.dil_sign_phase2_dev(P(z), P(h), P(f), P(cs), P(ys), P(w0), P(w1), P(s1h), P(s2h), P(t0h), 5, n, 1, stream)
+            return L.dil_sign_phase1_dev(P(w1), P(w0), P(A5), P(ys), 5, n, 1, 0, stream) | \
+                L.dil_sign_phase2_skey_dev(P(z), P(h), P(f), P(cs), P(ys), P(w0), P(w1), P(s1h), P(s2h), P(t0h), 5, n, 1, 0, stream)
         ms, _ = timed(one)
         out["attempt_ms_per_rank_slice"] = sharding.max_over_ranks(ms)
         return z, h, f

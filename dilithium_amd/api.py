@@ -193,33 +193,40 @@ def sign_phase1(A, y, level, shared_key=False):
     return w1, w0
 
 
-def sign_phase2(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False):
+def sign_phase2(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False, small_key=False):
+    """small_key: the caller vouches for a key decoded from secret-key bytes and a challenge from SampleInBall
+    (dil_sign_phase2_skey_dev: the small-product kernels); default: any residues (dil_sign_phase2_dev)"""
     K, Lv = _kl(level)
     B = y.numel() // (Lv * N)
     z = torch.empty((B, Lv, N), dtype=torch.int32, device=y.device)
     h = torch.empty((B, K, N), dtype=torch.uint8, device=y.device)
     flags = torch.empty((B,), dtype=torch.int32, device=y.device)
-    _lib.check(_lib.load().dil_sign_phase2_dev(_dev(z, torch.int32), _dev(h, torch.uint8), _dev(flags, torch.int32),
-                                               _dev(c, torch.int32), _dev(y, torch.int32), _dev(w0, torch.int32),
-                                               _dev(w1, torch.uint8), _dev(s1hat, torch.int32), _dev(s2hat, torch.int32),
-                                               _dev(t0hat, torch.int32), level, B, int(shared_key), _stream()),
-               "dil_sign_phase2_dev")
+    args = (_dev(z, torch.int32), _dev(h, torch.uint8), _dev(flags, torch.int32), _dev(c, torch.int32), _dev(y, torch.int32),
+            _dev(w0, torch.int32), _dev(w1, torch.uint8), _dev(s1hat, torch.int32), _dev(s2hat, torch.int32), _dev(t0hat, torch.int32),
+            level, B, int(shared_key))
+    if small_key:
+        _lib.check(_lib.load().dil_sign_phase2_skey_dev(*args, 0, _stream()), "dil_sign_phase2_skey_dev")
+    else:
+        _lib.check(_lib.load().dil_sign_phase2_dev(*args, _stream()), "dil_sign_phase2_dev")
     return z, h, flags
 
 
-def sign_phase2_early(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False):
+def sign_phase2_early(c, y, w0, w1, s1hat, s2hat, t0hat, level, shared_key=False, small_key=False):
     """phase 2 as the signing loop runs it: stops at an attempt's first failed check (r0 rows -> 2, z rows -> 1, c t0
-    rows -> 4); z, h complete only where flags == 0.  w0 is IN/OUT (holds r0 of the evaluated rows afterwards)."""
+    rows -> 4); z, h complete only where flags == 0.  w0 is IN/OUT (holds r0 of the evaluated rows afterwards).
+    small_key: as the loop itself calls it (dil_sign_phase2_skey_dev with early_exit = 1)"""
     K, Lv = _kl(level)
     B = y.numel() // (Lv * N)
     z = torch.zeros((B, Lv, N), dtype=torch.int32, device=y.device)
     h = torch.zeros((B, K, N), dtype=torch.uint8, device=y.device)
     flags = torch.empty((B,), dtype=torch.int32, device=y.device)
-    _lib.check(_lib.load().dil_sign_phase2_early_dev(_dev(z, torch.int32), _dev(h, torch.uint8), _dev(flags, torch.int32),
-                                                     _dev(c, torch.int32), _dev(y, torch.int32), _dev(w0, torch.int32),
-                                                     _dev(w1, torch.uint8), _dev(s1hat, torch.int32), _dev(s2hat, torch.int32),
-                                                     _dev(t0hat, torch.int32), level, B, int(shared_key), _stream()),
-               "dil_sign_phase2_early_dev")
+    args = (_dev(z, torch.int32), _dev(h, torch.uint8), _dev(flags, torch.int32), _dev(c, torch.int32), _dev(y, torch.int32),
+            _dev(w0, torch.int32), _dev(w1, torch.uint8), _dev(s1hat, torch.int32), _dev(s2hat, torch.int32), _dev(t0hat, torch.int32),
+            level, B, int(shared_key))
+    if small_key:
+        _lib.check(_lib.load().dil_sign_phase2_skey_dev(*args, 1, _stream()), "dil_sign_phase2_skey_dev")
+    else:
+        _lib.check(_lib.load().dil_sign_phase2_early_dev(*args, _stream()), "dil_sign_phase2_early_dev")
     return z, h, flags
 
 
@@ -415,8 +422,7 @@ def verify_sig_expanded(A, pk, sig, mu, level, shared_pk=False):
 
 
 def verify_wire_core(A, pk, sig, level, shared_pk=False):
-    """the fused wire-format verify kernel: (w1 packed uint8 [B, K*128|192], verdict int32 [B] with bits 2 | 4);
-    A = None: the kernel that samples A from the keys' rho itself (a key per signature)"""
+    """the fused wire-format verify kernel: (w1 packed uint8 [B, K*128|192], verdict int32 [B] with bits 2 | 4)"""
     K, _ = _kl(level)
     B = sig.shape[0]
     w1p = torch.empty((B, K * (192 if level == 2 else 128)), dtype=torch.uint8, device=sig.device)

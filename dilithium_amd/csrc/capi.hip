@@ -37,11 +37,8 @@ const OptName* option_table(int* n)
         {"aux_overlap", "DIL_AUX_OVERLAP", &cfg.aux_overlap},
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
-        {"gen_a", "DIL_GEN_A", &cfg.gen_a},
-        {"verify_chunks", "DIL_VERIFY_CHUNKS", &cfg.verify_chunks},
         {"packed_y", "DIL_PACKED_Y", &cfg.packed_y},
         {"fuse_challenge", "DIL_FUSE_CHALLENGE", &cfg.fuse_challenge},
-        {"sign_overlap", "DIL_SIGN_OVERLAP", &cfg.sign_overlap},
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
         {"two_lane_max_sponges", "DIL_TWO_LANE_MAX", &dil::two_lane_max_sponges},
@@ -159,10 +156,8 @@ bool AuxStream::ensure()
 {
     if (s) return true;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; return false; }
-    bool ok = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-    for (hipEvent_t& e : chunk_ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    const bool ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         destroy();
         return false;
@@ -173,13 +168,8 @@ void AuxStream::destroy()
 {
     if (fork) (void)hipEventDestroy(fork);
     if (join) (void)hipEventDestroy(join);
-    for (hipEvent_t& e : chunk_ev) {
-        if (e) (void)hipEventDestroy(e);
-        e = nullptr;
-    }
     if (s) (void)hipStreamDestroy(s);
-    if (s2) (void)hipStreamDestroy(s2);
-    s = s2 = nullptr;
+    s = nullptr;
     fork = join = nullptr;
 }
 }  // namespace rt
@@ -562,6 +552,15 @@ int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c
 {
     DIL_ENTER(d, T);
     return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, T, S(stream));
+}
+
+int dil_sign_phase2_skey_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, int32_t* w0,
+                             const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
+                             size_t batch, int shared_key, int early_exit, void* stream)
+{
+    DIL_ENTER(d, T);
+    return (int)dil::launch_sign2(level, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, T, S(stream), dil::KeyMap(),
+                                  early_exit ? w0 : nullptr, dil::Y_I32, /*small_key=*/true);
 }
 
 int dil_sign_phase2_early_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, int32_t* w0,

@@ -35,17 +35,8 @@ struct Config {
     std::atomic<int> fuse_wire{1};         // DIL_FUSE_WIRE: 0 = wire-format verify runs the unfused (codec + core) sequence
     std::atomic<int> fuse_keygen{1};       // DIL_FUSE_KEYGEN: 0 = keygen's mat-vec, Power2Round and t1 / t0 packing as separate kernels
     std::atomic<int> a24{1};               // DIL_A24: 0 = the composite calls keep per-item matrices as int32 in HBM (1: 24-bit packed)
-    std::atomic<int> gen_a{0};             // DIL_GEN_A: 1 = wire-format verify with a key per signature samples A inside the verifying kernel
-    std::atomic<int> sign_overlap{0};      // DIL_SIGN_OVERLAP: 1 = large signing rounds run hash + SampleInBall of one half of the entries on the helper
-                                           // stream beside the other half's polynomial kernels.  Built and measured in round 3: SLOWER (level 3, 8192
-                                           // messages: 1.42 -> 1.77 ms; level 5: 1.59 -> 2.07 ms; profiles/r03j_sign_overlap.txt) -- a cross-stream
-                                           // dependency costs ~20 us and a round needs four.  Default 0.
     std::atomic<int> fuse_challenge{1};    // DIL_FUSE_CHALLENGE: 1 = the signing loop hashes c~ and samples c in ONE launch (0: challenge hash, then SampleInBall)
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
-    std::atomic<int> verify_chunks{1};     // DIL_VERIFY_CHUNKS: wire-format verify, a key per signature: > 1 = ExpandA / fused kernel / challenge hash
-                                           // pipelined over this many chunks on three streams.  Built and measured in round 3, SLOWER at every
-                                           // level and size (level 3, 8192: 286 us one pass, 389 / 442 / 641 us with 2 / 4 / 8 chunks; 65536: 1.81
-                                           // vs 1.95-2.01 ms; profiles/r03f_verify_chunks.txt) -- default 1 = one pass
 };
 extern Config cfg;
 std::atomic<int>* option_slot(const char* name);     // nullptr: unknown option
@@ -69,13 +60,10 @@ struct ArenaPool {
 };
 
 // helper stream of the composite calls: latency-bound independent parts run beside the caller's stream
-constexpr int AUX_MAX_CHUNKS = 8;
 struct AuxStream {
     std::mutex mu;
     hipStream_t s = nullptr;
-    hipStream_t s2 = nullptr;                                  // second helper: the chunk pipelines' third lane (scheme.hip)
     hipEvent_t fork = nullptr, join = nullptr;
-    hipEvent_t chunk_ev[2 * AUX_MAX_CHUNKS + 1] = {};          // per chunk: producer done, consumer done; + the last lane's end
     bool ensure();
     void destroy();
 };

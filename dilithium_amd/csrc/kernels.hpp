@@ -74,7 +74,9 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
                         const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km = KeyMap(),
                         int32_t* w0_scratch = nullptr,    // == w0: rejected attempts stop at their first failed check
-                        int y_fmt = Y_I32);
+                        int y_fmt = Y_I32,
+                        bool small_key = false);          // the caller vouches for |c s1|, |c s2| <= 1023 and |c t0| < 2^18 (a key decoded from sk
+                                                          // bytes, c from SampleInBall): SmallPair / exact tails; false: any residues
 
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
@@ -100,9 +102,6 @@ hipError_t launch_sign_void_bad(uint8_t* sig, size_t sig_bytes, int32_t* attempt
 hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t batch, hipStream_t s);
 
 // ---- wire-format fused verify (wire_kernels.hip): packed z / t1 / hints / c in, packed w1 + verdict bits 2|4 out ----
-// wire-format verify with ExpandA inside the kernel (gen_kernels.hip): distinct public keys only
-hipError_t launch_verify_wire_gen(int level, uint8_t* w1p, int32_t* verdict, const uint8_t* pk, size_t pk_stride, const uint8_t* sig,
-                                  size_t sig_stride, const uint32_t* cbits, size_t batch, const Tables& t, hipStream_t s);
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
                               const Tables& t, hipStream_t s, int a_fmt = A_I32);

@@ -61,7 +61,7 @@ inline LaunchRecord* launch_records(int* count)
 {
     static LaunchRecord tab[] = {{"matvec_wpi"},  {"sign1_wpi"},     {"matvec_shared"},   {"sign1_shared"},       {"keygen_wpi"},
                                  {"verify_wpi"},  {"verify_shared"}, {"sign2_wpi"},       {"sign2_early_wpi"},    {"verify_wire_wpi"},
-                                 {"verify_wire_shared"}, {"verify_wire_gen"}, {"sign1_packed_wpi"}, {"sign1_packed_shared"}};
+                                 {"verify_wire_shared"}};
     if (count) *count = (int)(sizeof(tab) / sizeof(tab[0]));
     return tab;
 }

@@ -43,38 +43,61 @@ __device__ __forceinline__ int32_t sgn(int32_t x)
     return m;
 }
 
-#ifdef DIL_BFLY64     // variant builds only (A/B, profiles/r04*): the constant product through two 64-bit multiply-adds
-// y * w = hi32(p - m q) with p = y wt (v_mad_i64_i32), m = lo32(p) q^-1 (v_mul_lo_u32), p - m q (v_mad_i64_i32): no wq operand
-__device__ __forceinline__ int64_t mad64(int32_t a, int32_t b, int64_t c)
+// Two forms of the constant product, chosen per translation unit (-DDIL_MAD64 or a #define before the first include):
+//   0  v_mul_lo_u32 + 2 x v_mul_hi_i32 + v_sub          (4 instructions, ~15.7 issue cycles; needs wq = wt q^-1)
+//   1  p = y wt as v_mad_i64_i32, m = lo32(p) q^-1, hi32(p - m q) as a second v_mad_i64_i32   (3 instructions, ~14.8 cycles)
+// Same integer either way (p - m q has a zero low word, so its high word is hi(p) - hi(m q)).  Measured (profiles/r04c_*):
+// the VALU-bound fused pipelines gain 2-2.6 % with form 1, the HBM-bound standalone transforms LOSE 5 % (the 64-bit pairs
+// cost registers there), so pipelines.hip / wire_kernels.hip select 1 and kernels.hip keeps 0.
+#ifndef DIL_MAD64
+#define DIL_MAD64 0
+#endif
+__device__ __forceinline__ int64_t mad64(int32_t a, int32_t b, int64_t c)     // a * b + c, one v_mad_i64_i32
 {
     int64_t d;
     asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
     return d;
 }
-__device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t)
+
+// y * w for a table constant w = (wt, wq):  wt = centred(w * 2^32 mod q), wq = wt * q^-1 mod 2^32.
+// Any int32 y; |result| < q (|y * wt| < 2^31 * q/2).
+__device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
 {
+#if DIL_MAD64
     int64_t p;
     asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(y), "v"(wt) : "vcc");
     const int32_t m = (int32_t)((uint32_t)p * QINV);
     return (int32_t)(mad64(m, -Q, p) >> 32);
-}
-#define DIL_MONT_TW_DEFINED
-#endif
-#ifndef DIL_MONT_TW_DEFINED
-// y * w for a table constant w = (wt, wq):  wt = centred(w * 2^32 mod q), wq = wt * q^-1 mod 2^32.
-// Any int32 y; |result| < q (|y * wt| < 2^31 * q/2).      v_mul_lo_u32, 2 x v_mul_hi_i32, v_sub
-__device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
-{
+#else
     const int32_t m = (int32_t)((uint32_t)y * wq);
     return mulhi_i32(y, wt) - mulhi_i32(m, Q);
+#endif
+}
+// the same with a wave-uniform constant as the SCALAR operand of the multiplies (ntt_core.hpp TwLdsC: the uniform pass)
+__device__ __forceinline__ int32_t mont_tw_s(int32_t y, uint32_t wt, uint32_t wq)
+{
+#if DIL_MAD64
+    int64_t p;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(y), "s"(wt) : "vcc");
+    const int32_t m = (int32_t)((uint32_t)p * QINV);
+    return (int32_t)(mad64(m, -Q, p) >> 32);
+#else
+    int32_t m, h;
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"(y), "s"(wq));
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(h) : "v"(y), "s"(wt));
+    return h - mulhi_i32(m, Q);
+#endif
 }
 
-#endif
 // p * 2^-32 mod q for |p| < 2^31 * q;  |result| < q.
 __device__ __forceinline__ int32_t mont_red64(int64_t p)
 {
     const int32_t m = (int32_t)((uint32_t)p * QINV);
+#if DIL_MAD64
+    return (int32_t)(mad64(m, -Q, p) >> 32);
+#else
     return (int32_t)(p >> 32) - mulhi_i32(m, Q);
+#endif
 }
 
 // a * b * 2^-32 mod q (generic Montgomery product; v_mad_i64_i32 gives the 64-bit product)
@@ -97,6 +120,21 @@ __device__ __forceinline__ uint32_t canon_pm2q(int32_t x)
     uint32_t t = (uint32_t)x + 2u * (uint32_t)Q;
     t = min(t, t - 2u * (uint32_t)Q);
     return min(t, t - (uint32_t)Q);
+}
+// r in (-q, q), any representative of a value whose true size is known: V = v + off with 0 <= V < q  ->  V exactly.
+// x = r + off is V - q, V or V + q; as unsigned numbers exactly one of x, x + q, x - q is V and it is the smallest (a wrapped one is
+// huge): add + 2 add + v_min3_u32.  This is how the pipelines read SMALL results (c s, c t0, w0 - c s2) off a lazy residue without
+// canonicalising it first.
+__device__ __forceinline__ uint32_t min3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t exact_plus(int32_t r, uint32_t off)
+{
+    const uint32_t x = (uint32_t)r + off;
+    return min3_u32(x, x + (uint32_t)Q, x - (uint32_t)Q);
 }
 // [0, 2q) -> [0, q)
 __device__ __forceinline__ uint32_t canon_2q(uint32_t x) { return min(x, x - (uint32_t)Q); }

@@ -347,13 +347,6 @@ __device__ __forceinline__ void fwd_pass(int32_t (&r)[4], const Tw8& t)
 }
 
 // the same pass with wave-uniform twiddles as the SCALAR operand of the multiplies (TwLdsC: forward pass 0)
-__device__ __forceinline__ int32_t mont_tw_s(int32_t y, uint32_t wt, uint32_t wq)
-{
-    int32_t m, h;
-    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"(y), "s"(wq));
-    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(h) : "v"(y), "s"(wt));
-    return h - mulhi_i32(m, Q);
-}
 __device__ __forceinline__ void ct_bfly_s(int32_t& x, int32_t& y, uint32_t wt, uint32_t wq)
 {
     const int32_t t = mont_tw_s(y, wt, wq);

@@ -161,11 +161,51 @@ struct SmallPair {
     // r in (-q, q), r == x + 2^11 y (mod q) with |x|, |y| < 2^10  ->  x, y
     __device__ __forceinline__ static void split(int32_t r, int32_t& x, int32_t& y)
     {
-        const uint32_t t = canon_pm2q(r + OFF);            // (x + 2^10) + 2^11 (y + 2^10) in [0, 2^22): its own canonical residue
+        const uint32_t t = exact_plus(r, OFF);             // (x + 2^10) + 2^11 (y + 2^10) in [0, 2^22): its own canonical residue
         x = (int32_t)(t & ((1u << BITS) - 1)) - HALF;
         y = (int32_t)(t >> BITS) - HALF;
     }
 };
+
+// Sign phase 2, one coefficient of row k after the transforms (FSM2 combined_top.v:1981-2229: norm_check.v:84-105, makehint.v:98-99),
+// in EXACT centred integers instead of canonical residues (round 4: 16 instead of 23 instructions per coefficient).
+//   w0   LowBits(w) as phase 1 leaves it: the residue in [0, q) of w0c in (-gamma2, gamma2]
+//   cs2  c s2, exact (|cs2| <= 1023: SmallPair::split, or small_exact() of a lone row)
+//   b    INTT(c^ o t0^): any representative in (-q, q) of ct0, |ct0| <= tau 2^12 < 2^18
+// r0c = w0c - cs2 and ct0c are read off with exact_plus(), so r0c + ct0c is the centred representative of (r0 + ct0) mod q and the
+// reference's tests on residues become interval tests on small integers:
+//   reject 2:  |r0c| >= gamma2 - beta        reject 4:  |ct0c| >= gamma2
+//   hint (makehint.v:98-99: none if s <= gamma2, s > q - gamma2, or s == q - gamma2 with w1 == 0)
+//          <=>  s_c > gamma2  or  s_c < -gamma2  or  (s_c == -gamma2 and w1 != 0)
+template <int LEVEL>
+struct Phase2Coef {
+    static constexpr int32_t G2 = Par<LEVEL>::GAMMA2, GB = Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA;
+    // C1 = (q - 1) / 2 makes r0c the CENTRED representative of w0 - cs2 for every w0 in [0, q) -- also one that is no LowBits value
+    // (the low-level entry point accepts any residue; the interval tests then agree with the reference's on residues everywhere)
+    static constexpr uint32_t C1 = (uint32_t)(Q - 1) / 2, C2 = 1u << 18;
+    uint32_t u1, u2;          // r0c + C1 in [0, q), ct0c + C2 in [0, 2^19)
+    __device__ __forceinline__ Phase2Coef(uint32_t w0, int32_t cs2, int32_t b)
+    {
+        const uint32_t x = w0 - (uint32_t)cs2 + C1;        // in [C1 - 1023, q + C1 + 1023): r0c + C1, plus q in the upper part
+        u1 = min(x, x - (uint32_t)Q);
+        u2 = exact_plus(b, C2);
+    }
+    __device__ __forceinline__ bool rej_r0() const { return u1 - (C1 - (uint32_t)GB + 1u) >= 2u * (uint32_t)GB - 1u; }     // |r0c| >= gamma2 - beta
+    __device__ __forceinline__ bool rej_ct0() const { return u2 - (C2 - (uint32_t)G2 + 1u) >= 2u * (uint32_t)G2 - 1u; }   // |ct0c| >= gamma2
+    __device__ __forceinline__ bool hint(uint32_t w1) const
+    {
+        const uint32_t v = u1 + u2;                                              // s_c + C1 + C2
+        const bool outside = v - (C1 + C2 - (uint32_t)G2 + 1u) >= 2u * (uint32_t)G2;      // s_c >= gamma2 + 1 or s_c <= -gamma2
+        return outside && !(v == C1 + C2 - (uint32_t)G2 && w1 == 0u);
+    }
+    __device__ __forceinline__ uint32_t r0_canonical() const        // (the signing loop parks r0 in its scratch)
+    {
+        const int32_t r = (int32_t)(u1 - C1);
+        return (uint32_t)(r + (sgn(r) & Q));
+    }
+};
+// a lone row's product (no partner to pair with): lazy residue of a value with |v| <= 1023 -> v
+__device__ __forceinline__ int32_t small_exact(int32_t r) { return (int32_t)exact_plus(r, 1024u) - 1024; }
 
 // ---------------------------------------------------------------------------------------
 // Fused pipelines.  One workgroup per item (signature / verification), one wave per

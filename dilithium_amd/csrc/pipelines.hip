@@ -2,6 +2,9 @@
 // mat-vec (H9), verify core (H8), sign inner loop phases 1 and 2 (H10).
 //   rtl_src/combined_top.v:1207-1469 (verify), :1850-1933 (mat-vec / FSM1), :1946-2229 (FSM2)
 // Two shapes: workgroup-per-item (small batches, low latency) and wave-per-item (large batches).
+#ifndef DIL_MAD64
+#define DIL_MAD64 1        // the constant products as two v_mad_i64_i32 (modarith.hpp): these kernels are VALU-bound
+#endif
 #include "launch_util.hpp"
 #include "pipeline_common.hpp"
 #include "wire_common.hpp"
@@ -548,7 +551,12 @@ struct S2X {
 #ifndef DIL_S2_ATTR
 #define DIL_S2_ATTR __attribute__((amdgpu_waves_per_eu(5)))
 #endif
-template <int LEVEL, int YF, bool SH>      // SH: one key for the batch -- its s1^ + 2^11 s2^ rows are formed once per workgroup, in LDS
+// SMALL: the caller vouches for a SECRET KEY decoded from key bytes and a challenge from SampleInBall (dil_sign_phase2_skey_dev, the
+//        signing loop): |c s1|, |c s2| <= 1023 and |c t0| < 2^18, which is what lets one inverse transform carry c s1[k] and c s2[k]
+//        (SmallPair) and the row tails work on exact small integers (Phase2Coef).  !SMALL (dil_sign_phase2_dev: ANY residues): one
+//        transform per product, 1 + L + 2 K of them, and the reference's tests on canonical residues.
+// SH:    one key for the batch; with SMALL its s1^ + 2^11 s2^ rows are formed once per workgroup, in LDS.
+template <int LEVEL, int YF, bool SH, bool SMALL>
 __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
     const int32_t* __restrict__ c, const int32_t* __restrict__ y, const int32_t* __restrict__ w0,
@@ -557,13 +565,14 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
     const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    constexpr bool STAGED = SH && SMALL;        // the paired key rows live in LDS
     using XP = S2X;
     using PT = PipeTables<DIL_TWC>;
     constexpr int PAIR_AT = PT::DWORDS + 4 * 64 + 4 * XP::DW;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (SH ? L * 256 : 0)];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (STAGED ? L * 256 : 0)];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     PT::stage(lds, fwd_tab, inv_tab);
-    if (SH) SmallPair::stage_key<L>(reinterpret_cast<int32_t*>(lds + PAIR_AT), s1hat, s2hat);
+    if (STAGED) SmallPair::stage_key<L>(reinterpret_cast<int32_t*>(lds + PAIR_AT), s1hat, s2hat);
     __syncthreads();
     const int32_t* s12 = reinterpret_cast<const int32_t*>(lds + PAIR_AT);
     const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
@@ -579,28 +588,28 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
         int32_t ch[4], cp[4];
         load_strided(ch, c + it * 256, lane);
         int4 n1 = make_int4(0, 0, 0, 0), n2 = n1;
-        if (!SH || L < K) n2 = *reinterpret_cast<const int4*>(s2 + (SH ? L : 0) * 256 + 4 * lane);   // SH: s2's own rows matter from row L on
-        if (!SH) n1 = *reinterpret_cast<const int4*>(s1 + 4 * lane);
+        if (!STAGED || L < K) n2 = *reinterpret_cast<const int4*>(s2 + (STAGED ? L : 0) * 256 + 4 * lane);   // STAGED: s2's own rows matter from row L on
+        if (!STAGED) n1 = *reinterpret_cast<const int4*>(s1 + 4 * lane);
         ntt_fwd_core(ch, twf, lm);
-        if (!SH) {
+        if (SMALL && !SH) {
 #pragma unroll
             for (int m = 0; m < 4; m++) cp[m] = mont_mul(ch[m], SmallPair::SHIFT_R);      // c^ * 2^11
         }
         uint32_t bits = 0, nh = 0;
-        // Row k: c s1[k] and c s2[k] from ONE inverse transform (SmallPair: both products are tiny, so c^ o (s1^ + 2^11 s2^) carries
-        // them side by side in one residue), c t0[k] from a second -- 1 + 2 K transforms per attempt instead of 1 + L + 2 K.
+        // Row k (SMALL): c s1[k] and c s2[k] from ONE inverse transform (SmallPair: both products are tiny, so c^ o (s1^ + 2^11 s2^)
+        // carries them side by side in one residue), c t0[k] from a second -- 1 + 2 K transforms per attempt instead of 1 + L + 2 K.
         for (int k = 0; k < K; k++) {
-            const bool pair = k < L;
-            const int4 a1 = n1, a2 = n2, b0 = *reinterpret_cast<const int4*>(t0 + k * 256 + 4 * lane);      // (t0's row: used after the first transform)
+            const bool zrow = k < L, pair = SMALL && zrow;
+            const int4 a1 = n1, a2 = n2, b0 = *reinterpret_cast<const int4*>(t0 + k * 256 + 4 * lane);
             const size_t o = (it * K + k) * 256, oz = (it * L + k) * 256;
             int32_t wv0[4], yv[4];
             uint32_t wv1[4], hv[4];
             load_strided(wv0, w0 + o, lane);
             const uint32_t w1p = load_row_u8(w1 + o, lane);
-            if (pair) ys.raw(yv, y, it * L + k, lane);
+            if (zrow) ys.raw(yv, y, it * L + k, lane);
             if (k + 1 < K) {
-                if (!SH && k + 1 < L) n1 = *reinterpret_cast<const int4*>(s1 + (k + 1) * 256 + 4 * lane);
-                if (!SH || k + 1 > L) n2 = *reinterpret_cast<const int4*>(s2 + (k + 1) * 256 + 4 * lane);
+                if (!STAGED && k + 1 < L) n1 = *reinterpret_cast<const int4*>(s1 + (k + 1) * 256 + 4 * lane);
+                if (!STAGED || k + 1 > L) n2 = *reinterpret_cast<const int4*>(s2 + (k + 1) * 256 + 4 * lane);
             }
             int32_t a[4];
             if (pair && SH) {
@@ -619,26 +628,42 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
             ntt_inv_core(a, twi, lm);
             ntt_inv_core(b, twi, lm);
 #endif
+            int32_t cs1[4] = {0, 0, 0, 0};
+            if (!SMALL && zrow) {                   // generic: c s1[k] has a transform of its own
+                cs1[0] = mont_mul(ch[0], a1.x); cs1[1] = mont_mul(ch[1], a1.y); cs1[2] = mont_mul(ch[2], a1.z); cs1[3] = mont_mul(ch[3], a1.w);
+                ntt_inv_core(cs1, twi, lm);
+            }
             bool rej0 = false, rej1 = false, rej2 = false;
-            if (pair) {
+            if (zrow) {
                 ys.value(yv);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    int32_t cs1;
-                    SmallPair::split(a[m], cs1, a[m]);                       // a[m] := c s2, as the lone rows have it
-                    const uint32_t v = canon_pm2q(yv[m] + cs1);
+                    if (pair) SmallPair::split(a[m], cs1[m], a[m]);              // a[m] := c s2, exact
+                    const uint32_t v = canon_pm2q(yv[m] + cs1[m]);
                     rej0 |= norm_reject(v, Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA);
                     st_nt(z_out + oz + lane + 64 * m, (int32_t)v);
                 }
             }
+            if (SMALL && !zrow) {                   // a lone s2 row: its product is as small as the paired ones
+#pragma unroll
+                for (int m = 0; m < 4; m++) a[m] = small_exact(a[m]);
+            }
             unpack_row_u8(wv1, w1p, sc, lane);
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const uint32_t ct0 = canon_small(b[m]);
-                const uint32_t r0 = canon_pm2q(wv0[m] - a[m]);
-                rej1 |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
-                rej2 |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
-                const uint64_t hm = __ballot(make_hint_p<LEVEL>(canon_2q(r0 + ct0), wv1[m]));
+                uint64_t hm;
+                if (SMALL) {
+                    const Phase2Coef<LEVEL> pc((uint32_t)wv0[m], a[m], b[m]);
+                    rej1 |= pc.rej_r0();
+                    rej2 |= pc.rej_ct0();
+                    hm = __ballot(pc.hint(wv1[m]));
+                } else {
+                    const uint32_t ct0 = canon_small(b[m]);
+                    const uint32_t r0 = canon_pm2q(wv0[m] - a[m]);
+                    rej1 |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
+                    rej2 |= norm_reject(ct0, Par<LEVEL>::GAMMA2);
+                    hm = __ballot(make_hint_p<LEVEL>(canon_2q(r0 + ct0), wv1[m]));
+                }
                 hv[m] = mask_to_01(hm);
                 nh += __popcll(hm);
             }
@@ -1261,10 +1286,10 @@ hipError_t launch_verify(int level, uint8_t* w1, const int32_t* A, const int32_t
 hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y,
                         const int32_t* w0, const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat,
                         const int32_t* t0hat, size_t batch, int shared_key, const Tables& t, hipStream_t s, KeyMap km,
-                        int32_t* w0_scratch, int y_fmt)
+                        int32_t* w0_scratch, int y_fmt, bool small_key)
 {
     if (batch == 0) return hipSuccess;
-    if (y_fmt == Y_PACKED && !use_wpi(batch, t)) return hipErrorInvalidValue;      // packed y: wave-per-item shapes only
+    if (y_fmt == Y_PACKED && !(use_wpi(batch, t) && small_key)) return hipErrorInvalidValue;      // packed y: the signing loop's wave-per-item shapes only
     if (use_wpi(batch, t) && w0_scratch) {      // the signing loop's early-exit form (w0 is its own scratch, reused for r0)
         if (w0_scratch != w0) return hipErrorInvalidValue;
 #define DIL_S2E2(LV, YF, SH)                                                                                                     \
@@ -1274,10 +1299,11 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
         hipLaunchKernelGGL((sign2_early_wpi_kernel<LV, YF, SH>), g, 256, 0, s, z, h, flags, c, y, w0_scratch, w1, s1hat, s2hat, t0hat, batch, shared_key, \
                            km, t.fwd, t.inv_pipe);                                                                               \
     }
+    /* the staged, paired rows of the one-key form need the small-key promise; without it the per-item form serves one key too */ \
 #define DIL_S2E(LV)                                                \
     if (y_fmt == Y_PACKED && shared_key) DIL_S2E2(LV, Y_PACKED, true) \
     else if (y_fmt == Y_PACKED) DIL_S2E2(LV, Y_PACKED, false)      \
-    else if (shared_key) DIL_S2E2(LV, Y_I32, true)                 \
+    else if (shared_key && small_key) DIL_S2E2(LV, Y_I32, true)    \
     else DIL_S2E2(LV, Y_I32, false)                                \
     break
         switch (level) {
@@ -1291,18 +1317,20 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
         return hipGetLastError();
     }
     if (use_wpi(batch, t)) {
-#define DIL_S2W2(LV, YF, SH)                                                                                                     \
+#define DIL_S2W2(LV, YF, SH, SM)                                                                                                 \
     {                                                                                                                            \
-        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<LV, YF, SH>, 256, t.wpi_blocks_per_cu, t.device)); \
+        const int g = grid_for((batch + 3) / 4, t.num_cus * resident_blocks_per_cu(sign2_wpi_kernel<LV, YF, SH, SM>, 256, t.wpi_blocks_per_cu, t.device)); \
         note_launch("sign2_wpi", g, 4, batch);                                                                                   \
-        hipLaunchKernelGGL((sign2_wpi_kernel<LV, YF, SH>), g, 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, \
+        hipLaunchKernelGGL((sign2_wpi_kernel<LV, YF, SH, SM>), g, 256, 0, s, z, h, flags, c, y, w0, w1, s1hat, s2hat, t0hat, batch, shared_key, km, t.fwd, \
                            t.inv_pipe);                                                                                          \
     }
 #define DIL_S2W(LV)                                                \
-    if (y_fmt == Y_PACKED && shared_key) DIL_S2W2(LV, Y_PACKED, true) \
-    else if (y_fmt == Y_PACKED) DIL_S2W2(LV, Y_PACKED, false)      \
-    else if (shared_key) DIL_S2W2(LV, Y_I32, true)                 \
-    else DIL_S2W2(LV, Y_I32, false)                                \
+    if (y_fmt == Y_PACKED && shared_key) DIL_S2W2(LV, Y_PACKED, true, true) \
+    else if (y_fmt == Y_PACKED) DIL_S2W2(LV, Y_PACKED, false, true) \
+    else if (shared_key && small_key) DIL_S2W2(LV, Y_I32, true, true) \
+    else if (small_key) DIL_S2W2(LV, Y_I32, false, true)           \
+    else if (shared_key) DIL_S2W2(LV, Y_I32, true, false)          \
+    else DIL_S2W2(LV, Y_I32, false, false)                         \
     break
         switch (level) {
         case 2: DIL_S2W(2);

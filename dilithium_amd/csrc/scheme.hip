@@ -213,6 +213,7 @@ struct AttemptScratch {
     int a_fmt = dil::A_I32;      // format of the matrix the attempts multiply by (kernels.hpp)
     bool fuse_challenge = true;  // c~ and c by one launch (hash_kernels.hip challenge_sample_kernel)
     bool packed_y = false;       // the signing loop: y stays ExpandMask's raw stream in rounds large enough for the wave-per-item kernels
+    bool small_key = false;      // s1^ s2^ t0^ decoded from secret-key bytes, c from SampleInBall: phase 2 may use its small-product forms
     int alloc(StreamScratch& ws, int level, int K, int L, size_t batch)
     {
         y = ws.take<int32_t>(batch * L * 256);
@@ -276,16 +277,13 @@ struct AuxFork {
 int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                       const int32_t* t0hat, int level, size_t batch, int shared_key, hipStream_t s, dil::KeyMap km = dil::KeyMap(),
-                      int phases = 3, bool early_exit = false)
+                      bool early_exit = false)
 {
     // y: int32, or -- every round wide enough for the wave-per-item kernels -- the raw B-bit SHAKE256 stream, unpacked by phase 1 /
     // phase 2 as they load it (ExpandMask picks one or two lanes per sponge by the round's width either way)
-    const int y_fmt = (t.packed_y && phases == 3 && dil::fused_wpi_shape(batch, T)) ? dil::Y_PACKED : dil::Y_I32;
-    if (phases & 1) {
-        if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, batch, s));
-        else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
-    }
-    if (!(phases & 2)) return 0;
+    const int y_fmt = (t.packed_y && dil::fused_wpi_shape(batch, T)) ? dil::Y_PACKED : dil::Y_I32;
+    if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, batch, s));
+    else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
     // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
     DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt, y_fmt));
     if (t.fuse_challenge) {
@@ -295,68 +293,10 @@ int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ct
         DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
     }
     DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
-                              early_exit ? t.w0 : nullptr, y_fmt));
+                              early_exit ? t.w0 : nullptr, y_fmt, t.small_key));
     return 0;
 }
 
-// The same attempt over entries [off, off + cnt) of the per-entry arrays (per-key arrays are addressed through km)
-int sign_attempt_range(const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A,
-                       const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
-                       const int32_t* t0hat, int level, int K, int L, size_t off, size_t cnt, int shared_key, hipStream_t s, dil::KeyMap km,
-                       int phases = 3, bool early_exit = false)
-{
-    AttemptScratch u = t;
-    u.packed_y = t.packed_y && off == 0;         // (a packed stream is addressed from entry 0: split rounds keep int32)
-    u.y += off * L * 256; u.w1 += off * K * 256; u.w0 += off * K * 256; u.w1p += off * K * (level == 2 ? 192 : 128); u.c += off * 256;
-    km.base += (uint32_t)off;
-    return sign_attempt_impl(T, u, ctilde + off * 32, z + off * L * 256, h + off * K * 256, flags + off, A, mu + off * 64,
-                             rhoprime + off * 64, kappa + off, s1hat, s2hat, t0hat, level, cnt, shared_key, s, km, phases, early_exit);
-}
-
-
-// One round of the signing loop with its two latency-bound kernels (challenge hash: a chain of 7-9 permutations per entry;
-// SampleInBall: a serial loop per entry -- together 85 of a round's 455 us at level 3, during which the chip is ~85 % idle)
-// overlapped with polynomial work: the entries are cut in two halves, the caller's stream runs phase 1 of half A, phase 1 of half
-// B, phase 2 of A, phase 2 of B, the helper stream runs hash + SampleInBall of A beside phase 1 of B and those of B beside phase 2
-// of A.  (The FPGA overlaps the same way: operator 0 computes the next w while operator 1 judges the current attempt,
-// combined_top.v:1831,1853-1854,2016,2500 `fsm1_even`.)  ax must own the helper stream (ax.on).
-int sign_attempt_overlapped(Device& dv, const dil::Tables& T, const AttemptScratch& t, uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags,
-                            const int32_t* A, const uint8_t* mu, const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat,
-                            const int32_t* s2hat, const int32_t* t0hat, int level, int K, int L, size_t E, int shared_key, hipStream_t s,
-                            dil::KeyMap km, bool early_exit)
-{
-    const int y_fmt = t.packed_y ? dil::Y_PACKED : dil::Y_I32;
-    const size_t ypoly = y_fmt == dil::Y_PACKED ? (size_t)(level == 2 ? 576 : 640) : 1024, w1pb = (size_t)K * (level == 2 ? 192 : 128);
-    dil::rt::AuxStream& xs = dv.aux;
-    hipStream_t hs = xs.s;
-    if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, E, s));
-    else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, E, s));
-    const size_t half = E / 2;
-    const size_t off[2] = {0, half}, cnt[2] = {half, E - half};
-    auto ybase = [&](int i) { return reinterpret_cast<const int32_t*>(reinterpret_cast<const uint8_t*>(t.y) + off[i] * (size_t)L * ypoly); };
-    dil::KeyMap kmh[2] = {km, km};
-    kmh[1].base += (uint32_t)half;
-    for (int i = 0; i < 2; i++) {          // phase 1 of both halves on the caller's stream; each hands over to the helper as it ends
-        DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1 + off[i] * K * 256, t.w0 + off[i] * K * 256, A, ybase(i), cnt[i], shared_key,
-                                   T, s, kmh[i], t.w1p + off[i] * w1pb, t.a_fmt, y_fmt));
-        DIL_TRY(hipEventRecord(xs.chunk_ev[i], s));
-        DIL_TRY(hipStreamWaitEvent(hs, xs.chunk_ev[i], 0));
-        if (t.fuse_challenge) {
-            DIL_TRY(dil::launch_challenge_sample(ctilde + off[i] * 32, t.c + off[i] * 256, mu + off[i] * 64, t.w1p + off[i] * w1pb, level, cnt[i], hs));
-        } else {
-            DIL_TRY(dil::launch_challenge_hash(ctilde + off[i] * 32, nullptr, mu + off[i] * 64, t.w1p + off[i] * w1pb, level, nullptr, cnt[i], hs));
-            DIL_TRY(dil::launch_sample_in_ball(t.c + off[i] * 256, ctilde + off[i] * 32, level, cnt[i], hs));
-        }
-        DIL_TRY(hipEventRecord(xs.chunk_ev[2 + i], hs));
-    }
-    for (int i = 0; i < 2; i++) {
-        DIL_TRY(hipStreamWaitEvent(s, xs.chunk_ev[2 + i], 0));
-        int32_t* w0i = t.w0 + off[i] * K * 256;
-        DIL_TRY(dil::launch_sign2(level, z + off[i] * L * 256, h + off[i] * K * 256, flags + off[i], t.c + off[i] * 256, ybase(i), w0i,
-                                  t.w1 + off[i] * K * 256, s1hat, s2hat, t0hat, cnt[i], shared_key, T, s, kmh[i], early_exit ? w0i : nullptr, y_fmt));
-    }
-    return 0;
-}
 }  // namespace
 
 int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
@@ -531,16 +471,13 @@ int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t
     if ((rc = level_par(level, &p))) return rc;
     DIL_ENTER(dv, T);
     if (batch == 0) return 0;
+    if (!A) return (int)hipErrorInvalidValue;
     hipStream_t s = S(stream);
     StreamScratch ws(dv, s);
     uint32_t* cbits = ws.take<uint32_t>(batch * 64);
     if (ws.rc) return ws.rc;
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
     DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
-    if (!A) {                    // no expanded matrix: the kernel that samples A itself (a key per signature only)
-        if (shared_pk || (reinterpret_cast<uintptr_t>(pk) & 7)) return ws.close((int)hipErrorInvalidValue);
-        return ws.close((int)dil::launch_verify_wire_gen(level, w1_packed, verdict, pk, pkb, sig, sgb, cbits, batch, T, s));
-    }
     return ws.close((int)dil::launch_verify_wire(level, w1_packed, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
 }
 
@@ -555,27 +492,20 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_pk ? 1 : batch;
     const size_t w1b = (size_t)p.K * (level == 2 ? 192 : 128);
-    const bool few_keys_path = dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed) && !A_ready &&
-                               !(!shared_pk && dil::rt::cfg.gen_a.load(std::memory_order_relaxed)) && nk * p.K * p.L <= dil::EA_TWO_LANE_MAX &&
+    const bool few_keys_path = dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed) && !A_ready && nk * p.K * p.L <= dil::EA_TWO_LANE_MAX &&
                                dil::rt::cfg.aux_overlap.load(std::memory_order_relaxed);
     if (mu_pending && !few_keys_path && (rc = mu_pending->join())) return rc;      // only that path defers the join to mu's first use
     if (dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed)) {
         // Fused path: ExpandA (helper stream when it is latency-bound) beside SampleInBall, then ONE kernel that reads
         // the packed z / t1 / hints and writes packed w1 (+ the ||z|| and hint-encoding verdict bits), then the challenge
         // hash compared with c~ in place.  No int32 z / t1 / h / c / w1 temporaries.
-        const bool gen_a = !A_ready && !shared_pk && dil::rt::cfg.gen_a.load(std::memory_order_relaxed);
-        int32_t* A = A_ready ? const_cast<int32_t*>(A_ready) : gen_a ? nullptr : ws.take<int32_t>(nk * p.K * p.L * 256);
+        // (Sampling A INSIDE the verifying kernel -- the reference's gen_a_ext.v feeding the MAC -- was built in round 2, measured slower
+        //  than ExpandA -> HBM -> this kernel (297 vs 239 us per 8192, profiles/r02_gen_a.txt) and removed in round 4; so was a
+        //  three-stream chunk pipeline of ExpandA / fused kernel / challenge hash (round 3, profiles/r03f_verify_chunks.txt).)
+        int32_t* A = A_ready ? const_cast<int32_t*>(A_ready) : ws.take<int32_t>(nk * p.K * p.L * 256);
         uint32_t* cbits = ws.take<uint32_t>(batch * 64);
         uint8_t* w1p = ws.take<uint8_t>(batch * w1b);
         if (ws.rc) return ws.rc;
-        if (gen_a) {
-            // option gen_a, a key per signature: A is sampled inside the verifying kernel and consumed coefficient by
-            // coefficient (gen_kernels.hip) -- no ExpandA launch, no A in HBM.  Not the default: the lane-per-sponge
-            // multiply-accumulate and the LDS-capped occupancy cost more than the A stream (profiles/r02_gen_a.txt)
-            DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
-            DIL_TRY(dil::launch_verify_wire_gen(level, w1p, verdict, pk, pkb, sig, sgb, cbits, batch, T, s));
-            return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
-        }
         if (A_ready) {               // the matrix is already there: SampleInBall, the fused kernel, the challenge hash
             DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
             DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
@@ -604,42 +534,6 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         //  63.1 us and ExpandA's 48-byte pieces cost 8 us more than its 64-byte ones; profiles/r02_a24.txt.  The format
         //  parameter stays for A/B runs: option a24 = 2 forces the packed form here too.)
         const int a_fmt = (!shared_pk && dil::rt::cfg.a24.load(std::memory_order_relaxed) == 2) ? matrix_format(nk, p.K, p.L) : dil::A_I32;
-        // Option verify_chunks > 1 (OFF by default): three lanes over chunks of the batch -- ExpandA of chunk i + 1 on one helper
-        // stream, the fused kernel of chunk i on the caller's, the challenge hash of chunk i - 1 on a second helper (the reference
-        // streams A in while z decodes, combined_top.v:1149-1207).  On paper ExpandA (Keccak-VALU-bound, 170 us per 8192 level-3
-        // keys) hides the HBM-bound fused kernel (59 us) and all but the last latency-bound hash (51 us): 283 -> ~230 us.  Measured
-        // (profiles/r03f_verify_chunks.txt): 286 us in one pass, 389 / 442 / 641 us with 2 / 4 / 8 chunks, and no gain at 65536
-        // either -- a cross-stream dependency costs ~15-20 us, the throughput-form ExpandA of a quarter batch is one wave per SIMD
-        // (70-80 % of its rate), and both kernels want the same VALUs.  The one-pass sequence below stays the default.
-        int chunks = dil::rt::cfg.verify_chunks.load(std::memory_order_relaxed);
-        chunks = std::min<int>(std::min<int>(chunks, dil::rt::AUX_MAX_CHUNKS), (int)(batch / 1024));
-        if (!shared_pk && chunks >= 2 && ax.on) {
-            dil::rt::AuxStream& xs = dv.aux;
-            hipStream_t s_ea = xs.s, s_hash = xs.s2;
-            DIL_TRY(hipEventRecord(xs.fork, s));                          // both helper lanes start after whatever is already on `s`
-            DIL_TRY(hipStreamWaitEvent(s_ea, xs.fork, 0));
-            DIL_TRY(hipStreamWaitEvent(s_hash, xs.fork, 0));
-            DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));      // latency-bound, beside the first ExpandA
-            const size_t per = (batch + chunks - 1) / chunks;
-            int nch = 0;
-            for (size_t off = 0; off < batch; off += per, nch++) {
-                const size_t cnt = std::min(per, batch - off);
-                int32_t* Ac = A + off * (size_t)(p.K * p.L) * (a_fmt == dil::A_P24 ? 192 : 256);
-                hipEvent_t ea_done = xs.chunk_ev[2 * nch], v_done = xs.chunk_ev[2 * nch + 1];
-                DIL_TRY(dil::launch_expand_a(Ac, pk + off * pkb, pkb, level, cnt, s_ea, a_fmt));
-                DIL_TRY(hipEventRecord(ea_done, s_ea));
-                DIL_TRY(hipStreamWaitEvent(s, ea_done, 0));
-                DIL_TRY(dil::launch_verify_wire(level, w1p + off * w1b, verdict + off, Ac, pk + off * pkb, pkb, sig + off * sgb, sgb, cbits + off * 64,
-                                                cnt, 0, T, s, a_fmt));
-                DIL_TRY(hipEventRecord(v_done, s));
-                DIL_TRY(hipStreamWaitEvent(s_hash, v_done, 0));
-                DIL_TRY(dil::launch_challenge_hash(nullptr, verdict + off, mu + off * 64, w1p + off * w1b, level, sig + off * sgb, cnt, s_hash, sgb));
-            }
-            hipEvent_t all_done = xs.chunk_ev[2 * dil::rt::AUX_MAX_CHUNKS];
-            DIL_TRY(hipEventRecord(all_done, s_hash));
-            DIL_TRY(hipStreamWaitEvent(s, all_done, 0));                  // (s_ea is joined through the last chunk's ea_done)
-            return 0;
-        }
         hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;
         hipStream_t sc = a_sponges <= batch ? s : ax.fork(batch);
         DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, sa, a_fmt));
@@ -778,12 +672,12 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         att.a_fmt = matrix_format(nk, p.K, p.L);
         att.packed_y = dil::rt::cfg.packed_y.load(std::memory_order_relaxed) != 0;
         att.fuse_challenge = dil::rt::cfg.fuse_challenge.load(std::memory_order_relaxed) != 0;
+        att.small_key = true;            // s1^ s2^ t0^ come from unpack(sk) and c from SampleInBall: the small-product kernels are exact (pipelines.hip)
         const bool few = nk * p.K * p.L <= dil::EA_TWO_LANE_MAX;            // (then the matrix format is int32)
         if (!few) DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s, att.a_fmt));
         DIL_TRY(dil::launch_sign_setup(level, A, few, s1h, s2h, t0h, sk, nk, rp, attempts, mu, sk_stride, batch, T, s));
     }
 
-    AuxFork overlap(dv, s, /*defer=*/dil::rt::cfg.sign_overlap.load(std::memory_order_relaxed) == 0);
     struct EventGuard {
         hipEvent_t ev = nullptr;
         ~EventGuard() { if (ev) (void)hipEventDestroy(ev); }
@@ -824,13 +718,9 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
             DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
             DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
         }
-        // large rounds: the latency-bound hash kernels of one half of the entries run beside the polynomial kernels of the other
-        if (overlap.on && E >= 2 * 4096 && dil::fused_wpi_shape(E / 2, T)) {
-            if ((rc = sign_attempt_overlapped(dv, T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, E, shared_sk, s, keys, sign_early)))
-                return rc;
-        } else if ((rc = sign_attempt_range(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, p.K, p.L, 0, E, shared_sk, s, keys, 3,
-                                            sign_early)))
-            return rc;
+        // (Two stream-level overlaps of a round's latency-bound hash kernels with its polynomial kernels were built in rounds 2 / 3 and
+        //  measured slower -- 1.42 -> 1.77 ms per 8192 level-3 signatures, profiles/r03j_sign_overlap.txt -- and are gone.)
+        if ((rc = sign_attempt_impl(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, E, shared_sk, s, keys, sign_early))) return rc;
         // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
         DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s));
         // the pending count goes home NOW, marked by an event; the winners' packing is queued behind it, so the host wakes up,

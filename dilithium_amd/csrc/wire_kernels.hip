@@ -9,6 +9,9 @@
 // instead of 45 KiB plus the codec kernels' own read + write of the same fields.  The ||z|| < gamma1 - beta check
 // (norm_check.v:84-105) and the hint-encoding validation ride along (z is in registers anyway).
 // Same arithmetic as verify_wpi_kernel / verify_shared_kernel (pipelines.hip): combined_top.v:1207-1469.
+#ifndef DIL_MAD64
+#define DIL_MAD64 1        // the constant products as two v_mad_i64_i32 (modarith.hpp): these kernels are VALU-bound
+#endif
 #include <algorithm>
 #include "launch_util.hpp"
 #include "wire_common.hpp"

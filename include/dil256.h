@@ -63,9 +63,6 @@ int dil_shutdown(void);
  *                                   Both shapes compute identical results; tests run both on the same input.
  *   "fuse_wire"   (DIL_FUSE_WIRE)   1 = wire-format verification reads packed z / t1 / hints in the fused kernel
  *                                   (default), 0 = separate codec kernels + int32 verify core
- *   "gen_a"       (DIL_GEN_A)       1 = wire-format verification with a public key per signature samples A = ExpandA(rho)
- *                                   INSIDE the verifying kernel (gen_kernels.hip; A never crosses HBM); 0 (default) = ExpandA
- *                                   to HBM, then the fused kernel -- measured faster on MI355X (profiles/r02_gen_a.txt)
  *   "a24"         (DIL_A24)         1 (default) = inside dil_keygen_dev / dil_sign_* a matrix per key crosses HBM as 24-bit
  *                                   packed coefficients (768 bytes per polynomial) when the batch is large: the mat-vec kernels are
  *                                   bound by that stream (level 3, 8192 keys: 85 -> 51 us); 0 = as int32; 2 = packed in
@@ -144,20 +141,32 @@ int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const i
  *   flags[i]: bit0 ||z|| >= gamma1-beta, bit1 ||r0|| >= gamma2-beta, bit2 ||ct0|| >= gamma2,
  *   bit3 #hints > omega  (norm_check.v:84-105, makehint.v:98-99,176-177); 0 = accept.
  * s1hat [batch|1][L][256], s2hat / t0hat [batch|1][K][256]: NTT domain, canonical.
- * Precondition of phase 2: ||c s1||_inf, ||c s2||_inf <= 1023 -- true for every challenge (tau coefficients +-1) with every s1, s2 a
- * secret-key byte string can decode to (|s| <= 11 at worst), the only inputs the scheme produces.  The wave-per-item kernels read
- * c s1[k] and c s2[k] off ONE inverse transform of c^ o (s1^[k] + 2^11 s2^[k]) (1 + 2 K transforms per attempt instead of
- * 1 + L + 2 K); outside the bound the two would overlap.  Results inside it are the reference's integers, bit for bit. */
+ * dil_sign_phase2_dev accepts ANY residues in c, s1hat, s2hat, t0hat, w0 (one inverse transform per product, 1 + L + 2 K per attempt,
+ * the reference's tests on canonical residues). */
 int dil_sign_phase1_dev(uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y, int level, size_t batch,
                         int shared_key, void* stream);
 int dil_sign_phase2_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, const int32_t* w0,
                         const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
                         size_t batch, int shared_key, void* stream);
 
-/* Phase 2 as the signing LOOP runs it (dil_sign_dev): an attempt is abandoned at its FIRST failed check; flags != 0 iff the attempt is
+/* Phase 2 for a SECRET KEY DECODED FROM KEY BYTES and a challenge from SampleInBall -- what the signing loop (dil_sign_dev) runs.
+ * The caller vouches for ||c s1||_inf, ||c s2||_inf <= 1023 and ||c t0||_inf < 2^18: true for every challenge (tau coefficients +-1)
+ * with every (s1, s2, t0) a secret-key BYTE STRING can decode to -- eta-bit fields give |s| <= 11 at worst, 13-bit fields t0 in
+ * (-2^12, 2^12] -- and false for arbitrary residues, which is why this is an entry point of its own and not a comment on
+ * dil_sign_phase2_dev (round-3 advisor finding).  Inside the bound the kernels read c s1[k] and c s2[k] off ONE inverse transform of
+ * c^ o (s1^[k] + 2^11 s2^[k]) (1 + 2 K transforms per attempt instead of 1 + L + 2 K) and run the norm checks and MakeHint on exact
+ * small integers instead of canonical residues; z, h, flags are the reference's, bit for bit (tests/test_gpu_persistent_parity.py,
+ * incl. the extremes of what key bytes decode to).  Outside it the results are undefined (never out-of-bounds accesses).
+ * early_exit != 0: the loop's form, see dil_sign_phase2_early_dev below (w0 is then IN/OUT); with shared_key the rows run in turn,
+ * r0[k] before z[k] (one transform yields both). */
+int dil_sign_phase2_skey_dev(int32_t* z, uint8_t* h, int32_t* flags, const int32_t* c, const int32_t* y, int32_t* w0,
+                             const uint8_t* w1, const int32_t* s1hat, const int32_t* s2hat, const int32_t* t0hat, int level,
+                             size_t batch, int shared_key, int early_exit, void* stream);
+
+/* Phase 2 with the signing loop's EARLY EXIT, for arbitrary residues (dil_sign_dev): an attempt is abandoned at its FIRST failed check; flags != 0 iff the attempt is
  * rejected and names that first check: 2 an r0 row, 1 a z row, 4 a c t0 row (| 8 for too many hints counted so far; 8 alone: all checks
- * ran, hint count over omega).  Order of evaluation: shared_key: rows k = 0 .. K-1 in turn, r0[k] before z[k] (one transform yields
- * both, see below); a key per item: all r0 rows, then all z rows; then the c t0 rows.  z and h are complete only where flags == 0.
+ * ran, hint count over omega).  Order of evaluation: all r0 rows, then all z rows, then the c t0 rows (dil_sign_phase2_skey_dev with
+ * shared_key: rows k = 0 .. K-1 in turn, r0[k] before z[k]).  z and h are complete only where flags == 0.
  * w0 is IN/OUT: on return it holds r0 = w0 - c s2 of the rows that were evaluated.  (The reference's FSM2, combined_top.v:1981-2229,
  * evaluates every check and tests `reject_mh || norm_rejected` at the end, :2218; stopping early is this runtime's.)  Batches below
  * the wave-per-item threshold (8 x #CUs items, option fused_mode) run the full phase 2 instead: every flag bit, w0 untouched. */
@@ -228,9 +237,8 @@ int dil_verify_sig_expanded_dev(int32_t* verdict, const int32_t* A, const uint8_
  * ([batch|1][pk_bytes]) and sig ([batch][sig_bytes]) in wire format -- packed z, t1, hints; c = SampleInBall(c~) -- with
  * A [batch|1][K][L][256] already expanded, and writes w1 PACKED ([batch][K * 128|192] bytes, encoder.v:96-133) plus
  * verdict[i] = bit1 (value 2) ||z|| >= gamma1 - beta | bit2 (value 4) malformed hint encoding.
- * A == NULL (shared_pk must be 0, pk 8-byte aligned): the kernel that samples A = ExpandA(rho) itself while it multiplies
- * (gen_kernels.hip; gen_a_ext.v / sampler_a_ext.v feeding the MAC, combined_top.v:1149-1207) -- what dil_verify_sig_dev runs
- * for a key per signature. */
+ * A == NULL: hipErrorInvalidValue.  (Round 2's variant that sampled A = ExpandA(rho) inside the verifying kernel measured slower
+ * than ExpandA -> HBM -> this kernel, profiles/r02_gen_a.txt, and was removed in round 4.) */
 int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t* A, const uint8_t* pk, const uint8_t* sig, int level,
                              size_t batch, int shared_pk, void* stream);
 

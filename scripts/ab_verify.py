@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--shared", action="store_true")
 ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1", "sign2", "ntt"])
 ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--generic", action="store_true", help="sign2: the entry point for arbitrary residues even where the small-key one exists")
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
@@ -55,6 +56,8 @@ for path in a.libs:
     L_.dil_matvec_dev.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
     L_.dil_sign_phase1_dev.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
     L_.dil_sign_phase2_dev.argtypes = [C.c_void_p] * 10 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+    if hasattr(L_, "dil_sign_phase2_skey_dev"):          # round 4: the small-key kernels have an entry point of their own
+        L_.dil_sign_phase2_skey_dev.argtypes = [C.c_void_p] * 10 + [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
     L_.dil_event_elapsed_ms.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
     assert L_.dil_init(0) == 0
     libs.append((os.path.basename(path), L_))
@@ -90,6 +93,8 @@ def run(L_, reps):
             rc = L_.dil_matvec_dev(p(w), p(A), p(z), a.level, n, sh, None)
         elif a.kind == "sign1":
             rc = L_.dil_sign_phase1_dev(p(w1), p(w0), p(A), p(z), a.level, n, sh, None)
+        elif hasattr(L_, "dil_sign_phase2_skey_dev") and not a.generic:
+            rc = L_.dil_sign_phase2_skey_dev(p(zo), p(ho), p(fl), p(c), p(z), p(A), p(w1in), p(s1h), p(s2h), p(t0h), a.level, n, sh, 0, None)
         else:
             rc = L_.dil_sign_phase2_dev(p(zo), p(ho), p(fl), p(c), p(z), p(A), p(w1in), p(s1h), p(s2h), p(t0h), a.level, n, sh, None)
         assert rc == 0

@@ -38,7 +38,7 @@ while time.time() - t0 < budget:
         ow1, ow0 = o.sign_phase1(level, As, ys)
         assert (gw1.cpu().numpy() == ow1).all() and (gw0.cpu().numpy() == ow0).all(), ("sign1", level, n, shared, mode, seed)
         zz, hh, fl = api.sign_phase2(dev(torch, cs), dev(torch, ys), dev(torch, ow0), dev(torch, ow1, np.uint8), dev(torch, s1h), dev(torch, s2h),
-                                     dev(torch, t0h), level, shared_key=shared)
+                                     dev(torch, t0h), level, shared_key=shared, small_key=bool(rng.integers(0, 2)))
         oz, oh, ofl = o.sign_phase2(level, cs, ys, ow0, ow1, s1h, s2h, t0h)
         assert (fl.cpu().numpy() == ofl).all() and (zz.cpu().numpy() == oz).all() and (hh.cpu().numpy() == oh).all(), ("sign2", level, n, shared, mode, seed)
     cases += 1

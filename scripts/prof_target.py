@@ -70,7 +70,7 @@ def main():
         s1h, s2h, t0h = rnd(1, L, 256), rnd(1, K, 256), rnd(1, K, 256)
         for _ in range(reps):
             w1, w0 = api.sign_phase1(A, y, 5, shared_key=True)
-            api.sign_phase2(c, y, w0, w1, s1h, s2h, t0h, 5, shared_key=True)
+            api.sign_phase2(c, y, w0, w1, s1h, s2h, t0h, 5, shared_key=True, small_key=True)
     if what in ("hash", "scheme"):
         n = 8192
         u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g)  # noqa: E731

@@ -27,7 +27,7 @@ P1=${PIPESTATUS[0]}
 
 say "== pass 2: hipcc host code with clang's -fsanitize=address,undefined: libdil256.so (capi / scheme / multi_gpu host paths)"
 SRC=""
-for f in kernels pipelines hash_kernels codec_kernels wire_kernels gen_kernels capi scheme multi_gpu; do SRC="$SRC dilithium_amd/csrc/$f.hip"; done
+for f in kernels pipelines hash_kernels codec_kernels  wire_kernels capi scheme multi_gpu; do SRC="$SRC dilithium_amd/csrc/$f.hip"; done
 hipcc --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wall -pthread $SANFLAGS -fno-sanitize=vptr,function -shared-libsan $SRC -o $SAN/libdil256.so >> $LOG 2>&1 \
     || { say "libdil256 san build FAILED"; exit 1; }
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)

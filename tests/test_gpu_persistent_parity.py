@@ -82,11 +82,14 @@ def test_verify_wpi_level3_20000_vs_oracle(gpu, oracle):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("small", [True, False])
 @pytest.mark.parametrize("shared,n,min_steps", [(True, 9216, 2), (True, 40000, 3), (False, 9216, 2), (False, 20000, 3)])
-def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, min_steps):
+def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, min_steps, small):
     """phase 1 (matvec_shared / matvec_wpi <OUT_W1W0>: w1, w0), phase 2 (sign2_wpi_kernel: z, h, flags) and the signing
     loop's early-exit phase 2 (sign2_early_wpi_kernel through its in/out w0 scratch: first failed check, z / h of the
-    accepted attempts), one key and a key per item, every attempt of the batch"""
+    accepted attempts), one key and a key per item, every attempt of the batch.  small: the entry point that takes the caller's
+    word for a key decoded from key bytes (dil_sign_phase2_skey_dev: paired rows, exact small-integer tails -- the signing loop's
+    kernels) / the one for arbitrary residues (dil_sign_phase2_dev, dil_sign_phase2_early_dev: one transform per product)"""
     from dilithium_amd import api
     nk = 1 if shared else n
     A, y, c, _, _ = big_inputs(level, n, 7000 + 10 * level + n + shared, nk)
@@ -100,7 +103,7 @@ def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, mi
     # phase 2, every check of every attempt
     dc, dy, dw0, dw1 = dev(gpu, c), dev(gpu, y), dev(gpu, ow0), dev(gpu, ow1, np.uint8)
     ds1, ds2, dt0 = dev(gpu, s1h), dev(gpu, s2h), dev(gpu, t0h)
-    z, h, fl = api.sign_phase2(dc, dy, dw0, dw1, ds1, ds2, dt0, level, shared_key=shared)
+    z, h, fl = api.sign_phase2(dc, dy, dw0, dw1, ds1, ds2, dt0, level, shared_key=shared, small_key=small)
     steps("sign2_wpi", n, min_steps)
     oz, oh, ofl = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
     assert (fl.cpu().numpy() == ofl).all()
@@ -111,7 +114,7 @@ def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, mi
     # z[k] (-> 1); a key per item -- all r0 rows, then all z rows); then the c t0 rows (-> 4 [| 8]).  The expectation is rebuilt row
     # by row from the oracle's z and c s2.
     w0s = dw0.clone()
-    ze, he, fle = api.sign_phase2_early(dc, dy, w0s, dw1, ds1, ds2, dt0, level, shared_key=shared)
+    ze, he, fle = api.sign_phase2_early(dc, dy, w0s, dw1, ds1, ds2, dt0, level, shared_key=shared, small_key=small)
     steps("sign2_early_wpi", n, min_steps)
     fle = fle.cpu().numpy()
     K, L = KL[level]
@@ -131,8 +134,8 @@ def test_sign_phases_persistent_loop_vs_oracle(gpu, oracle, level, shared, n, mi
         first_z[lo:hi] = np.where(bad_z.any(axis=1), bad_z.argmax(axis=1), 99)
     r0f, zf, ctf = (ofl & 2) != 0, (ofl & 1) != 0, (ofl & 4) != 0
     assert ((first_r0 < 99) == r0f).all() and ((first_z < 99) == zf).all()             # the rebuilt rows agree with the oracle's flags
-    if shared:
-        want = np.where(first_r0 <= first_z, 2, 1)         # one key: rows in turn, r0[k] before z[k] (both from one transform)
+    if shared and small:
+        want = np.where(first_r0 <= first_z, 2, 1)         # one key, paired rows: rows in turn, r0[k] before z[k] (both from one transform)
     else:
         want = np.where(first_r0 < 99, 2, 1)               # a key per item: all r0 rows, then all z rows
     early = r0f | zf
@@ -174,11 +177,14 @@ def test_sign_phase2_paired_rows_at_the_edge_of_what_key_bytes_decode_to(gpu, or
         c[i, 7 * i:7 * i + tau] = 1 if i % 2 == 0 else Q - 1
     s1h = oracle.ntt(np.mod(s1, Q).astype(np.int32))
     s2h = oracle.ntt(np.mod(s2, Q).astype(np.int32))
-    t0h = oracle.ntt(np.mod(rng.integers(-(1 << 12) + 1, (1 << 12) + 1, (nk, K, N)), Q).astype(np.int32))
+    t0 = rng.integers(-(1 << 12) + 1, (1 << 12) + 1, (nk, K, N))
+    t0[:, :, 60:188] = 1 << 12                           # the 13-bit field decodes to 2^12 - v: (-2^12, 2^12]; |c t0| reaches tau 2^12 < 2^18,
+    t0[:, 0, 60:188] = -(1 << 12) + 1                    # the bound the exact small-integer row tails (Phase2Coef) rest on
+    t0h = oracle.ntt(np.mod(t0, Q).astype(np.int32))
     ow1, ow0 = oracle.sign_phase1(level, A, y)
     del A
     z, h, fl = api.sign_phase2(dev(gpu, c), dev(gpu, y), dev(gpu, ow0), dev(gpu, ow1, np.uint8), dev(gpu, s1h), dev(gpu, s2h), dev(gpu, t0h),
-                               level, shared_key=shared)
+                               level, shared_key=shared, small_key=True)
     steps("sign2_wpi", n, 2)
     oz, oh, ofl = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
     assert (fl.cpu().numpy() == ofl).all()
@@ -187,6 +193,35 @@ def test_sign_phase2_paired_rows_at_the_edge_of_what_key_bytes_decode_to(gpu, or
     cs = oracle.invntt(oracle.pointwise(np.broadcast_to(oracle.ntt(c[:1]), (L, N)).copy(), np.ascontiguousarray(s1h[0])))
     big = np.abs(np.where(cs > Q // 2, cs.astype(np.int64) - Q, cs)).max()
     assert big == tau * -lo and dk.PARAMS[level].beta < big <= 1023
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("shared", [True, False])
+def test_sign_phase2_generic_entry_takes_any_residues(gpu, oracle, level, shared):
+    """dil_sign_phase2_dev / dil_sign_phase2_early_dev promise nothing about their inputs' size (round-3 advisor finding: the paired-row
+    kernels silently depended on |c s| <= 1023): UNIFORM residues for c, s1^, s2^, t0^ and w0 -- products of full size -- at a batch the
+    wave-per-item kernels serve, every z, h and flag vs the oracle; the early-exit form's flags where they are determined."""
+    from dilithium_amd import api
+    n = 9216
+    nk = 1 if shared else n
+    K, L = KL[level]
+    rng = np.random.default_rng(4100 + level + shared)
+    u = lambda *sh: rng.integers(0, Q, sh, dtype=np.int64).astype(np.int32)  # noqa: E731
+    c, y, w0, s1h, s2h, t0h = u(n, N), u(n, L, N), u(n, K, N), u(nk, L, N), u(nk, K, N), u(nk, K, N)
+    w1 = rng.integers(0, 44 if level == 2 else 16, (n, K, N)).astype(np.uint8)
+    w1[:, :, ::3] = 0                                     # (w1 == 0 is the special case of MakeHint)
+    z, h, fl = api.sign_phase2(dev(gpu, c), dev(gpu, y), dev(gpu, w0), dev(gpu, w1, np.uint8), dev(gpu, s1h), dev(gpu, s2h), dev(gpu, t0h),
+                               level, shared_key=shared)
+    steps("sign2_wpi", n, 2)
+    oz, oh, ofl = oracle.sign_phase2(level, c, y, w0, w1, s1h, s2h, t0h)
+    assert (fl.cpu().numpy() == ofl).all()
+    assert (z.cpu().numpy() == oz).all() and (h.cpu().numpy() == oh).all()
+    w0s = dev(gpu, w0)
+    _, _, fle = api.sign_phase2_early(dev(gpu, c), dev(gpu, y), w0s, dev(gpu, w1, np.uint8), dev(gpu, s1h), dev(gpu, s2h), dev(gpu, t0h),
+                                      level, shared_key=shared)
+    fle = fle.cpu().numpy()
+    assert ((fle != 0) == (ofl != 0)).all()               # uniform residues: every attempt is rejected, by an r0 row
+    assert (fle[(ofl & 2) != 0] == 2).all()
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
