@@ -484,7 +484,7 @@ def main():
             a_ms, _ = timed(attempt)
             p1_ms, _ = timed(lambda i: L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream))
             p2_ms, _ = timed(lambda i: L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1,
-                                                             stream))
+                                                                  0, stream))
             sv = pmc_sign_valu()
             sec["other_configs"] = {
                 "configs[2] level-2 A.y matvec batch=4096 distinct A (4 rotating matrices)": {

@@ -542,20 +542,18 @@ struct S2X {
     using type = XAllLds;
     static constexpr int DW = 256;
 };
-// Five waves per SIMD (<= 96 VGPRs): the per-item-key form of the paired rows wants 105-113 registers, and at four waves per SIMD it
-// loses more to exposed latency than the saved transforms give back (level 5, 8192 attempts: 77.7 us at four waves, 69.1 at five
-// with 2-10 spilled registers; the unpaired kernel: 74.0; profiles/r03_small_pair.txt).  The one-key form fits without help.
+// Waves per SIMD.  Round 3 held these kernels at five (<= 96 VGPRs: the per-item-key form of the paired rows wanted 105-113 registers
+// and lost more to exposed latency at four waves than the saved transforms gave back).  With two transforms side by side per row
+// (ntt_inv_core2) a wave hides its own latency and wants the registers instead: four waves (<= 128 VGPRs, no spills) beat five
+// and six at every level and key form -- level 5, 8192 attempts, one key: 53.2 us at four, 55.3 at five, 53.8 at six; a key per
+// attempt: 64.1 / 64.9 / 76.4 (spills) -- profiles/r04e_ab_s2_waves_prefetch.txt.  A row-ahead prefetch of w0 / y / w1 does not pay
+// (vmcnt retires in order: waiting for the row's key operand then waits for the prefetch too).
 #ifndef DIL_S2_DUAL
 #define DIL_S2_DUAL 1
 #endif
 #ifndef DIL_S2_ATTR
-#define DIL_S2_ATTR __attribute__((amdgpu_waves_per_eu(5)))
+#define DIL_S2_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #endif
-// SMALL: the caller vouches for a SECRET KEY decoded from key bytes and a challenge from SampleInBall (dil_sign_phase2_skey_dev, the
-//        signing loop): |c s1|, |c s2| <= 1023 and |c t0| < 2^18, which is what lets one inverse transform carry c s1[k] and c s2[k]
-//        (SmallPair) and the row tails work on exact small integers (Phase2Coef).  !SMALL (dil_sign_phase2_dev: ANY residues): one
-//        transform per product, 1 + L + 2 K of them, and the reference's tests on canonical residues.
-// SH:    one key for the batch; with SMALL its s1^ + 2^11 s2^ rows are formed once per workgroup, in LDS.
 template <int LEVEL, int YF, bool SH, bool SMALL>
 __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 GPU visit: parity tests (+ the persistent-loop step log), kernel-coverage trace, smoke, bench, rocprofv3 kernel stats of the
+# Round-4 GPU visit (round 3: gpu_r03.sh): parity tests (+ the persistent-loop step log), kernel-coverage trace, smoke, bench, rocprofv3 kernel stats of the
 # same bench command, HBM-traffic PMC passes (each its own run; kernel trace only).
-#   gpurun --timeout 2400 -- bash scripts/gpu_r03.sh [tag] [what...]     what: tests cover smoke bench prof pmc signpmc   (default: all)
-TAG=${1:-r03z}; shift
+#   gpurun --timeout 2400 -- bash scripts/gpu_r04.sh [tag] [what...]     what: tests cover smoke bench prof pmc signpmc   (default: all)
+TAG=${1:-r04z}; shift
 WHAT=${@:-tests cover smoke bench prof pmc signpmc}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
@@ -65,7 +65,7 @@ if has signpmc; then      # counter evidence for the sign path: sign2_wpi_kernel
   cd /tmp
   i=0
   for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
-             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
              "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
     timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $OUT/${TAG}_spmc$i -o p -- python $GRAFT_REPO_ROOT/scripts/prof_target.py sign 3 > $OUT/${TAG}_spmc$i.log 2>&1
