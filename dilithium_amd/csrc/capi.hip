@@ -10,10 +10,12 @@
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 namespace {
 constexpr int64_t Q = DIL_Q;
 void build_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe);
+void mailbox_destroy(dil::rt::Device& d);
 }  // namespace
 
 namespace dil {
@@ -38,6 +40,8 @@ const OptName* option_table(int* n)
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
         {"packed_y", "DIL_PACKED_Y", &cfg.packed_y},
+        {"host_mailbox", "DIL_HOST_MAILBOX", &cfg.host_mailbox},
+        {"mailbox_idle_us", "DIL_MAILBOX_IDLE_US", &cfg.mailbox_idle_us},
         {"fuse_challenge", "DIL_FUSE_CHALLENGE", &cfg.fuse_challenge},
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
@@ -86,6 +90,7 @@ int init_device(Device& d, int id)
 // tear one device down (caller holds d.mu; `d.id` is made current for the frees and restored by the caller)
 void destroy_device(Device& d)
 {
+    ::mailbox_destroy(d);
     d.arenas.clear();
     d.aux.destroy();
     if (d.hp.ready) {
@@ -259,6 +264,90 @@ void build_tables(uint32_t* fwd, uint32_t* inv, uint32_t* inv_pipe)
 
 
 
+
+// ---- host mailbox (kernels.hpp Mailbox): batch-of-one calls without a launch ----------------------------------
+constexpr int MB_FALLBACK = -1;          // not served here (off, busy, broken): the caller takes the launch path
+inline uint32_t mb_read(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+double now_us()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+int mailbox_start(Device& d, const dil::Tables& T)          // (re)launch the resident wave; d.mbox.mu held
+{
+    dil::rt::MailboxHost& m = d.mbox;
+    __atomic_store_n(&m.host->state, (uint32_t)dil::MB_ALIVE, __ATOMIC_RELEASE);
+    const uint64_t ticks = (uint64_t)std::max(1, dil::rt::cfg.mailbox_idle_us.load(std::memory_order_relaxed)) * 100;   // 100 MHz
+    m.launches++;
+    return (int)dil::launch_mailbox(m.dev, __atomic_load_n(&m.host->done_seq, __ATOMIC_ACQUIRE), ticks, T, m.stream);
+}
+// one request: in0 (and in1) are copied into the mailbox, the wave is woken (or launched), `out` receives the 1 KiB result
+int mailbox_call(int op, int mapping, const int32_t* in0, const int32_t* in1, int32_t* out)
+{
+    if (!dil::rt::cfg.host_mailbox.load(std::memory_order_relaxed)) return MB_FALLBACK;
+    DIL_ENTER(d, T);
+    dil::rt::MailboxHost& m = d.mbox;
+    std::unique_lock<std::mutex> lk(m.mu, std::try_to_lock);
+    if (!lk.owns_lock() || m.broken) return MB_FALLBACK;
+    if (!m.host) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(dil::Mailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&m.dev), p, 0) != hipSuccess ||
+            hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p) (void)hipHostFree(p);
+            m.broken = true;
+            return MB_FALLBACK;
+        }
+        m.host = static_cast<dil::Mailbox*>(p);
+        memset(m.host, 0, sizeof(dil::Mailbox));
+    }
+    dil::Mailbox* mb = m.host;
+    memcpy(mb->in0, in0, 1024);
+    if (in1) memcpy(mb->in1, in1, 1024);
+    mb->op = (uint32_t)op;
+    mb->mapping = (uint32_t)mapping;
+    const uint32_t seq = ++m.seq;
+    __atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);                  // the request is out before `state` is read (see mailbox_kernel's retirement)
+    m.calls++;
+    const double t0 = now_us();
+    for (uint64_t spins = 0;; spins++) {
+        if (mb_read(&mb->done_seq) == seq) break;
+        if (mb_read(&mb->state) == (uint32_t)dil::MB_DEAD) {
+            if (mb_read(&mb->done_seq) == seq) break;          // served just before it retired
+            const int rc = mailbox_start(d, T);
+            if (rc) {
+                m.broken = true;
+                return rc;
+            }
+        }
+        if ((spins & 1023) == 1023 && now_us() - t0 > 2e6) {   // 2 s without an answer: never again (the launch path still works)
+            m.broken = true;
+            return (int)hipErrorLaunchTimeOut;
+        }
+        __builtin_ia32_pause();
+    }
+    memcpy(out, mb->out, 1024);
+    return 0;
+}
+void mailbox_destroy(Device& d)
+{
+    dil::rt::MailboxHost& m = d.mbox;
+    std::lock_guard<std::mutex> lk(m.mu);
+    if (!m.host) return;
+    if (mb_read(&m.host->state) != (uint32_t)dil::MB_DEAD) {     // ask the wave to leave, then wait for its stream
+        m.host->op = (uint32_t)dil::MB_QUIT;
+        __atomic_store_n(&m.host->req_seq, ++m.seq, __ATOMIC_RELEASE);
+    }
+    (void)hipStreamSynchronize(m.stream);
+    (void)hipStreamDestroy(m.stream);
+    (void)hipHostFree(m.host);
+    m.host = m.dev = nullptr;
+    m.stream = nullptr;
+    m.broken = false;
+}
 
 int ensure_scratch(Device& d, size_t bytes)
 {
@@ -440,12 +529,20 @@ int dil_invntt_dev(int32_t* polys, size_t batch, void* stream)
 }
 int dil_ntt_host(int32_t* polys, size_t batch)
 {
+    if (batch == 1) {
+        const int rc = mailbox_call(dil::MB_FWD, 0, polys, nullptr, polys);
+        if (rc != MB_FALLBACK) return rc;
+    }
     return host_inplace(polys, batch, [](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
         return (int)dil::launch_ntt(false, dil::LAYOUT_POLY, 0, p, n, t, st);
     });
 }
 int dil_invntt_host(int32_t* polys, size_t batch)
 {
+    if (batch == 1) {
+        const int rc = mailbox_call(dil::MB_INV, 0, polys, nullptr, polys);
+        if (rc != MB_FALLBACK) return rc;
+    }
     return host_inplace(polys, batch, [](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
         return (int)dil::launch_ntt(true, dil::LAYOUT_POLY, 0, p, n, t, st);
     });
@@ -474,6 +571,10 @@ int dil_poly_sub_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batc
 }
 int dil_pointwise_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
 {
+    if (batch == 1) {
+        const int rc = mailbox_call(dil::MB_PW_MUL, 0, a, b, c);
+        if (rc != MB_FALLBACK) return rc;
+    }
     return host_binary(c, a, b, batch, [batch](int32_t* da, int32_t* db, const dil::Tables& t) {
         return dil::launch_pointwise(dil::OP_MUL, da, da, db, nullptr, batch, t, 0);
     });
@@ -503,6 +604,10 @@ int dil_bram_mul_dev(int32_t* ram, const int32_t* mul_ram, size_t batch, int map
 int dil_bram_fwdntt_host(int32_t* ram, size_t batch, int mapping)
 {
     if (int rc = check_mapping(mapping)) return rc;
+    if (batch == 1) {
+        const int rc = mailbox_call(dil::MB_BRAM_FWD, mapping, ram, nullptr, ram);
+        if (rc != MB_FALLBACK) return rc;
+    }
     return host_inplace(ram, batch, [mapping](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
         return (int)dil::launch_ntt(false, dil::LAYOUT_BRAM, mapping, p, n, t, st);
     });
@@ -510,6 +615,10 @@ int dil_bram_fwdntt_host(int32_t* ram, size_t batch, int mapping)
 int dil_bram_invntt_host(int32_t* ram, size_t batch, int mapping)
 {
     if (int rc = check_mapping(mapping)) return rc;
+    if (batch == 1) {
+        const int rc = mailbox_call(dil::MB_BRAM_INV, mapping, ram, nullptr, ram);
+        if (rc != MB_FALLBACK) return rc;
+    }
     return host_inplace(ram, batch, [mapping](int32_t* p, size_t n, const dil::Tables& t, hipStream_t st) {
         return (int)dil::launch_ntt(true, dil::LAYOUT_BRAM, mapping, p, n, t, st);
     });
@@ -517,9 +626,23 @@ int dil_bram_invntt_host(int32_t* ram, size_t batch, int mapping)
 int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping)
 {
     if (int rc = check_mapping(mapping)) return rc;
+    if (batch == 1) {
+        const int rc = mailbox_call(dil::MB_BRAM_MUL, mapping, ram, mul_ram, ram);
+        if (rc != MB_FALLBACK) return rc;
+    }
     return host_binary(ram, ram, mul_ram, batch, [batch, mapping](int32_t* da, int32_t* db, const dil::Tables& t) {
         return dil::launch_bram_mul(da, db, batch, mapping, t, 0);
     });
+}
+
+int dil_mailbox_stats(uint64_t* calls, uint64_t* launches, int* alive)
+{
+    DIL_ENTER(d, T);
+    std::lock_guard<std::mutex> lk(d.mbox.mu);
+    if (calls) *calls = d.mbox.calls;
+    if (launches) *launches = d.mbox.launches;
+    if (alive) *alive = d.mbox.host ? (int)mb_read(&d.mbox.host->state) : 0;
+    return d.mbox.broken ? (int)hipErrorLaunchTimeOut : 0;
 }
 
 int dil_ntt_traffic_dev(int32_t* polys, size_t batch, int inverse, void* stream)

@@ -36,6 +36,9 @@ struct Config {
     std::atomic<int> fuse_keygen{1};       // DIL_FUSE_KEYGEN: 0 = keygen's mat-vec, Power2Round and t1 / t0 packing as separate kernels
     std::atomic<int> a24{1};               // DIL_A24: 0 = the composite calls keep per-item matrices as int32 in HBM (1: 24-bit packed)
     std::atomic<int> fuse_challenge{1};    // DIL_FUSE_CHALLENGE: 1 = the signing loop hashes c~ and samples c in ONE launch (0: challenge hash, then SampleInBall)
+    std::atomic<int> host_mailbox{0};      // DIL_HOST_MAILBOX: 1 = the *_host entry points serve batch == 1 through the resident mailbox wave
+                                           // (libdil256_ref.so turns it on: its ntt() / invntt() / ... are batch-of-one calls)
+    std::atomic<int> mailbox_idle_us{200}; // DIL_MAILBOX_IDLE_US: the mailbox wave retires after this long without a request
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
 };
 extern Config cfg;
@@ -77,6 +80,17 @@ struct HostPipe {
     int pin = -1;
 };
 
+// the host mailbox of the batch-of-one drop-in calls (kernels.hpp Mailbox; capi.hip mailbox_call)
+struct MailboxHost {
+    std::mutex mu;                  // one request at a time; a second caller takes the launch path instead of waiting
+    dil::Mailbox* host = nullptr;   // pinned, device-mapped
+    dil::Mailbox* dev = nullptr;    // the same memory as the device sees it
+    hipStream_t stream = nullptr;
+    uint32_t seq = 0;
+    bool broken = false;            // a request timed out: the mailbox is not used again in this process
+    uint64_t launches = 0, calls = 0;
+};
+
 struct Device {
     std::mutex mu;                  // guards (re)initialisation and teardown only
     std::atomic<bool> ready{false};
@@ -90,6 +104,7 @@ struct Device {
     HostPipe hp;
     ArenaPool arenas;
     AuxStream aux;
+    MailboxHost mbox;
     // launch configuration for a call made now: device constants + the current options
     dil::Tables tables() const;
 };

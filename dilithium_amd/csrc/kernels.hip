@@ -261,8 +261,103 @@ __global__ __launch_bounds__(256) void bram_mul_kernel(int32_t* ram, const int32
 }
 
 // ---------------------------------------------------------------------------------------
+// Host mailbox (kernels.hpp): one resident wave serving batch-of-one requests from pinned host memory.
+// Same arithmetic as the batched kernels above -- ntt_fwd_core / ntt_inv_core on 4 coefficients per lane, the `bram` address
+// maps, mulmod_true -- on ONE polynomial that never touches device memory: loads and stores go to the mailbox over PCIe.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mb_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mb_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// the request header (req_seq, op, mapping: one 16-byte piece of one cache line) in ONE system-scope load = one PCIe read: the host
+// stores op / mapping before req_seq, so a header that shows the new sequence number carries its operation too -- a round trip
+// less per call than polling the word and then fetching the rest
+__device__ __forceinline__ uint4 mb_load_header(const Mailbox* mb)
+{
+    uint4 h;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(h) : "v"(&mb->req_seq) : "memory");
+    return h;
+}
+
+__global__ __launch_bounds__(64) void mailbox_kernel(Mailbox* mb, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab,
+                                                     uint32_t last_done, uint64_t idle_ticks)
+{
+    const int lane = threadIdx.x & 63;
+    TwRegs twf, twi;
+    twf.load(fwd_tab, lane);
+    twi.load(inv_tab, lane);
+    const LaneMasks lm(lane);
+    uint32_t done = last_done, served = 0;
+    uint64_t t_last = wall_clock64();                   // 100 MHz, independent of the shader clock
+    for (;;) {
+        uint4 hdr = mb_load_header(mb);
+        uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.x);
+        if (seq == done) {
+            if (wall_clock64() - t_last < idle_ticks) continue;
+            // retire -- unless a request slips in: announce, look once more (a PCIe read cannot overtake the posted write before
+            // it, so either this read sees the request or the host, which reads `state` after posting, sees EXITING / DEAD)
+            if (lane == 0) mb_store(&mb->state, MB_EXITING);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            hdr = mb_load_header(mb);
+            seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.x);
+            if (seq == done) {
+                if (lane == 0) {
+                    mb_store(&mb->served, served);
+                    mb_store(&mb->state, MB_DEAD);
+                }
+                return;
+            }
+            if (lane == 0) mb_store(&mb->state, MB_ALIVE);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // the payload was written before req_seq
+        const uint32_t op = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y);
+        const int mapping = __builtin_amdgcn_readfirstlane((int)hdr.z);
+        if (op == MB_QUIT) {
+            if (lane == 0) {
+                mb_store(&mb->done_seq, seq);
+                mb_store(&mb->state, MB_DEAD);
+            }
+            return;
+        }
+        int32_t r[4];
+        if (op == MB_FWD || op == MB_BRAM_FWD) {
+            const bool br = op == MB_BRAM_FWD;
+#pragma unroll
+            for (int m = 0; m < 4; m++) r[m] = mb->in0[br ? fwd_in_off<LAYOUT_BRAM>(lane + 64 * m, mapping) : lane + 64 * m];
+            ntt_fwd_core(r, twf, lm);
+            int32_t* o = mb->out + (br ? fwd_out_row_off<LAYOUT_BRAM>(lane, mapping) : 4 * lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (int32_t)canon_any(r[j]);
+        } else if (op == MB_INV || op == MB_BRAM_INV) {
+            const bool br = op == MB_BRAM_INV;
+            const int32_t* in = mb->in0 + (br ? inv_in_row_off<LAYOUT_BRAM>(lane, mapping) : 4 * lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) r[j] = in[j];
+            ntt_inv_core(r, twi, lm);
+#pragma unroll
+            for (int m = 0; m < 4; m++) mb->out[br ? inv_out_off<LAYOUT_BRAM>(lane + 64 * m, mapping) : lane + 64 * m] = (int32_t)canon_small(r[m]);
+        } else {                                          // MB_PW_MUL: out = in0 o in1;  MB_BRAM_MUL: ram[map(l)] *= mul_ram[l] (ntt2x2_mul.cpp:33-59)
+            const int row = op == MB_BRAM_MUL ? resolve_row(mapping, lane) : lane;
+#pragma unroll
+            for (int j = 0; j < 4; j++) mb->out[4 * row + j] = (int32_t)canon_small(mulmod_true(mb->in0[4 * row + j], mb->in1[4 * lane + j]));
+        }
+        served++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) mb_store(&mb->done_seq, seq);
+        done = seq;
+        t_last = wall_clock64();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, const Tables& t, hipStream_t s)
+{
+    hipLaunchKernelGGL(mailbox_kernel, 1, 64, 0, s, mb_dev, t.fwd, t.inv, last_done, idle_ticks);
+    return hipGetLastError();
+}
+
 hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, size_t batch,
                       const Tables& t, hipStream_t s)
 {

@@ -42,6 +42,25 @@ struct Tables {
 hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, size_t batch, const Tables& t, hipStream_t s);
 // the transforms' loads and stores without the arithmetic (bench.py roofline.achievable); scrambles `polys`
 hipError_t launch_ntt_traffic(bool inverse, int32_t* polys, size_t batch, const Tables& t, hipStream_t s);
+// ---- host mailbox: the drop-in surface's batch-of-one calls (ntt(), invntt(), pointwise_barrett(), ntt2x2_* on one `bram`) ----
+// A launch per call costs ~43 us (two hipMemcpy + a launch + a synchronisation) for 1 KiB of work -- 20 x the CPU reference it
+// replaces.  Instead ONE wave stays resident while calls keep coming and serves them from a mailbox in pinned, device-mapped
+// host memory: the caller writes its polynomial(s) and bumps `req_seq`; the wave polls that word over PCIe, reads the payload,
+// transforms it in registers, writes the result and `done_seq` back; the caller spins on `done_seq` in its own memory.  No
+// launch, no hipMemcpy, no stream synchronisation on the path: ~5 us a call (profiles/r04*_mailbox.txt).  The wave retires after
+// `idle_ticks` without a request (a resident kernel would otherwise hold hipDeviceSynchronize() forever) and is relaunched by the
+// next call; `state` closes the race between "retiring" and "a request just arrived" (capi.hip mailbox_call).
+enum { MB_FWD = 0, MB_INV = 1, MB_PW_MUL = 2, MB_BRAM_FWD = 3, MB_BRAM_INV = 4, MB_BRAM_MUL = 5, MB_QUIT = 6 };
+enum { MB_DEAD = 0, MB_ALIVE = 1, MB_EXITING = 2 };
+struct Mailbox {
+    // host -> device (one cache line)
+    uint32_t req_seq, op, mapping, pad0[13];
+    // device -> host (one cache line)
+    uint32_t done_seq, state, served, pad1[13];
+    int32_t in0[256], in1[256], out[256];
+};
+hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, const Tables& t, hipStream_t s);
+
 hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t* b, const int32_t* acc, size_t batch,
                             const Tables& t, hipStream_t s);
 hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);

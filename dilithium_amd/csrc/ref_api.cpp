@@ -21,6 +21,15 @@ inline void ok(const char* what, int rc)
     if (rc) die(what, rc);
 }
 
+// Every function of this library is a batch of one: serve them from the resident mailbox wave (include/dil256.h "HOST MAILBOX")
+// instead of a launch per call, unless the environment says otherwise.
+struct MailboxOn {
+    MailboxOn()
+    {
+        if (!getenv("DIL_HOST_MAILBOX")) (void)dil_set_option("host_mailbox", 1);
+    }
+} mailbox_on;
+
 // zeta^brv8(k), zeta = 1753, centred -- the table of consts.cpp:64-97, computed at compile time
 constexpr int64_t Qc = DILITHIUM_Q;
 constexpr unsigned brv8(unsigned x)

@@ -121,6 +121,19 @@ int dil_bram_fwdntt_host(int32_t* ram, size_t batch, int mapping);
 int dil_bram_invntt_host(int32_t* ram, size_t batch, int mapping);
 int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping);
 
+/* The HOST MAILBOX behind the batch == 1 case of the *_host entry points above (option "host_mailbox" / DIL_HOST_MAILBOX; off by default
+ * in libdil256.so, ON in libdil256_ref.so, whose ntt() / invntt() / pointwise_barrett() / ntt2x2_*() are batch-of-one calls by contract).
+ * A launch per call costs ~43 us for 1 KiB of work.  With the option on, ONE resident wavefront serves such calls from a mailbox in pinned,
+ * device-mapped host memory: the caller's polynomial(s) are memcpy'd in, a sequence word is bumped, the wave -- polling that word over
+ * PCIe -- transforms the polynomial in registers and writes result + sequence back; no launch, no hipMemcpy, no synchronisation on the
+ * path (~5 us a call).  The wave retires after "mailbox_idle_us" (default 200) without a request, so that hipDeviceSynchronize() is
+ * held for at most that long, and the next call relaunches it; a call that finds the mailbox busy (another host thread) or unusable
+ * takes the launch path.  Results are bit-identical to the launch path (tests/test_gpu_mailbox.py; the reference's unchanged
+ * hardware_code/ntt2x2_test.cpp at its own 10^6 iterations runs through it).  Runtime utility without a reference counterpart.
+ * dil_mailbox_stats: requests served through the mailbox / launches of the resident wave so far on the current device, and whether
+ * the wave is resident right now (0 retired, 1 serving, 2 retiring). */
+int dil_mailbox_stats(uint64_t* calls, uint64_t* launches, int* alive);
+
 /* ---- H9: mat-vec  w[k] = INTT(sum_l A[k][l] o NTT(y[l]))  (combined_top.v:1850-1933) -----
  * level in {2,3,5} selects (K,L) = (4,4)/(6,5)/(8,7).  A: [batch|1][K][L][256] NTT domain,
  * row-major as the RTL stores it (combined_top.v:1370); shared_A != 0 -> one A for the batch.
