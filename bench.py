@@ -588,6 +588,21 @@ def main():
                     call()
                 torch.cuda.synchronize()
                 lat[name] = (time.perf_counter() - t0) / 20 * 1e3
+            # the drop-in surface's batch-of-one call (libdil256_ref.so ntt() = dil_ntt_host(a, 1)): resident mailbox wave vs a launch
+            # per call; host wall time per call, ctypes' ~1 us included in both
+            import ctypes as _C
+            one = np.arange(256, dtype=np.int32)
+            onep = one.ctypes.data_as(_C.POINTER(_C.c_int32))
+            for mode, key, reps in ((1, "ntt_host_batch_1_us", 5000), (0, "ntt_host_batch_1_launch_path_us", 300)):
+                L.dil_set_option(b"host_mailbox", mode)
+                for _ in range(20):
+                    L.dil_ntt_host(onep, 1)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    L.dil_ntt_host(onep, 1)
+                lat[key] = (time.perf_counter() - t0) / reps * 1e6
+            L.dil_set_option(b"host_mailbox", 0)
+            torch.cuda.synchronize()
             sec["scheme_level3_wire_format"]["latency"] = lat
         except Exception as e:  # noqa: BLE001
             sec["scheme_level3_wire_format"] = {"error": repr(e)}
