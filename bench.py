@@ -38,7 +38,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK = 256 * 4 * 2.4e9 / 4    # wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles per instruction
+VALU_PEAK = 256 * 4 * 2.4e9 / 4    # wave64 VALU instructions/s at the DATA-SHEET clock: 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles per instruction
+#                                    (the sign leg also reports the fraction at the clock OBSERVED during its timed region)
 NTT_BYTES = 2048               # 1 KiB read + 1 KiB written per transform
 VERIFY3_BYTES = 45 * 1024 + 0  # z 5 + c 1 + t1 6 + A 30 KiB + h 1.5 + w1 1.5 KiB (distinct pk)
 BATCH = 65536
@@ -145,6 +146,38 @@ def cpu_baseline_verify(target_s=5.0):
             "sample": f"{64 * reps} level-3 verify cores (oracle C restatement) in {tt:.1f} s, 1 thread"}
 
 
+def cpu_baseline_verify_all_threads(target_s=4.0):
+    """the oracle's level-3 verify core on every visible hardware thread at once (time-bounded), quota-aware like the NTT leg"""
+    import threading
+    from oracle.oracle import Oracle
+    o = Oracle()
+    nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ins = [synth_verify(16, 300 + i) for i in range(min(nthreads, 8))]
+    done = [0] * nthreads
+    deadline = [0.0]
+
+    def work(i):
+        A, z, c, t1, h = ins[i % len(ins)]
+        n = 0
+        while time.perf_counter() < deadline[0]:
+            o.time_verify_core(3, A, z, c, t1, h)
+            n += 16
+        done[i] = n
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    t0 = time.perf_counter()
+    deadline[0] = t0 + target_s
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    quota, qsrc = cpu_quota()
+    return {"value": sum(done) / dt, "unit": "verify/s", "threads": nthreads, "cores": round(quota, 2) if quota else nthreads,
+            "kind": "port", "sample": f"{sum(done)} level-3 verify cores on {nthreads} threads in {dt:.1f} s; CPU quota: "
+                                      f"{'%.2f CPUs' % quota if quota else 'none'} ({qsrc})"}
+
+
 def synth_verify(n, seed):
     from oracle.oracle import splitmix64_polys, Q, N
     K, L, tau, g1 = 6, 5, 49, 1 << 19
@@ -158,6 +191,42 @@ def synth_verify(n, seed):
     t1 = rng.integers(0, 1 << 10, (n, K, N)).astype(np.int32)
     h = (rng.random((n, K, N)) < 0.03).astype(np.uint8)
     return A, z, c, t1, h
+
+
+def system_clocks():
+    """best-effort sclk / mclk [MHz] from the driver (amdsmi, then sysfs, then rocm-smi); {} where the container shows none"""
+    out = {}
+    try:
+        import glob
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            for name, key in (("pp_dpm_sclk", "sclk_mhz"), ("pp_dpm_mclk", "mclk_mhz")):
+                p = os.path.join(card, name)
+                if key not in out and os.path.exists(p):
+                    cur = [ln for ln in open(p).read().splitlines() if ln.strip().endswith("*")]
+                    if cur:
+                        out[key] = float(cur[0].split(":")[1].strip().split("M")[0])
+                        out["source"] = os.path.dirname(p) + "/pp_dpm_{sclk,mclk}, read AFTER the timed regions (the GPU is idle by then: " \
+                                        "the clock under load is shader_mhz_*)"
+            if out:
+                return out
+    except Exception:
+        pass
+    try:
+        import subprocess
+        txt = subprocess.run(["rocm-smi", "-c", "--json"], capture_output=True, text=True, timeout=10).stdout
+        d = json.loads(txt)
+        card = d[sorted(d)[0]]
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl and "sclk_mhz" not in out:
+                out["sclk_mhz"] = float("".join(ch for ch in v if ch.isdigit() or ch == "."))
+            if "mclk" in kl and "mclk_mhz" not in out:
+                out["mclk_mhz"] = float("".join(ch for ch in v if ch.isdigit() or ch == "."))
+        if out:
+            out["source"] = "rocm-smi -c --json"
+    except Exception:
+        pass
+    return out
 
 
 def pmc_traffic(kernel_key):
@@ -250,6 +319,23 @@ def main():
         dlib.check(rc, "timed launches")
         return per, used
 
+    probe_stream = torch.cuda.Stream()
+    probe_buf = torch.zeros(4, dtype=torch.int64, device="cuda")
+
+    def with_clock(fn, span_ms):
+        """run fn() while a one-lane probe kernel on a side stream measures the effective shader clock over about span_ms
+        (csrc/kernels.hip clock_probe_kernel: shader cycles per 100 MHz tick); returns (fn's result, MHz or None)"""
+        try:
+            torch.cuda.synchronize()
+            dlib.check(L.dil_clock_probe_dev(P(probe_buf), max(1000, int(span_ms * 1000)), C.c_void_p(probe_stream.cuda_stream)), "clock probe")
+            res = fn()
+            probe_stream.synchronize()
+            c0, c1, r0, r1 = [int(x) for x in probe_buf.cpu().tolist()]
+            mhz = (c1 - c0) / max(1, r1 - r0) * 100.0
+            return res, (mhz if 200.0 < mhz < 5000.0 else None)
+        except Exception:   # noqa: BLE001
+            return fn(), None
+
     # ---- inputs, resident in HBM ------------------------------------------------------------
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     NS = max(1, args.streams)
@@ -323,7 +409,8 @@ def main():
 
     # the same steps on ONE stream: the per-kernel roofline (no overlap between launches; each launch's share of the region
     # includes its ~2 us dispatch gap, so this is a lower bound of what rocprofv3 reports per kernel)
-    one = measure(K, one=True, min_total_ms=args.total_ms / 2, min_regions=max(3, args.regions // 2))
+    one, ntt_mhz = with_clock(lambda: measure(K, one=True, min_total_ms=args.total_ms / 2, min_regions=max(3, args.regions // 2)),
+                              args.total_ms / 2)
     one_stream_value = world * 2 * BATCH / one["median"]
     launch_ms = one["median"] / 2 * 1e3
     kernel_gbs = NTT_BYTES * BATCH / (launch_ms * 1e-3) / 1e9
@@ -394,7 +481,21 @@ def main():
                                "with `concurrent_launches_overlapped` launches in flight"},
         "llc_resident_value": llc_value,
         "one_stream_value": one_stream_value,
+        "clocks": dict(system_clocks(), shader_mhz_during_one_stream_ntt=ntt_mhz,
+                       shader_mhz_source="in-kernel probe on a side stream over the one-stream regions: shader cycle counter (s_memtime) "
+                                         "against the constant 100 MHz counter (s_memrealtime); data-sheet maximum 2400"),
     }
+    if world > 1:       # falsifiable on the multi-GPU node: what RCCL itself says about the job, and where every rank sits
+        ones = torch.ones(1, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(ones)
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local, "device": int(dev), "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+        everyone = [None] * world
+        torch.distributed.all_gather_object(everyone, mine)
+        out["distributed"] = {"backend": torch.distributed.get_backend(), "rccl_nranks": int(round(float(ones.item()))),
+                              "world_size": torch.distributed.get_world_size(), "ranks": everyone,
+                              "distinct_devices": len({(e["device"], e["pci_bus_id"], e["uuid"]) for e in everyone})}
 
     # ---- secondary: Dilithium-3 verify core, configs[3], and the other configs -------------------
     if not args.no_secondary:
@@ -465,6 +566,7 @@ def main():
             A2 = [rnd(4096, 4, 4, 256) for _ in range(4)]           # 4 x 64 MiB of A: rotating, HBM-streaming
             y2, wout = rnd(4096, 4, 256), torch.empty((4096, 4, 256), dtype=torch.int32, device="cuda")
             m_ms, _ = timed(lambda i: L.dil_matvec_dev(P(wout), P(A2[i % 4]), P(y2), 2, 4096, 0, stream))
+            ms_ms, _ = timed(lambda i: L.dil_matvec_dev(P(wout), P(A2[0]), P(y2), 2, 4096, 1, stream))     # ONE matrix for the batch (report both)
             # a real key and real challenges (phase 2 reads c s1 and c s2 off one transform, exact for valid inputs: DESIGN.md 4)
             small = lambda lim, *sh: (torch.randint(-lim, lim + 1, sh, dtype=torch.int64, device="cuda", generator=g2) % 8380417).to(torch.int32)  # noqa: E731
             A5, y5 = rnd(1, 8, 7, 256), small((1 << 19) - 1, 8192, 7, 256)
@@ -481,14 +583,21 @@ def main():
             def attempt(i):
                 return L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream) | \
                     L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1, 0, stream)
-            a_ms, _ = timed(attempt)
+            (a_ms, _), sign_mhz = with_clock(lambda: timed(attempt), 3 * args.min_ms)
             p1_ms, _ = timed(lambda i: L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream))
             p2_ms, _ = timed(lambda i: L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1,
                                                                   0, stream))
             sv = pmc_sign_valu()
             sec["other_configs"] = {
                 "configs[2] level-2 A.y matvec batch=4096 distinct A (4 rotating matrices)": {
-                    "matvecs_per_s": 4096 / (m_ms * 1e-3), "ms": m_ms, "GBps": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9},
+                    "matvecs_per_s": 4096 / (m_ms * 1e-3), "ms": m_ms, "GBps": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9,
+                    "bytes_per_matvec": 24 * 1024, "frac_of_hbm_peak": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel": "matvec_wpi_kernel<4,4,2,OUT_W>"},
+                "configs[2] level-2 A.y matvec batch=4096 shared A (one matrix, LDS-resident)": {
+                    "matvecs_per_s": 4096 / (ms_ms * 1e-3), "ms": ms_ms, "bytes_per_matvec": 8 * 1024,
+                    "GBps": (8 * 1024 * 4096 + 16 * 1024) / (ms_ms * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": (8 * 1024 * 4096 + 16 * 1024) / (ms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel": "matvec_shared_kernel<4,4,2,OUT_W,16>", "bound": "valu / launch (32 MiB of traffic)"},
                 "configs[4] level-5 sign attempt (phase1+phase2) batch=8192 per GPU, shared key": {
                     "attempts_per_s": 8192 / (a_ms * 1e-3), "ms": a_ms, "phase1_ms": p1_ms, "phase2_ms": p2_ms,
                     "roofline": None if not sv else {
@@ -497,6 +606,13 @@ def main():
                         "valu_insts_per_attempt": sv, "source": "profiles/pmc_summary.json (committed SQ_INSTS_VALU passes of these kernels / 8192)",
                         "phase1_frac": sv["phase1"] * 8192 / (p1_ms * 1e-3) / VALU_PEAK,
                         "phase2_frac": sv["phase2"] * 8192 / (p2_ms * 1e-3) / VALU_PEAK,
+                        "shader_mhz_observed": sign_mhz,
+                        "peak_at_observed_clock": None if not sign_mhz else VALU_PEAK * sign_mhz / 2400.0,
+                        "phase1_frac_at_observed_clock": None if not sign_mhz else sv["phase1"] * 8192 / (p1_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
+                        "phase2_frac_at_observed_clock": None if not sign_mhz else sv["phase2"] * 8192 / (p2_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
+                        "hbm": {"bytes_per_attempt": 45 * 1024 + 1024, "note": "y 7 + w0 8 + w1 2 + w1 packed 1 KiB (phase 1) and c 1 + y 7 + "
+                                "w0 8 + w1 2 + z 7 + h 2 KiB (phase 2): the int32 planes of the public entry points",
+                                "frac_of_hbm_peak": (46 * 1024) * 8192 / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                         "note": "the measured issue cost of this instruction mix is ~4.3 cycles (multiplies 4.4, adds 2.5), and the "
                                 "transform alone reaches 0.62-0.67 of this peak in a compute-only loop (profiles/r03c_tune_xchg.txt)"}}}
         except Exception as e:  # noqa: BLE001
@@ -624,6 +740,10 @@ def main():
                 out["cpu_baseline"]["all_threads"] = {"error": repr(e)}
             if not args.no_secondary:
                 out["secondary"]["cpu_baseline"] = cpu_baseline_verify()
+                try:
+                    out["secondary"]["cpu_baseline"]["all_threads"] = cpu_baseline_verify_all_threads()
+                except Exception as e:  # noqa: BLE001
+                    out["secondary"]["cpu_baseline"]["all_threads"] = {"error": repr(e)}
         print(json.dumps(out))
     sharding.barrier()
     if world > 1:
@@ -657,7 +777,7 @@ def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
         f = torch.empty((n,), dtype=torch.int32, device="cuda")
 
         def one(i):
-            return L.dil_sign_phase1_dev(P(w1), P(w0), P(A5), P(ys), 5, n, 1, 0, stream) | \
+            return L.dil_sign_phase1_dev(P(w1), P(w0), P(A5), P(ys), 5, n, 1, stream) | \
                 L.dil_sign_phase2_skey_dev(P(z), P(h), P(f), P(cs), P(ys), P(w0), P(w1), P(s1h), P(s2h), P(t0h), 5, n, 1, 0, stream)
         ms, _ = timed(one)
         out["attempt_ms_per_rank_slice"] = sharding.max_over_ranks(ms)
@@ -674,8 +794,13 @@ def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
     out.update({"workload": "BASELINE configs[4]: level 5 (K=8, L=7) sign inner loop, one key, batch = 8192 per GPU x "
                             f"{world} GPU(s) = {total}, contiguous slices (run_sharded), gather of z + h + flag slabs",
                 "attempts_per_s": total / (out["attempt_ms_per_rank_slice"] * 1e-3),
-                "final_gather_ms": sharding.max_over_ranks(gather_ms),
+                "final_gather_ms": sharding.max_over_ranks(gather_ms) if world > 1 else None,      # at N = 1 there is nothing to gather
                 "final_gather_bytes": int(gz.numel() * 4 + gh.numel() + gf.numel() * 4),
+                "final_gather_GBps_per_gpu_received": (None if world == 1 else
+                                                       int(gz.numel() * 4 + gh.numel() + gf.numel() * 4) * (world - 1) / world
+                                                       / (sharding.max_over_ranks(gather_ms) * 1e-3) / 1e9),
+                "xgmi_bound_GBps_per_gpu": None if world == 1 else 153.0 * min(world - 1, 7),
+                "xgmi_bound_source": "SURVEY.md 5: 7 xGMI links x ~153 GB/s per GPU, point to point",
                 "accept_rate": float((gf == 0).float().mean())})
     # the whole signing loop (rejection sampling to completion) on the same sharding: KAT-style deterministic signatures
     gm = torch.Generator(device="cuda").manual_seed(777)
@@ -697,7 +822,8 @@ def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
     gsig = sharding.gather_slabs(sig, total)
     torch.cuda.synchronize()
     out["signatures_per_s"] = total / (out["sign_ms_per_rank_slice"] * 1e-3)
-    out["signature_gather_ms"] = sharding.max_over_ranks((time.perf_counter() - t0) * 1e3)
+    sg_ms_ = sharding.max_over_ranks((time.perf_counter() - t0) * 1e3)
+    out["signature_gather_ms"] = sg_ms_ if world > 1 else None
     out["signature_gather_bytes"] = int(gsig.numel())
     lo = 0 if world == 1 else (total // 2)
     vd = api.verify_sig(pk, gsig[lo:lo + 2048].contiguous(), mu[lo:lo + 2048].contiguous(), 5, shared_pk=True)

@@ -635,6 +635,13 @@ int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int ma
     });
 }
 
+int dil_clock_probe_dev(uint64_t* out4, unsigned spin_us, void* stream)
+{
+    DIL_ENTER(d, T);
+    if (!out4) return (int)hipErrorInvalidValue;
+    return (int)dil::launch_clock_probe(out4, (uint64_t)spin_us * 100, S(stream));
+}
+
 int dil_mailbox_stats(uint64_t* calls, uint64_t* launches, int* alive)
 {
     DIL_ENTER(d, T);

@@ -349,9 +349,28 @@ __global__ __launch_bounds__(64) void mailbox_kernel(Mailbox* mb, const uint32_t
     }
 }
 
+// Shader-clock probe (bench.py): one lane reads the shader cycle counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime), dozes for `spin_ticks` of the latter and reads both again -- effective shader clock = d(cycles) / d(ticks) x 100 MHz
+// over exactly the interval in which the kernels being timed run beside it on another stream.  (The chip clocks to its power budget:
+// a VALU-dense kernel sustains 1.9-2.3 GHz, not the 2.4 GHz of the data sheet, MI355X_MICROARCH.md "DVFS give-back".)
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint64_t* out, uint64_t spin_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const uint64_t r0 = wall_clock64(), c0 = clock64();
+    while (wall_clock64() - r0 < spin_ticks) __builtin_amdgcn_s_sleep(64);
+    const uint64_t c1 = clock64(), r1 = wall_clock64();
+    out[0] = c0; out[1] = c1; out[2] = r0; out[3] = r1;
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+hipError_t launch_clock_probe(uint64_t* out4, uint64_t spin_ticks, hipStream_t s)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, 1, 64, 0, s, out4, spin_ticks);
+    return hipGetLastError();
+}
+
 hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, const Tables& t, hipStream_t s)
 {
     hipLaunchKernelGGL(mailbox_kernel, 1, 64, 0, s, mb_dev, t.fwd, t.inv, last_done, idle_ticks);

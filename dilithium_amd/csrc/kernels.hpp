@@ -59,6 +59,7 @@ struct Mailbox {
     uint32_t done_seq, state, served, pad1[13];
     int32_t in0[256], in1[256], out[256];
 };
+hipError_t launch_clock_probe(uint64_t* out4, uint64_t spin_ticks, hipStream_t s);   // bench.py: effective shader clock
 hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, const Tables& t, hipStream_t s);
 
 hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t* b, const int32_t* acc, size_t batch,

@@ -16,7 +16,6 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <mutex>
 #include <stdio.h>
@@ -72,35 +71,61 @@ int for_each_device(size_t batch, int G, F&& fn)
 }
 
 // ---- RCCL, bound at first use ---------------------------------------------------------------------------------------
+// The handful of NCCL-API declarations this file needs, stated here instead of #include <rccl/rccl.h>: the library then builds
+// on hosts without the RCCL headers and cannot pick up prototypes that differ from the library it finds at run time -- these are
+// the stable NCCL 2.x C ABI (opaque communicator pointer, int-sized enums), and ncclGetVersion() is checked against it below
+// (round-3 advisor finding).
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;                    // ncclSuccess = 0
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint8 = 1;      // nccl.h: ncclInt8 = 0, ncclUint8 = 1
 struct Rccl {
     void* so = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclBroadcast) Broadcast = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    int version = 0;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    const char* why = "";
     bool load()
     {
         if (so) return true;
+        void* h = nullptr;
         const char* names[] = {"librccl.so", "librccl.so.1"};
         for (const char* n : names)                      // an RCCL this process already carries (PyTorch's) wins
-            if ((so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
+            if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break;
         const char* paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-        for (int i = 0; !so && i < 3; i++) so = dlopen(paths[i], RTLD_NOW | RTLD_LOCAL);
-        if (!so) return false;
+        for (int i = 0; !h && i < 3; i++) h = dlopen(paths[i], RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            why = "librccl not found";
+            return false;
+        }
 #define DIL_SYM(f)                                                      \
-    f = reinterpret_cast<decltype(f)>(dlsym(so, "nccl" #f));            \
+    f = reinterpret_cast<decltype(f)>(dlsym(h, "nccl" #f));             \
     if (!f) {                                                           \
-        so = nullptr;                                                   \
+        why = "librccl lacks nccl" #f;                                  \
+        dlclose(h);                                                     \
         return false;                                                   \
     }
-        DIL_SYM(CommInitAll) DIL_SYM(CommDestroy) DIL_SYM(AllGather) DIL_SYM(Broadcast) DIL_SYM(Send) DIL_SYM(Recv)
-        DIL_SYM(GroupStart) DIL_SYM(GroupEnd) DIL_SYM(GetErrorString)
+        DIL_SYM(GetVersion) DIL_SYM(CommInitAll) DIL_SYM(CommDestroy) DIL_SYM(CommAbort) DIL_SYM(AllGather) DIL_SYM(Broadcast) DIL_SYM(Send)
+        DIL_SYM(Recv) DIL_SYM(GroupStart) DIL_SYM(GroupEnd) DIL_SYM(GetErrorString)
 #undef DIL_SYM
+        // NCCL_VERSION_CODE = major * 10000 + minor * 100 + patch from 2.9 on (major * 1000 + ... before): the declarations above are
+        // the 2.x ABI with ncclSend / ncclRecv (2.7+)
+        if (GetVersion(&version) != ncclSuccess || version < 2700 || (version >= 10000 && version / 10000 != 2)) {
+            why = "unsupported RCCL version (need the NCCL 2.x API, 2.7 or later)";
+            dlclose(h);
+            return false;
+        }
+        so = h;
         return true;
     }
 };
@@ -155,8 +180,8 @@ int multi_ensure(int ndev, int* G_out)
     if (m.G == G) return 0;
     if (m.G) multi_teardown_locked();
     if (!m.rccl.load()) {
-        const char* why = dlerror();
-        snprintf(m.last_error, sizeof(m.last_error), "librccl not found: %s", why ? why : "");
+        const char* dl = dlerror();
+        snprintf(m.last_error, sizeof(m.last_error), "%s%s%s", m.rccl.why, dl ? ": " : "", dl ? dl : "");
         return DIL_ERR_RCCL;
     }
     int cur = 0;
@@ -232,8 +257,22 @@ int gather_slabs(void* const* bufs, size_t item_bytes, size_t batch, int root, i
         }
 #undef DIL_IN_GROUP
         const ncclResult_t ge = m.rccl.GroupEnd();
-        if (bad != ncclSuccess) return rccl_fail(bad, bad_what);
-        if (ge != ncclSuccess) return rccl_fail(ge, "ncclGroupEnd");
+        if (bad != ncclSuccess || ge != ncclSuccess) {
+            // A group that was closed with only part of its operations enqueued can leave the ranks that did enqueue waiting for the
+            // ones that did not: abort every communicator (ncclCommAbort also releases work already on the streams), drain the
+            // streams, and drop the state so that the next call builds fresh communicators (round-3 advisor finding).
+            int cur = 0;
+            const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+            for (int g = 0; g < G; g++) {
+                if (m.comm[(size_t)g]) (void)m.rccl.CommAbort(m.comm[(size_t)g]);
+                m.comm[(size_t)g] = nullptr;
+            }
+            for (int g = 0; g < G; g++)
+                if (hipSetDevice(g) == hipSuccess) (void)hipStreamSynchronize(m.stream[(size_t)g]);
+            if (have_cur) (void)hipSetDevice(cur);
+            multi_teardown_locked();
+            return bad != ncclSuccess ? rccl_fail(bad, bad_what) : rccl_fail(ge, "ncclGroupEnd");
+        }
     } else if (G == 1 && batch > 0 && item_bytes > 0) {
         // one device: the slab IS the array; still one (trivial) RCCL collective so that the path is the one a node runs
         DIL_NCCL(m.rccl.AllGather(bufs[0], bufs[0], batch * item_bytes, ncclUint8, m.comm[0], m.stream[0]), "ncclAllGather");
@@ -255,7 +294,13 @@ hipStream_t dev_stream(int g) { return g_multi.stream[(size_t)g]; }
 
 extern "C" {
 
-const char* dil_multi_last_error(void) { return g_multi.last_error; }
+const char* dil_multi_last_error(void)
+{
+    static thread_local char copy[256];
+    std::lock_guard<std::mutex> lk(g_multi.mu);
+    snprintf(copy, sizeof(copy), "%s", g_multi.last_error);
+    return copy;
+}
 
 int dil_multi_init(int ndev)
 {

@@ -790,6 +790,9 @@ int dil_sign_msg_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const u
     if (batch == 0) return 0;
     if (batch > 0x3fffffffull || max_attempts <= 0) return (int)hipErrorInvalidValue;
     if (reinterpret_cast<uintptr_t>(sk) & 7) return (int)hipErrorInvalidValue;
+    // attempts[i] = -1 is the ONLY sign that item i's message reference left the blob (its signature bytes are zeroed): the call is
+    // asynchronous and cannot turn device-side findings into a return code, so the array is mandatory here (round-3 advisor finding)
+    if (!attempts) return (int)hipErrorInvalidValue;
     hipStream_t s = S(stream);
     StreamScratch ws(dv, s);
     uint8_t* mu = ws.take<uint8_t>(batch * 64);

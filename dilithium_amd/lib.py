@@ -48,6 +48,7 @@ SIGNATURES = {
     "dil_sign_phase1_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase2_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase2_early_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_clock_probe_dev": [_vp, C.c_uint, _vp],
     "dil_mailbox_stats": [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)],
     "dil_sign_phase2_skey_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
     "dil_launch_info": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(_sz)],

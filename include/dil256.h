@@ -271,7 +271,7 @@ int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8
  * per item, offsets[i] (uint64, byte offset into the blob) and lengths[i] (uint32); any alignment, zero length allowed; msgs may be
  * NULL when msgs_bytes == 0 (every message empty).  An item whose (offset, length) leaves the blob is never read past the blob: it is
  * hashed as an empty message and FLAGGED -- dil_mu_dev: bad[i] = 1 (bad may be NULL); dil_sign_msg_dev: attempts[i] = -1 and a zeroed
- * signature; dil_verify_msg_dev: verdict bit3 (value 8).
+ * signature (`attempts` is therefore MANDATORY there: NULL -> hipErrorInvalidValue); dil_verify_msg_dev: verdict bit3 (value 8).
  * dil_mu_dev:         mu[i] (64 B, 8-byte aligned) from tr at tr + i * tr_stride (32 B, 8-byte aligned; stride 0 = one tr)
  * dil_sign_msg_dev:   dil_sign_dev on (sk, M): tr is read from the secret key
  * dil_verify_msg_dev: dil_verify_sig_dev on (pk, M, sig): tr = SHAKE256(pk) is computed on the device first */
@@ -344,6 +344,11 @@ int dil_verify_dev(int32_t* verdict, const int32_t* A, const uint8_t* ctilde, co
 int dil_sign_attempt_dev(uint8_t* ctilde, int32_t* z, uint8_t* h, int32_t* flags, const int32_t* A, const uint8_t* mu,
                          const uint8_t* rhoprime, const uint32_t* kappa, const int32_t* s1hat, const int32_t* s2hat,
                          const int32_t* t0hat, int level, size_t batch, int shared_key, void* stream);
+
+/* Effective shader clock over an interval (bench.py): a one-lane kernel on `stream` samples the shader cycle counter and the constant
+ * 100 MHz counter, dozes spin_us microseconds and samples again: out4 (device, 4 x uint64) = {cycles0, cycles1, ticks0, ticks1};
+ * clock [MHz] = (cycles1 - cycles0) / (ticks1 - ticks0) x 100.  Launch it on a side stream around the kernels being timed. */
+int dil_clock_probe_dev(uint64_t* out4, unsigned spin_us, void* stream);
 
 /* ---- timing helpers (hipEvent on the caller's stream; used by bench.py; runtime utilities without a reference counterpart) ---- */
 int dil_event_create(void** ev);

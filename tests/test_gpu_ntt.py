@@ -122,6 +122,43 @@ def test_linearity_property(gpu):
     assert int(s.min()) >= 0 and int(s.max()) < Q
 
 
+def test_pointwise_and_mac_at_the_product_extremes(gpu):
+    """(+-(q-1)) x (+-(q-1)) and acc = +-(q-1) on EVERY lane (ref_ntt.cpp:49-57, butterfly.v:144-150): the largest 64-bit products
+    mont_mul's bound argument (modarith.hpp) has to cover, with the accumulator at both ends; against independent integer arithmetic"""
+    from dilithium_amd import api
+    torch = gpu
+    ext = [Q - 1, -(Q - 1), 1, -1, 0, (Q - 1) // 2, -((Q - 1) // 2), (Q + 1) // 2]
+    rows_a, rows_b, rows_c = [], [], []
+    for x in ext:
+        for y in ext:
+            for z in (Q - 1, -(Q - 1), 0):
+                rows_a.append(np.full(256, x)), rows_b.append(np.full(256, y)), rows_c.append(np.full(256, z))
+    # and every lane its own mix of the extremes
+    rng = np.random.default_rng(3)
+    for _ in range(16):
+        rows_a.append(rng.choice(ext, 256)), rows_b.append(rng.choice(ext, 256)), rows_c.append(rng.choice([Q - 1, -(Q - 1)], 256))
+    a, b, acc = (np.stack(r).astype(np.int32) for r in (rows_a, rows_b, rows_c))
+    ta, tb, tacc = dev(torch, a), dev(torch, b), dev(torch, acc)
+    tc = torch.empty_like(ta)
+    prod = a.astype(np.int64) * b.astype(np.int64)
+    api.pointwise_barrett(tc, ta, tb)
+    assert (host(tc) == np.mod(prod, Q)).all()
+    api.pointwise_acc(tc, tacc, ta, tb)
+    assert (host(tc) == np.mod(acc.astype(np.int64) + prod, Q)).all()
+    api.poly_add(tc, ta, tb)
+    assert (host(tc) == np.mod(a.astype(np.int64) + b, Q)).all()
+    api.poly_sub(tc, ta, tb)
+    assert (host(tc) == np.mod(a.astype(np.int64) - b, Q)).all()
+    for mapping in (0, 1, 2):                       # the hardware model's MUL on `bram` under every MAPPING, same extremes
+        ram = ta.clone()
+        api.ntt2x2_mul(ram, tb, mapping)
+        r = np.arange(64)
+        row = r if mapping == 0 else ((r % 4) * 16 + r // 4 if mapping == 1 else (r % 16) * 4 + r // 16)
+        want = a.reshape(-1, 64, 4).astype(np.int64).copy()
+        want[:, row, :] = np.mod(want[:, row, :] * b.reshape(-1, 64, 4).astype(np.int64), Q)
+        assert (host(ram).reshape(-1, 64, 4) == np.mod(want, Q)).all(), mapping
+
+
 def test_pointwise_mac_add_sub(gpu, oracle, golden):
     from dilithium_amd import api
     torch = gpu

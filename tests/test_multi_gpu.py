@@ -196,3 +196,74 @@ def test_cpp_host_program_on_every_gpu(gpu):
     _build()
     out = subprocess.run([os.path.join(CPP, "test_multi_dev")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_every_visible_gpu_ragged_rccl_gather_and_reinit(gpu, oracle):
+    """NOT parametrised over a GPU count and never skipped: whatever number N of GPUs this box shows is the world size.  BASELINE
+    configs[4]'s shape -- level-5 sign phases on 8192 N + 3 items (ragged by construction for N > 1) -- through
+    dil_sign_phases_multi_dev gathered to every device AND to the LAST device (a ragged root), every (z, h, flag) vs the oracle; then
+    dil_multi_shutdown() + dil_shutdown(), a fresh dil_multi_init() and a ragged NTT batch (communicators rebuilt); and, for N >= 2, one process per GPU over
+    RCCL (run_sharded + gather_slabs) on the same item count.  On the one-GPU box this is the world-size-1 path; on the 8-GPU node
+    it is the first thing that fails if RCCL's ragged paths do not work."""
+    from dilithium_amd import lib as dlib, sharding
+    from oracle import dilithium_kat as dk
+    from oracle.oracle import splitmix64_polys, Q
+    ndev = gpu.cuda.device_count()
+    assert ndev >= 1
+    L_ = dlib.load()
+    dlib.check(L_.dil_multi_init(ndev), "dil_multi_init")
+    dev = lambda g: gpu.device(f"cuda:{g}")  # noqa: E731
+    level, n = 5, 8192 * ndev + 3
+    p = dk.PARAMS[level]
+    K, Lv = p.K, p.L
+    rng = np.random.default_rng(19)
+    A = splitmix64_polys(K * Lv, seed=18).reshape(1, K, Lv, 256)
+    y = np.mod(rng.integers(-(p.gamma1 - 1), p.gamma1 + 1, (n, Lv, 256)), Q).astype(np.int32)
+    c = np.zeros((n, 256), np.int32)
+    c[:, ::5] = 1
+    c[:, 1::9] = Q - 1
+    s1h = oracle.ntt(np.mod(rng.integers(-p.eta, p.eta + 1, (1, Lv, 256)), Q).astype(np.int32))
+    s2h = oracle.ntt(np.mod(rng.integers(-p.eta, p.eta + 1, (1, K, 256)), Q).astype(np.int32))
+    t0h = oracle.ntt(np.mod(rng.integers(-4095, 4097, (1, K, 256)), Q).astype(np.int32))
+    ow1, ow0 = oracle.sign_phase1(level, A, y)
+    oz, oh, of = oracle.sign_phase2(level, c, y, ow0, ow1, s1h, s2h, t0h)
+    for root in (-1, ndev - 1):
+        per = {k: [] for k in ("z", "h", "f", "A", "y", "c", "s1", "s2", "t0", "w1", "w0")}
+        for g in range(ndev):
+            lo, hi = sharding.shard_range(n, g, ndev)
+            up = lambda x: gpu.from_numpy(np.ascontiguousarray(x)).to(dev(g))  # noqa: E731
+            per["z"].append(gpu.zeros((n, Lv, 256), dtype=gpu.int32, device=dev(g)))
+            per["h"].append(gpu.zeros((n, K, 256), dtype=gpu.uint8, device=dev(g)))
+            per["f"].append(gpu.full((n,), -1, dtype=gpu.int32, device=dev(g)))
+            per["A"].append(up(A)); per["s1"].append(up(s1h)); per["s2"].append(up(s2h)); per["t0"].append(up(t0h))
+            per["y"].append(up(y[lo:hi])); per["c"].append(up(c[lo:hi]))
+            per["w1"].append(gpu.empty((hi - lo, K, 256), dtype=gpu.uint8, device=dev(g)))
+            per["w0"].append(gpu.empty((hi - lo, K, 256), dtype=gpu.int32, device=dev(g)))
+        dlib.check(L_.dil_sign_phases_multi_dev(*[_ptrs(per[k]) for k in ("z", "h", "f", "A", "y", "c", "s1", "s2", "t0", "w1", "w0")],
+                                                level, n, 1, root, ndev), "dil_sign_phases_multi_dev")
+        for g in (range(ndev) if root < 0 else [root]):
+            assert (per["f"][g].cpu().numpy() == of).all() and (per["z"][g].cpu().numpy() == oz).all() and (per["h"][g].cpu().numpy() == oh).all(), (root, g)
+        del per
+    # shutdown, then the communicators again
+    gpu.cuda.synchronize()
+    dlib.check(L_.dil_multi_shutdown(), "dil_multi_shutdown")          # communicators and per-device streams gone ...
+    dlib.check(L_.dil_shutdown(), "dil_shutdown")                      # ... and every device's runtime state
+    dlib.check(L_.dil_multi_init(ndev), "dil_multi_init after shutdown")
+    m = 1000 * ndev + 1
+    a = splitmix64_polys(m, seed=23)
+    bufs = []
+    for g in range(ndev):
+        lo, hi = sharding.shard_range(m, g, ndev)
+        t = gpu.zeros((m, 256), dtype=gpu.int32, device=dev(g))
+        t[lo:hi] = gpu.from_numpy(a[lo:hi]).to(dev(g))
+        bufs.append(t)
+    dlib.check(L_.dil_ntt_multi_dev(_ptrs(bufs), m, 0, -1, ndev), "dil_ntt_multi_dev after re-init")
+    want = oracle.ntt(a)
+    for g in range(ndev):
+        assert (bufs[g].cpu().numpy() == want).all(), g
+    gpu.cuda.set_device(0)
+    # one process per GPU over RCCL on the same ragged item count
+    if ndev >= 2:
+        r = _launch_ranks(ndev, "hip", n)
+        assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
