@@ -504,6 +504,12 @@ def main():
         vsets = []
         for j in range(VSETS):
             A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank + 100 * j)
+            if os.environ.get("DIL_BENCH_VERIFY_UNIFORM"):     # experiment: uniform residues everywhere, as scripts/ab_verify.py feeds the kernel
+                gz = torch.Generator(device="cuda").manual_seed(j)
+                ur = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=gz)  # noqa: E731
+                vsets.append((ur(VBATCH, 6, 5, 256), ur(VBATCH, 5, 256), ur(VBATCH, 256), cu(t1_), cu(h),
+                              torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
+                continue
             vsets.append((cu(A), cu(z), cu(c), cu(t1_), cu(h), torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
         dA, dz, dc, dt1, dh, w1 = vsets[0]
         vptr = [[P(t) for t in vs_] for vs_ in vsets]
@@ -514,7 +520,7 @@ def main():
             return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, stream)
 
         sharding.barrier()
-        v_ms, v_reps = timed(vstep)
+        (v_ms, v_reps), v_mhz = with_clock(lambda: timed(vstep), 3 * args.min_ms)
         v_ms = sharding.max_over_ranks(v_ms)
         v_gbs = VERIFY3_BYTES * VBATCH / (v_ms * 1e-3) / 1e9
         vtraffic = pmc_traffic("verify_kernel")
@@ -525,7 +531,7 @@ def main():
                "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": vtraffic,
                             "traffic_source": "profiles/pmc_summary.json (committed PMC passes)" if vtraffic else None,
-                            "avg_launch_ms": v_ms}}
+                            "avg_launch_ms": v_ms, "shader_mhz_observed": v_mhz}}
         # the same launches alternating over TWO streams (input set j on stream j): the next launch's ramp hides the
         # previous one's tail and the dispatch gap -- the aggregate rate, reported beside the single-kernel fraction
         if NS > 1 and not args.no_verify_overlap:

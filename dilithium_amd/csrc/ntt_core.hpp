@@ -501,6 +501,38 @@ __device__ __forceinline__ void ntt_inv_core2(int32_t (&a)[4], int32_t (&b)[4], 
     inv_pass<true>(b, t3);
 }
 
+// A forward and an inverse transform side by side (the fused verify kernel: NTT(t1[k+1] 2^13) beside INTT(row k)): two independent
+// chains again, each with its own table; the exchanges share the wave's buffer in program order.
+template <class TWF, class TWI, class X10>
+__device__ __forceinline__ void ntt_fwd_inv_pair(int32_t (&f)[4], int32_t (&g)[4], const TWF& twf, const TWI& twi, const X10& x10)
+{
+    const auto f0 = twf.template get<0>();
+    const auto g0 = twi.template get<0>();
+    const auto f1 = twf.template get<1>();
+    const auto g1 = twi.template get<1>();
+    DIL_TW_FENCE();
+    fwd_pass(f, f0);
+    do_x54(x10, f, 0);
+    inv_pass<false>(g, g0);
+    x10(g);
+    const auto f2 = twf.template get<2>();
+    const auto g2 = twi.template get<2>();
+    DIL_TW_FENCE();
+    fwd_pass(f, f1);
+    do_x32(x10, f, 0);
+    inv_pass<false>(g, g1);
+    do_x32(x10, g, 0);
+    const auto f3 = twf.template get<3>();
+    const auto g3 = twi.template get<3>();
+    DIL_TW_FENCE();
+    fwd_pass(f, f2);
+    x10(f);
+    inv_pass<false>(g, g2);
+    do_x54(x10, g, 0);
+    fwd_pass(f, f3);
+    inv_pass<true>(g, g3);
+}
+
 // N forward transforms side by side (the L polynomials of a vector that lives in registers anyway): one set of twiddle reads for
 // all of them, N independent dependency chains per pass
 template <int N, class TW, class X10>

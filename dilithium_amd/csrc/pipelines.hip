@@ -279,6 +279,9 @@ struct YSrc<LEVEL, Y_PACKED> {
 // mat-vec / sign phase 1, wave-per-item.  Per item: issue row-0 loads | L forward NTTs on registers
 // loaded during the PREVIOUS item's row phase, y^ -> this wave's LDS slice | issue the NEXT item's y
 // loads | K rows: MAC from LDS, prefetch row k+1, INTT, (Decompose), store.
+#ifndef DIL_MVW_DUAL
+#define DIL_MVW_DUAL 1      // the L forward transforms side by side, the K inverse ones in pairs (rows k, k + 1 of the two-row ring)
+#endif
 template <int K, int L, int LEVEL, int OUT, int AF, int YF>
 __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
@@ -286,14 +289,16 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     KeyMap km, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     using XP = X10Pick<true>;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
+    using PT = PipeTables<DIL_TWC>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    uint32_t* xb = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + wv * XP::DW;   // exchange buffer, also the output transpose
+    PT::stage(lds, fwd_tab, inv_tab);
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
+    uint32_t* xb = lds + PT::DWORDS + 4 * L * 256 + 4 * 64 + wv * XP::DW;   // exchange buffer, also the output transpose
     const typename XP::type lm(xb, lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + wv * 64;   // byte-plane scratch
-    uint32_t* yl = lds + 2 * TW_TABLE_DWORDS + wv * (L * 256);
+    uint32_t* sc = lds + PT::DWORDS + 4 * L * 256 + wv * 64;   // byte-plane scratch
+    uint32_t* yl = lds + PT::DWORDS + wv * (L * 256);
     const size_t nwaves = (size_t)gridDim.x * 4;
     size_t it = (size_t)blockIdx.x * 4 + wv;
     const YSrc<LEVEL, YF> ys(lane);
@@ -312,14 +317,41 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
 #pragma unroll
         for (int j = 0; j < NR; j++) Ar[j].load(Ait + (size_t)j * L * PD, lane, !shared_A && km.S == 1);
 #pragma unroll
-        for (int l = 0; l < L; l++) {
-            ys.value(yr.v[l]);
-            ntt_fwd_core(yr.v[l], twf, lm);
-            *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
-        }
+        for (int l = 0; l < L; l++) ys.value(yr.v[l]);
+#if DIL_MVW_DUAL
+        ntt_fwd_coreN<L>(yr.v, twf, lm);
+#else
+#pragma unroll
+        for (int l = 0; l < L; l++) ntt_fwd_core(yr.v[l], twf, lm);
+#endif
+#pragma unroll
+        for (int l = 0; l < L; l++) *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) load_y(itn);
+#if DIL_MVW_DUAL
+        if constexpr (NR == 2 && K % 2 == 0) {
+            // rows k and k + 1 sit in the ring's two buffers: both multiply-accumulates, then both inverse transforms side by side
+#pragma unroll
+            for (int k = 0; k < K; k += 2) {
+                int64_t acc[4] = {0, 0, 0, 0}, acd[4] = {0, 0, 0, 0};
+                mac_row<L>(acc, Ar[0], yl, lane);
+                mac_row<L>(acd, Ar[1], yl, lane);
+                if (k + 2 < K) {
+                    Ar[0].load(Ait + (size_t)(k + 2) * L * PD, lane, !shared_A && km.S == 1);
+                    Ar[1].load(Ait + (size_t)(k + 3) * L * PD, lane, !shared_A && km.S == 1);
+                }
+                int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+                int32_t rd[4] = {mont_red64(acd[0]), mont_red64(acd[1]), mont_red64(acd[2]), mont_red64(acd[3])};
+                DIL_SCHED_FENCE();
+                ntt_inv_core2(r, rd, twi, lm);
+                DIL_SCHED_FENCE();
+                emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, nullptr);
+                emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k + 1) * 256, rd, sc, lane, nullptr);
+            }
+            continue;
+        }
+#endif
         constexpr int ROW_UNROLL = NR > 1 ? K : 1;           // the ring's slot index must be static
 #pragma unroll ROW_UNROLL
         for (int k = 0; k < K; k++) {
@@ -450,6 +482,20 @@ __global__ __launch_bounds__(256) void keygen_wpi_kernel(
 #ifndef DIL_VW_WAVES
 #define DIL_VW_WAVES(LEVEL) ((LEVEL) == 2 ? 4 : 3)
 #endif
+// exchange policy of the VALU-bound kernels: all three exchanges of a transform through a 1-KiB per-wave LDS buffer (ntt_core.hpp XAllLds)
+struct S2X {
+    using type = XAllLds;
+    static constexpr int DW = 256;
+};
+#ifndef DIL_VW_TWC
+#define DIL_VW_TWC 1        // compact twiddle tables (ntt_core.hpp TwLdsC)
+#endif
+#ifndef DIL_VW_XALL
+#define DIL_VW_XALL 0       // 1: all three exchanges of a transform through the wave's LDS buffer (0: only the (1:0) one)
+#endif
+#ifndef DIL_VW_DUAL
+#define DIL_VW_DUAL 2       // 1: the z-phase's L + 1 forward transforms side by side; 2: and NTT(t1[k+1] 2^13) beside INTT(row k)
+#endif
 template <int LEVEL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVES(LEVEL), DIL_VW_WAVES(LEVEL)))) void verify_wpi_kernel(
     uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
@@ -457,22 +503,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+#if DIL_VW_XALL
+    using XP = S2X;
+#else
     using XP = X10Pick<true>;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
+#endif
+    using PT = PipeTables<DIL_VW_TWC>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    const typename XP::type lm(lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + 4 * 64 + wv * XP::DW, lane);
-    uint32_t* sc = lds + 2 * TW_TABLE_DWORDS + 4 * L * 256 + wv * 64;   // byte-plane scratch
-    uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + wv * (L * 256);   // this wave's private slice
+    PT::stage(lds, fwd_tab, inv_tab);
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
+    const typename XP::type lm(lds + PT::DWORDS + 4 * L * 256 + 4 * 64 + wv * XP::DW, lane);
+    uint32_t* sc = lds + PT::DWORDS + 4 * L * 256 + wv * 64;   // byte-plane scratch
+    uint32_t* zl = lds + PT::DWORDS + wv * (L * 256);   // this wave's private slice
     const size_t nwaves = (size_t)gridDim.x * 4;
     size_t it = (size_t)blockIdx.x * 4 + wv;
-    RawPolys<L, false> zr;              // verify: default cache policy for the time-domain inputs
-    int32_t cr[4] = {0, 0, 0, 0};
-    if (it < batch) {
-        zr.load(z + it * L * 256, lane);
-        load_strided<false>(cr, c + it * 256, lane);
-    }
+    int32_t zc[L + 1][4];               // z[0 .. L-1] and c: verify keeps the default cache policy for its time-domain inputs
+    auto load_zc = [&](size_t i) {
+#pragma unroll
+        for (int l = 0; l < L; l++) load_strided<false>(zc[l], z + (i * L + l) * 256, lane);
+        load_strided<false>(zc[L], c + i * 256, lane);
+    };
+    if (it < batch) load_zc(it);
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
         const int32_t* Ait = A + it * (size_t)(K * L) * 256;       // a key per item (one key for the batch: verify_shared_kernel)
@@ -486,31 +539,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
         load_strided<false>(tn, t1it, lane);
         hn = load_row_u8(hit, lane);
         // z-phase
+#if DIL_VW_DUAL
+        ntt_fwd_coreN<L + 1>(zc, twf, lm);
+#else
 #pragma unroll
-        for (int l = 0; l < L; l++) {
-            VW_FWD(zr.v[l], twf, lm);
-            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zr.v[l][0], zr.v[l][1], zr.v[l][2], zr.v[l][3]);
-        }
-        int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
-        VW_FWD(ch, twf, lm);
+        for (int l = 0; l <= L; l++) VW_FWD(zc[l], twf, lm);
+#endif
+#pragma unroll
+        for (int l = 0; l < L; l++) *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zc[l][0], zc[l][1], zc[l][2], zc[l][3]);
+        int32_t ch[4] = {zc[L][0], zc[L][1], zc[L][2], zc[L][3]};
         DIL_SCHED_FENCE();
         // next item's time-domain inputs: a whole row phase to land
         const size_t itn = it + nwaves;
-        if (itn < batch) {
-            zr.load(z + itn * L * 256, lane);
-            load_strided<false>(cr, c + itn * 256, lane);
-        }
-        // (more matrix rows in flight per wave were tried in rounds 2 and 3: a ring of 2 / 3 row buffers at 2, 3 and 4 waves per
-        //  SIMD is within noise of this form at levels 3 and 5 -- 61.5-61.9 us vs 61.5 -- and slower at level 2 and with three
-        //  rows (level 5: 150 us, spills); two waves per SIMD lose 10 % whatever the depth: profiles/r03k_ab_vw.txt)
+        if (itn < batch) load_zc(itn);
+#if DIL_VW_DUAL == 2
+        // row k's INTT runs beside row k + 1's NTT(t1 2^13): th is always one row ahead
+        int32_t th[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
+        load_strided<false>(tn, t1it + 256, lane);
+        VW_FWD(th, twf, lm);
+#endif
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, zl, lane);
-            int32_t th[4];
             uint32_t hb[4];
+            unpack_row_u8(hb, hn, sc, lane);
+#if DIL_VW_DUAL == 2
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            if (k + 1 < K) {
+                VW_ALOAD(Ar, Ait + (size_t)(k + 1) * L * 256, lane, true);
+                hn = load_row_u8(hit + (k + 1) * 256, lane);
+#pragma unroll
+                for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;
+                if (k + 2 < K) load_strided<false>(tn, t1it + (k + 2) * 256, lane);
+                DIL_SCHED_FENCE();
+                ntt_fwd_inv_pair(th, r, twf, twi, lm);
+            } else {
+                DIL_SCHED_FENCE();
+                VW_INV(r, twi, lm);
+            }
+            DIL_SCHED_FENCE();
+#else
+            int32_t th[4];
 #pragma unroll
             for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
-            unpack_row_u8(hb, hn, sc, lane);
             if (k + 1 < K) {
                 VW_ALOAD(Ar, Ait + (size_t)(k + 1) * L * 256, lane, true);
                 load_strided<false>(tn, t1it + (k + 1) * 256, lane);
@@ -525,6 +600,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
             DIL_SCHED_FENCE();
             VW_INV(r, twi, lm);
             DIL_SCHED_FENCE();
+#endif
             const size_t o = (it * K + k) * 256;
             uint32_t wb[4];
 #pragma unroll
@@ -538,10 +614,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
 // exchanges of its transforms go through a 1-KiB per-wave LDS buffer (ntt_core.hpp XAllLds) instead of permlane / DPP / v_bfi --
 // measured -10 % at every level (level 5, one key, 8192 attempts: 78.2 -> 69.5 us; profiles/r03l_ab_s2.txt).  The gain needs
 // occupancy: at 2-3 waves per SIMD the LDS round trips are exposed and the register form wins (profiles/r03c_tune_xchg.txt).
-struct S2X {
-    using type = XAllLds;
-    static constexpr int DW = 256;
-};
 // Waves per SIMD.  Round 3 held these kernels at five (<= 96 VGPRs: the per-item-key form of the paired rows wanted 105-113 registers
 // and lost more to exposed latency at four waves than the saved transforms gave back).  With two transforms side by side per row
 // (ntt_inv_core2) a wave hides its own latency and wants the registers instead: four waves (<= 128 VGPRs, no spills) beat five

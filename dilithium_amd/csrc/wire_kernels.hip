@@ -38,6 +38,14 @@ template <int LEVEL> struct WireSh { static constexpr int NW = 12; static conste
 // ---------------------------------------------------------------------------------------------------------
 // distinct public keys: wave per item, A streamed from HBM (expanded by expand_a_kernel), everything else packed
 // ---------------------------------------------------------------------------------------------------------
+#ifndef DIL_WW_TWC
+#define DIL_WW_TWC 1        // compact twiddle tables
+#endif
+#ifndef DIL_WW_DUAL
+// forward transforms in pairs, NTT(t1[k+1] 2^13) beside INTT(row k): level 3 83.8 -> 81.2 us, level 2 65.5 -> 62.1 us per 8192; not at
+// level 5, where the second chain's registers spill under the 168-VGPR cap (126.5 -> 130.2 us): profiles/r04l_ab_wire_matvec.txt
+#define DIL_WW_DUAL(LEVEL) ((LEVEL) != 5)
+#endif
 #ifndef DIL_WW_WAVES
 #define DIL_WW_WAVES(LEVEL) 3      // waves per SIMD the register allocator aims for (168 VGPRs)
 #endif
@@ -48,15 +56,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
     const uint32_t* __restrict__ cbits, size_t batch, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
+    constexpr bool DUAL = DIL_WW_DUAL(LEVEL);
     using W = Wire<LEVEL>;
     // per wave: L KiB of z^ | 64 dwords byte scratch | 64 dwords hint bitmap
     using XP = X10Pick<true>;
+    using PT = PipeTables<DIL_WW_TWC>;
     constexpr int WAVE_DW = L * 256 + 64 + 64 + XP::DW;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + 4 * WAVE_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + 4 * WAVE_DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
-    uint32_t* zl = lds + 2 * TW_TABLE_DWORDS + wv * WAVE_DW;
+    PT::stage(lds, fwd_tab, inv_tab);
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
+    uint32_t* zl = lds + PT::DWORDS + wv * WAVE_DW;
     uint32_t* sc = zl + L * 256;
     uint32_t* bm = sc + 64;
     const typename XP::type lm(bm + 64, lane);
@@ -73,6 +84,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
         hb0 = (lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + lane] : 0;          // (61 hint bytes at level 3: never read past the signature)
         hb1 = (64 + lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + 64 + lane] : 0;
     };
+    auto t1_row = [&](int32_t (&th)[4], const uint32_t (&tn)[4]) {               // t1[k] 2^13 from its packed 10-bit fields (decoder.v:96-100)
+        uint32_t f[4];
+        plt.fields(f, tn);
+#pragma unroll
+        for (int m = 0; m < 4; m++) th[m] = (int32_t)(f[m] << 13);
+    };
     if (it < batch) load_item(it);
     __syncthreads();                               // tables staged (the only barrier)
     for (; it < batch; it += nwaves) {
@@ -85,6 +102,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
         plt.load(tn, t1it);
         const bool bad = hints_to_bitmap<LEVEL>(bm, sc, hb0, hb1, lane);
         int32_t zmax = 0;
+        int32_t ch[4];
+        decode_c(ch, cb);
+        if constexpr (DUAL) {
+        // the L + 1 forward transforms two at a time (ntt_core.hpp ntt_fwd_core2: one set of twiddle reads, two dependency chains)
+#pragma unroll
+        for (int l = 0; l + 1 < L; l += 2) {
+            int32_t r[4], q[4];
+            decode_z<LEVEL>(r, zr.v[l], plz, zmax);
+            decode_z<LEVEL>(q, zr.v[l + 1], plz, zmax);
+            ntt_fwd_core2(r, q, twf, lm);
+            *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<int4*>(zl + (l + 1) * 256 + 4 * lane) = make_int4(q[0], q[1], q[2], q[3]);
+        }
+        if (L & 1) {
+            int32_t r[4];
+            decode_z<LEVEL>(r, zr.v[L - 1], plz, zmax);
+            ntt_fwd_core2(r, ch, twf, lm);
+            *reinterpret_cast<int4*>(zl + (L - 1) * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
+        } else {
+            ntt_fwd_core(ch, twf, lm);
+        }
+        } else {
 #pragma unroll
         for (int l = 0; l < L; l++) {
             int32_t r[4];
@@ -92,26 +131,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
             ntt_fwd_core(r, twf, lm);
             *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(r[0], r[1], r[2], r[3]);
         }
-        int32_t ch[4];
-        decode_c(ch, cb);
         ntt_fwd_core(ch, twf, lm);
+        }
         DIL_SCHED_FENCE_W();
         const size_t itn = it + nwaves;
         if (itn < batch) load_item(itn);
         const bool zrej = __ballot(zmax >= Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA) != 0;
         if (lane == 0) verdict[it] = (zrej ? 2 : 0) | (bad ? 4 : 0);
+        // DUAL: row k's INTT runs beside row k + 1's NTT(t1 2^13) (ntt_fwd_inv_pair): th is always one row ahead
+        int32_t th[4] = {0, 0, 0, 0};
+        if constexpr (DUAL) {
+            t1_row(th, tn);
+            plt.load(tn, t1it + 320);
+            ntt_fwd_core(th, twf, lm);
+        }
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, zl, lane);
-            int32_t th[4];
-            {
-                uint32_t f[4];
-                plt.fields(f, tn);
-#pragma unroll
-                for (int m = 0; m < 4; m++) th[m] = (int32_t)(f[m] << 13);   // decoder.v:96-100
-            }
             uint32_t hb[4];
             row_hint_bits(hb, bm, k, lane);
+            int32_t r[4];
+            if constexpr (DUAL) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
+#pragma unroll
+            for (int m = 0; m < 4; m++) r[m] = mont_red64(acc[m]);
+            if (k + 1 < K) {
+                Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, true);
+                t1_row(th, tn);
+                if (k + 2 < K) plt.load(tn, t1it + (k + 2) * 320);
+                DIL_SCHED_FENCE_W();
+                ntt_fwd_inv_pair(th, r, twf, twi, lm);
+            } else {
+                DIL_SCHED_FENCE_W();
+                ntt_inv_core(r, twi, lm);
+            }
+            DIL_SCHED_FENCE_W();
+            } else {
+            t1_row(th, tn);
             if (k + 1 < K) {
                 Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, true);
                 plt.load(tn, t1it + (k + 1) * 320);
@@ -121,10 +178,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
             DIL_SCHED_FENCE_W();
 #pragma unroll
             for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
-            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+#pragma unroll
+            for (int m = 0; m < 4; m++) r[m] = mont_red64(acc[m]);
             DIL_SCHED_FENCE_W();
             ntt_inv_core(r, twi, lm);
             DIL_SCHED_FENCE_W();
+            }
             uint32_t wb[4];
 #pragma unroll
             for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);

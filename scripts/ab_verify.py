@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--level", type=int, default=3)
 ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--shared", action="store_true")
-ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1", "sign2", "ntt"])
+ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1", "sign2", "ntt", "wire"])
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--generic", action="store_true", help="sign2: the entry point for arbitrary residues even where the small-key one exists")
 ap.add_argument("--reps", type=int, default=30)
@@ -46,6 +46,14 @@ nk = 1 if a.shared else n
 s1h, s2h, t0h = rnd(nk, L, 256), rnd(nk, K, 256), rnd(nk, K, 256)
 w1in = torch.randint(0, 16, (n, K, 256), dtype=torch.uint8, device="cuda", generator=g)
 p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+PKB, SGB = {2: 1312, 3: 1952, 5: 2592}[a.level], {2: 2420, 3: 3293, 5: 4595}[a.level]
+wire_in = []
+if a.kind == "wire":        # wire-format fused verify kernel: random key / signature BYTES (timing and bit-equality across builds only)
+    for _ in range(2):
+        wire_in.append((torch.randint(0, 256, (1 if a.shared else n, PKB), dtype=torch.uint8, device="cuda", generator=g),
+                        torch.randint(0, 256, (n, SGB), dtype=torch.uint8, device="cuda", generator=g)))
+w1pk = torch.empty((n, K * (192 if a.level == 2 else 128)), dtype=torch.uint8, device="cuda")
+vdw = torch.empty((n,), dtype=torch.int32, device="cuda")
 nttb = [rnd(65536, 256) for _ in range(8)] if a.kind == "ntt" else []
 libs = []
 for path in a.libs:
@@ -58,6 +66,7 @@ for path in a.libs:
     L_.dil_sign_phase2_dev.argtypes = [C.c_void_p] * 10 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
     if hasattr(L_, "dil_sign_phase2_skey_dev"):          # round 4: the small-key kernels have an entry point of their own
         L_.dil_sign_phase2_skey_dev.argtypes = [C.c_void_p] * 10 + [C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    L_.dil_verify_wire_core_dev.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_size_t, C.c_int, C.c_void_p]
     L_.dil_event_elapsed_ms.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
     assert L_.dil_init(0) == 0
     libs.append((os.path.basename(path), L_))
@@ -87,6 +96,8 @@ def run(L_, reps):
         if a.kind == "ntt":
             b = nttb[i & 7]
             rc = L_.dil_ntt_dev(p(b), 65536, None) | L_.dil_invntt_dev(p(b), 65536, None)
+        elif a.kind == "wire":
+            rc = L_.dil_verify_wire_core_dev(p(w1pk), p(vdw), p(A), p(wire_in[i & 1][0]), p(wire_in[i & 1][1]), a.level, n, sh, None)
         elif a.kind == "verify":
             rc = L_.dil_verify_core_dev(p(w1), p(A), p(z), p(c), p(t1), p(h), a.level, n, sh, None)
         elif a.kind == "matvec":
@@ -104,7 +115,7 @@ ref = None
 for name, L_ in libs:            # all builds must agree bit for bit
     run(L_, 2)
     torch.cuda.synchronize()
-    out = {"verify": w1, "matvec": w, "sign1": w0, "sign2": zo, "ntt": nttb[0] if nttb else w1}[a.kind].clone()
+    out = {"verify": w1, "matvec": w, "sign1": w0, "sign2": zo, "ntt": nttb[0] if nttb else w1, "wire": w1pk}[a.kind].clone()
     if ref is None:
         ref = out
     if "_no" not in name:            # ablation builds (libdil256_no*.so) compute something else on purpose
