@@ -52,42 +52,26 @@ __device__ __forceinline__ int32_t sgn(int32_t x)
 #ifndef DIL_MAD64
 #define DIL_MAD64 0
 #endif
-// (the instruction also writes a carry mask; it goes to a scratch SGPR pair of the compiler's choosing -- naming VCC would chain
-//  every multiply-add of a wave through one register)
-#ifndef DIL_MAD64_VCC
-#define DIL_MAD64_VCC 0
-#endif
+// (the instruction also writes a carry mask: it goes to a scratch SGPR pair of the compiler's choosing; VCC measured the same)
 __device__ __forceinline__ int64_t mad64(int32_t a, int32_t b, int64_t c)     // a * b + c, one v_mad_i64_i32
 {
     int64_t d;
-#if DIL_MAD64_VCC
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
-#else
     uint64_t carry;
     asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
-#endif
     return d;
 }
 __device__ __forceinline__ int64_t mul64(int32_t a, int32_t b)                 // a * b, one v_mad_i64_i32 with a zero addend
 {
     int64_t d;
-#if DIL_MAD64_VCC
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
-#else
     uint64_t carry;
     asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
-#endif
     return d;
 }
 __device__ __forceinline__ int64_t mul64_s(int32_t a, uint32_t b_scalar)       // the same with a wave-uniform (SGPR) factor
 {
     int64_t d;
-#if DIL_MAD64_VCC
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b_scalar) : "vcc");
-#else
     uint64_t carry;
     asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_scalar));
-#endif
     return d;
 }
 

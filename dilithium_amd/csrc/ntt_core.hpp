@@ -247,41 +247,26 @@ __device__ __forceinline__ void LaneMasks::operator()(int32_t (&r)[4]) const { x
 // Bank arithmetic (MI355X_MICROARCH.md, LDS table): a ds_write_b32 is served in two groups of 32 lanes against 32 banks of 4 bytes,
 // a ds_read_b128 in four irregular groups of 16 lanes and a ds_read_b64 in two groups of 32, both against 64 banks.  Round 3's
 // slot maps were derived for 64 write banks and measured 2-way on every store (SQ_LDS_BANK_CONFLICT = 77-84 % of the LDS
-// instruction cycles of the sign kernels, profiles/r03z_sign_pmc.txt).  These are conflict-free on both sides:
+// instruction cycles of the sign kernels, profiles/r03z_sign_pmc.txt; with these maps 18 % / 27 %, profiles/r04e_sign_pmc.txt -- what
+// is left are the byte-plane scratch stores.  In TIME the two sets of maps are within noise of each other, as the guide says of
+// 2-way ds_write_b32 conflicts: profiles/r04c_ab_dualN_slots_bf64.txt).  These are conflict-free on both sides:
 //   S = 2  lane = (l5, l4, b, lo):  slot = 32 l5 + 16 b1 + 8 b0 + 4 l4 + lo        store bank = 4 (4 l4 + lo) + bw
 //   S = 0  lane = (q, b), q = 4 bit: slot = 32 q3 + 16 b0 + 8 b1 + ((q & 7) ^ b0)  store bank = 4 ((q & 7) ^ j0) + bw
 //   S = 4  lane = (b, lo4): the 32 lanes of a store group hold only two values of bw, so one 16-byte slot per reader can use at
 //          most half the banks.  The reader's four dwords are therefore split over two 8-byte halves in two planes -- writers
 //          with bw < 2 fill plane 0, the others plane 1, dword = 128 plane + 2 reader_lane + (bw & 1), store bank = 2 lo4 + bw,
 //          -- and read back as two ds_read_b64 (the same 4 LDS cycles as one ds_read_b128).
-#ifndef DIL_XS4
-#define DIL_XS4 1
-#endif
-#ifndef DIL_XS2
-#define DIL_XS2 1
-#endif
-#ifndef DIL_XS0
-#define DIL_XS0 1
-#endif
 template <int S>
 __device__ __forceinline__ uint32_t xslot(uint32_t lane, uint32_t field)
 {
-    if (S == 4) {                                   // (round-3 map; the round-4 form of S = 4 has two planes, see XLdsAt)
-        const uint32_t lo4 = lane & 15, g = (0x78u >> (2 * (lo4 >> 2))) & 3u;
-        return 4 * lo4 + (field ^ g);
-    }
-    if (S == 2) {
-        if (DIL_XS2) return 32 * (lane >> 5) + 16 * (field >> 1) + 8 * (field & 1) + 4 * ((lane >> 4) & 1) + (lane & 3);
-        const uint32_t h = lane >> 4, lo = lane & 3;
-        return 16 * h + 4 * lo + (field ^ lo);
-    }
+    static_assert(S == 2 || S == 0, "S = 4 uses the two-plane form");
+    if (S == 2) return 32 * (lane >> 5) + 16 * (field >> 1) + 8 * (field & 1) + 4 * ((lane >> 4) & 1) + (lane & 3);
     const uint32_t q = lane >> 2;
-    if (DIL_XS0) return 32 * (q >> 3) + 16 * (field & 1) + 8 * (field >> 1) + ((q & 7) ^ (field & 1));
-    return 4 * q + (field ^ (q & 3));
+    return 32 * (q >> 3) + 16 * (field & 1) + 8 * (field >> 1) + ((q & 7) ^ (field & 1));
 }
 template <int S>
 struct XLdsAt {
-    static constexpr bool TWO_PLANES = S == 4 && DIL_XS4;
+    static constexpr bool TWO_PLANES = S == 4;
     uint32_t* wr[4];          // where this lane's register j goes
     const uint32_t* rd;       // this lane's 16-byte slot (two planes: its 8 bytes of plane 0; plane 1 is 128 dwords on)
     __device__ __forceinline__ void init(uint32_t* wave_buf /* 256 dwords */, int lane)

@@ -1102,6 +1102,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
 // workgroup by its first K waves (VY_NTT_T1, combined_top.v:1259) -- cheaper than a second launch.
 // z^ stays in registers (a lane multiplies the coefficients it transformed itself), as y^ in matvec_shared_kernel: no per-wave
 // LDS slice, 16 waves per workgroup at every level (level 5 was 11), and all three exchanges through LDS.
+#ifndef DIL_VS_DUAL
+#define DIL_VS_DUAL 1
+#endif
 template <int LEVEL, int NW>
 __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
     uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
@@ -1150,22 +1153,68 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
 #pragma unroll
             for (int l = 0; l < L; l++) load_strided<false>(zh[l], z + (it * L + l) * 256, lane);
         }
+        if (PFZ) {
 #pragma unroll
-        for (int l = 0; l < L; l++) {
-            if (PFZ) {
+            for (int l = 0; l < L; l++) {
 #pragma unroll
                 for (int m = 0; m < 4; m++) zh[l][m] = zr.v[l][m];
             }
-            ntt_fwd_core(zh[l], twf, lm);
         }
         int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
+#if DIL_VS_DUAL
+        ntt_fwd_coreN<L>(zh, twf, lm);                  // the L forward transforms side by side; c joins the first inverse pair's slot
         ntt_fwd_core(ch, twf, lm);
+#else
+#pragma unroll
+        for (int l = 0; l < L; l++) ntt_fwd_core(zh[l], twf, lm);
+        ntt_fwd_core(ch, twf, lm);
+#endif
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) {
             if (PFZ) zr.load(z + itn * L * 256, lane);
             load_strided<false>(cr, c + itn * 256, lane);
         }
+#if DIL_VS_DUAL
+        static_assert(K % 2 == 0, "rows are processed in pairs");
+        for (int k = 0; k < K; k += 2) {                // rows k, k + 1: both multiply-accumulates, then both inverse transforms side by side
+            int64_t acc[4] = {0, 0, 0, 0}, acd[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int4 a = *reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane);
+                const int4 d = *reinterpret_cast<const int4*>(Al + ((k + 1) * L + l) * 256 + 4 * lane);
+                acc[0] += (int64_t)a.x * zh[l][0];
+                acc[1] += (int64_t)a.y * zh[l][1];
+                acc[2] += (int64_t)a.z * zh[l][2];
+                acc[3] += (int64_t)a.w * zh[l][3];
+                acd[0] += (int64_t)d.x * zh[l][0];
+                acd[1] += (int64_t)d.y * zh[l][1];
+                acd[2] += (int64_t)d.z * zh[l][2];
+                acd[3] += (int64_t)d.w * zh[l][3];
+            }
+            const int4 th = *reinterpret_cast<const int4*>(Tl + k * 256 + 4 * lane);
+            const int4 td = *reinterpret_cast<const int4*>(Tl + (k + 1) * 256 + 4 * lane);
+            acc[0] -= (int64_t)ch[0] * th.x; acc[1] -= (int64_t)ch[1] * th.y; acc[2] -= (int64_t)ch[2] * th.z; acc[3] -= (int64_t)ch[3] * th.w;
+            acd[0] -= (int64_t)ch[0] * td.x; acd[1] -= (int64_t)ch[1] * td.y; acd[2] -= (int64_t)ch[2] * td.z; acd[3] -= (int64_t)ch[3] * td.w;
+            const uint32_t hn2 = load_row_u8(hit + (k + 1) * 256, lane);
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            int32_t rd[4] = {mont_red64(acd[0]), mont_red64(acd[1]), mont_red64(acd[2]), mont_red64(acd[3])};
+            DIL_SCHED_FENCE();
+            ntt_inv_core2(r, rd, twi, lm);
+            DIL_SCHED_FENCE();
+            uint32_t hb[4], wb[4];
+            unpack_row_u8(hb, hn, sc, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+            store_row_u8(w1_out + (it * K + k) * 256, wb, sc, lane);
+            unpack_row_u8(hb, hn2, sc, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(rd[m]), hb[m]);
+            store_row_u8(w1_out + (it * K + k + 1) * 256, wb, sc, lane);
+            if (k + 2 < K) hn = load_row_u8(hit + (k + 2) * 256, lane);
+        }
+        if (false)
+#endif
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll

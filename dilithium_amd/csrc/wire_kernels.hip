@@ -28,11 +28,14 @@ namespace dil {
 #endif
 template <int LEVEL> struct WireSh;
 #if DIL_VWS_SHAPE == 0
-template <> struct WireSh<2> { static constexpr int NW = 16; static constexpr bool PFZ = false; using X = XAllLds; };   // 124 VGPRs
-template <> struct WireSh<3> { static constexpr int NW = 16; static constexpr bool PFZ = false; using X = X10Dpp; };    // 122 VGPRs
-template <> struct WireSh<5> { static constexpr int NW = 12; static constexpr bool PFZ = false; using X = XAllLds; };   // 12 waves: up to 168 VGPRs
+#ifndef DIL_VWS_DUAL
+#define DIL_VWS_DUAL 1      // transforms side by side (forward: all L; inverse: row pairs)
+#endif
+template <> struct WireSh<2> { static constexpr int NW = 16; static constexpr bool PFZ = false, DUAL = DIL_VWS_DUAL; using X = XAllLds; };
+template <> struct WireSh<3> { static constexpr int NW = 16; static constexpr bool PFZ = false, DUAL = DIL_VWS_DUAL; using X = X10Dpp; };
+template <> struct WireSh<5> { static constexpr int NW = 12; static constexpr bool PFZ = false, DUAL = DIL_VWS_DUAL; using X = XAllLds; };   // 12 waves: up to 168 VGPRs
 #else        // A/B: every level at 12 waves with prefetch and LDS exchanges
-template <int LEVEL> struct WireSh { static constexpr int NW = 12; static constexpr bool PFZ = true; using X = XAllLds; };
+template <int LEVEL> struct WireSh { static constexpr int NW = 12; static constexpr bool PFZ = true, DUAL = true; using X = XAllLds; };
 #endif
 
 // ---------------------------------------------------------------------------------------------------------
@@ -207,14 +210,16 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
     // workgroup at every level -- as verify_shared_kernel / matvec_shared_kernel (pipelines.hip)
     constexpr int XDW = 256;
     constexpr int WAVE_DW = 64 + 64 + XDW;           // byte scratch | hint bitmap | exchange buffer
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * TW_TABLE_DWORDS + (K * L + K) * 256 + NW * WAVE_DW];
+    using PT = PipeTables<DIL_WW_TWC>;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + (K * L + K) * 256 + NW * WAVE_DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
-    stage_tables(lds, fwd_tab, inv_tab);
-    uint32_t* Al = lds + 2 * TW_TABLE_DWORDS;
+    PT::stage(lds, fwd_tab, inv_tab);
+    uint32_t* Al = lds + PT::DWORDS;
     uint32_t* Tl = Al + K * L * 256;
     for (int i = threadIdx.x; i < K * L * 64; i += blockDim.x)
         reinterpret_cast<uint4*>(Al)[i] = reinterpret_cast<const uint4*>(A)[i];
-    const TwLds twf{lds, lane}, twi{lds + TW_TABLE_DWORDS, lane};
+    const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
+    const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
     uint32_t* sc = Tl + K * 256 + wv * WAVE_DW;
     uint32_t* bm = sc + 64;
     const typename WireSh<LEVEL>::X lm(bm + 64, lane);
@@ -253,18 +258,51 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
         int32_t zh[L][4];
         if (!PFZ) zr.load(sig + it * sig_stride + 32, plz);
 #pragma unroll
-        for (int l = 0; l < L; l++) {
-            decode_z<LEVEL>(zh[l], zr.v[l], plz, zmax);
-            ntt_fwd_core(zh[l], twf, lm);
-        }
+        for (int l = 0; l < L; l++) decode_z<LEVEL>(zh[l], zr.v[l], plz, zmax);
         int32_t ch[4];
         decode_c(ch, cb);
+        if constexpr (WireSh<LEVEL>::DUAL) {
+            ntt_fwd_coreN<L>(zh, twf, lm);          // side by side: one set of twiddle reads, L dependency chains
+        } else {
+#pragma unroll
+            for (int l = 0; l < L; l++) ntt_fwd_core(zh[l], twf, lm);
+        }
         ntt_fwd_core(ch, twf, lm);
         DIL_SCHED_FENCE_W();
         const size_t itn = it + nwaves;
         if (itn < batch) load_item(itn);
         const bool zrej = __ballot(zmax >= Par<LEVEL>::GAMMA1 - Par<LEVEL>::BETA) != 0;
         if (lane == 0) verdict[it] = (zrej ? 2 : 0) | (bad ? 4 : 0);
+        if constexpr (WireSh<LEVEL>::DUAL) {
+        for (int k = 0; k < K; k += 2) {                // rows k, k + 1: both multiply-accumulates, then both inverse transforms side by side
+            int64_t acc[4] = {0, 0, 0, 0}, acd[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int4 a = *reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane);
+                const int4 d = *reinterpret_cast<const int4*>(Al + ((k + 1) * L + l) * 256 + 4 * lane);
+                acc[0] += (int64_t)a.x * zh[l][0]; acc[1] += (int64_t)a.y * zh[l][1]; acc[2] += (int64_t)a.z * zh[l][2]; acc[3] += (int64_t)a.w * zh[l][3];
+                acd[0] += (int64_t)d.x * zh[l][0]; acd[1] += (int64_t)d.y * zh[l][1]; acd[2] += (int64_t)d.z * zh[l][2]; acd[3] += (int64_t)d.w * zh[l][3];
+            }
+            const int4 th = *reinterpret_cast<const int4*>(Tl + k * 256 + 4 * lane);
+            const int4 td = *reinterpret_cast<const int4*>(Tl + (k + 1) * 256 + 4 * lane);
+            acc[0] -= (int64_t)ch[0] * th.x; acc[1] -= (int64_t)ch[1] * th.y; acc[2] -= (int64_t)ch[2] * th.z; acc[3] -= (int64_t)ch[3] * th.w;
+            acd[0] -= (int64_t)ch[0] * td.x; acd[1] -= (int64_t)ch[1] * td.y; acd[2] -= (int64_t)ch[2] * td.z; acd[3] -= (int64_t)ch[3] * td.w;
+            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
+            int32_t rd[4] = {mont_red64(acd[0]), mont_red64(acd[1]), mont_red64(acd[2]), mont_red64(acd[3])};
+            DIL_SCHED_FENCE_W();
+            ntt_inv_core2(r, rd, twi, lm);
+            DIL_SCHED_FENCE_W();
+            uint32_t hb[4], wb[4];
+            row_hint_bits(hb, bm, k, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(r[m]), hb[m]);
+            store_row_w1_packed<LEVEL>(w1p_out + (it * K + k) * W::W1_ROW_BYTES, wb, sc, lane);
+            row_hint_bits(hb, bm, k + 1, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) wb[m] = use_hint<LEVEL>(canon_small(rd[m]), hb[m]);
+            store_row_w1_packed<LEVEL>(w1p_out + (it * K + k + 1) * W::W1_ROW_BYTES, wb, sc, lane);
+        }
+        } else
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
