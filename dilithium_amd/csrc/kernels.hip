@@ -82,13 +82,28 @@ __device__ __forceinline__ int inv_out_off(int i, int mapping)
 // HBM traffic: 1 KiB in (4 coalesced 256-B dword loads per wave) + 1 KiB out (one 1-KiB
 // dwordx4 store per wave) per polynomial.
 // ---------------------------------------------------------------------------------------
+// A/B hooks of the launch shape (profiles/r04o_ab_ntt_shapes_prio.txt: 1 / 2 / 4 waves per workgroup x 4 ... 16 workgroups per CU, with
+// and without s_setprio 3 around the loop's memory instructions -- 50.9-53.5 us per forward + inverse pair, all within +-1.5 % of
+// the shipped shape; with r01_tune_ntt.txt, r03e_tune_ntt2.txt and r04i_* the shape, prefetch depth, exchange policy and product form
+// of this kernel are exhausted: it runs at 0.91 of its own loads and stores)
+#ifndef DIL_NTT_WPB
+#define DIL_NTT_WPB 4          // waves per workgroup of the standalone transforms (the blocks-per-CU option scales by 4 / WPB)
+#endif
+#ifndef DIL_NTT_PRIO
+#define DIL_NTT_PRIO 0         // s_setprio around the memory instructions of the persistent loop
+#endif
+#if DIL_NTT_PRIO
+#define NTT_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define NTT_PRIO(p) ((void)0)
+#endif
 template <int LAYOUT>
-__global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ polys, size_t batch,
+__global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_fwd_kernel(int32_t* __restrict__ polys, size_t batch,
                                                        const uint32_t* __restrict__ tw_tab, int mapping)
 {
     const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * 4;
+    const size_t wave = (size_t)blockIdx.x * DIL_NTT_WPB + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * DIL_NTT_WPB;
     if (wave >= batch) return;
     int off[4];
 #pragma unroll
@@ -119,23 +134,27 @@ __global__ __launch_bounds__(256) void ntt_fwd_kernel(int32_t* __restrict__ poly
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
         const size_t pn = p + nwaves;
+        NTT_PRIO(3);
         if (pn < batch) {
 #pragma unroll
             for (int m = 0; m < 4; m++) nxt[m] = ld_s(polys + pn * 256 + off[m]);
         }
+        NTT_PRIO(0);
         ntt_fwd_core(r, tw, xp);
-        st_nt4(polys + p * 256 + out_off, canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
+        const uint32_t o0 = canon_any(r[0]), o1 = canon_any(r[1]), o2 = canon_any(r[2]), o3 = canon_any(r[3]);
+        NTT_PRIO(3);
+        st_nt4(polys + p * 256 + out_off, o0, o1, o2, o3);
     }
 }
 
 // H3/H5/H6 inverse NTT (x 256^-1), batched, in place.  Inputs in (-q, q) (or canonical).
 template <int LAYOUT>
-__global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ polys, size_t batch,
+__global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_inv_kernel(int32_t* __restrict__ polys, size_t batch,
                                                        const uint32_t* __restrict__ tw_tab, int mapping)
 {
     const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * 4;
+    const size_t wave = (size_t)blockIdx.x * DIL_NTT_WPB + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * DIL_NTT_WPB;
     if (wave >= batch) return;
     const int in_off = inv_in_row_off<LAYOUT>(lane, mapping);
     int off[4];
@@ -149,7 +168,9 @@ __global__ __launch_bounds__(256) void ntt_inv_kernel(int32_t* __restrict__ poly
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
         const size_t pn = p + nwaves;
+        NTT_PRIO(3);
         if (pn < batch) nxt = ld_nt4(polys + pn * 256 + in_off);
+        NTT_PRIO(0);
         ntt_inv_core(r, tw, xp);
         if (LAYOUT == LAYOUT_BRAM && mapping == MAP_NATURAL) {
             // outputs of this (op, mapping) land at 16 (lane>>2) + 4 m + (lane&3): transpose inside each quad and
@@ -208,11 +229,11 @@ __global__ __launch_bounds__(256) void pointwise_kernel(int32_t* c, const int32_
 // wave and polynomial; inverse: mirrored -- so that the bench line carries, beside the 8 TB/s spec, what this access pattern
 // reaches on the box it runs on.  Scrambles the buffer (a lane's four strided values leave as one row); scratch data only.
 template <bool INVERSE>
-__global__ __launch_bounds__(256) void ntt_traffic_kernel(int32_t* __restrict__ polys, size_t batch)
+__global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_traffic_kernel(int32_t* __restrict__ polys, size_t batch)
 {
     const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * 4;
+    const size_t wave = (size_t)blockIdx.x * DIL_NTT_WPB + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * DIL_NTT_WPB;
     if (wave >= batch) return;
     if (!INVERSE) {
         int32_t nxt[4];
@@ -381,14 +402,14 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
                       const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = grid_for((batch + 3) / 4, t.num_cus * t.ntt_blocks_per_cu);
+    const int grid = grid_for((batch + DIL_NTT_WPB - 1) / DIL_NTT_WPB, t.num_cus * t.ntt_blocks_per_cu * 4 / DIL_NTT_WPB);
     const uint32_t* tab = inverse ? t.inv : t.fwd;   // standalone flavour of the inverse table
     if (!inverse) {
-        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_POLY>, grid, 256, 0, s, polys, batch, tab, mapping);
-        else hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_BRAM>, grid, 256, 0, s, polys, batch, tab, mapping);
+        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_POLY>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
+        else hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_BRAM>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
     } else {
-        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_POLY>, grid, 256, 0, s, polys, batch, tab, mapping);
-        else hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_BRAM>, grid, 256, 0, s, polys, batch, tab, mapping);
+        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_POLY>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
+        else hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_BRAM>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
     }
     return hipGetLastError();
 }
@@ -396,9 +417,9 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
 hipError_t launch_ntt_traffic(bool inverse, int32_t* polys, size_t batch, const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = grid_for((batch + 3) / 4, t.num_cus * t.ntt_blocks_per_cu);      // the transforms' own launch shape
-    if (inverse) hipLaunchKernelGGL(ntt_traffic_kernel<true>, grid, 256, 0, s, polys, batch);
-    else hipLaunchKernelGGL(ntt_traffic_kernel<false>, grid, 256, 0, s, polys, batch);
+    const int grid = grid_for((batch + DIL_NTT_WPB - 1) / DIL_NTT_WPB, t.num_cus * t.ntt_blocks_per_cu * 4 / DIL_NTT_WPB);      // the transforms' own launch shape
+    if (inverse) hipLaunchKernelGGL(ntt_traffic_kernel<true>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch);
+    else hipLaunchKernelGGL(ntt_traffic_kernel<false>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch);
     return hipGetLastError();
 }
 
