@@ -967,8 +967,13 @@ __device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a
 #define MVS_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
 #define MVS_INV(r, tw, x) ntt_inv_core(r, tw, x)
 #endif
-#ifndef DIL_MVS_PFY
-#define DIL_MVS_PFY(L) ((L) <= 5)
+#ifndef DIL_MVS_PFN
+// Level 5: nothing is prefetched.  Three of the seven polynomials would fit beside seven transforms in flight under 128 VGPRs and
+// make the kernel 2 % faster on its own (45.5 vs 46.1 us) -- but with them bench.py's attempt (phase 1, then phase 2, over ONE set of
+// buffers: 223 MB, Infinity-Cache-resident) takes 134.7 instead of 103.9 us, while the same pair over two rotating sets (HBM-streaming)
+// is unchanged (105.9 vs 106.6): profiles/r04q_ab_pf.txt, r04r_ab_pair.txt.  Unexplained; the cache-resident regime is the one the
+// signing loop's narrow rounds run in, so the prefetch stays off where it was off.
+#define DIL_MVS_PFN(L) ((L) <= 5 ? (L) : 0)
 #endif
 #ifndef MVS_FWDN
 #define MVS_FWDN(v, tw, x) ntt_fwd_coreN<L>(v, tw, x)
@@ -1017,37 +1022,50 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
     const YSrc<LEVEL, YF> ys(lane);
     // the next item's y is prefetched a whole row phase ahead where the registers allow it; at level 5 that second copy (28 VGPRs)
     // does not fit beside seven transforms in flight under the 128-register cap: y is loaded where it is used
-    constexpr bool PFY = DIL_MVS_PFY(L);
-    RawPolys<PFY ? L : 1> yr;
+    constexpr int PF = DIL_MVS_PFN(L);             // polynomials of the NEXT item's y that are prefetched a whole row phase ahead
+    RawPolys<PF ? PF : 1> yr;
     auto load_y = [&](size_t i) {
 #pragma unroll
-        for (int l = 0; l < (PFY ? L : 0); l++) ys.raw(yr.v[l], y, i * L + l, lane);
+        for (int l = 0; l < PF; l++) ys.raw(yr.v[l], y, i * L + l, lane);
     };
     if (it < batch) load_y(it);
     __syncthreads();                               // tables + key staged (the only barrier)
     for (; it < batch; it += nwaves) {
         int32_t yh[L][4];
-        if (!PFY) {
 #pragma unroll
-            for (int l = 0; l < L; l++) ys.raw(yh[l], y, it * L + l, lane);
-        }
+        for (int l = PF; l < L; l++) ys.raw(yh[l], y, it * L + l, lane);        // the rest is fetched now and lands under the first group's transforms
 #pragma unroll
-        for (int l = 0; l < L; l++) {
-            if (PFY) {
+        for (int l = 0; l < PF; l++) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) yh[l][m] = yr.v[l][m];
-            }
-            ys.value(yh[l]);
+            for (int m = 0; m < 4; m++) yh[l][m] = yr.v[l][m];
         }
 #if DIL_MVS_DUAL == 2
-        MVS_FWDN(yh, twf, lm);
-#elif DIL_MVS_DUAL
+        if constexpr (PF > 0 && PF < L) {
+            // two groups: the prefetched polynomials are transformed while the others' loads are in flight
+            int32_t (&ga)[PF][4] = reinterpret_cast<int32_t (&)[PF][4]>(yh[0]);
+            int32_t (&gb)[L - PF][4] = reinterpret_cast<int32_t (&)[L - PF][4]>(yh[PF]);
+#pragma unroll
+            for (int l = 0; l < PF; l++) ys.value(yh[l]);
+            ntt_fwd_coreN<PF>(ga, twf, lm);
+#pragma unroll
+            for (int l = PF; l < L; l++) ys.value(yh[l]);
+            ntt_fwd_coreN<L - PF>(gb, twf, lm);
+        } else {
+#pragma unroll
+            for (int l = 0; l < L; l++) ys.value(yh[l]);
+            MVS_FWDN(yh, twf, lm);
+        }
+#else
+#pragma unroll
+        for (int l = 0; l < L; l++) ys.value(yh[l]);
+#if DIL_MVS_DUAL
 #pragma unroll
         for (int l = 0; l + 1 < L; l += 2) MVS_FWD2(yh[l], yh[l + 1], twf, lm);
         if (L & 1) MVS_FWD(yh[L - 1], twf, lm);
 #else
 #pragma unroll
         for (int l = 0; l < L; l++) MVS_FWD(yh[l], twf, lm);
+#endif
 #endif
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;

@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--level", type=int, default=3)
 ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--shared", action="store_true")
-ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1", "sign2", "ntt", "wire"])
+ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1", "sign2", "ntt", "wire", "pair"])
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--generic", action="store_true", help="sign2: the entry point for arbitrary residues even where the small-key one exists")
 ap.add_argument("--reps", type=int, default=30)
@@ -71,7 +71,7 @@ for path in a.libs:
     assert L_.dil_init(0) == 0
     libs.append((os.path.basename(path), L_))
 E = libs[0][1]
-if a.kind == "sign2":
+if a.kind in ("sign2", "pair"):
     # phase 2 needs a REAL challenge and key: c = SampleInBall(c~) (tau coefficients +-1), s1 / s2 with |coefficients| <= eta, t0 below 2^12 --
     # the kernel reads c s1 and c s2 off one transform, which is exact for such inputs only (pipeline_common.hpp SmallPair)
     E.dil_sample_in_ball_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
@@ -104,6 +104,9 @@ def run(L_, reps):
             rc = L_.dil_matvec_dev(p(w), p(A), p(z), a.level, n, sh, None)
         elif a.kind == "sign1":
             rc = L_.dil_sign_phase1_dev(p(w1), p(w0), p(A), p(z), a.level, n, sh, None)
+        elif a.kind == "pair":           # the attempt as bench.py times it: phase 1, then phase 2 on its outputs (one key: A, y vary per set)
+            rc = L_.dil_sign_phase1_dev(p(w1), p(w0), p(A), p(z), a.level, n, sh, None)
+            rc |= L_.dil_sign_phase2_skey_dev(p(zo), p(ho), p(fl), p(c), p(z), p(w0), p(w1), p(s1h), p(s2h), p(t0h), a.level, n, sh, 0, None)
         elif hasattr(L_, "dil_sign_phase2_skey_dev") and not a.generic:
             rc = L_.dil_sign_phase2_skey_dev(p(zo), p(ho), p(fl), p(c), p(z), p(A), p(w1in), p(s1h), p(s2h), p(t0h), a.level, n, sh, 0, None)
         else:
@@ -115,7 +118,7 @@ ref = None
 for name, L_ in libs:            # all builds must agree bit for bit
     run(L_, 2)
     torch.cuda.synchronize()
-    out = {"verify": w1, "matvec": w, "sign1": w0, "sign2": zo, "ntt": nttb[0] if nttb else w1, "wire": w1pk}[a.kind].clone()
+    out = {"verify": w1, "matvec": w, "sign1": w0, "sign2": zo, "ntt": nttb[0] if nttb else w1, "wire": w1pk, "pair": zo}[a.kind].clone()
     if ref is None:
         ref = out
     if "_no" not in name:            # ablation builds (libdil256_no*.so) compute something else on purpose
