@@ -281,26 +281,34 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(VEC* __restrict__ dst,
 }
 
 // kappa[e] = (a0 + e % S) * L      (the reference's y-nonce counter advances by L per attempt)
-__global__ __launch_bounds__(256) void sign_kappa_kernel(uint32_t* __restrict__ kappa, uint32_t a0, uint32_t L, uint32_t S, size_t entries)
+__global__ __launch_bounds__(256) void sign_kappa_kernel(uint32_t* __restrict__ kappa, int32_t* __restrict__ flags, uint32_t a0, uint32_t L,
+                                                         uint32_t S, size_t entries)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < entries) kappa[e] = (a0 + (uint32_t)(e % S)) * L;
+    if (e < entries) {
+        kappa[e] = (a0 + (uint32_t)(e % S)) * L;
+        flags[e] = -1;
+    }
 }
 
 // Start of a signing round in ONE launch (was two gathers, the kappa kernel and a memset): for entry e of pending item
 // i = e / S:  mu_c[e] = mu[item(i)], rp_c[e] = rho'[item(i)] (64 bytes each, as 4 x 16 B per thread), kappa[e] = (a0 + e % S) * L,
-// and the round's two counters are cleared.  gather == false (first round of a full batch, S == 1): only kappa + counters.
+// the entry's flag = -1 ("no verdict yet": phase 2 of a speculative round looks at the flags of an item's earlier attempts while it
+// runs, pipelines.hip), and the round's two counters are cleared.  gather == false (first round of a full batch, S == 1): no gathers.
 __global__ __launch_bounds__(256) void sign_round_setup_kernel(uint4* __restrict__ mu_c, uint4* __restrict__ rp_c,
-                                                               uint32_t* __restrict__ kappa, int32_t* __restrict__ counts,
+                                                               uint32_t* __restrict__ kappa, int32_t* __restrict__ flags,
+                                                               int32_t* __restrict__ counts, uint32_t* __restrict__ tickets,
                                                                const uint4* __restrict__ mu, const uint4* __restrict__ rp,
                                                                const int32_t* __restrict__ idx, uint32_t a0, uint32_t L, uint32_t S,
                                                                size_t entries, int gather)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < 2) counts[g] = 0;
+    if (g < 2) counts[g] = 0;          // pending, winners
+    for (size_t i = g; i < (size_t)TICKET_WORDS; i += (size_t)gridDim.x * blockDim.x) tickets[i] = 0;      // phase 2's work queues (KeyMap::ticket)
     const size_t e = g >> 2, w = g & 3;
     if (e >= entries) return;
     if (w == 0) kappa[e] = (a0 + (uint32_t)(e % S)) * L;
+    if (w == 1) flags[e] = -1;
     if (gather) {
         const size_t i = e / S, item = idx ? (size_t)idx[i] : i;
         mu_c[g] = mu[item * 4 + w];
@@ -405,14 +413,15 @@ hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, si
     return hipGetLastError();
 }
 
-hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, uint32_t S, size_t entries, hipStream_t s)
+hipError_t launch_sign_kappa(uint32_t* kappa, int32_t* flags, uint32_t a0, uint32_t L, uint32_t S, size_t entries, hipStream_t s)
 {
     if (entries == 0) return hipSuccess;
-    hipLaunchKernelGGL(sign_kappa_kernel, (int)((entries + 255) / 256), 256, 0, s, kappa, a0, L, S, entries);
+    hipLaunchKernelGGL(sign_kappa_kernel, (int)((entries + 255) / 256), 256, 0, s, kappa, flags, a0, L, S, entries);
     return hipGetLastError();
 }
 
-hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* counts, const uint8_t* mu, const uint8_t* rp,
+hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* flags, int32_t* counts, uint32_t* tickets,
+                                   const uint8_t* mu, const uint8_t* rp,
                                    const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, hipStream_t s)
 {
     if (entries == 0) return hipSuccess;
@@ -420,7 +429,8 @@ hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa
          reinterpret_cast<uintptr_t>(rp)) & 15)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(sign_round_setup_kernel, (int)((entries * 4 + 255) / 256), 256, 0, s, reinterpret_cast<uint4*>(mu_c),
-                       reinterpret_cast<uint4*>(rp_c), kappa, counts, reinterpret_cast<const uint4*>(mu), reinterpret_cast<const uint4*>(rp),
+                       reinterpret_cast<uint4*>(rp_c), kappa, flags, counts, tickets, reinterpret_cast<const uint4*>(mu),
+                       reinterpret_cast<const uint4*>(rp),
                        idx, a0, L, S, entries, gather ? 1 : 0);
     return hipGetLastError();
 }

@@ -67,10 +67,21 @@ hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t*
 hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);
 // Optional key indirection of the per-item-key pipelines (the signing loop's speculative entries): entry `it` uses the
 // key material of row idx[(base + it) / S] (idx == nullptr: that row number itself).  Default = identity.
+constexpr int TICKET_PARTS = 64, TICKET_STRIDE = 32, TICKET_WORDS = TICKET_PARTS * TICKET_STRIDE;
+constexpr int FLAG_SUPERSEDED = 16;      // sign-loop flag of an attempt dropped because an earlier attempt of its item was accepted
 struct KeyMap {
     const int32_t* idx = nullptr;
     uint32_t S = 1;
     uint32_t base = 0;          // entry number of this launch's item 0 (a round may be split over two streams)
+    // Speculative signing rounds (scheme.hip sign_core): entry e = j * S + a is attempt a of pending item j, and only the FIRST
+    // accepted attempt of an item is ever used.  spec_n = the round's pending items (0: off) lets the early-exit phase 2 walk the
+    // entries attempt-major and drop an entry whose item already shows an accepted earlier attempt (pipelines.hip).
+    uint32_t spec_n = 0;
+    // Work queues of such a launch (TICKET_WORDS zeroed device words; nullptr: static striding): attempts cost between nothing
+    // (dropped) and a full phase 2 (accepted), so the persistent waves draw their next entry from a counter instead of striding.
+    // One counter cannot serve a launch (12 ns per atomic on one address: 300 us for 24576 entries, measured): workgroup b draws
+    // from queue b % TICKET_PARTS, which holds the entries u = b % TICKET_PARTS (mod TICKET_PARTS), each on its own 128-byte line.
+    uint32_t* ticket = nullptr;
     __host__ __device__ size_t key(size_t it) const
     {
         const uint32_t i = (base + (uint32_t)it) / S;
@@ -160,8 +171,8 @@ hipError_t launch_power2round(int32_t* t1, int32_t* t0, const int32_t* w, const 
 hipError_t launch_or_flag(int32_t* verdict, const int32_t* flag, int bit, size_t n, const Tables& t, hipStream_t s);
 hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, size_t row_bytes, uint32_t S, size_t entries,
                               const Tables& t, hipStream_t s);
-hipError_t launch_sign_kappa(uint32_t* kappa, uint32_t a0, uint32_t L, uint32_t S, size_t entries, hipStream_t s);
-hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* counts, const uint8_t* mu, const uint8_t* rp,
+hipError_t launch_sign_kappa(uint32_t* kappa, int32_t* flags, uint32_t a0, uint32_t L, uint32_t S, size_t entries, hipStream_t s);
+hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* flags, int32_t* counts, uint32_t* tickets, const uint8_t* mu, const uint8_t* rp,
                                    const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, hipStream_t s);
 hipError_t launch_sign_collect_ct(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
                                   const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, uint8_t* sig, size_t sig_stride,

@@ -778,13 +778,39 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
     uint32_t* sc = lds + PT::DWORDS + wv * 64;   // byte-plane scratch
     const YSrc<LEVEL, YF> ys(lane);
     const size_t nwaves = (size_t)gridDim.x * 4;
-    for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
+    // entries in turn: by stride, or (signing loop) from this workgroup's queue -- the next ticket is drawn at the top of an
+    // entry and needed at its end
+    const uint32_t parts = gridDim.x < (uint32_t)TICKET_PARTS ? gridDim.x : (uint32_t)TICKET_PARTS, part = blockIdx.x % parts;
+    uint32_t* const queue = km.ticket ? km.ticket + part * TICKET_STRIDE : nullptr;
+    auto draw = [&]() -> size_t {
+        uint32_t tk = 0;
+        if (lane == 0) tk = atomicAdd(queue, 1u);
+        return part + (size_t)parts * __builtin_amdgcn_readfirstlane(tk);
+    };
+    size_t un = 0;
+    for (size_t u = queue ? draw() : (size_t)blockIdx.x * 4 + wv; u < batch; u = un) {
+        un = queue ? draw() : u + nwaves;
+        // A speculative round (km.spec_n pending items x km.S attempts each, entry = item * S + attempt) is walked attempt-major:
+        // by the time the waves reach attempt a of an item, its earlier attempts have mostly reported, and an entry behind an
+        // accepted one is dropped unread -- the loop only ever takes an item's FIRST accepted attempt, so the signatures do not
+        // depend on what is dropped (a stale or late flag merely costs the work).  Flags are preset to -1 by the round's set-up.
+        size_t it = u;
+        int32_t earlier = -1;
+        if (km.spec_n) {
+            const uint32_t at = (uint32_t)u / km.spec_n, j = (uint32_t)u - at * km.spec_n;
+            it = (size_t)j * km.S + at;
+            if (lane < (int)at) earlier = __hip_atomic_load(flags_out + (size_t)j * km.S + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const int32_t* s1 = s1hat + (shared_key ? 0 : km.key(it) * L) * 256;
         const int32_t* s2 = s2hat + (shared_key ? 0 : km.key(it) * K) * 256;
         const int32_t* t0 = t0hat + (shared_key ? 0 : km.key(it) * K) * 256;
         int32_t ch[4];
         load_strided(ch, c + it * 256, lane);
         int4 kn = make_int4(0, 0, 0, 0);
+        if (__ballot(earlier == 0)) {
+            if (lane == 0) __hip_atomic_store(flags_out + it, (int32_t)FLAG_SUPERSEDED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         if (SH && L < K) kn = *reinterpret_cast<const int4*>(s2 + L * 256 + 4 * lane);         // one key: s2's own rows matter from row L on
         if (!SH) kn = *reinterpret_cast<const int4*>(s2 + 4 * lane);
         ntt_fwd_core(ch, twf, lm);
@@ -918,7 +944,10 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
                 }
             }
         }
-        if (lane == 0) flags_out[it] = (int32_t)(bits | (nh > (uint32_t)Par<LEVEL>::OMEGA ? 8u : 0u));
+        // (agent scope: the waves that look at this flag before starting a later attempt of the same item may sit on another XCD)
+        if (lane == 0)
+            __hip_atomic_store(flags_out + it, (int32_t)(bits | (nh > (uint32_t)Par<LEVEL>::OMEGA ? 8u : 0u)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -628,6 +628,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     const int opt_cap = dil::rt::cfg.sign_cap.load(std::memory_order_relaxed);
     const int sign_waste = dil::rt::cfg.sign_waste.load(std::memory_order_relaxed);
     const bool sign_early = dil::rt::cfg.sign_early.load(std::memory_order_relaxed) != 0;
+    const int sign_skip = dil::rt::cfg.sign_skip.load(std::memory_order_relaxed);       // bit 0: drop superseded attempts, bit 1: work queue
     // (a round never uses more than batch * s_max entries: a single signature gets 64 entries, not 16384)
     // default width: about one expected signature's worth of attempts per item in the first round (mean attempts 4.3 / 5.1 /
     // 3.9 at levels 2 / 3 / 5), between 16384 and 32768 entries -- below that the round's kernels sit on their latency
@@ -650,6 +651,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     int32_t* wini = ws.take<int32_t>(batch);
     int32_t* own_attempts = attempts ? nullptr : ws.take<int32_t>(batch);
     int32_t* counts = ws.take<int32_t>(2);               // [0] pending, [1] winners
+    uint32_t* tickets = ws.take<uint32_t>(dil::TICKET_WORDS);      // phase 2's work queues (KeyMap::ticket)
     // per entry
     uint32_t* kap = ws.take<uint32_t>(cap);
     uint8_t* ct = ws.take<uint8_t>(cap * 32);
@@ -706,17 +708,21 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         dil::KeyMap keys;                                // per-item keys are read in place through the pending list
         keys.idx = idx_cur;
         keys.S = (uint32_t)S_;
+        // attempts behind an item's first accepted one are never used: phase 2 may drop them as it goes (its early-exit form only)
+        keys.spec_n = (S_ > 1 && sign_early && (sign_skip & 1)) ? (uint32_t)n : 0;
+        keys.ticket = (sign_early && (sign_skip & 2)) ? tickets : nullptr;
         // one launch: gathers of mu / rho' for the entries, kappa = (a0 + e % S) L, counters cleared
         if (((reinterpret_cast<uintptr_t>(mu)) & 15) == 0) {
-            DIL_TRY(dil::launch_sign_round_setup(mu_c, rp_c, kap, counts, mu, rp, idx_cur, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E,
+            DIL_TRY(dil::launch_sign_round_setup(mu_c, rp_c, kap, fl, counts, tickets, mu, rp, idx_cur, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E,
                                                  !direct, s));
         } else {                                         // caller's mu only 8-byte aligned: the generic kernels
             if (!direct) {
                 DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, T, s));
                 DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, T, s));
             }
-            DIL_TRY(dil::launch_sign_kappa(kap, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
+            DIL_TRY(dil::launch_sign_kappa(kap, fl, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
             DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
+            DIL_TRY(hipMemsetAsync(tickets, 0, dil::TICKET_WORDS * 4, s));
         }
         // (Two stream-level overlaps of a round's latency-bound hash kernels with its polynomial kernels were built in rounds 2 / 3 and
         //  measured slower -- 1.42 -> 1.77 ms per 8192 level-3 signatures, profiles/r03j_sign_overlap.txt -- and are gone.)

@@ -73,6 +73,10 @@ int dil_shutdown(void);
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it
+ *   "sign_skip"   (DIL_SIGN_SKIP)   the signing loop's speculative rounds (several attempts per pending message at once, the first
+ *                                   accepted one wins): bit 0 = phase 2 drops an attempt whose message already shows an accepted
+ *                                   earlier attempt, bit 1 = its waves draw attempts from work queues instead of striding; default 3.
+ *                                   Signatures and attempt counts do not depend on it.
  *   "sign_early", "sign_cap", "sign_waste", "aux_overlap", "ntt_blocks_per_cu", "wpi_blocks_per_cu",
  *   "fused_wgs_per_cu"              tuning knobs
  * Unknown name -> hipErrorInvalidValue.  (Options, device queries and error strings are runtime utilities: the reference -- synthesised

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
 : > $OUT/${TAG}_option_matrix.txt
 for setting in "DIL_FUSE_CHALLENGE=0" "DIL_PACKED_Y=0" "DIL_FUSED_MODE=1" "DIL_FUSED_MODE=2" "DIL_AUX_OVERLAP=0" "DIL_ZEROIZE=1" \
-               "DIL_A24=0" "DIL_A24=2" "DIL_SIGN_EARLY=0" "DIL_FUSE_WIRE=0" "DIL_FUSE_KEYGEN=0" "DIL_SIGN_CAP=8192"; do
+               "DIL_A24=0" "DIL_A24=2" "DIL_SIGN_EARLY=0" "DIL_FUSE_WIRE=0" "DIL_FUSE_KEYGEN=0" "DIL_SIGN_CAP=8192" "DIL_SIGN_SKIP=0" "DIL_SIGN_SKIP=1"; do
   # (tests that assert a specific kernel shape / launch record are deselected where the option changes the shape on purpose)
   DESEL="--deselect tests/test_gpu_mailbox.py::test_reference_unchanged_hw_main_at_its_own_iteration_count --deselect tests/test_gpu_fuzz.py"   # (option-independent, 150 s)
   case "$setting" in DIL_FUSED_MODE=1) DESEL="$DESEL --deselect tests/test_gpu_persistent_parity.py";; esac

@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT
-bash scripts/gpu_r04.sh r04z tests cover smoke bench prof pmc signpmc > gpurun_out/r04z_round.log 2>&1
-tail -3 gpurun_out/r04z_round.log | cut -c1-200
-bash scripts/gpu_scale.sh 100 > gpurun_out/r04z_scale.log 2>&1; tail -1 gpurun_out/r04z_scale.log
+#!/bin/bash
+# scratch: one GPU visit
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_codecs.py tests/test_gpu_persistent_parity.py tests/test_gpu_wire.py tests/test_gpu_msg.py tests/test_gpu_dispatch_parity.py -x -q -m gpu 2>&1 | tail -5
+python scripts/ab_sign_skip.py > gpurun_out/r04s_ab_sign_skip.txt 2>&1

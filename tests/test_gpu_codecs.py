@@ -505,7 +505,9 @@ def test_concurrent_calls_on_two_streams(gpu, kat_msgs):
 @pytest.mark.parametrize("n", [700, 3000, 9000])
 def test_sign_options_give_identical_signatures(gpu, level, n):
     """the signing loop's alternative code paths against each other on the same messages: y as int32 vs ExpandMask's raw stream (the
-    one- and the two-lanes-per-sponge writers: wide and narrow rounds), the challenge as one launch vs two, early-exit phase 2 vs full"""
+    one- and the two-lanes-per-sponge writers: wide and narrow rounds), the challenge as one launch vs two, early-exit phase 2 vs full,
+    and phase 2 of a speculative round with / without dropping the attempts behind an accepted one and with / without its work queues
+    (option sign_skip: the default 3 = both, then 0, 1, 2)"""
     from dilithium_amd import api
     g = gpu.Generator(device="cuda").manual_seed(31 * level + n)
     seed = gpu.randint(0, 256, (1, 32), dtype=gpu.uint8, device="cuda", generator=g)
@@ -519,9 +521,17 @@ def test_sign_options_give_identical_signatures(gpu, level, n):
             sig, att = api.sign(sk, mu, level, shared_sk=True)
             api.set_option(opt, 1)
             assert gpu.equal(sig, ref) and gpu.equal(att, ref_att), opt
+        for mode in (0, 1, 2):
+            api.set_option("sign_skip", mode)
+            sig, att = api.sign(sk, mu, level, shared_sk=True)
+            assert gpu.equal(sig, ref) and gpu.equal(att, ref_att), ("sign_skip", mode)
+            if n == 3000:                                  # a key per item: the per-item form of the early-exit kernel
+                sigd, attd = api.sign(sk.repeat(n, 1), mu, level)
+                assert gpu.equal(sigd, ref) and gpu.equal(attd, ref_att), ("sign_skip", mode, "key per item")
     finally:
         for opt in ("packed_y", "fuse_challenge", "sign_early"):
             api.set_option(opt, 1)
+        api.set_option("sign_skip", 3)
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
