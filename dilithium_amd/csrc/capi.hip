@@ -36,7 +36,6 @@ const OptName* option_table(int* n)
         {"sign_early", "DIL_SIGN_EARLY", &cfg.sign_early},
         {"sign_waste", "DIL_SIGN_WASTE", &cfg.sign_waste},
         {"sign_skip", "DIL_SIGN_SKIP", &cfg.sign_skip},
-        {"sign_runahead", "DIL_SIGN_RUNAHEAD", &cfg.sign_runahead},
         {"sign_cap", "DIL_SIGN_CAP", &cfg.sign_cap},
         {"aux_overlap", "DIL_AUX_OVERLAP", &cfg.aux_overlap},
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},

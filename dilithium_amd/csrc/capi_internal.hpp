@@ -29,7 +29,6 @@ struct Config {
     std::atomic<int> fused_wgs_per_cu{4};  // DIL_FUSED_WGPC
     std::atomic<int> sign_early{1};        // DIL_SIGN_EARLY: 0 = the signing loop evaluates every check of every attempt
     std::atomic<int> sign_skip{3};         // DIL_SIGN_SKIP: bit 0 = phase 2 of a speculative round drops the attempts behind an accepted one, bit 1 = its waves draw entries from a queue
-    std::atomic<int> sign_runahead{1};     // DIL_SIGN_RUNAHEAD: 0 = the signing loop waits for every round's pending count before it queues the next
     std::atomic<int> sign_waste{6144};     // DIL_SIGN_WASTE: speculative entries a round may expect to waste
     std::atomic<int> sign_cap{0};          // DIL_SIGN_CAP: entries in flight per signing round (0 = default 16384)
     std::atomic<int> aux_overlap{1};       // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream

@@ -54,28 +54,6 @@ __global__ __launch_bounds__(256) void unpack_kernel(int32_t* __restrict__ out, 
 // ---------------------------------------------------------------------------------------
 // 8 coefficients make exactly BITS bytes: one thread per such group (32 per polynomial), two 16-B
 // loads, fields assembled at compile-time bit positions in a 160-bit accumulator.
-// one group: coefficients src[0 .. 7] (any representative) -> BITS bytes at dst (any alignment)
-template <int BITS>
-__device__ __forceinline__ void pack_group(uint8_t* __restrict__ dst, const int32_t* __restrict__ src8, int xf, int32_t offset)
-{
-    const int4* src = reinterpret_cast<const int4*>(src8);
-    const int4 lo = src[0], hi = src[1];
-    const int32_t c[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        int32_t v = c[i] % QC;                                     // any representative
-        v += (v >> 31) & QC;                                       // canonical
-        v -= (((QC - 1) / 2 - v) >> 31) & QC;                      // centred
-        const uint32_t f = (uint32_t)(xf == XF_OFFSET_MINUS ? offset - v : v) & ((1u << BITS) - 1);
-        const int bit = i * BITS, wi = bit >> 5, sh = bit & 31;
-        w[wi] |= f << sh;
-        if (sh + BITS > 32) w[wi + 1] |= f >> (32 - sh);
-    }
-#pragma unroll
-    for (int bt = 0; bt < BITS; bt++) dst[bt] = (uint8_t)(w[bt >> 2] >> (8 * (bt & 3)));
-}
-
 template <int BITS>
 __global__ __launch_bounds__(256) void pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
                                                    const int32_t* __restrict__ in, int polys, int xf, int32_t offset,
@@ -88,8 +66,23 @@ __global__ __launch_bounds__(256) void pack_kernel(uint8_t* __restrict__ out, si
         const size_t item = g / ((size_t)polys * 32);
         const uint32_t r = (uint32_t)(g % ((size_t)polys * 32)), poly = r >> 5, grp = r & 31;
         const size_t irow = map.src_row ? (size_t)map.src_row[item] : item, orow = map.dst_row ? (size_t)map.dst_row[item] : item;
-        pack_group<BITS>(out + orow * out_stride + out_offset + (size_t)poly * (32 * BITS) + (size_t)grp * BITS,
-                         in + (irow * polys + poly) * 256 + grp * 8, xf, offset);
+        const int4* src = reinterpret_cast<const int4*>(in + (irow * polys + poly) * 256 + grp * 8);
+        const int4 lo = src[0], hi = src[1];
+        const int32_t c[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int32_t v = c[i] % QC;                                     // any representative
+            v += (v >> 31) & QC;                                       // canonical
+            v -= (((QC - 1) / 2 - v) >> 31) & QC;                      // centred
+            const uint32_t f = (uint32_t)(xf == XF_OFFSET_MINUS ? offset - v : v) & ((1u << BITS) - 1);
+            const int bit = i * BITS, wi = bit >> 5, sh = bit & 31;
+            w[wi] |= f << sh;
+            if (sh + BITS > 32) w[wi + 1] |= f >> (32 - sh);
+        }
+        uint8_t* dst = out + orow * out_stride + out_offset + (size_t)poly * (32 * BITS) + (size_t)grp * BITS;
+#pragma unroll
+        for (int bt = 0; bt < BITS; bt++) dst[bt] = (uint8_t)(w[bt >> 2] >> (8 * (bt & 3)));
     }
 }
 
@@ -192,8 +185,16 @@ __global__ __launch_bounds__(256) void hint_unpack_kernel(uint8_t* __restrict__ 
 }
 
 // pack: h [K][256] bytes -> omega + K bytes (makehint.v:104-150).  One wave per item.
-__device__ __forceinline__ void hint_pack_item(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int K, int omega, int lane)
+__global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
+                                                        const uint8_t* __restrict__ h, int K, int omega, size_t nitems, RowMap map)
 {
+    const int lane = threadIdx.x & 63;
+    const size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (map.count) nitems = min(nitems, (size_t)*map.count);
+    if (it >= nitems) return;
+    const size_t irow = map.src_row ? (size_t)map.src_row[it] : it, orow = map.dst_row ? (size_t)map.dst_row[it] : it;
+    uint8_t* dst = out + orow * out_stride + out_offset;
+    const uint8_t* src = h + irow * (size_t)K * 256;
     for (int t = lane; t < omega + K; t += 64) dst[t] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     int count = 0;                                   // wave-uniform
@@ -208,17 +209,6 @@ __device__ __forceinline__ void hint_pack_item(uint8_t* __restrict__ dst, const 
         }
         if (lane == 0) dst[omega + k] = (uint8_t)(count < omega ? count : omega);
     }
-}
-
-__global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
-                                                        const uint8_t* __restrict__ h, int K, int omega, size_t nitems, RowMap map)
-{
-    const int lane = threadIdx.x & 63;
-    const size_t it = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (map.count) nitems = min(nitems, (size_t)*map.count);
-    if (it >= nitems) return;
-    const size_t irow = map.src_row ? (size_t)map.src_row[it] : it, orow = map.dst_row ? (size_t)map.dst_row[it] : it;
-    hint_pack_item(out + orow * out_stride + out_offset, h + irow * (size_t)K * 256, K, omega, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -290,28 +280,6 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(VEC* __restrict__ dst,
     }
 }
 
-// Attempts per pending item of a signing round (scheme.hip sign_core): as many as fit in `cap` entries, at most s_max and what
-// max_attempts leaves, but only while the work expected to be wasted on attempts after an item's first success,
-// n (1 - 0.8^(S-1)) entries, stays below `waste`.  One rule for the host and for the device-sized rounds.
-__host__ __device__ inline uint32_t sign_round_width(uint32_t n, uint32_t a0, uint32_t cap, uint32_t s_max, uint32_t max_attempts, uint32_t waste)
-{
-    if (n == 0 || a0 >= max_attempts) return 0;
-    uint32_t s_lim = cap / n < s_max ? cap / n : s_max;
-    if (max_attempts - a0 < s_lim) s_lim = max_attempts - a0;
-    uint32_t S = 1;
-    double keep = 1.0;                               // 0.8^(S-1)
-    while (S < s_lim) {
-        keep *= 0.8;
-        if ((double)n * (1.0 - keep) > (double)waste) break;
-        S++;
-    }
-    return S;
-}
-uint32_t sign_round_width_host(uint32_t n, uint32_t a0, uint32_t cap, uint32_t s_max, uint32_t max_attempts, uint32_t waste)
-{
-    return sign_round_width(n, a0, cap, s_max, max_attempts, waste);
-}
-
 // kappa[e] = (a0 + e % S) * L      (the reference's y-nonce counter advances by L per attempt)
 __global__ __launch_bounds__(256) void sign_kappa_kernel(uint32_t* __restrict__ kappa, int32_t* __restrict__ flags, uint32_t a0, uint32_t L,
                                                          uint32_t S, size_t entries)
@@ -332,11 +300,10 @@ __global__ __launch_bounds__(256) void sign_round_setup_kernel(uint4* __restrict
                                                                int32_t* __restrict__ counts, uint32_t* __restrict__ tickets,
                                                                const uint4* __restrict__ mu, const uint4* __restrict__ rp,
                                                                const int32_t* __restrict__ idx, uint32_t a0, uint32_t L, uint32_t S,
-                                                               size_t entries, int gather, RoundDesc* __restrict__ desc)
+                                                               size_t entries, int gather)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g < 2) counts[g] = 0;          // pending, winners
-    if (g == 0) *desc = RoundDesc{(uint32_t)(entries / S), S, (uint32_t)entries, a0};      // (what a device-sized next round starts from)
     for (size_t i = g; i < (size_t)TICKET_WORDS; i += (size_t)gridDim.x * blockDim.x) tickets[i] = 0;      // phase 2's work queues (KeyMap::ticket)
     const size_t e = g >> 2, w = g & 3;
     if (e >= entries) return;
@@ -349,33 +316,6 @@ __global__ __launch_bounds__(256) void sign_round_setup_kernel(uint4* __restrict
     }
 }
 
-// The same for a round the host queued BEFORE the previous round reported (run-ahead): the pending count is read from the previous
-// round's counters, the width follows from sign_round_width() here, and thread 0 leaves (n, S, E, a0) in *desc for the round's other
-// kernels (kernels.hpp RoundDesc).  counts / desc alternate between two slots by round parity, so nothing read here is written here.
-// The grid covers `cap` entries.
-__global__ __launch_bounds__(256) void sign_round_setup_dev_kernel(uint4* __restrict__ mu_c, uint4* __restrict__ rp_c,
-                                                                   uint32_t* __restrict__ kappa, int32_t* __restrict__ flags,
-                                                                   int32_t* __restrict__ counts, uint32_t* __restrict__ tickets,
-                                                                   RoundDesc* __restrict__ desc, const int32_t* __restrict__ counts_prev,
-                                                                   const RoundDesc* __restrict__ desc_prev, const uint4* __restrict__ mu,
-                                                                   const uint4* __restrict__ rp, const int32_t* __restrict__ idx, uint32_t L,
-                                                                   uint32_t cap, uint32_t s_max, uint32_t max_attempts, uint32_t waste)
-{
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = (uint32_t)counts_prev[0], a0 = desc_prev->a0 + desc_prev->S;
-    const uint32_t S = sign_round_width(n, a0, cap, s_max, max_attempts, waste), entries = n * S;
-    if (g < 2) counts[g] = 0;
-    if (g == 0) *desc = RoundDesc{n, S, entries, a0};
-    for (size_t i = g; i < (size_t)TICKET_WORDS; i += (size_t)gridDim.x * blockDim.x) tickets[i] = 0;
-    const size_t e = g >> 2, w = g & 3;
-    if (e >= entries) return;
-    if (w == 0) kappa[e] = (a0 + (uint32_t)(e % S)) * L;
-    if (w == 1) flags[e] = -1;
-    const size_t item = (size_t)idx[e / S];
-    mu_c[g] = mu[item * 4 + w];
-    rp_c[g] = rp[item * 4 + w];
-}
-
 // End of a signing round, one thread per pending item: the FIRST accepted of its S speculative attempts wins -> the
 // (entry, item) pair goes on the winners list (packed into the item's signature slot by the RowMap-driven codec launches
 // that follow), the attempt count is recorded and the winner's c~ (32 bytes, any alignment) is copied into its signature
@@ -384,14 +324,8 @@ __global__ __launch_bounds__(256) void sign_collect_ct_kernel(int32_t* __restric
                                                               int32_t* __restrict__ win_entry, int32_t* __restrict__ win_item,
                                                               int32_t* __restrict__ counts, const int32_t* __restrict__ flags,
                                                               const int32_t* __restrict__ idx, int a0, int S, size_t n,
-                                                              uint8_t* __restrict__ sig, size_t sig_stride, const uint8_t* __restrict__ ct,
-                                                              const RoundDesc* __restrict__ rd)
+                                                              uint8_t* __restrict__ sig, size_t sig_stride, const uint8_t* __restrict__ ct)
 {
-    if (rd) {                                        // a device-sized round: the grid covers an upper bound of n
-        n = rd->n;
-        S = (int)rd->S;
-        a0 = (int)rd->a0;
-    }
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t item = idx ? idx[i] : (int32_t)i;
@@ -488,8 +422,7 @@ hipError_t launch_sign_kappa(uint32_t* kappa, int32_t* flags, uint32_t a0, uint3
 
 hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* flags, int32_t* counts, uint32_t* tickets,
                                    const uint8_t* mu, const uint8_t* rp,
-                                   const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, RoundDesc* desc,
-                                   hipStream_t s)
+                                   const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, hipStream_t s)
 {
     if (entries == 0) return hipSuccess;
     if ((reinterpret_cast<uintptr_t>(mu_c) | reinterpret_cast<uintptr_t>(rp_c) | reinterpret_cast<uintptr_t>(mu) |
@@ -498,32 +431,17 @@ hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa
     hipLaunchKernelGGL(sign_round_setup_kernel, (int)((entries * 4 + 255) / 256), 256, 0, s, reinterpret_cast<uint4*>(mu_c),
                        reinterpret_cast<uint4*>(rp_c), kappa, flags, counts, tickets, reinterpret_cast<const uint4*>(mu),
                        reinterpret_cast<const uint4*>(rp),
-                       idx, a0, L, S, entries, gather ? 1 : 0, desc);
-    return hipGetLastError();
-}
-
-hipError_t launch_sign_round_setup_dev(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* flags, int32_t* counts, uint32_t* tickets,
-                                       RoundDesc* desc, const int32_t* counts_prev, const RoundDesc* desc_prev, const uint8_t* mu,
-                                       const uint8_t* rp, const int32_t* idx, uint32_t L, uint32_t cap, uint32_t s_max, uint32_t max_attempts,
-                                       uint32_t waste, hipStream_t s)
-{
-    if ((reinterpret_cast<uintptr_t>(mu_c) | reinterpret_cast<uintptr_t>(rp_c) | reinterpret_cast<uintptr_t>(mu) |
-         reinterpret_cast<uintptr_t>(rp)) & 15)
-        return hipErrorInvalidValue;
-    if (!idx || cap == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sign_round_setup_dev_kernel, (int)(((size_t)cap * 4 + 255) / 256), 256, 0, s, reinterpret_cast<uint4*>(mu_c),
-                       reinterpret_cast<uint4*>(rp_c), kappa, flags, counts, tickets, desc, counts_prev, desc_prev,
-                       reinterpret_cast<const uint4*>(mu), reinterpret_cast<const uint4*>(rp), idx, L, cap, s_max, max_attempts, waste);
+                       idx, a0, L, S, entries, gather ? 1 : 0);
     return hipGetLastError();
 }
 
 hipError_t launch_sign_collect_ct(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
                                   const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, uint8_t* sig, size_t sig_stride,
-                                  const uint8_t* ct, hipStream_t s, const RoundDesc* rd)
+                                  const uint8_t* ct, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(sign_collect_ct_kernel, (int)((n + 255) / 256), 256, 0, s, attempts, next_idx, win_entry, win_item, counts, flags,
-                       idx, a0, S, n, sig, sig_stride, ct, rd);
+                       idx, a0, S, n, sig, sig_stride, ct);
     return hipGetLastError();
 }
 

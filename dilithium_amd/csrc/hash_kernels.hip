@@ -155,15 +155,12 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_kernel(int32_t* __restric
 // polynomial's contiguous 136 bytes (a lane's own stream would be 8 bytes per instruction at a 640-byte stride).
 template <int B>
 __global__ __launch_bounds__(HASH_BS) void expand_mask_raw_kernel(uint8_t* __restrict__ yp, const uint64_t* __restrict__ rhoprime,
-                                                                  const uint32_t* __restrict__ kappa, int L, size_t nitems,
-                                                                  const RoundDesc* __restrict__ rd)
+                                                                  const uint32_t* __restrict__ kappa, int L, size_t nitems)
 {
     constexpr int POLYB = 32 * B, QW = POLYB / 8, NBLK = (QW + 16) / 17, LASTW = QW - 17 * (NBLK - 1);   // 80 (72) qwords, 5 blocks, 12 (4) in the last
     static_assert(HASH_BS == 64, "one wave per workgroup");
     const int lane = threadIdx.x;
-    if (rd) nitems = rd->E;                          // a device-sized signing round (kernels.hpp): the grid covers an upper bound
     const size_t first = (size_t)blockIdx.x * 64, total = nitems * (size_t)L;
-    if (first >= total) return;
     size_t p = first + lane;
     if (p >= total) p = total - 1;                   // lanes past the end run along (they help store) but own nothing
     const int live = (int)(total - first < 64 ? total - first : 64);
@@ -204,16 +201,13 @@ __global__ __launch_bounds__(HASH_BS) void expand_mask_raw_kernel(uint8_t* __res
 // per polynomial.  The narrow late rounds of the signing loop were 76 us of int32 extraction (expand_mask2_kernel); this is ~45.
 template <int B>
 __global__ __launch_bounds__(HASH_BS) void expand_mask_raw2_kernel(uint8_t* __restrict__ yp, const uint64_t* __restrict__ rhoprime,
-                                                                   const uint32_t* __restrict__ kappa, int L, size_t nitems,
-                                                                   const RoundDesc* __restrict__ rd)
+                                                                   const uint32_t* __restrict__ kappa, int L, size_t nitems)
 {
     constexpr int POLYB = 32 * B, DW = POLYB / 4, NBLK = (DW + 33) / 34, LASTD = DW - 34 * (NBLK - 1);   // 160 (144) dwords, 5 blocks, 24 (8) in the last
     static_assert(HASH_BS == 64, "one wave per workgroup");
     const int lane = threadIdx.x, col = lane >> 1;
     const bool hi = (lane & 1) != 0;
-    if (rd) nitems = rd->E;
     const size_t first = (size_t)blockIdx.x * 32, total = nitems * (size_t)L;
-    if (first >= total) return;
     size_t p = first + col;
     if (p >= total) p = total - 1;                   // pairs past the end run along (they help store) but own nothing
     const int live = (int)(total - first < 32 ? total - first : 32);
@@ -557,16 +551,14 @@ __global__ __launch_bounds__(HASH_BS) void challenge_hash2_kernel(uint32_t* __re
 template <bool TWO>
 __global__ __launch_bounds__(64) void challenge_sample_kernel(uint32_t* __restrict__ ctilde_out, int32_t* __restrict__ c_out,
                                                               const uint32_t* __restrict__ mu, const uint32_t* __restrict__ w1p, int w1_words,
-                                                              int tau, size_t batch, const RoundDesc* __restrict__ rd)
+                                                              int tau, size_t batch)
 {
     constexpr int ITEMS = TWO ? 32 : 64;
     __shared__ __attribute__((aligned(16))) uint8_t lds[SibLds<ITEMS>::BYTES];
     int8_t* cl = reinterpret_cast<int8_t*>(lds);
     uint32_t* rb = reinterpret_cast<uint32_t*>(lds + SibLds<ITEMS>::CL_BYTES);
     const int lane = threadIdx.x, col = TWO ? lane >> 1 : lane;
-    if (rd) batch = rd->E;                           // a device-sized signing round (kernels.hpp): the grid covers an upper bound
     const size_t base = (size_t)blockIdx.x * ITEMS, item = base + col;
-    if (base >= batch) return;
     const bool live = item < batch;
     const size_t ii = live ? item : batch - 1;               // a dead column hashes a valid entry again and stores nothing
     sib_clear(cl, SibLds<ITEMS>::CL_BYTES);
@@ -635,8 +627,7 @@ hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t
     return hipGetLastError();
 }
 
-hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1p, int level, size_t batch, hipStream_t s,
-                                   const RoundDesc* rd)
+hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1p, int level, size_t batch, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
@@ -644,10 +635,10 @@ hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* m
     const int words = K * (level == 2 ? 192 : 128) / 8, tau = level == 2 ? 39 : level == 3 ? 49 : 60;
     if (few_sponges(batch))
         hipLaunchKernelGGL(challenge_sample_kernel<true>, (int)((batch + 31) / 32), 64, 0, s, reinterpret_cast<uint32_t*>(ctilde), c,
-                           reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words, tau, batch, rd);
+                           reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words, tau, batch);
     else
         hipLaunchKernelGGL(challenge_sample_kernel<false>, (int)((batch + 63) / 64), 64, 0, s, reinterpret_cast<uint32_t*>(ctilde), c,
-                           reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words, tau, batch, rd);
+                           reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words, tau, batch);
     return hipGetLastError();
 }
 
@@ -735,8 +726,7 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s,
-                                     const RoundDesc* rd)
+hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s)
 {
     if (nitems == 0) return hipSuccess;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
@@ -746,13 +736,13 @@ hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
     if (total <= (size_t)two_lane_max_sponges.load(std::memory_order_relaxed)) {        // latency-bound: two lanes per sponge
         const int grid = (int)((total + 31) / 32);
-        if (level == 2) hipLaunchKernelGGL(expand_mask_raw2_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems, rd);
-        else hipLaunchKernelGGL(expand_mask_raw2_kernel<20>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems, rd);
+        if (level == 2) hipLaunchKernelGGL(expand_mask_raw2_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
+        else hipLaunchKernelGGL(expand_mask_raw2_kernel<20>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
         return hipGetLastError();
     }
     const int grid = (int)((total + HASH_BS - 1) / HASH_BS);
-    if (level == 2) hipLaunchKernelGGL(expand_mask_raw_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems, rd);
-    else hipLaunchKernelGGL(expand_mask_raw_kernel<20>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems, rd);
+    if (level == 2) hipLaunchKernelGGL(expand_mask_raw_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
+    else hipLaunchKernelGGL(expand_mask_raw_kernel<20>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
     return hipGetLastError();
 }
 

@@ -67,13 +67,6 @@ hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t*
 hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);
 // Optional key indirection of the per-item-key pipelines (the signing loop's speculative entries): entry `it` uses the
 // key material of row idx[(base + it) / S] (idx == nullptr: that row number itself).  Default = identity.
-// A signing round whose width is decided ON THE DEVICE (scheme.hip sign_core, run-ahead rounds): the round's set-up kernel derives
-// (n pending items, S attempts each, E = n S entries, a0 attempts already failed) from the previous round's pending count and
-// every kernel of the round reads it from here instead of from its launch arguments -- the host has queued the round before the
-// previous one has reported.  Launch grids are sized for an upper bound of E; surplus workgroups leave at once.
-struct RoundDesc {
-    uint32_t n, S, E, a0;
-};
 constexpr int TICKET_PARTS = 64, TICKET_STRIDE = 32, TICKET_WORDS = TICKET_PARTS * TICKET_STRIDE;
 constexpr int FLAG_SUPERSEDED = 16;      // sign-loop flag of an attempt dropped because an earlier attempt of its item was accepted
 struct KeyMap {
@@ -89,15 +82,6 @@ struct KeyMap {
     // One counter cannot serve a launch (12 ns per atomic on one address: 300 us for 24576 entries, measured): workgroup b draws
     // from queue b % TICKET_PARTS, which holds the entries u = b % TICKET_PARTS (mod TICKET_PARTS), each on its own 128-byte line.
     uint32_t* ticket = nullptr;
-    const RoundDesc* rd = nullptr;      // device-sized round: S, spec_n (if set: "on") and the launch's batch come from *rd
-    // the launch's batch and this map's fields as the kernel should see them
-    __device__ size_t resolve(size_t batch)
-    {
-        if (!rd) return batch;
-        S = rd->S;
-        spec_n = (spec_n && S > 1) ? rd->n : 0;
-        return rd->E;
-    }
     __host__ __device__ size_t key(size_t it) const
     {
         const uint32_t i = (base + (uint32_t)it) / S;
@@ -133,12 +117,10 @@ hipError_t launch_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_stride_b
                              size_t rp_stride, int level, int eta, size_t nkeys, hipStream_t s);
 hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 // y as the raw B-bit stream (Y_PACKED), lane per sponge: the signing loop's large rounds
-hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s,
-                                     const RoundDesc* rd = nullptr);
+hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, size_t nitems, hipStream_t s);
 // the signing loop's challenge in one launch: c~ = H(mu || w1_packed) -> ctilde (32 B per entry) AND c = SampleInBall(c~) -> c (int32 [256] per entry)
-hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1p, int level, size_t batch, hipStream_t s,
-                                   const RoundDesc* rd = nullptr);
+hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1p, int level, size_t batch, hipStream_t s);
 hipError_t launch_pack_w1(uint8_t* out, const uint8_t* w1, int level, size_t nitems, const Tables& t, hipStream_t s);
 // expect (may be nullptr): 32 bytes per item at expect + i * expect_stride, any alignment (c~ read in place from a signature)
 hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int level,
@@ -191,15 +173,10 @@ hipError_t launch_gather_rows(void* dst, const void* src, const int32_t* idx, si
                               const Tables& t, hipStream_t s);
 hipError_t launch_sign_kappa(uint32_t* kappa, int32_t* flags, uint32_t a0, uint32_t L, uint32_t S, size_t entries, hipStream_t s);
 hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* flags, int32_t* counts, uint32_t* tickets, const uint8_t* mu, const uint8_t* rp,
-                                   const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, RoundDesc* desc, hipStream_t s);
-hipError_t launch_sign_round_setup_dev(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa, int32_t* flags, int32_t* counts, uint32_t* tickets,
-                                       RoundDesc* desc, const int32_t* counts_prev, const RoundDesc* desc_prev, const uint8_t* mu,
-                                       const uint8_t* rp, const int32_t* idx, uint32_t L, uint32_t cap, uint32_t s_max, uint32_t max_attempts,
-                                       uint32_t waste, hipStream_t s);
-uint32_t sign_round_width_host(uint32_t n, uint32_t a0, uint32_t cap, uint32_t s_max, uint32_t max_attempts, uint32_t waste);
+                                   const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, hipStream_t s);
 hipError_t launch_sign_collect_ct(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
                                   const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, uint8_t* sig, size_t sig_stride,
-                                  const uint8_t* ct, hipStream_t s, const RoundDesc* rd = nullptr);
+                                  const uint8_t* ct, hipStream_t s);
 hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,
                              int nbytes, size_t nitems, const Tables& t, hipStream_t s, RowMap map = RowMap());
 

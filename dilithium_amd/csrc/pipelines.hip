@@ -285,11 +285,9 @@ struct YSrc<LEVEL, Y_PACKED> {
 template <int K, int L, int LEVEL, int OUT, int AF, int YF>
 __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
-    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch_arg, int shared_A,
-    KeyMap km_arg, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch, int shared_A,
+    KeyMap km, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
-    KeyMap km = km_arg;
-    const size_t batch = km.resolve(batch_arg);           // (a device-sized signing round: kernels.hpp RoundDesc)
     using XP = X10Pick<true>;
     using PT = PipeTables<DIL_TWC>;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
@@ -761,12 +759,10 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
     const int32_t* __restrict__ c, const int32_t* __restrict__ y, int32_t* __restrict__ w0,
     const uint8_t* __restrict__ w1, const int32_t* __restrict__ s1hat, const int32_t* __restrict__ s2hat,
-    const int32_t* __restrict__ t0hat, size_t batch_arg, int shared_key, KeyMap km_arg, const uint32_t* __restrict__ fwd_tab,
+    const int32_t* __restrict__ t0hat, size_t batch, int shared_key, KeyMap km, const uint32_t* __restrict__ fwd_tab,
     const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    KeyMap km = km_arg;
-    const size_t batch = km.resolve(batch_arg);           // (a device-sized signing round: kernels.hpp RoundDesc)
     using XP = S2X;
     using PT = PipeTables<DIL_TWC>;
     constexpr int PAIR_AT = PT::DWORDS + 4 * 64 + 4 * XP::DW;
@@ -1030,10 +1026,9 @@ __device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a
 template <int K, int L, int LEVEL, int OUT, int NW, int YF>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS_WGS * NW / 4))) void matvec_shared_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
-    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch_arg, const RoundDesc* __restrict__ rd,
+    const int32_t* __restrict__ A, const int32_t* __restrict__ y, size_t batch,
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
-    const size_t batch = rd ? (size_t)rd->E : batch_arg;           // (a device-sized signing round: kernels.hpp RoundDesc)
     // All three exchanges through LDS (S2X = XAllLds), as in phase 2: with y^ in registers the LDS pipe serves only A and the
     // twiddles, and at 4 waves per SIMD the exchange-free transforms win 3-6 % (level 5 sign phase 1: 51.1 -> 48.0 us).  The (1:0)
     // exchange ALONE through LDS (one ds_write_b128 + four ds_read_b32) costs 20 % here: profiles/r03m_ab_x.txt.
@@ -1332,7 +1327,7 @@ static hipError_t launch_matvec_level(int32_t* w, uint8_t* w1, int32_t* w0, cons
         const int g = grid_for((batch + NW - 1) / NW,
                                t.num_cus * resident_blocks_per_cu(matvec_shared_kernel<K, L, LEVEL, OUT, NW, YF>, 64 * NW, DIL_MVS_WGS, t.device));
         note_launch(OUT == OUT_W ? "matvec_shared" : "sign1_shared", g, NW, batch);
-        hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW, YF>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, km.rd, t.fwd,
+        hipLaunchKernelGGL((matvec_shared_kernel<K, L, LEVEL, OUT, NW, YF>), g, 64 * NW, 0, s, w, w1, w0, A, y, batch, t.fwd,
                            t.inv_pipe);
         return hipGetLastError();
     }

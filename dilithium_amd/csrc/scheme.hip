@@ -5,7 +5,6 @@
 #include "capi_internal.hpp"
 
 #include <algorithm>
-#include <cmath>
 #include <stdlib.h>
 
 using dil::rt::S;
@@ -136,12 +135,12 @@ struct StreamScratch {
         }
         return static_cast<T*>(q);
     }
-    // sixteen pinned host words (per arena; a private allocation when the call has no arena)
+    // two pinned host words (per arena; a private allocation when the call has no arena)
     int32_t* own_pinned = nullptr;
     int32_t* pinned_words()
     {
         int32_t** slot = arena ? &arena->pinned : &own_pinned;
-        if (!*slot && hipHostMalloc(reinterpret_cast<void**>(slot), 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+        if (!*slot && hipHostMalloc(reinterpret_cast<void**>(slot), 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
             *slot = nullptr;
             rc = rc ? rc : (int)hipErrorOutOfMemory;
         }
@@ -283,13 +282,12 @@ int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ct
     // y: int32, or -- every round wide enough for the wave-per-item kernels -- the raw B-bit SHAKE256 stream, unpacked by phase 1 /
     // phase 2 as they load it (ExpandMask picks one or two lanes per sponge by the round's width either way)
     const int y_fmt = (t.packed_y && dil::fused_wpi_shape(batch, T)) ? dil::Y_PACKED : dil::Y_I32;
-    if (km.rd && !(y_fmt == dil::Y_PACKED && t.fuse_challenge && early_exit)) return (int)hipErrorInvalidValue;   // device-sized rounds: these kernels only
-    if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, batch, s, km.rd));
+    if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, batch, s));
     else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
     // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
     DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt, y_fmt));
     if (t.fuse_challenge) {
-        DIL_TRY(dil::launch_challenge_sample(ctilde, t.c, mu, t.w1p, level, batch, s, km.rd));
+        DIL_TRY(dil::launch_challenge_sample(ctilde, t.c, mu, t.w1p, level, batch, s));
     } else {
         DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
         DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
@@ -630,7 +628,6 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     const int opt_cap = dil::rt::cfg.sign_cap.load(std::memory_order_relaxed);
     const int sign_waste = dil::rt::cfg.sign_waste.load(std::memory_order_relaxed);
     const bool sign_early = dil::rt::cfg.sign_early.load(std::memory_order_relaxed) != 0;
-    const bool sign_runahead = dil::rt::cfg.sign_runahead.load(std::memory_order_relaxed) != 0;
     const int sign_skip = dil::rt::cfg.sign_skip.load(std::memory_order_relaxed);       // bit 0: drop superseded attempts, bit 1: work queue
     // (a round never uses more than batch * s_max entries: a single signature gets 64 entries, not 16384)
     // default width: about one expected signature's worth of attempts per item in the first round (mean attempts 4.3 / 5.1 /
@@ -653,7 +650,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     int32_t* wine = ws.take<int32_t>(batch);             // winners of a round: entry, item
     int32_t* wini = ws.take<int32_t>(batch);
     int32_t* own_attempts = attempts ? nullptr : ws.take<int32_t>(batch);
-    int32_t* ctl = ws.take<int32_t>(12);                 // the loop's control words (below): counters and round descriptors, two slots
+    int32_t* counts = ws.take<int32_t>(2);               // [0] pending, [1] winners
     uint32_t* tickets = ws.take<uint32_t>(dil::TICKET_WORDS);      // phase 2's work queues (KeyMap::ticket)
     // per entry
     uint32_t* kap = ws.take<uint32_t>(cap);
@@ -666,7 +663,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     AttemptScratch att;
     if ((rc = att.alloc(ws, level, p.K, p.L, cap))) return rc;
     if (!attempts) attempts = own_attempts;
-    int32_t* host_ctl = ws.pinned_words();               // pageable memory would make the read-back a blocking staged copy
+    int32_t* host_counts = ws.pinned_words();            // pageable memory would make the read-back a blocking staged copy
     if (ws.rc) return ws.rc;
 
     {
@@ -688,103 +685,65 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         ~EventGuard() { if (ev) (void)hipEventDestroy(ev); }
     } counted;
     DIL_TRY(hipEventCreateWithFlags(&counted.ev, hipEventDisableTiming));
-    // Control words of the loop, two slots alternating by round parity (a round's set-up reads the previous round's slot and clears
-    // its own): ctl[2 par + {0, 1}] = pending / winners after the round, ctl[4 + 4 par ...] = the round's (n, S, E, a0).
-    auto counts_of = [&](int par) { return ctl + 2 * par; };
-    auto desc_of = [&](int par) { return reinterpret_cast<dil::RoundDesc*>(ctl + 4 + 4 * par); };
-    int32_t* const idx_buf[2] = {idx0, idx1};            // pending list written by round r: idx_buf[r & 1]
-    // RUN-AHEAD.  A round needs the previous round's pending count only to size itself.  While that count is predictable -- it
-    // shrinks by q^S with q = 1 - 1 / (mean attempts), to within a few per cent for hundreds of items -- the host does not wait
-    // for it: the next round is queued at once, its set-up kernel reads the count on the device, derives the width by the same
-    // rule and leaves (n, S, E, a0) for the round's kernels, whose grids cover the upper bound `cap` (kernels.hpp RoundDesc).
-    // The host synchronises only when the prediction says the round after would be narrow (< ra_min items: the narrow kernel
-    // shapes are chosen from the exact count) -- once per call at 8192 messages instead of once per round.
-    const bool mu16 = (reinterpret_cast<uintptr_t>(mu) & 15) == 0;
-    const bool run_ahead_ok = sign_runahead && sign_early && att.packed_y && att.fuse_challenge && mu16 && dil::fused_wpi_shape(cap, T);
-    const double q_fail = level == 2 ? 0.77 : level == 3 ? 0.804 : 0.74;
-    const size_t ra_min = 400;
-    size_t n = batch, n_ub = batch;                      // pending items: exact (after a synchronisation) / upper bound
-    double n_pred = (double)batch;
-    int a0 = 0, a0_pred = 0;                             // attempts every pending item has already failed
-    bool exact = true;
-    int last_S = 0;
-    for (int r = 0;; r++) {
-        const int par = r & 1;
-        int32_t* const counts = counts_of(par);
-        int32_t *idx_cur = r ? idx_buf[par ^ 1] : nullptr, *idx_next = idx_buf[par];
+    int32_t *idx_cur = nullptr, *idx_next = idx0;
+    size_t n = batch;
+    int a0 = 0;                                          // attempts every pending item has already failed
+    while (n > 0 && a0 < max_attempts) {
+        // Attempts per pending item this round: as many as fit in `cap` entries, but only while the work expected to be
+        // wasted on attempts after an item's first success, n * (1 - (1-p)^(S-1)) entries with p ~ 0.2, stays below the
+        // work a saved round's fixed latency is worth (option sign_waste entries; matters for batches >> 16384).
+        int S_ = 1;
+        {
+            const int s_lim = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
+            double keep = 1.0;                       // (1-p)^(S-1)
+            while (S_ < s_lim) {
+                keep *= 0.8;
+                if ((double)n * (1.0 - keep) > (double)sign_waste) break;
+                S_++;
+            }
+        }
+        const size_t E = n * (size_t)S_;
+        const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
+        const uint8_t *mur = direct ? mu : mu_c, *rpr = direct ? rp : rp_c;
         dil::KeyMap keys;                                // per-item keys are read in place through the pending list
         keys.idx = idx_cur;
+        keys.S = (uint32_t)S_;
+        // attempts behind an item's first accepted one are never used: phase 2 may drop them as it goes (its early-exit form only)
+        keys.spec_n = (S_ > 1 && sign_early && (sign_skip & 1)) ? (uint32_t)n : 0;
         keys.ticket = (sign_early && (sign_skip & 2)) ? tickets : nullptr;
-        size_t E;
-        if (exact) {
-            if (n == 0 || a0 >= max_attempts) break;
-            // Attempts per pending item this round: as many as fit in `cap` entries, but only while the work expected to be
-            // wasted on attempts after an item's first success stays below the work a saved round's fixed latency is worth
-            // (option sign_waste entries; matters for batches >> 16384) -- codec_kernels.hip sign_round_width().
-            const int S_ = (int)dil::sign_round_width_host((uint32_t)n, (uint32_t)a0, (uint32_t)cap, (uint32_t)s_max, (uint32_t)max_attempts,
-                                                          (uint32_t)sign_waste);
-            E = n * (size_t)S_;
-            const bool direct = !idx_cur && S_ == 1;     // first round of a full batch: the caller's arrays as they are
-            const uint8_t *mur = direct ? mu : mu_c, *rpr = direct ? rp : rp_c;
-            keys.S = (uint32_t)S_;
-            // attempts behind an item's first accepted one are never used: phase 2 may drop them as it goes (its early-exit form only)
-            keys.spec_n = (S_ > 1 && sign_early && (sign_skip & 1)) ? (uint32_t)n : 0;
-            // one launch: gathers of mu / rho' for the entries, kappa = (a0 + e % S) L, flags = "no verdict", counters cleared
-            if (mu16) {
-                DIL_TRY(dil::launch_sign_round_setup(mu_c, rp_c, kap, fl, counts, tickets, mu, rp, idx_cur, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E,
-                                                     !direct, desc_of(par), s));
-            } else {                                     // caller's mu only 8-byte aligned: the generic kernels
-                if (!direct) {
-                    DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, T, s));
-                    DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, T, s));
-                }
-                DIL_TRY(dil::launch_sign_kappa(kap, fl, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
-                DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
-                DIL_TRY(hipMemsetAsync(tickets, 0, dil::TICKET_WORDS * 4, s));
+        // one launch: gathers of mu / rho' for the entries, kappa = (a0 + e % S) L, counters cleared
+        if (((reinterpret_cast<uintptr_t>(mu)) & 15) == 0) {
+            DIL_TRY(dil::launch_sign_round_setup(mu_c, rp_c, kap, fl, counts, tickets, mu, rp, idx_cur, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E,
+                                                 !direct, s));
+        } else {                                         // caller's mu only 8-byte aligned: the generic kernels
+            if (!direct) {
+                DIL_TRY(dil::launch_gather_rows(mu_c, mu, idx_cur, 64, (uint32_t)S_, E, T, s));
+                DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, T, s));
             }
-            // (Two stream-level overlaps of a round's latency-bound hash kernels with its polynomial kernels were built in rounds 2 / 3 and
-            //  measured slower -- 1.42 -> 1.77 ms per 8192 level-3 signatures, profiles/r03j_sign_overlap.txt -- and are gone.)
-            if ((rc = sign_attempt_impl(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, E, shared_sk, s, keys, sign_early))) return rc;
-            // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
-            DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s));
-            last_S = S_;
-            n_pred = (double)n;
-            a0_pred = a0;
-            n_ub = n;
-        } else {
-            // a device-sized round: width and entry count unknown here, grids for `cap` entries and n_ub items
-            keys.rd = desc_of(par);
-            keys.spec_n = (sign_skip & 1) ? 1 : 0;       // "on": the kernel takes n from *rd
-            E = std::min<size_t>(cap, n_ub * (size_t)s_max);
-            DIL_TRY(dil::launch_sign_round_setup_dev(mu_c, rp_c, kap, fl, counts, tickets, desc_of(par), counts_of(par ^ 1), desc_of(par ^ 1), mu, rp,
-                                                     idx_cur, (uint32_t)p.L, (uint32_t)cap, (uint32_t)s_max, (uint32_t)max_attempts,
-                                                     (uint32_t)sign_waste, s));
-            if ((rc = sign_attempt_impl(T, att, ct, z, h, fl, A, mu_c, rp_c, kap, s1h, s2h, t0h, level, E, shared_sk, s, keys, sign_early))) return rc;
-            DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, 0, 1, n_ub, sig, sgb, ct, s, keys.rd));
-            last_S = (int)dil::sign_round_width_host((uint32_t)std::max(1.0, n_pred), (uint32_t)a0_pred, (uint32_t)cap, (uint32_t)s_max,
-                                                     (uint32_t)max_attempts, (uint32_t)sign_waste);
+            DIL_TRY(dil::launch_sign_kappa(kap, fl, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
+            DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
+            DIL_TRY(hipMemsetAsync(tickets, 0, dil::TICKET_WORDS * 4, s));
         }
-        // the control words go home NOW, marked by an event; the winners' packing is queued behind them, so a host that waits
-        // wakes up, sizes the next round and has its launches in the queue while the packing kernels still run
-        DIL_TRY(hipMemcpyAsync(host_ctl, ctl, 12 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        // (Two stream-level overlaps of a round's latency-bound hash kernels with its polynomial kernels were built in rounds 2 / 3 and
+        //  measured slower -- 1.42 -> 1.77 ms per 8192 level-3 signatures, profiles/r03j_sign_overlap.txt -- and are gone.)
+        if ((rc = sign_attempt_impl(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, E, shared_sk, s, keys, sign_early))) return rc;
+        // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
+        DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s));
+        // the pending count goes home NOW, marked by an event; the winners' packing is queued behind it, so the host wakes up,
+        // sizes the next round and has its launches in the queue while the packing kernels still run
+        DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
         DIL_TRY(hipEventRecord(counted.ev, s));
         dil::RowMap win;
         win.src_row = wine;
         win.dst_row = wini;
         win.count = counts + 1;
-        DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n_ub, T, s, win));
-        DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n_ub, s, win));
-        // what the round probably left
-        n_pred *= std::pow(q_fail, last_S);
-        a0_pred += last_S;
-        if (run_ahead_ok && n_pred >= (double)ra_min && a0_pred + s_max < max_attempts) {
-            exact = false;
-            continue;
-        }
+        DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, T, s, win));
+        DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n, s, win));
         DIL_TRY(hipEventSynchronize(counted.ev));
-        n = (size_t)host_ctl[2 * par];
-        a0 = exact ? a0 + last_S : (int)(host_ctl[4 + 4 * par + 3] + host_ctl[4 + 4 * par + 1]);   // (a device-sized round: its a0 + S, as the device had them)
-        exact = true;
+        n = (size_t)host_counts[0];
+        a0 += S_;
+        idx_cur = idx_next;
+        idx_next = idx_cur == idx0 ? idx1 : idx0;
     }
     return n == 0 ? 0 : DIL_ERR_UNFINISHED;
 }
