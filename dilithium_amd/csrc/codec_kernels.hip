@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256) void hint_unpack_kernel(uint8_t* __restrict__ 
     if (lane == 0) bad[it] = any ? 1 : 0;
 }
 
-// pack: h [K][256] bytes -> omega + K bytes (makehint.v:104-150).  One wave per item.
+// pack: h [K][256] bytes -> omega + K bytes (makehint.v:104-150).  One wave per item; a row is read as one dword per lane
+// (coefficients 4 lane .. 4 lane + 3) and all K loads are issued before anything waits -- a byte per lane and chunk was a chain of
+// 4 K dependent loads (10.5 -> ~6 us per signing round, profiles/r04u_ab_sign_finish.txt).  Positions ascend by coefficient.
 __global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ out, size_t out_stride, size_t out_offset,
                                                         const uint8_t* __restrict__ h, int K, int omega, size_t nitems, RowMap map)
 {
@@ -195,18 +197,37 @@ __global__ __launch_bounds__(256) void hint_pack_kernel(uint8_t* __restrict__ ou
     const size_t irow = map.src_row ? (size_t)map.src_row[it] : it, orow = map.dst_row ? (size_t)map.dst_row[it] : it;
     uint8_t* dst = out + orow * out_stride + out_offset;
     const uint8_t* src = h + irow * (size_t)K * 256;
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {                    // (K <= 8; a clamped row instead of a branch keeps the loads together)
+        uint32_t v;
+        __builtin_memcpy(&v, src + (k < K ? k : 0) * 256 + 4 * lane, 4);
+        w[k] = v;
+    }
     for (int t = lane; t < omega + K; t += 64) dst[t] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const unsigned long long lt = (1ull << lane) - 1;
     int count = 0;                                   // wave-uniform
-    for (int k = 0; k < K; k++) {
-        for (int chunk = 0; chunk < 4; chunk++) {
-            const int idx = chunk * 64 + lane;
-            const bool bit = src[k * 256 + idx] != 0;
-            const unsigned long long m = __ballot(bit);
-            const int before = __popcll(m & ((1ull << lane) - 1));
-            if (bit && count + before < omega) dst[count + before] = (uint8_t)idx;
-            count += __popcll(m);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= K) break;
+        bool nz[4];
+        int below = 0, total = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            nz[b] = ((w[k] >> (8 * b)) & 0xFFu) != 0;
+            const unsigned long long m = __ballot(nz[b]);
+            below += __popcll(m & lt);
+            total += __popcll(m);
         }
+        int r = count + below;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (nz[b]) {
+                if (r < omega) dst[r] = (uint8_t)(4 * lane + b);
+                r++;
+            }
+        count += total;
         if (lane == 0) dst[omega + k] = (uint8_t)(count < omega ? count : omega);
     }
 }
