@@ -79,6 +79,8 @@ inline void note_launch(const char* family, int grid, int items_per_block, size_
         }
 }
 
+// (A "balanced" grid -- the largest one that gives every block the same number of passes, 683 instead of 768 workgroups for 8192
+//  level-3 verifications -- was measured slower, 63.5 vs 58.5 us: more waves in flight beat an even tail.)
 static inline int grid_for(size_t work_blocks, int max_blocks)
 {
     if (work_blocks < 1) work_blocks = 1;
