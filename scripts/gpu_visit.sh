@@ -1,4 +1,6 @@
 #!/bin/bash
 # scratch: one GPU visit
-bash scripts/gpu_r04.sh r04zz tests cover smoke bench prof pmc signpmc
-bash scripts/gpu_scale.sh 100
+mkdir -p gpurun_out
+python scripts/fuzz_parity.py 480 404 > gpurun_out/r04zz_fuzz_parity.txt 2>&1
+python scripts/fuzz_scheme.py 480 405 > gpurun_out/r04zz_fuzz_scheme.txt 2>&1
+tail -2 gpurun_out/r04zz_fuzz_parity.txt gpurun_out/r04zz_fuzz_scheme.txt
