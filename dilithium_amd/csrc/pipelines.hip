@@ -751,6 +751,7 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
 // complete only when flags == 0, which is all the loop reads.  r0 is parked in the attempt's own w0 scratch until (C).
 //   one key (SH):   rows k = 0 .. K-1 in turn: r0[k] = w0[k] - c s2[k], then z[k] = y[k] + c s1[k] for k < L -- one inverse
 //                   transform per row gives both (SmallPair, the key's paired rows staged in LDS) -- then (C) c t0 and the hints.
+//                   (w0 / y of row k + 1 loaded under row k: 1259 -> 1274 us per 8192 level-3 signatures, 5528 -> 5569 per 65536 -- not kept.)
 //   a key per item: (A) all r0 rows (61 % of level-5 attempts fail one), (B) all z rows (34 %), (C): every key row is HBM traffic
 //                   of its own there, so the rows that reject most go first and nothing is paired.
 // Expected inverse transforms per level-5 attempt: ~6 (one key) / ~10 (a key per item) instead of 16 / 23 for the full kernels.

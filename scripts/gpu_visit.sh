@@ -1,6 +1,6 @@
 #!/bin/bash
 # scratch: one GPU visit
 mkdir -p gpurun_out
-python scripts/fuzz_parity.py 480 404 > gpurun_out/r04zz_fuzz_parity.txt 2>&1
-python scripts/fuzz_scheme.py 480 405 > gpurun_out/r04zz_fuzz_scheme.txt 2>&1
-tail -2 gpurun_out/r04zz_fuzz_parity.txt gpurun_out/r04zz_fuzz_scheme.txt
+for i in 1 2 3; do
+for v in cur s2epf; do for n in 8192 65536; do echo "$v n=$n"; DIL_LIB_PATH=scripts/bin/libdil256_$v.so python scripts/bench_scheme.py $n 2>&1 | grep "sign shared"; done; done
+done
