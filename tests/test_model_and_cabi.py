@@ -150,3 +150,27 @@ def test_use_hint_half_bucket_form_over_the_whole_field():
             else:
                 n = n & 15
             assert (n == want).all(), (level, hint)
+
+
+def test_every_option_is_documented_and_round_trips_without_gpu(lib):
+    """dil_set_option / dil_get_option (include/dil256.h): every name in the library's option table is described in the header or
+    in INTEGRATION.md, reads back what was set, and an unknown name is refused -- all without a GPU"""
+    import ctypes as C
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = open(os.path.join(root, "dilithium_amd", "csrc", "capi.hip")).read()
+    names = re.findall(r'\{"([a-z0-9_]+)", "DIL_[A-Z0-9_]+", &', table)
+    assert len(names) >= 15 and "sign_skip" in names
+    docs = open(os.path.join(root, "include", "dil256.h")).read() + open(os.path.join(root, "INTEGRATION.md")).read()
+    for name in names:
+        assert name in docs, f"option {name} is not documented"
+        v = C.c_int(-1)
+        assert lib.dil_get_option(name.encode(), C.byref(v)) == 0, name
+        old = v.value
+        assert lib.dil_set_option(name.encode(), old + 1) == 0
+        assert lib.dil_get_option(name.encode(), C.byref(v)) == 0 and v.value == old + 1
+        assert lib.dil_set_option(name.encode(), old) == 0
+    v = C.c_int(0)
+    assert lib.dil_get_option(b"no_such_option", C.byref(v)) != 0
+    assert lib.dil_set_option(b"no_such_option", 1) != 0
