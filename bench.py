@@ -302,44 +302,54 @@ def main():
 
     def timed(fn, st=None, min_ms=None):
         """average milliseconds per call of fn() (direct C-ABI launches on stream `st`): HIP events around a region that is
-        at least min_ms long -- the repeat count comes from a calibration pass, not from --steps.  Two measured regions, the
-        faster one counts: the composite calls synchronise with the host every rejection round, and one descheduling of this
+        at least min_ms long -- the repeat count comes from a calibration pass, not from --steps.  One region unmeasured, then three measured ones of which the
+        MEDIAN counts: the composite calls synchronise with the host every rejection round, and one descheduling of this
         process inside a 25-ms region was seen to halve a rate (profiles/r04zz_bench.log, sign at 8192: 3.9 M/s beside 6.5-6.8
-        in the same visit's other two bench runs).  Returns (ms per call, calls in a measured region)."""
+        in the same visit's other two bench runs); the median shrugs one such region off without favouring a fast one (the
+        fastest of the three can be a region at a higher clock).  Returns (ms per call, calls in a measured region)."""
         st = stream if st is None else st
         min_ms = args.min_ms if min_ms is None else min_ms
         e0, e1 = ev(), ev()
-        reps, used, rc, best = 4, 4, 0, None
-        for phase in range(4):                   # warm-up, then calibrate, then the two measured regions
-            L.dil_event_record(e0, st)
-            for i in range(reps):
-                rc |= fn(i)
+        reps, used, rc, pers = 4, 4, 0, []
+        for phase in range(6):                   # warm-up, calibrate, one full region unmeasured, then the three measured regions
+            L.dil_event_record(e0, st)           # (the chip needs > 50 ms of a kernel's load to settle: the fused verify core ran
+            for i in range(reps):                #  63.1 us per launch in the region after the calibration pass and 59.0 / 59.1 in
+                rc |= fn(i)                      #  the next two -- profiles/r04w_verify_transient.txt has the curve after idle)
             L.dil_event_record(e1, st)
             used = reps
             per = max(elapsed(e0, e1) / reps, 1e-4)
-            if phase >= 2:
-                best = per if best is None else min(best, per)
-            else:
+            if phase >= 3:
+                pers.append(per)
+            elif phase < 2:
                 reps = max(10, int(min_ms / per) + 1)
         dlib.check(rc, "timed launches")
-        return best, used
+        timed.last_regions = list(pers)
+        return sorted(pers)[1], used
 
     probe_stream = torch.cuda.Stream()
     probe_buf = torch.zeros(4, dtype=torch.int64, device="cuda")
 
-    def with_clock(fn, span_ms):
-        """run fn() while a one-lane probe kernel on a side stream measures the effective shader clock over about span_ms
-        (csrc/kernels.hip clock_probe_kernel: shader cycles per 100 MHz tick); returns (fn's result, MHz or None)"""
+    probe_effect = {}
+
+    def with_clock(fn, span_ms, tag=None):
+        """fn() ALONE on the device is the measurement; then fn() once more while a one-lane probe kernel on a side stream
+        measures the effective shader clock over about span_ms (csrc/kernels.hip clock_probe_kernel: shader cycles per 100 MHz
+        tick).  Two passes because the probe is not free for every kernel: a second active queue was seen to cost the fused
+        verify kernel 5-6 % (63.4 vs 59.5 us per launch), which is instrumentation, not the kernel.  Returns (the first pass's
+        result, MHz or None); probe_effect[tag] keeps the second pass's result beside it."""
+        res = fn()
         try:
             torch.cuda.synchronize()
             dlib.check(L.dil_clock_probe_dev(P(probe_buf), max(1000, int(span_ms * 1000)), C.c_void_p(probe_stream.cuda_stream)), "clock probe")
-            res = fn()
+            again = fn()
             probe_stream.synchronize()
+            if tag:
+                probe_effect[tag] = again
             c0, c1, r0, r1 = [int(x) for x in probe_buf.cpu().tolist()]
             mhz = (c1 - c0) / max(1, r1 - r0) * 100.0
             return res, (mhz if 200.0 < mhz < 5000.0 else None)
         except Exception:   # noqa: BLE001
-            return fn(), None
+            return res, None
 
     # ---- inputs, resident in HBM ------------------------------------------------------------
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -525,7 +535,13 @@ def main():
             return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, stream)
 
         sharding.barrier()
-        (v_ms, v_reps), v_mhz = with_clock(lambda: timed(vstep), 3 * args.min_ms)
+        v_regions = []
+
+        def timed_v():
+            r = timed(vstep)
+            v_regions.append(list(timed.last_regions))
+            return r
+        (v_ms, v_reps), v_mhz = with_clock(timed_v, 5 * args.min_ms, "verify")
         v_ms = sharding.max_over_ranks(v_ms)
         v_gbs = VERIFY3_BYTES * VBATCH / (v_ms * 1e-3) / 1e9
         vtraffic = pmc_traffic("verify_kernel")
@@ -536,7 +552,10 @@ def main():
                "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": vtraffic,
                             "traffic_source": "profiles/pmc_summary.json (committed PMC passes)" if vtraffic else None,
-                            "avg_launch_ms": v_ms, "shader_mhz_observed": v_mhz}}
+                            "avg_launch_ms": v_ms, "shader_mhz_observed": v_mhz,
+                            "avg_launch_ms_beside_clock_probe": probe_effect.get("verify", (None,))[0],
+                            "region_ms": {"alone": v_regions[0] if v_regions else None,
+                                          "beside_clock_probe": v_regions[1] if len(v_regions) > 1 else None}}}
         # the same launches alternating over TWO streams (input set j on stream j): the next launch's ramp hides the
         # previous one's tail and the dispatch gap -- the aggregate rate, reported beside the single-kernel fraction
         if NS > 1 and not args.no_verify_overlap:
@@ -557,7 +576,7 @@ def main():
             v2_gbs = VERIFY3_BYTES * VBATCH / (v2_ms * 1e-3) / 1e9
             sec["roofline"].update({"achieved_overlapped": v2_gbs, "frac_overlapped": v2_gbs / HBM_PEAK_GBS,
                                     "concurrent_launches_overlapped": 2, "overlapped_value": world * VBATCH / (v2_ms * 1e-3),
-                                    "timing": "frac = per-launch share of back-to-back launches on ONE stream (HIP events, the faster of two regions); "
+                                    "timing": "frac = per-launch share of back-to-back launches on ONE stream (HIP events, the median of three regions); "
                                               "frac_overlapped = the same launches alternating over two streams, host clock around "
                                               "a synchronised region"})
         # the same launches over ONE input set (360 MiB, partly served by the 256 MiB Infinity Cache), for context
@@ -594,7 +613,7 @@ def main():
             def attempt(i):
                 return L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream) | \
                     L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1, 0, stream)
-            (a_ms, _), sign_mhz = with_clock(lambda: timed(attempt), 3 * args.min_ms)
+            (a_ms, _), sign_mhz = with_clock(lambda: timed(attempt), 5 * args.min_ms, "attempt")
             # the same pair over TWO rotating sets of buffers (2 x 223 MB: past the 256 MiB Infinity Cache), as the headline and the
             # verify leg are measured: the HBM-streaming figure.  (One set = 223 MB is largely cache-resident.)
             y5b = small((1 << 19) - 1, 8192, 7, 256)
@@ -631,7 +650,7 @@ def main():
                         "valu_insts_per_attempt": sv, "source": "profiles/pmc_summary.json (committed SQ_INSTS_VALU passes of these kernels / 8192)",
                         "phase1_frac": sv["phase1"] * 8192 / (p1_ms * 1e-3) / VALU_PEAK,
                         "phase2_frac": sv["phase2"] * 8192 / (p2_ms * 1e-3) / VALU_PEAK,
-                        "shader_mhz_observed": sign_mhz,
+                        "shader_mhz_observed": sign_mhz, "attempt_ms_beside_clock_probe": probe_effect.get("attempt", (None,))[0],
                         "peak_at_observed_clock": None if not sign_mhz else VALU_PEAK * sign_mhz / 2400.0,
                         "phase1_frac_at_observed_clock": None if not sign_mhz else sv["phase1"] * 8192 / (p1_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
                         "phase2_frac_at_observed_clock": None if not sign_mhz else sv["phase2"] * 8192 / (p2_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
@@ -699,7 +718,7 @@ def main():
             sec["scheme_level3_wire_format"] = {
                 "note": "pk/sk/sig bytes in HBM -> bytes in HBM; SHAKE, samplers, codecs, rejection loop all on the device; "
                         "verification reads the packed fields inside the fused kernel (no int32 temporaries).  Rates are whole calls "
-                        "timed with HIP events around back-to-back calls on one stream (the faster of two regions of >= 25 ms); the sign rates are therefore HOST-INCLUSIVE: "
+                        "timed with HIP events around back-to-back calls on one stream (the median of three regions of >= 25 ms); the sign rates are therefore HOST-INCLUSIVE: "
                         "dil_sign_dev synchronises the stream once per rejection round (an 8-byte count read back, ~10 us per round)",
                 "keygen_per_s": per_s(kg_ms), "sign_shared_key_per_s": per_s(sg_ms), "sign_distinct_keys_per_s": per_s(sgd_ms),
                 "verify_shared_pk_per_s": per_s(vf_ms), "verify_distinct_pk_per_s": per_s(vfd_ms),
