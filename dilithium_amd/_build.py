@@ -11,11 +11,12 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdil256.so")
+OBJ_DIR = os.path.join(PKG, "build")       # git-ignored
 # reference-identical C++ signatures (include/dil256_ref.hpp); DIL_REF_LIB_PATH: another build of it (scripts/san_check.sh)
 REF_LIB_BUILT = os.path.join(PKG, "libdil256_ref.so")                      # what build_ref() writes
 REF_LIB = os.environ.get("DIL_REF_LIB_PATH", REF_LIB_BUILT)              # what the tests load
-SOURCES = ["kernels.hip", "pipelines.hip", "hash_kernels.hip", "codec_kernels.hip", "wire_kernels.hip", "capi.hip", "scheme.hip", "multi_gpu.hip"]
-HEADERS = ["variants.hpp", "capi_internal.hpp", "modarith.hpp", "ntt_core.hpp", "kernels.hpp", "device_common.hpp", "pipeline_common.hpp", "launch_util.hpp", "keccak.hpp", "wire_common.hpp", "sampler_bodies.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
+SOURCES = ["kernels.hip", "pipelines.hip", "hash_kernels.hip", "coop_kernels.hip", "codec_kernels.hip", "wire_kernels.hip", "capi.hip", "scheme.hip", "multi_gpu.hip"]
+HEADERS = ["variants.hpp", "capi_internal.hpp", "modarith.hpp", "ntt_core.hpp", "kernels.hpp", "device_common.hpp", "pipeline_common.hpp", "launch_util.hpp", "keccak.hpp", "keccak_coop.hpp", "coop_bodies.hpp", "wire_common.hpp", "sampler_bodies.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
            os.path.join("..", "..", "include", "dil256_ref.hpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-pthread"]
 
@@ -28,7 +29,15 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _compile_one(hipcc: str, src: str, obj: str, verbose: bool) -> None:
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """one object per translation unit (in parallel; only the stale ones unless `force`), then the link"""
     if not force and not _stale():
         if not os.path.exists(REF_LIB_BUILT):
             build_ref(verbose)
@@ -36,7 +45,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libdil256.so")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+    jobs, objs = [], []
+    for src_name in SOURCES:
+        src, obj = os.path.join(CSRC, src_name), os.path.join(OBJ_DIR, src_name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append((src, obj))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as pool:
+        for f in [pool.submit(_compile_one, hipcc, src, obj, verbose) for src, obj in jobs]:
+            f.result()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -47,6 +47,7 @@ const OptName* option_table(int* n)
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
         {"two_lane_max_sponges", "DIL_TWO_LANE_MAX", &dil::two_lane_max_sponges},
+        {"coop_max", "DIL_COOP_MAX", &dil::coop_max_sponges},
     };
     *n = (int)(sizeof(tab) / sizeof(tab[0]));
     return tab;

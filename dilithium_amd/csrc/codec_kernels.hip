@@ -531,6 +531,7 @@ hipError_t launch_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, si
 {
     if (nitems == 0) return hipSuccess;
     const size_t total = nitems * (size_t)(L + K);
+    if (coop_wanted(total)) return launch_coop_expand_s(s1, s2, rhoprime, rp_stride, eta, L, K, nitems, s);
     if (eta == 2)
         hipLaunchKernelGGL(expand_s_fast_kernel<2>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, s1, s2, L, rhoprime, rp_stride, 0,
                            L + K, nitems);

@@ -465,6 +465,7 @@ hipError_t launch_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uin
                      const uint32_t* lengths, int32_t* bad, size_t batch, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
+    if (coop_wanted(batch)) return launch_coop_mu(mu, tr, tr_stride, msgs, msgs_bytes, offsets, lengths, bad, batch, s);
     hipLaunchKernelGGL(mu_kernel, (int)((batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint64_t*>(mu), tr, tr_stride, msgs,
                        msgs_bytes, offsets, lengths, bad, batch);
     return hipGetLastError();
@@ -615,6 +616,7 @@ hipError_t launch_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
     const int words = K * (level == 2 ? 192 : 128) / 8;
+    if (coop_wanted(batch)) return launch_coop_challenge_hash(out32, verdict, mu, w1p, words, expect, expect_stride, batch, s);
     if (few_sponges(batch)) {
         hipLaunchKernelGGL(challenge_hash2_kernel, (int)((2 * batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint32_t*>(out32),
                            verdict, reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words,
@@ -633,6 +635,7 @@ hipError_t launch_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* m
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
     const int words = K * (level == 2 ? 192 : 128) / 8, tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    if (coop_wanted(batch)) return launch_coop_challenge_sample(ctilde, c, mu, w1p, words, tau, batch, s);
     if (few_sponges(batch))
         hipLaunchKernelGGL(challenge_sample_kernel<true>, (int)((batch + 31) / 32), 64, 0, s, reinterpret_cast<uint32_t*>(ctilde), c,
                            reinterpret_cast<const uint32_t*>(mu), reinterpret_cast<const uint32_t*>(w1p), words, tau, batch);
@@ -656,6 +659,7 @@ hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int
 {
     if (batch == 0) return hipSuccess;
     if ((out_bytes & 7) || (in_bytes & 7) || out_bytes <= 0 || in_bytes < 0) return hipErrorInvalidValue;
+    if (coop_wanted(batch)) return launch_coop_shake256(out, out_bytes, in, in_bytes, batch, s);
     if (few_sponges(batch)) {
         hipLaunchKernelGGL(shake256_batch2_kernel, (int)((2 * batch + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, reinterpret_cast<uint32_t*>(out),
                            out_bytes / 8, reinterpret_cast<const uint32_t*>(in), in_bytes / 8, batch);
@@ -676,6 +680,7 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
         hipLaunchKernelGGL(expand_a_fast_kernel<true>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
         return hipGetLastError();
     }
+    if (coop_wanted(total)) return launch_coop_expand_a(A, rho, rho_stride_bytes, K, L, nitems, s);      // a sponge per wavefront
     if (total <= EA_TWO_LANE_MAX) {        // latency-bound: two lanes per sponge
         hipLaunchKernelGGL(expand_a_kernel<true>, (int)((2 * total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A,
                            reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
@@ -714,6 +719,7 @@ hipError_t launch_expand_mask(int32_t* y, const uint8_t* rhoprime, const uint32_
     const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t total = nitems * (size_t)L;
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
+    if (coop_wanted(total)) return launch_coop_expand_mask(y, false, rhoprime, kappa, level, nitems, s);
     if (total <= (size_t)two_lane_max_sponges.load(std::memory_order_relaxed)) {        // latency-bound: two lanes per sponge
         const int grid = (int)((2 * total + HASH_BS - 1) / HASH_BS);
         if (level == 2) hipLaunchKernelGGL(expand_mask2_kernel<18>, grid, HASH_BS, 0, s, y, rp, kappa, L, nitems);
@@ -734,6 +740,7 @@ hipError_t launch_expand_mask_packed(uint8_t* yp, const uint8_t* rhoprime, const
     const int L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t total = nitems * (size_t)L;
     const uint64_t* rp = reinterpret_cast<const uint64_t*>(rhoprime);
+    if (coop_wanted(total)) return launch_coop_expand_mask(yp, true, rhoprime, kappa, level, nitems, s);
     if (total <= (size_t)two_lane_max_sponges.load(std::memory_order_relaxed)) {        // latency-bound: two lanes per sponge
         const int grid = (int)((total + 31) / 32);
         if (level == 2) hipLaunchKernelGGL(expand_mask_raw2_kernel<18>, grid, HASH_BS, 0, s, yp, rp, kappa, L, nitems);
@@ -751,6 +758,7 @@ hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, s
     if (nitems == 0) return hipSuccess;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    if (coop_wanted(nitems)) return launch_coop_sample_in_ball(c, nullptr, ctilde, 32, tau, nitems, s);
     hipLaunchKernelGGL(sample_in_ball_kernel, (int)((nitems + 63) / 64), 64, 0, s, c, reinterpret_cast<const uint64_t*>(ctilde), tau, nitems);
     return hipGetLastError();
 }

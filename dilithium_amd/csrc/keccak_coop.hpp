@@ -1,0 +1,131 @@
+// keccak_coop.hpp -- Keccak-f[1600] with ONE state spread over a wavefront, for the latency-bound sponge chains
+// (narrow signing rounds, single signatures / verifications / key generations).  What the reference does with one
+// state per Keccak core and a round per cycle (rtl_src/keccak_datapath.vhd:97,116-117; three cores, combined_top.v:225-231;
+// the challenge path gen_c.v:163-196,318-339).  keccak.hpp's lane-per-sponge forms run a 120..182-instruction round as one
+// dependent chain per lane; here a round is ~30 instructions:
+//
+//   lane L = 32 h + l : dword h (0 = low, 1 = high half) of state word w,  l = w (w < 15) or w + 1 (w >= 15), w = x + 5 y
+//   -> row 0 of a half-wave holds the planes y = 0, 1, 2 as three groups of five lanes, row 1 the planes y = 3, 4
+//      (lanes 15, 26..31 of each half idle and hold zero)
+//   theta  column parity: two DPP row shifts + one v_permlane16_swap; the x -+ 1 neighbours of the parity by DPP (cyclic over five
+//          lanes: a shifted copy supplies the wrapped lane); rot(C, 1) needs the other half: one v_permlane32_swap; D goes back
+//          to the other planes by two more row shifts
+//   rho+pi ONE gather: every lane fetches "its" source dword and that word's other half with two ds_bpermute_b32 (the half swap
+//          of the rotations by >= 32 is folded into the gather addresses) and one v_alignbit_b32 with a per-lane amount
+//   chi    the x + 1, x + 2 neighbours by DPP, one v_bitop3_b32
+//   iota   the round constants sit one per lane in a VGPR that shifts down one lane per round (DPP wave_shl:1)
+//
+// Written from FIPS 202; checked against the lane-per-sponge form and hashlib (tests/test_gpu_hash.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dil {
+
+__device__ __constant__ uint8_t KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+__device__ __constant__ uint32_t KECCAK_RC32[48] = {      // [0..24): low halves, [24..48): high halves
+    0x00000001u, 0x00008082u, 0x0000808au, 0x80008000u, 0x0000808bu, 0x80000001u, 0x80008081u, 0x00008009u,
+    0x0000008au, 0x00000088u, 0x80008009u, 0x8000000au, 0x8000808bu, 0x0000008bu, 0x00008089u, 0x00008003u,
+    0x00008002u, 0x00000080u, 0x0000800au, 0x8000000au, 0x80008081u, 0x00008080u, 0x80000001u, 0x80008008u,
+    0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u,
+    0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x80000000u,
+    0x80000000u, 0x80000000u, 0x00000000u, 0x80000000u, 0x80000000u, 0x80000000u, 0x00000000u, 0x80000000u};
+
+namespace coop {
+
+constexpr int SHL(int n) { return 0x100 | n; }       // DPP row_shl:n -- lane i reads lane i + n of its row of 16
+constexpr int SHR(int n) { return 0x110 | n; }       // DPP row_shr:n -- lane i reads lane i - n
+constexpr int WAVE_SHL1 = 0x130;                     // lane i reads lane i + 1 across the whole wave
+
+template <int CTRL, int ROWS = 0xF, int BANKS = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)           // lanes without a source (or masked off) read 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, BANKS, true);
+}
+template <int CTRL, int ROWS = 0xF, int BANKS = 0xF>
+__device__ __forceinline__ uint32_t dpp_keep(uint32_t old, uint32_t v)   // lanes without a source (or masked off) keep `old`
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, BANKS, false);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)   // mask ? a : b, bitwise (v_bfi_b32)
+{
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+
+__device__ __forceinline__ int lane_of_word(int w) { return w < 15 ? w : w + 1; }
+
+// The per-lane constants of the permutation and the sponge around it (a dozen VGPRs, computed once per kernel).
+struct Lane {
+    uint32_t idx_own, idx_par;   // ds_bpermute byte addresses of rho + pi
+    uint32_t sh;                 // v_alignbit amount
+    uint32_t m_g0;               // all-ones in the first five lanes of every row (where the parities live)
+    uint32_t m_x4, m_x3;         // all-ones where x == 4 / x >= 3 (the lanes whose x + 1 / x + 2 neighbour wraps)
+    uint32_t m_hi;               // all-ones in lanes 32..63
+    uint32_t m_iota;             // all-ones in lanes 0 and 32 (state word 0)
+    uint32_t rc0;                // round constants: lane r = low half of RC[r], lane 32 + r = high half
+    int word;                    // state word of this lane, -1 for an idle lane
+    int half;                    // 0 / 1
+    int dword;                   // 2 * word + half: this lane's dword of the state seen as 50 little-endian dwords (-1: idle)
+
+    __device__ __forceinline__ void init(int lane)
+    {
+        const int l = lane & 31;
+        half = lane >> 5;
+        const bool live = l < 26 && l != 15;
+        word = live ? (l < 15 ? l : l - 1) : -1;
+        dword = live ? 2 * word + half : -1;
+        const int X = live ? word % 5 : 0, Y = live ? word / 5 : 0;
+        const int ws = (X + 3 * Y) % 5 + 5 * X;                  // pi: b[X][Y] = rot(a[(X + 3 Y) % 5][X])
+        const int n = KECCAK_RHO[ws], m = n & 31;
+        const int hs = half ^ (n >= 32 ? 1 : 0);                 // rotation by >= 32 = half swap + rotation by n - 32
+        sh = (uint32_t)((32 - m) & 31);
+        idx_own = live ? 4u * (uint32_t)(32 * hs + lane_of_word(ws)) : 4u * (uint32_t)lane;
+        idx_par = live ? (m == 0 ? idx_own : 4u * (uint32_t)(32 * (hs ^ 1) + lane_of_word(ws))) : idx_own;
+        m_g0 = (lane & 15) < 5 ? ~0u : 0u;
+        m_x4 = live && X == 4 ? ~0u : 0u;
+        m_x3 = live && X >= 3 ? ~0u : 0u;
+        m_hi = half ? ~0u : 0u;
+        m_iota = l == 0 ? ~0u : 0u;
+        rc0 = l < 24 ? KECCAK_RC32[24 * half + l] : 0u;
+    }
+};
+
+// 24 rounds on the wave's state: v = this lane's dword (idle lanes: 0 in, 0 out)
+__device__ __forceinline__ uint32_t permute(uint32_t v, const Lane& k)
+{
+    uint32_t rc = k.rc0;
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        // theta
+        uint32_t p = v ^ dpp0<SHL(5)>(v);
+        p ^= dpp0<SHL(10), 0x5>(v);                                    // rows 0 / 2: the third plane of the row
+        const auto pq = __builtin_amdgcn_permlane16_swap(p, p, false, false);
+        const uint32_t c = pq[0] ^ pq[1];                                // column parity C[x] in the first five lanes of rows 0..3
+        const uint32_t cm = dpp_keep<SHR(1)>(dpp0<SHL(4)>(c), c);        // C[x - 1]: lane 0 has no source under row_shr:1 and keeps lane 4's
+        const uint32_t cp = dpp_keep<SHL(1), 0xF, 0xD>(dpp0<SHR(4)>(c), c);   // C[x + 1]: bank 1 (lane 4) keeps lane 0's
+        const auto hl = __builtin_amdgcn_permlane32_swap(cp, cp, false, false);    // [0] = low halves everywhere, [1] = high halves
+        const uint32_t other = bfi(k.m_hi, hl[0], hl[1]);
+        const uint32_t rot = __builtin_amdgcn_alignbit(cp, other, 31);   // this half of rot64(C[x + 1], 1)
+        const uint32_t d = __builtin_amdgcn_bitop3_b32(cm, rot, k.m_g0, 0x28);   // (cm ^ rot) & m_g0
+        v ^= d;
+        v ^= dpp0<SHR(5)>(d);
+        v ^= dpp0<SHR(10), 0x5>(d);
+        // rho + pi
+        const uint32_t own = (uint32_t)__builtin_amdgcn_ds_bpermute((int)k.idx_own, (int)v);
+        const uint32_t par = (uint32_t)__builtin_amdgcn_ds_bpermute((int)k.idx_par, (int)v);
+        const uint32_t b = __builtin_amdgcn_alignbit(own, par, k.sh);
+        // chi
+        const uint32_t b1 = bfi(k.m_x4, dpp0<SHR(4)>(b), dpp0<SHL(1)>(b));
+        const uint32_t b2 = bfi(k.m_x3, dpp0<SHR(3)>(b), dpp0<SHL(2)>(b));
+        v = __builtin_amdgcn_bitop3_b32(b, b1, b2, 0xD2);                // b ^ (~b1 & b2)
+        // iota
+        v = __builtin_amdgcn_bitop3_b32(v, rc, k.m_iota, 0x78);          // v ^ (rc & m_iota)
+        rc = dpp0<WAVE_SHL1>(rc);
+    }
+    return v;
+}
+
+}  // namespace coop
+}  // namespace dil

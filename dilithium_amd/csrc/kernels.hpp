@@ -109,6 +109,20 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
                         bool small_key = false);          // the caller vouches for |c s1|, |c s2| <= 1023 and |c t0| < 2^18 (a key decoded from sk
                                                           // bytes, c from SampleInBall): SmallPair / exact tails; false: any residues
 
+// ---- the same operations with one sponge per wavefront (coop_kernels.hip): what the launchers below run for calls with few sponges ----
+extern std::atomic<int> coop_max_sponges;          // option "coop_max": a call with at most this many sponges runs them one per wavefront (0: never)
+bool coop_wanted(size_t sponges);
+hipError_t launch_coop_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
+hipError_t launch_coop_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int w1_words, const uint8_t* expect,
+                                      size_t expect_stride, size_t batch, hipStream_t s);
+hipError_t launch_coop_challenge_sample(uint8_t* ctilde, int32_t* c, const uint8_t* mu, const uint8_t* w1p, int w1_words, int tau, size_t batch, hipStream_t s);
+hipError_t launch_coop_sample_in_ball(int32_t* c, uint32_t* cbits, const uint8_t* ctilde, size_t ct_stride, int tau, size_t nitems, hipStream_t s);   // c or cbits
+hipError_t launch_coop_expand_mask(void* y, bool raw, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
+hipError_t launch_coop_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int K, int L, size_t nitems, hipStream_t s);
+hipError_t launch_coop_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t rp_stride, int eta, int L, int K, size_t nitems, hipStream_t s);
+hipError_t launch_coop_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
+                          const uint32_t* lengths, int32_t* bad, size_t batch, hipStream_t s);
+
 // ---- row N1: SHAKE-bound samplers (hash_kernels.hip) ----
 hipError_t launch_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
 hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int level, size_t nitems, hipStream_t s, int a_fmt = A_I32);

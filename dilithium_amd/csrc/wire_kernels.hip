@@ -526,6 +526,7 @@ hipError_t launch_sample_in_ball_bits(uint32_t* cbits, const uint8_t* ctilde, si
     if (nitems == 0) return hipSuccess;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    if (coop_wanted(nitems)) return launch_coop_sample_in_ball(nullptr, cbits, ctilde, ct_stride, tau, nitems, s);
     hipLaunchKernelGGL(sample_in_ball_bits_kernel, (int)((nitems + 63) / 64), 64, 0, s, cbits, ctilde, ct_stride, tau, nitems);
     return hipGetLastError();
 }
