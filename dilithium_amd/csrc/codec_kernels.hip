@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 #include "modarith.hpp"
 #include "sampler_bodies.hpp"
+#include "coop_bodies.hpp"
 
 namespace dil {
 
@@ -98,8 +99,17 @@ template <int EB>
 __global__ __launch_bounds__(64) void keygen_finish_kernel(uint8_t* __restrict__ sk, size_t sk_bytes, const uint8_t* __restrict__ pk,
                                                            size_t pk_bytes, const uint8_t* __restrict__ e, const int32_t* __restrict__ s1,
                                                            const int32_t* __restrict__ s2, int L, int K, int32_t eta, unsigned h_blocks,
-                                                           size_t nkeys)
+                                                           size_t nkeys, int coop_h)
 {
+    if (blockIdx.x < h_blocks && coop_h) {         // few keys: a key per workgroup, its sponge spread over the wave (coop_bodies.hpp)
+        const size_t i = blockIdx.x;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sk + i * sk_bytes);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(e + i * 128);
+        if (threadIdx.x < 8) dst[threadIdx.x] = src[threadIdx.x];                    // rho
+        else if (threadIdx.x < 16) dst[threadIdx.x] = src[16 + threadIdx.x];         // key
+        coop::shake256_body(dst + 16, 4, reinterpret_cast<const uint32_t*>(pk + i * pk_bytes), (int)(pk_bytes / 8));
+        return;
+    }
     if (blockIdx.x < h_blocks) {
         const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
         const size_t i = t >> 1;
@@ -500,12 +510,13 @@ hipError_t launch_keygen_finish(uint8_t* sk, size_t sk_bytes, const uint8_t* pk,
     if (nkeys == 0) return hipSuccess;
     if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(e) | sk_bytes | pk_bytes) & 3)
         return hipErrorInvalidValue;
-    const unsigned h_blocks = (unsigned)((2 * nkeys + 63) / 64);
+    const int coop_h = coop_wanted(nkeys);
+    const unsigned h_blocks = coop_h ? (unsigned)nkeys : (unsigned)((2 * nkeys + 63) / 64);
     const size_t p_blocks = (nkeys * (size_t)(L + K) * 32 + 63) / 64;
     if (h_blocks + p_blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(h_blocks + p_blocks);
-    if (eta_bits == 3) hipLaunchKernelGGL(keygen_finish_kernel<3>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys);
-    else if (eta_bits == 4) hipLaunchKernelGGL(keygen_finish_kernel<4>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys);
+    if (eta_bits == 3) hipLaunchKernelGGL(keygen_finish_kernel<3>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys, coop_h);
+    else if (eta_bits == 4) hipLaunchKernelGGL(keygen_finish_kernel<4>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys, coop_h);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -224,6 +224,16 @@ __device__ __forceinline__ void shake256_body(uint32_t* __restrict__ out, int ou
     }
 }
 
+// rho' = SHAKE256(key (32 B) || mu (64 B), 64): deterministic signing's seed of the mask (combined_top.v sign set-up, :1694-1790)
+__device__ __forceinline__ void rhoprime_body(uint32_t* __restrict__ rp, const uint32_t* __restrict__ key, const uint32_t* __restrict__ mu)
+{
+    Sponge<17> sp;
+    sp.init(threadIdx.x);
+    sp.absorb_all([&](int d) { return d < 8 ? key[d] : mu[d - 8]; }, 12);
+    const int d = sp.k.dword;
+    if (d >= 0 && d < 16) rp[d] = sp.v;
+}
+
 // ExpandMask's sponge: SHAKE256(rho' (64 B) || LE16(nonce)), before its first permutation
 __device__ __forceinline__ void mask_seed(Sponge<17>& sp, const uint32_t* __restrict__ rhoprime, uint32_t nonce)
 {

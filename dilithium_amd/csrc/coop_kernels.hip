@@ -87,6 +87,45 @@ __global__ __launch_bounds__(64) void coop_mu_kernel(uint32_t* __restrict__ mu, 
     coop::mu_body(mu + i * 16, reinterpret_cast<const uint32_t*>(tr + i * tr_stride), inside ? msgs + off : msgs, inside ? len : 0u);
 }
 
+// Composite launches of the few-key paths, as in wire_kernels.hip / hash_kernels.hip: independent latency-bound jobs side by side in ONE launch.
+//   verification: A = ExpandA(rho) of the key(s) beside c = SampleInBall(c~) of the signatures
+__global__ __launch_bounds__(64) void coop_expand_a_sib_kernel(int32_t* __restrict__ A, const uint32_t* __restrict__ rho, size_t rho_stride_dwords, int K, int L,
+                                                               unsigned a_blocks, uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde,
+                                                               size_t ct_stride, int tau)
+{
+    __shared__ __attribute__((aligned(16))) coop::SibShared sh;
+    if (blockIdx.x < a_blocks) {
+        const size_t p = blockIdx.x, item = p / (size_t)(K * L);
+        const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
+        coop::expand_a_body(A + p * 256, rho + item * rho_stride_dwords, (uint32_t)j | ((uint32_t)i << 8), reinterpret_cast<uint32_t*>(sh.c));
+        return;
+    }
+    const size_t item = blockIdx.x - a_blocks;
+    coop::Sponge<17> sp;
+    sp.init(threadIdx.x);
+    coop::sib_seed(sp, ctilde + item * ct_stride);
+    coop::sib_sample(sp, tau, sh, threadIdx.x);
+    coop::sib_store_bits(cbits + item * 64, sh, threadIdx.x);
+}
+//   key generation: A = ExpandA(rho) beside (s1, s2) = ExpandS(rho')
+template <int ETA>
+__global__ __launch_bounds__(64) void coop_expand_a_s_kernel(int32_t* __restrict__ A, const uint32_t* __restrict__ rho, size_t rho_stride_dwords, int K, int L,
+                                                             unsigned a_blocks, int32_t* __restrict__ s1, int32_t* __restrict__ s2,
+                                                             const uint8_t* __restrict__ rhoprime, size_t rp_stride)
+{
+    __shared__ uint32_t blk[44];
+    if (blockIdx.x < a_blocks) {
+        const size_t p = blockIdx.x, item = p / (size_t)(K * L);
+        const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
+        coop::expand_a_body(A + p * 256, rho + item * rho_stride_dwords, (uint32_t)j | ((uint32_t)i << 8), blk);
+        return;
+    }
+    const size_t p = blockIdx.x - a_blocks, item = p / (size_t)(L + K);
+    const int j = (int)(p % (size_t)(L + K));
+    int32_t* out = j < L ? s1 + (item * L + j) * 256 : s2 + (item * K + (j - L)) * 256;
+    coop::expand_s_body<ETA>(out, rhoprime + item * rp_stride, (uint32_t)j, blk);
+}
+
 // ---- launchers (the callers have validated level / alignment) ----------------------------------------------------------------
 static inline bool grid_ok(size_t n) { return n > 0 && n <= 0x7fffffffull; }
 
@@ -147,6 +186,28 @@ hipError_t launch_coop_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprim
     if (!grid_ok(total)) return hipErrorInvalidValue;
     if (eta == 2) hipLaunchKernelGGL(coop_expand_s_kernel<2>, (unsigned)total, 64, 0, s, s1, s2, L, K, rhoprime, rp_stride);
     else hipLaunchKernelGGL(coop_expand_s_kernel<4>, (unsigned)total, 64, 0, s, s1, s2, L, K, rhoprime, rp_stride);
+    return hipGetLastError();
+}
+hipError_t launch_coop_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, size_t nkeys, int K, int L, uint32_t* cbits, const uint8_t* ctilde,
+                                    size_t ct_stride, int tau, size_t nitems, hipStream_t s)
+{
+    const size_t a_blocks = nkeys * (size_t)(K * L);
+    if (!grid_ok(a_blocks + nitems)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(coop_expand_a_sib_kernel, (unsigned)(a_blocks + nitems), 64, 0, s, A, reinterpret_cast<const uint32_t*>(rho), rho_stride_bytes / 4, K, L,
+                       (unsigned)a_blocks, cbits, ctilde, ct_stride, tau);
+    return hipGetLastError();
+}
+hipError_t launch_coop_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t rp_stride,
+                                  int K, int L, int eta, size_t nkeys, hipStream_t s)
+{
+    const size_t a_blocks = nkeys * (size_t)(K * L), s_blocks = nkeys * (size_t)(L + K);
+    if (!grid_ok(a_blocks + s_blocks)) return hipErrorInvalidValue;
+    if (eta == 2)
+        hipLaunchKernelGGL(coop_expand_a_s_kernel<2>, (unsigned)(a_blocks + s_blocks), 64, 0, s, A, reinterpret_cast<const uint32_t*>(rho), rho_stride_bytes / 4, K, L,
+                           (unsigned)a_blocks, s1, s2, rhoprime, rp_stride);
+    else
+        hipLaunchKernelGGL(coop_expand_a_s_kernel<4>, (unsigned)(a_blocks + s_blocks), 64, 0, s, A, reinterpret_cast<const uint32_t*>(rho), rho_stride_bytes / 4, K, L,
+                           (unsigned)a_blocks, s1, s2, rhoprime, rp_stride);
     return hipGetLastError();
 }
 hipError_t launch_coop_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,

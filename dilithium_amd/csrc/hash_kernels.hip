@@ -701,6 +701,7 @@ hipError_t launch_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_stride_b
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     if ((rho_stride_bytes & 7) || (reinterpret_cast<uintptr_t>(rho) & 7)) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    if (coop_wanted(nkeys * (size_t)(K * L))) return launch_coop_expand_a_s(A, rho, rho_stride_bytes, s1, s2, rhoprime, rp_stride, K, L, eta, nkeys, s);
     const unsigned a_blocks = (unsigned)((2 * nkeys * (size_t)(K * L) + HASH_BS - 1) / HASH_BS);
     const unsigned s_blocks = (unsigned)((nkeys * (size_t)(K + L) + HASH_BS - 1) / HASH_BS);
     if (eta == 2)

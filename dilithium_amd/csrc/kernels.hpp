@@ -120,6 +120,10 @@ hipError_t launch_coop_sample_in_ball(int32_t* c, uint32_t* cbits, const uint8_t
 hipError_t launch_coop_expand_mask(void* y, bool raw, const uint8_t* rhoprime, const uint32_t* kappa, int level, size_t nitems, hipStream_t s);
 hipError_t launch_coop_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int K, int L, size_t nitems, hipStream_t s);
 hipError_t launch_coop_expand_s(int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t rp_stride, int eta, int L, int K, size_t nitems, hipStream_t s);
+hipError_t launch_coop_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, size_t nkeys, int K, int L, uint32_t* cbits, const uint8_t* ctilde,
+                                    size_t ct_stride, int tau, size_t nitems, hipStream_t s);
+hipError_t launch_coop_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_stride_bytes, int32_t* s1, int32_t* s2, const uint8_t* rhoprime, size_t rp_stride,
+                                  int K, int L, int eta, size_t nkeys, hipStream_t s);
 hipError_t launch_coop_mu(uint8_t* mu, const uint8_t* tr, size_t tr_stride, const uint8_t* msgs, size_t msgs_bytes, const uint64_t* offsets,
                           const uint32_t* lengths, int32_t* bad, size_t batch, hipStream_t s);
 

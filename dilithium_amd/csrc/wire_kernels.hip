@@ -17,6 +17,7 @@
 #include "wire_common.hpp"
 #include "keccak.hpp"
 #include "sampler_bodies.hpp"
+#include "coop_bodies.hpp"
 
 namespace dil {
 
@@ -378,13 +379,19 @@ __global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A,
                                                         int32_t* __restrict__ s2h, int32_t* __restrict__ t0h, const uint8_t* __restrict__ sk,
                                                         size_t sk_bytes, size_t nk, uint64_t* __restrict__ rp, int32_t* __restrict__ attempts,
                                                         const uint64_t* __restrict__ mu, size_t key_stride, size_t batch,
-                                                        const uint32_t* __restrict__ fwd_tab)
+                                                        const uint32_t* __restrict__ fwd_tab, int coop_a, int coop_rp)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L, ETA = LEVEL == 3 ? 4 : 2, EB = LEVEL == 3 ? 4 : 3, NP = L + 2 * K;
     __shared__ uint32_t ring[CoeffSink::LDS_DWORDS_PER_WAVE];
     const int lane = threadIdx.x;
     if (blockIdx.x < a_blocks) {
-        expand_a_body<true>(A, reinterpret_cast<const uint64_t*>(sk), sk_bytes / 8, K, L, nk, blockIdx.x, ring);
+        if (coop_a) {                             // a polynomial per workgroup, its sponge spread over the wave (coop_bodies.hpp)
+            const size_t p = blockIdx.x, key = p / (size_t)(K * L);
+            const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
+            coop::expand_a_body(A + p * 256, reinterpret_cast<const uint32_t*>(sk + key * sk_bytes), (uint32_t)j | ((uint32_t)i << 8), ring);
+        } else {
+            expand_a_body<true>(A, reinterpret_cast<const uint64_t*>(sk), sk_bytes / 8, K, L, nk, blockIdx.x, ring);
+        }
         return;
     }
     const size_t u0 = blockIdx.x - a_blocks;
@@ -420,6 +427,13 @@ __global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A,
                                                              (int32_t)canon_any(r[3]));
       }
       return;
+    }
+    if (coop_rp) {                                // a message per workgroup
+        const size_t it = u0 - u_blocks;
+        coop::rhoprime_body(reinterpret_cast<uint32_t*>(rp + it * 8), reinterpret_cast<const uint32_t*>(sk + it * key_stride + 32),
+                            reinterpret_cast<const uint32_t*>(mu + it * 8));
+        if (lane == 0) attempts[it] = 0;
+        return;
     }
     const size_t item = (u0 - u_blocks) * 64 + lane;
     if (item >= batch) return;
@@ -491,14 +505,15 @@ hipError_t launch_sign_setup(int level, int32_t* A, bool expand_a_here, int32_t*
     if ((reinterpret_cast<uintptr_t>(sk) | reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(rp) | key_stride) & 7) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t skb = 96 + (size_t)(L + K) * 32 * (level == 3 ? 4 : 3) + (size_t)K * 416;
-    const unsigned a_blocks = expand_a_here ? (unsigned)((2 * nk * (size_t)(K * L) + 63) / 64) : 0u;
+    const int coop_a = expand_a_here && coop_wanted(nk * (size_t)(K * L)), coop_rp = coop_wanted(batch);
+    const unsigned a_blocks = !expand_a_here ? 0u : coop_a ? (unsigned)(nk * (size_t)(K * L)) : (unsigned)((2 * nk * (size_t)(K * L) + 63) / 64);
     const size_t npoly = nk * (size_t)(L + 2 * K);
     const unsigned u_blocks = (unsigned)std::min<size_t>(npoly, (size_t)t.num_cus * 32);       // 8 waves per SIMD, grid-stride over the polynomials
-    const size_t blocks = a_blocks + u_blocks + (batch + 63) / 64;
+    const size_t blocks = a_blocks + u_blocks + (coop_rp ? batch : (batch + 63) / 64);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
 #define DIL_SS(LV)                                                                                                                   \
     hipLaunchKernelGGL(sign_setup_kernel<LV>, (unsigned)blocks, 64, 0, s, A, a_blocks, u_blocks, s1h, s2h, t0h, sk, skb, nk,                   \
-                       reinterpret_cast<uint64_t*>(rp), attempts, reinterpret_cast<const uint64_t*>(mu), key_stride, batch, t.fwd)
+                       reinterpret_cast<uint64_t*>(rp), attempts, reinterpret_cast<const uint64_t*>(mu), key_stride, batch, t.fwd, coop_a, coop_rp)
     if (level == 2) DIL_SS(2);
     else if (level == 3) DIL_SS(3);
     else DIL_SS(5);
@@ -514,6 +529,8 @@ hipError_t launch_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride
     if ((rho_stride_bytes & 7) || (reinterpret_cast<uintptr_t>(rho) & 7)) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
+    if (coop_wanted(nkeys * (size_t)(K * L) + nitems))
+        return launch_coop_expand_a_sib(A, rho, rho_stride_bytes, nkeys, K, L, cbits, ctilde, ct_stride, tau, nitems, s);
     const unsigned a_blocks = (unsigned)((2 * nkeys * (size_t)(K * L) + 63) / 64);
     const unsigned c_blocks = (unsigned)((nitems + 63) / 64);
     hipLaunchKernelGGL(expand_a_sib_kernel, a_blocks + c_blocks, 64, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L,

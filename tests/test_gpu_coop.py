@@ -78,33 +78,6 @@ def test_challenge_hash_and_sample(gpu, coop, level, n):
     assert gpu.equal(s_a, s_b) and gpu.equal(s_a, c_a)
 
 
-def test_sample_in_ball_second_block(gpu, coop):
-    """a SampleInBall that needs MORE than the 128 candidate bytes of its first rate block: searched for on the host (about one c~ in
-    10^5 at level 5), then the device forms must follow the sampler into the second block"""
-    from dilithium_amd import api
-    p = dk.PARAMS[5]
-    found = []
-    k = 0
-    while len(found) < 2 and k < 2_000_000:
-        ct = hashlib.sha256(b"sib" + k.to_bytes(4, "little")).digest()
-        stream = hashlib.shake_256(ct).digest(136)
-        i, used = 256 - p.tau, 8
-        while i < 256 and used < 136:
-            if stream[used] <= i:
-                i += 1
-            used += 1
-        if i < 256:
-            found.append(ct)
-        k += 1
-    if not found:
-        pytest.skip("no two-block SampleInBall seed found in the search budget")
-    ct = np.frombuffer(b"".join(found), dtype=np.uint8).reshape(-1, 32)
-    a, b = coop(lambda: api.sample_in_ball(cu(gpu, ct), 5))
-    assert gpu.equal(a, b)
-    for i in range(len(found)):
-        assert (a[i].cpu().numpy() == dk.canon(dk.sample_in_ball(p, found[i]))).all()
-
-
 @pytest.mark.parametrize("level", [2, 3, 5])
 @pytest.mark.parametrize("n", [1, 63, 1101])
 def test_expand_mask(gpu, coop, level, n):
