@@ -92,8 +92,9 @@ struct Lane {
     }
 };
 
-// 24 rounds on the wave's state: v = this lane's dword (idle lanes: 0 in, 0 out)
-__device__ __forceinline__ uint32_t permute(uint32_t v, const Lane& k)
+// 24 rounds on the wave's state: v = this lane's dword (idle lanes: 0 in, 0 out).  Reference form, as the compiler schedules it
+// (34 VALU instructions per round); permute() below is the same round written out by hand.
+__device__ __forceinline__ uint32_t permute_c(uint32_t v, const Lane& k)
 {
     uint32_t rc = k.rc0;
 #pragma unroll 1
@@ -124,6 +125,71 @@ __device__ __forceinline__ uint32_t permute(uint32_t v, const Lane& k)
         v = __builtin_amdgcn_bitop3_b32(v, rc, k.m_iota, 0x78);          // v ^ (rc & m_iota)
         rc = dpp0<WAVE_SHL1>(rc);
     }
+    return v;
+}
+
+// The same 24 rounds by hand: 29 VALU instructions per round.  What the compiler cannot do: fold the row shifts into the xors
+// (v_xor_b32_dpp), select the wrapped x + 1 neighbour with v_cndmask_b32_dpp under a loop-invariant VCC (= lanes with x != 4), place the
+// independent instructions into the wait states the DPP / v_permlane reads need after a VALU write, and run the iota bookkeeping under
+// the gather's LDS round trip.
+__device__ __forceinline__ uint32_t permute(uint32_t v, const Lane& k)
+{
+    uint32_t rc = k.rc0, p, q, cm, cp, t, u, d, own, par, b, b1, b2, ri;
+    const uint64_t not_x4 = __builtin_amdgcn_ballot_w64(k.m_x4 == 0);
+    asm volatile(
+        "s_mov_b64 vcc, %[nx4]\n\t"
+        "s_movk_i32 s30, 24\n"
+        "1:\n\t"
+        // theta: column parity
+        "v_xor_b32_dpp %[p], %[v], %[v] row_shl:5 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_and_b32 %[ri], %[rc], %[mi]\n\t"
+        "v_xor_b32_dpp %[p], %[v], %[p] row_shl:10 row_mask:0x5 bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32 %[q], %[p]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %[p], %[q]\n\t"
+        "v_xor_b32 %[p], %[p], %[q]\n\t"
+        "v_mov_b32_dpp %[rc], %[rc] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 0\n\t"
+        // C[x - 1], C[x + 1] (cyclic over the five lanes of the first group of each row)
+        "v_mov_b32_dpp %[cm], %[p] row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[cp], %[p] row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[cm], %[p] row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[cp], %[p] row_shl:1 row_mask:0xf bank_mask:0xd\n\t"
+        "v_mov_b32 %[t], %[cp]\n\t"
+        "v_mov_b32 %[u], %[cp]\n\t"
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %[t], %[u]\n\t"
+        "v_bfi_b32 %[t], %[mh], %[t], %[u]\n\t"
+        "v_alignbit_b32 %[t], %[cp], %[t], 31\n\t"
+        "v_bitop3_b32 %[d], %[cm], %[t], %[mg] bitop3:0x28\n\t"
+        "v_xor_b32 %[v], %[v], %[d]\n\t"
+        "s_nop 0\n\t"
+        "v_xor_b32_dpp %[v], %[d], %[v] row_shr:5 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_xor_b32_dpp %[v], %[d], %[v] row_shr:10 row_mask:0x5 bank_mask:0xf bound_ctrl:0\n\t"
+        // rho + pi
+        "ds_bpermute_b32 %[own], %[io], %[v]\n\t"
+        "ds_bpermute_b32 %[par], %[ip], %[v]\n\t"
+        "s_add_i32 s30, s30, -1\n\t"
+        "s_cmp_lg_u32 s30, 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_alignbit_b32 %[b], %[own], %[par], %[sh]\n\t"
+        "s_nop 1\n\t"
+        // chi
+        "v_mov_b32_dpp %[b1], %[b] row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[b2], %[b] row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_mov_b32_dpp %[t], %[b] row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_cndmask_b32_dpp %[b1], %[b], %[b1], vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_bfi_b32 %[b2], %[m3], %[t], %[b2]\n\t"
+        "v_bitop3_b32 %[v], %[b], %[b1], %[b2] bitop3:0xd2\n\t"
+        // iota
+        "v_xor_b32 %[v], %[v], %[ri]\n\t"
+        "s_nop 0\n\t"                      // (the next round opens with a DPP read of v)
+        "s_cbranch_scc1 1b\n\t"
+        : [v] "+v"(v), [rc] "+v"(rc), [p] "=&v"(p), [q] "=&v"(q), [cm] "=&v"(cm), [cp] "=&v"(cp), [t] "=&v"(t), [u] "=&v"(u), [d] "=&v"(d),
+          [own] "=&v"(own), [par] "=&v"(par), [b] "=&v"(b), [b1] "=&v"(b1), [b2] "=&v"(b2), [ri] "=&v"(ri)
+        : [nx4] "s"(not_x4), [mi] "v"(k.m_iota), [mh] "v"(k.m_hi), [mg] "v"(k.m_g0), [m3] "v"(k.m_x3), [io] "v"(k.idx_own), [ip] "v"(k.idx_par),
+          [sh] "v"(k.sh)
+        : "vcc", "scc", "s30", "memory");
     return v;
 }
 
