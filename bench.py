@@ -24,6 +24,11 @@ Also reported on the same JSON line:
                 restatement (kind "port") -- on one host core, bounded sample.
   secondary     Dilithium-3 verify cores / s (configs[3], batch 8192, distinct pk) with its own
                 roofline fraction; and the final RCCL gather time when N > 1.
+  end_to_end    SURVEY 8(d): the same two workloads through the HOST-pointer entry points (H2D + kernel + D2H), pageable and
+                page-locked caller buffers, against the link's own copy rate measured in the run; never `value`.
+
+Layout: `Bench` holds what every leg shares (library handle, streams, the event-timed `timed()` region, the clock probe);
+one function per leg fills its part of the JSON line; main() strings them together.
 """
 import argparse
 import json
@@ -250,66 +255,54 @@ def pmc_sign_valu():
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--prewarm-ms", type=float, default=200.0,
-                    help="untimed: keep launching steps for this long before the W warm-up steps, so that the GPU has "
-                         "left its idle power state (short runs measured 10 %% low without it)")
-    ap.add_argument("--rotate", type=int, default=8, help="distinct resident batches the steps rotate over")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the steps alternate over (step i runs on stream i %% S; a batch always stays on one "
-                         "stream).  2 keeps a second launch in flight, which fills the dispatch gap and the ramp/tail of "
-                         "every kernel: +15 %% over one stream")
-    ap.add_argument("--region-ms", type=float, default=50.0,
-                    help="a timed region of the headline is a whole number of K-step groups at least this long")
-    ap.add_argument("--regions", type=int, default=7, help="timed regions of the headline (at least)")
-    ap.add_argument("--total-ms", type=float, default=400.0, help="the headline's regions add up to at least this much")
-    ap.add_argument("--min-ms", type=float, default=25.0,
-                    help="every secondary leg is timed for at least this long, whatever --steps says")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--no-verify-overlap", action="store_true",
-                    help="skip the two-stream leg of the secondary verify core (profiling runs: keeps rocprofv3's average "
-                         "duration of verify_wpi_kernel a single-kernel figure)")
-    args = ap.parse_args()
 
-    from dilithium_amd import api, sharding
-    from dilithium_amd import lib as dlib
-    import ctypes as C
 
-    rank, world, local = sharding.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = sharding.local_device(local)
-    torch.cuda.set_device(dev)
-    api.init(dev)
-    L = dlib.load()
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+class Bench:
+    """what the legs share: arguments, the library, streams, the timing helpers"""
 
-    def ev():
-        e = C.c_void_p()
-        dlib.check(L.dil_event_create(C.byref(e)))
+    def __init__(self, args):
+        from dilithium_amd import api, sharding
+        from dilithium_amd import lib as dlib
+        import ctypes as C
+        self.args, self.api, self.sharding, self.dlib, self.C = args, api, sharding, dlib, C
+        self.rank, self.world, self.local = sharding.init_distributed()
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}"
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        self.dev = sharding.local_device(self.local)
+        torch.cuda.set_device(self.dev)
+        api.init(self.dev)
+        self.L = dlib.load()
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        self.probe_stream = torch.cuda.Stream()
+        self.probe_buf = torch.zeros(4, dtype=torch.int64, device="cuda")
+        self.probe_effect = {}
+        self.last_regions = []
+        self.NS = max(1, args.streams)
+        self.tstreams = [torch.cuda.Stream() for _ in range(self.NS)] if self.NS > 1 else [torch.cuda.current_stream()]
+        self.hstreams = [C.c_void_p(ts.cuda_stream) for ts in self.tstreams]
+
+    def ev(self):
+        e = self.C.c_void_p()
+        self.dlib.check(self.L.dil_event_create(self.C.byref(e)))
         return e
 
-    def elapsed(a, b):
-        ms = C.c_float()
-        dlib.check(L.dil_event_elapsed_ms(C.byref(ms), a, b))
+    def elapsed(self, a, b):
+        ms = self.C.c_float()
+        self.dlib.check(self.L.dil_event_elapsed_ms(self.C.byref(ms), a, b))
         return float(ms.value)
 
-    def timed(fn, st=None, min_ms=None):
+    def timed(self, fn, st=None, min_ms=None):
         """average milliseconds per call of fn() (direct C-ABI launches on stream `st`): HIP events around a region that is
         at least min_ms long -- the repeat count comes from a calibration pass, not from --steps.  One region unmeasured, then three measured ones of which the
         MEDIAN counts: the composite calls synchronise with the host every rejection round, and one descheduling of this
         process inside a 25-ms region was seen to halve a rate (profiles/r04zz_bench.log, sign at 8192: 3.9 M/s beside 6.5-6.8
         in the same visit's other two bench runs); the median shrugs one such region off without favouring a fast one (the
         fastest of the three can be a region at a higher clock).  Returns (ms per call, calls in a measured region)."""
-        st = stream if st is None else st
-        min_ms = args.min_ms if min_ms is None else min_ms
-        e0, e1 = ev(), ev()
+        L, dlib = self.L, self.dlib
+        st = self.stream if st is None else st
+        min_ms = self.args.min_ms if min_ms is None else min_ms
+        e0, e1 = self.ev(), self.ev()
         reps, used, rc, pers = 4, 4, 0, []
         for phase in range(6):                   # warm-up, calibrate, one full region unmeasured, then the three measured regions
             L.dil_event_record(e0, st)           # (the chip needs > 50 ms of a kernel's load to settle: the fused verify core ran
@@ -317,21 +310,16 @@ def main():
                 rc |= fn(i)                      #  the next two -- profiles/r04w_verify_transient.txt has the curve after idle)
             L.dil_event_record(e1, st)
             used = reps
-            per = max(elapsed(e0, e1) / reps, 1e-4)
+            per = max(self.elapsed(e0, e1) / reps, 1e-4)
             if phase >= 3:
                 pers.append(per)
             elif phase < 2:
                 reps = max(10, int(min_ms / per) + 1)
         dlib.check(rc, "timed launches")
-        timed.last_regions = list(pers)
+        self.last_regions = list(pers)
         return sorted(pers)[1], used
 
-    probe_stream = torch.cuda.Stream()
-    probe_buf = torch.zeros(4, dtype=torch.int64, device="cuda")
-
-    probe_effect = {}
-
-    def with_clock(fn, span_ms, tag=None):
+    def with_clock(self, fn, span_ms, tag=None):
         """fn() ALONE on the device is the measurement; then fn() once more while a one-lane probe kernel on a side stream
         measures the effective shader clock over about span_ms (csrc/kernels.hip clock_probe_kernel: shader cycles per 100 MHz
         tick).  Two passes because the probe is not free for every kernel: a second active queue was seen to cost the fused
@@ -340,20 +328,26 @@ def main():
         res = fn()
         try:
             torch.cuda.synchronize()
-            dlib.check(L.dil_clock_probe_dev(P(probe_buf), max(1000, int(span_ms * 1000)), C.c_void_p(probe_stream.cuda_stream)), "clock probe")
+            self.dlib.check(self.L.dil_clock_probe_dev(self.P(self.probe_buf), max(1000, int(span_ms * 1000)),
+                                                        self.C.c_void_p(self.probe_stream.cuda_stream)), "clock probe")
             again = fn()
-            probe_stream.synchronize()
+            self.probe_stream.synchronize()
             if tag:
-                probe_effect[tag] = again
-            c0, c1, r0, r1 = [int(x) for x in probe_buf.cpu().tolist()]
+                self.probe_effect[tag] = again
+            c0, c1, r0, r1 = [int(x) for x in self.probe_buf.cpu().tolist()]
             mhz = (c1 - c0) / max(1, r1 - r0) * 100.0
             return res, (mhz if 200.0 < mhz < 5000.0 else None)
         except Exception:   # noqa: BLE001
             return res, None
 
+
+def leg_headline(cx):
+    """BASELINE configs[1]: the timed regions of `value`, the one-stream per-kernel roofline, its in-run yardstick (the traffic-only
+    skeleton), the LLC-resident variant.  Returns the JSON line's top level."""
+    args, api, sharding, dlib, C, L, P, stream = cx.args, cx.api, cx.sharding, cx.dlib, cx.C, cx.L, cx.P, cx.stream
+    rank, world, NS, hstreams, timed, with_clock, probe_effect = cx.rank, cx.world, cx.NS, cx.hstreams, cx.timed, cx.with_clock, cx.probe_effect
     # ---- inputs, resident in HBM ------------------------------------------------------------
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    NS = max(1, args.streams)
     R = max(1, args.rotate)
     R += (-R) % NS                                        # a batch must always meet the same stream
     bufs = [torch.randint(0, 8380417, (BATCH, 256), dtype=torch.int32, device="cuda", generator=g) for _ in range(R)]
@@ -361,9 +355,6 @@ def main():
     torch.cuda.synchronize()
 
     ptrs = [P(b) for b in bufs]                           # direct C-ABI calls: minimal host overhead
-    tstreams = [torch.cuda.Stream() for _ in range(NS)] if NS > 1 else [torch.cuda.current_stream()]
-    hstreams = [C.c_void_p(ts.cuda_stream) for ts in tstreams]
-
     def step(i, fixed=None, one=False):
         p = ptrs[(i % R) if fixed is None else (fixed + i % NS)]
         st = hstreams[0] if one else hstreams[i % NS]
@@ -500,304 +491,395 @@ def main():
                        shader_mhz_source="in-kernel probe on a side stream over the one-stream regions: shader cycle counter (s_memtime) "
                                          "against the constant 100 MHz counter (s_memrealtime); data-sheet maximum 2400"),
     }
-    if world > 1:       # falsifiable on the multi-GPU node: what RCCL itself says about the job, and where every rank sits
-        ones = torch.ones(1, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(ones)
-        props = torch.cuda.get_device_properties(dev)
-        mine = {"rank": rank, "local_rank": local, "device": int(dev), "name": props.name,
-                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
-        everyone = [None] * world
-        torch.distributed.all_gather_object(everyone, mine)
-        out["distributed"] = {"backend": torch.distributed.get_backend(), "rccl_nranks": int(round(float(ones.item()))),
-                              "world_size": torch.distributed.get_world_size(), "ranks": everyone,
-                              "distinct_devices": len({(e["device"], e["pci_bus_id"], e["uuid"]) for e in everyone})}
+    return out
 
-    # ---- secondary: Dilithium-3 verify core, configs[3], and the other configs -------------------
-    if not args.no_secondary:
-        cu = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
-        VSETS = 2                    # rotate over 2 input sets (2 x 360 MiB > the 256 MiB Infinity Cache): HBM-streaming
-        vsets = []
-        for j in range(VSETS):
-            A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank + 100 * j)
-            if os.environ.get("DIL_BENCH_VERIFY_UNIFORM"):     # experiment: uniform residues everywhere, as scripts/ab_verify.py feeds the kernel
-                gz = torch.Generator(device="cuda").manual_seed(j)
-                ur = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=gz)  # noqa: E731
-                vsets.append((ur(VBATCH, 6, 5, 256), ur(VBATCH, 5, 256), ur(VBATCH, 256), cu(t1_), cu(h),
-                              torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
-                continue
-            vsets.append((cu(A), cu(z), cu(c), cu(t1_), cu(h), torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
-        dA, dz, dc, dt1, dh, w1 = vsets[0]
-        vptr = [[P(t) for t in vs_] for vs_ in vsets]
-        torch.cuda.synchronize()
 
-        def vstep(i):
+def leg_distributed(cx, out):
+    """falsifiable on the multi-GPU node: what RCCL itself says about the job, and where every rank sits"""
+    rank, world = cx.rank, cx.world
+    ones = torch.ones(1, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+    torch.distributed.all_reduce(ones)
+    props = torch.cuda.get_device_properties(cx.dev)
+    mine = {"rank": rank, "local_rank": cx.local, "device": int(cx.dev), "name": props.name,
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+    everyone = [None] * world
+    torch.distributed.all_gather_object(everyone, mine)
+    out["distributed"] = {"backend": torch.distributed.get_backend(), "rccl_nranks": int(round(float(ones.item()))),
+                          "world_size": torch.distributed.get_world_size(), "ranks": everyone,
+                          "distinct_devices": len({(e["device"], e["pci_bus_id"], e["uuid"]) for e in everyone})}
+    try:      # which RCCL this is (multi_gpu.hip binds the same library at run time)
+        out["distributed"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        import ctypes.util
+        out["distributed"]["librccl"] = next((ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln), ctypes.util.find_library("rccl"))
+    except Exception as e:  # noqa: BLE001
+        out["distributed"]["rccl_version"] = repr(e)
+
+
+def leg_verify_core(cx):
+    """BASELINE configs[3]: the fused level-3 verify core, a key per item, rotating over input sets larger than the Infinity Cache"""
+    args, api, sharding, dlib, C, L, P, stream = cx.args, cx.api, cx.sharding, cx.dlib, cx.C, cx.L, cx.P, cx.stream
+    rank, world, NS, hstreams, timed, with_clock, probe_effect = cx.rank, cx.world, cx.NS, cx.hstreams, cx.timed, cx.with_clock, cx.probe_effect
+    cu = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
+    # rotate over FOUR input sets (1.44 GB, 5.6 x the 256 MiB Infinity Cache).  Rounds 1-4 rotated over two (720 MiB) and called that
+    # HBM-streaming; it is not: the cache keeps part of a set across one intervening launch -- 61.7 us per launch over two sets, 71.4 over
+    # three, four, six or eight (profiles/r05i_rotating_sets.txt).  The two-set figure stays beside this one as `two_rotating_sets`.
+    VSETS = 4
+    vsets = []
+    for j in range(VSETS):
+        A, z, c, t1_, h = synth_verify(VBATCH, 77 + rank + 100 * j)
+        if os.environ.get("DIL_BENCH_VERIFY_UNIFORM"):     # experiment: uniform residues everywhere, as scripts/ab_verify.py feeds the kernel
+            gz = torch.Generator(device="cuda").manual_seed(j)
+            ur = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=gz)  # noqa: E731
+            vsets.append((ur(VBATCH, 6, 5, 256), ur(VBATCH, 5, 256), ur(VBATCH, 256), cu(t1_), cu(h),
+                          torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
+            continue
+        vsets.append((cu(A), cu(z), cu(c), cu(t1_), cu(h), torch.empty((VBATCH, 6, 256), dtype=torch.uint8, device="cuda")))
+    dA, dz, dc, dt1, dh, w1 = vsets[0]
+    vptr = [[P(t) for t in vs_] for vs_ in vsets]
+    torch.cuda.synchronize()
+
+    def vstep(i):
+        pA, pz, pc, pt1, ph, pw1 = vptr[i % VSETS]
+        return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, stream)
+
+    sharding.barrier()
+    v_regions = []
+
+    def timed_v():
+        r = timed(vstep)
+        v_regions.append(list(cx.last_regions))
+        return r
+    (v_ms, v_reps), v_mhz = with_clock(timed_v, 5 * args.min_ms, "verify")
+    v_ms = sharding.max_over_ranks(v_ms)
+    v_gbs = VERIFY3_BYTES * VBATCH / (v_ms * 1e-3) / 1e9
+    vtraffic = pmc_traffic("verify_kernel")
+    sec = {"metric": "dilithium3_verify_cores_per_sec", "value": world * VBATCH / (v_ms * 1e-3), "unit": "verify/s",
+           "config": {"workload": "BASELINE configs[3]: level-3 verify core (NTT z, A.z - c.t1.2^d, INTT, "
+                                  "UseHint -> w1), batch=8192 per GPU, distinct pk (A, t1 per item)",
+                      "bytes_per_verify": VERIFY3_BYTES, "streams": 1, "rotating_input_sets": VSETS, "timed_launches": v_reps},
+           "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": vtraffic,
+                        "traffic_source": "profiles/pmc_summary.json (committed PMC passes)" if vtraffic else None,
+                        "avg_launch_ms": v_ms, "shader_mhz_observed": v_mhz,
+                        "avg_launch_ms_beside_clock_probe": probe_effect.get("verify", (None,))[0],
+                        "region_ms": {"alone": v_regions[0] if v_regions else None,
+                                      "beside_clock_probe": v_regions[1] if len(v_regions) > 1 else None}}}
+    # the same launches alternating over TWO streams (input set j on stream j): the next launch's ramp hides the
+    # previous one's tail and the dispatch gap -- the aggregate rate, reported beside the single-kernel fraction
+    if NS > 1 and not args.no_verify_overlap:
+        def vstep2(i):
             pA, pz, pc, pt1, ph, pw1 = vptr[i % VSETS]
-            return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, stream)
+            return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, hstreams[i % 2])     # (set i % 4 always meets stream i % 2)
+        reps2 = max(20, 2 * (v_reps // 2))
+        rc2 = 0
+        for i in range(8):
+            rc2 |= vstep2(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps2):
+            rc2 |= vstep2(i)
+        torch.cuda.synchronize()
+        dlib.check(rc2, "overlapped verify launches")
+        v2_ms = sharding.max_over_ranks((time.perf_counter() - t0) / reps2 * 1e3)
+        v2_gbs = VERIFY3_BYTES * VBATCH / (v2_ms * 1e-3) / 1e9
+        sec["roofline"].update({"achieved_overlapped": v2_gbs, "frac_overlapped": v2_gbs / HBM_PEAK_GBS,
+                                "concurrent_launches_overlapped": 2, "overlapped_value": world * VBATCH / (v2_ms * 1e-3),
+                                "timing": "frac = per-launch share of back-to-back launches on ONE stream (HIP events, the median of three regions); "
+                                          "frac_overlapped = the same launches alternating over two streams, host clock around "
+                                          "a synchronised region"})
+    # the same launches over ONE input set (360 MiB, partly served by the 256 MiB Infinity Cache), for context
+    l_ms, _ = timed(lambda i: L.dil_verify_core_dev(vptr[0][5], vptr[0][0], vptr[0][1], vptr[0][2], vptr[0][3], vptr[0][4], 3,
+                                                    VBATCH, 0, stream))
+    sec["llc_assisted_value"] = world * VBATCH / (l_ms * 1e-3)
+    # same pipeline with ONE public key for the whole batch (A, t1 staged in LDS): VALU-bound, reported beside it
+    s_ms, _ = timed(lambda i: L.dil_verify_core_dev(vptr[i % VSETS][5], vptr[0][0], vptr[i % VSETS][1], vptr[i % VSETS][2],
+                                                    vptr[0][3], vptr[i % VSETS][4], 3, VBATCH, 1, stream))
+    sec["shared_pk"] = {"value": VBATCH / (s_ms * 1e-3), "unit": "verify/s per GPU", "avg_launch_ms": s_ms,
+                        "bytes_per_verify": 15 * 1024, "kernel": "verify_shared_kernel<3,16>",
+                        "bound": "valu (key material LDS-resident)"}
+    # the same over TWO rotating sets, as rounds 1-4 measured this leg: partly served by the Infinity Cache
+    t_ms, _ = timed(lambda i: L.dil_verify_core_dev(vptr[i % 2][5], vptr[i % 2][0], vptr[i % 2][1], vptr[i % 2][2], vptr[i % 2][3], vptr[i % 2][4], 3,
+                                                    VBATCH, 0, stream))
+    sec["two_rotating_sets"] = {"value": world * VBATCH / (t_ms * 1e-3), "avg_launch_ms": t_ms, "bytes_resident": 2 * VERIFY3_BYTES * VBATCH,
+                                "frac": VERIFY3_BYTES * VBATCH / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "LLC-assisted: what BENCH_r01..r04 reported as the secondary value"}
+    return sec
 
-        sharding.barrier()
-        v_regions = []
 
-        def timed_v():
-            r = timed(vstep)
-            v_regions.append(list(timed.last_regions))
-            return r
-        (v_ms, v_reps), v_mhz = with_clock(timed_v, 5 * args.min_ms, "verify")
-        v_ms = sharding.max_over_ranks(v_ms)
-        v_gbs = VERIFY3_BYTES * VBATCH / (v_ms * 1e-3) / 1e9
-        vtraffic = pmc_traffic("verify_kernel")
-        sec = {"metric": "dilithium3_verify_cores_per_sec", "value": world * VBATCH / (v_ms * 1e-3), "unit": "verify/s",
-               "config": {"workload": "BASELINE configs[3]: level-3 verify core (NTT z, A.z - c.t1.2^d, INTT, "
-                                      "UseHint -> w1), batch=8192 per GPU, distinct pk (A, t1 per item)",
-                          "bytes_per_verify": VERIFY3_BYTES, "streams": 1, "rotating_input_sets": VSETS, "timed_launches": v_reps},
-               "roofline": {"bound": "hbm", "kernel": "verify_wpi_kernel<3>", "achieved": v_gbs, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": v_gbs / HBM_PEAK_GBS, "traffic": vtraffic,
-                            "traffic_source": "profiles/pmc_summary.json (committed PMC passes)" if vtraffic else None,
-                            "avg_launch_ms": v_ms, "shader_mhz_observed": v_mhz,
-                            "avg_launch_ms_beside_clock_probe": probe_effect.get("verify", (None,))[0],
-                            "region_ms": {"alone": v_regions[0] if v_regions else None,
-                                          "beside_clock_probe": v_regions[1] if len(v_regions) > 1 else None}}}
-        # the same launches alternating over TWO streams (input set j on stream j): the next launch's ramp hides the
-        # previous one's tail and the dispatch gap -- the aggregate rate, reported beside the single-kernel fraction
-        if NS > 1 and not args.no_verify_overlap:
-            def vstep2(i):
-                pA, pz, pc, pt1, ph, pw1 = vptr[i % VSETS]
-                return L.dil_verify_core_dev(pw1, pA, pz, pc, pt1, ph, 3, VBATCH, 0, hstreams[i % 2])
-            reps2 = max(20, 2 * (v_reps // 2))
-            rc2 = 0
-            for i in range(8):
-                rc2 |= vstep2(i)
+def leg_other_configs(cx, sec):
+    """configs[2] (level-2 mat-vec, per-item and shared matrix) and configs[4]'s per-GPU slice (level-5 sign attempt), for the record"""
+    args, api, sharding, dlib, C, L, P, stream = cx.args, cx.api, cx.sharding, cx.dlib, cx.C, cx.L, cx.P, cx.stream
+    rank, world, NS, hstreams, timed, with_clock, probe_effect = cx.rank, cx.world, cx.NS, cx.hstreams, cx.timed, cx.with_clock, cx.probe_effect
+    # configs[2] and configs[4] of BASELINE.json (parity-test configs; timed here for the record only)
+    g2 = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=g2)  # noqa: E731
+    try:
+        A2 = [rnd(4096, 4, 4, 256) for _ in range(16)]          # 16 x 64 MiB of A (4 x the Infinity Cache): rotating, HBM-streaming (rounds 1-4: 4 matrices = 256 MiB, LLC-assisted)
+        y2, wout = rnd(4096, 4, 256), torch.empty((4096, 4, 256), dtype=torch.int32, device="cuda")
+        m_ms, _ = timed(lambda i: L.dil_matvec_dev(P(wout), P(A2[i % 16]), P(y2), 2, 4096, 0, stream))
+        ms_ms, _ = timed(lambda i: L.dil_matvec_dev(P(wout), P(A2[0]), P(y2), 2, 4096, 1, stream))     # ONE matrix for the batch (SURVEY 8d: report both)
+        # a real key and real challenges (phase 2 reads c s1 and c s2 off one transform, exact for valid inputs: DESIGN.md 4)
+        small = lambda lim, *sh: (torch.randint(-lim, lim + 1, sh, dtype=torch.int64, device="cuda", generator=g2) % 8380417).to(torch.int32)  # noqa: E731
+        A5, y5 = rnd(1, 8, 7, 256), small((1 << 19) - 1, 8192, 7, 256)
+        c5 = api.sample_in_ball(torch.randint(0, 256, (8192, 32), dtype=torch.uint8, device="cuda", generator=g2), 5)
+        s1h, s2h, t0h = small(2, 1, 7, 256), small(2, 1, 8, 256), small(4095, 1, 8, 256)
+        for t in (s1h, s2h, t0h):
+            api.ntt(t)
+        w1s = torch.empty((8192, 8, 256), dtype=torch.uint8, device="cuda")
+        w0s = torch.empty((8192, 8, 256), dtype=torch.int32, device="cuda")
+        z5 = torch.empty((8192, 7, 256), dtype=torch.int32, device="cuda")
+        h5 = torch.empty((8192, 8, 256), dtype=torch.uint8, device="cuda")
+        f5 = torch.empty((8192,), dtype=torch.int32, device="cuda")
+
+        def attempt(i):
+            return L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream) | \
+                L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1, 0, stream)
+        (a_ms, _), sign_mhz = with_clock(lambda: timed(attempt), 5 * args.min_ms, "attempt")
+        # the same pair over TWO rotating sets of buffers (2 x 223 MB: past the 256 MiB Infinity Cache), as the headline and the
+        # verify leg are measured: the HBM-streaming figure.  (One set = 223 MB is largely cache-resident.)
+        y5b = small((1 << 19) - 1, 8192, 7, 256)
+        c5b = api.sample_in_ball(torch.randint(0, 256, (8192, 32), dtype=torch.uint8, device="cuda", generator=g2), 5)
+        rot = [(y5, c5, w1s, w0s, z5, h5), (y5b, c5b, torch.empty_like(w1s), torch.empty_like(w0s), torch.empty_like(z5), torch.empty_like(h5))]
+
+        def attempt_rot(i):
+            yy, cc, ww1, ww0, zz, hh = rot[i & 1]
+            return L.dil_sign_phase1_dev(P(ww1), P(ww0), P(A5), P(yy), 5, 8192, 1, stream) | \
+                L.dil_sign_phase2_skey_dev(P(zz), P(hh), P(f5), P(cc), P(yy), P(ww0), P(ww1), P(s1h), P(s2h), P(t0h), 5, 8192, 1, 0, stream)
+        ar_ms, _ = timed(attempt_rot)
+        p1_ms, _ = timed(lambda i: L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream))
+        p2_ms, _ = timed(lambda i: L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1,
+                                                              0, stream))
+        sv = pmc_sign_valu()
+        sec["other_configs"] = {
+            "configs[2] level-2 A.y matvec batch=4096 distinct A (16 rotating matrices)": {
+                "matvecs_per_s": 4096 / (m_ms * 1e-3), "ms": m_ms, "GBps": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9,
+                "bytes_per_matvec": 24 * 1024, "frac_of_hbm_peak": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel": "matvec_wpi_kernel<4,4,2,OUT_W>"},
+            "configs[2] level-2 A.y matvec batch=4096 shared A (one matrix, LDS-resident)": {
+                "matvecs_per_s": 4096 / (ms_ms * 1e-3), "ms": ms_ms, "bytes_per_matvec": 8 * 1024,
+                "GBps": (8 * 1024 * 4096 + 16 * 1024) / (ms_ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": (8 * 1024 * 4096 + 16 * 1024) / (ms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel": "matvec_shared_kernel<4,4,2,OUT_W,16>", "bound": "valu / launch (32 MiB of traffic)"},
+            "configs[4] level-5 sign attempt (phase1+phase2) batch=8192 per GPU, shared key": {
+                "attempts_per_s": 8192 / (a_ms * 1e-3), "ms": a_ms, "phase1_ms": p1_ms, "phase2_ms": p2_ms,
+                "buffers": "one set (y, c, w1, w0, z, h = 223 MB): largely Infinity-Cache-resident, as in rounds 1-3",
+                "hbm_streaming": {"attempts_per_s": 8192 / (ar_ms * 1e-3), "ms": ar_ms, "buffers": "two rotating sets (446 MB)",
+                                  "frac_of_hbm_peak": (46 * 1024) * 8192 / (ar_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "roofline": None if not sv else {
+                    "bound": "valu", "unit": "wave64 VALU instructions/s",
+                    "peak": VALU_PEAK, "peak_source": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (MI355X_MICROARCH.md)",
+                    "valu_insts_per_attempt": sv, "source": "profiles/pmc_summary.json (committed SQ_INSTS_VALU passes of these kernels / 8192)",
+                    "phase1_frac": sv["phase1"] * 8192 / (p1_ms * 1e-3) / VALU_PEAK,
+                    "phase2_frac": sv["phase2"] * 8192 / (p2_ms * 1e-3) / VALU_PEAK,
+                    "shader_mhz_observed": sign_mhz, "attempt_ms_beside_clock_probe": probe_effect.get("attempt", (None,))[0],
+                    "peak_at_observed_clock": None if not sign_mhz else VALU_PEAK * sign_mhz / 2400.0,
+                    "phase1_frac_at_observed_clock": None if not sign_mhz else sv["phase1"] * 8192 / (p1_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
+                    "phase2_frac_at_observed_clock": None if not sign_mhz else sv["phase2"] * 8192 / (p2_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
+                    "hbm": {"bytes_per_attempt": 45 * 1024 + 1024, "note": "y 7 + w0 8 + w1 2 + w1 packed 1 KiB (phase 1) and c 1 + y 7 + "
+                            "w0 8 + w1 2 + z 7 + h 2 KiB (phase 2): the int32 planes of the public entry points",
+                            "frac_of_hbm_peak": (46 * 1024) * 8192 / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "note": "the measured issue cost of this instruction mix is ~4.3 cycles (multiplies 4.4, adds 2.5), and the "
+                            "transform alone reaches 0.62-0.67 of this peak in a compute-only loop (profiles/r03c_tune_xchg.txt)"}}}
+    except Exception as e:  # noqa: BLE001
+        sec["other_configs"] = {"error": repr(e)}
+
+
+def leg_scheme(cx, sec):
+    """pk / sk / signature bytes in HBM -> bytes in HBM (level 3), rates at 8192 and 65536, and the
+    whole-call latencies at batch 1 / 64 / 1024"""
+    args, api, sharding, dlib, C, L, P, stream = cx.args, cx.api, cx.sharding, cx.dlib, cx.C, cx.L, cx.P, cx.stream
+    rank, world, NS, hstreams, timed, with_clock, probe_effect = cx.rank, cx.world, cx.NS, cx.hstreams, cx.timed, cx.with_clock, cx.probe_effect
+    # SURVEY 8(f) rows N1-N4: the whole scheme from wire bytes on the device (level 3, batch 8192 per GPU)
+    try:
+        g3 = torch.Generator(device="cuda").manual_seed(9 + rank)
+        u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g3)  # noqa: E731
+        seed, mu = u8(VBATCH, 32), u8(VBATCH, 64)
+        pkb, skb, sgb = api.pk_bytes(3), api.sk_bytes(3), api.sig_bytes(3)
+        pk = torch.empty((VBATCH, pkb), dtype=torch.uint8, device="cuda")
+        sk = torch.empty((VBATCH, skb), dtype=torch.uint8, device="cuda")
+        sig = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
+        sigd = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
+        att = torch.empty((VBATCH,), dtype=torch.int32, device="cuda")
+        vd = torch.empty((VBATCH,), dtype=torch.int32, device="cuda")
+        kg_ms, _ = timed(lambda i: L.dil_keygen_dev(P(pk), P(sk), P(seed), 3, VBATCH, stream))
+        sg_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, VBATCH, 1, 512, stream))
+        mean_att = float(att.float().mean())
+        sgd_ms, _ = timed(lambda i: L.dil_sign_dev(P(sigd), P(att), P(sk), P(mu), 3, VBATCH, 0, 512, stream))
+        vf_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
+        ok = int(vd.abs().sum()) == 0
+        vfd_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd), P(pk), P(sigd), P(mu), 3, VBATCH, 0, stream))
+        ok = ok and int(vd.abs().sum()) == 0
+        # the fused wire-format kernel alone (A expanded beforehand): bytes = 30 KiB A + packed z, t1, hints, c, w1
+        A3 = api.expand_a(pk[:, :32].contiguous(), 3)
+        w1p = torch.empty((VBATCH, 6 * 128), dtype=torch.uint8, device="cuda")
+        wk_ms, _ = timed(lambda i: L.dil_verify_wire_core_dev(P(w1p), P(vd), P(A3), P(pk), P(sigd), 3, VBATCH, 0, stream))
+        # verification against keys whose matrix was expanded once and is kept across calls (dil_verify_sig_expanded_dev)
+        vxd_ms, _ = timed(lambda i: L.dil_verify_sig_expanded_dev(P(vd), P(A3), P(pk), P(sigd), P(mu), 3, VBATCH, 0, stream))
+        ok = ok and int(vd.abs().sum()) == 0
+        vxs_ms, _ = timed(lambda i: L.dil_verify_sig_expanded_dev(P(vd), P(A3), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
+        ok = ok and int(vd.abs().sum()) == 0
+        # the same at 8 x the batch (65536 per GPU): the latency-bound hash kernels are amortised
+        BIG = 8 * VBATCH
+        mu_b = u8(BIG, 64)
+        sig_b = torch.empty((BIG, sgb), dtype=torch.uint8, device="cuda")
+        att_b = torch.empty((BIG,), dtype=torch.int32, device="cuda")
+        vd_b = torch.empty((BIG,), dtype=torch.int32, device="cuda")
+        sgb_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig_b), P(att_b), P(sk), P(mu_b), 3, BIG, 1, 512, stream))
+        vfb_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd_b), P(pk), P(sig_b), P(mu_b), 3, BIG, 1, stream))
+        ok = ok and int(vd_b.abs().sum()) == 0
+        seed_b = u8(BIG, 32)
+        pk_b = torch.empty((BIG, pkb), dtype=torch.uint8, device="cuda")
+        sk_b = torch.empty((BIG, skb), dtype=torch.uint8, device="cuda")
+        kgb_ms, _ = timed(lambda i: L.dil_keygen_dev(P(pk_b), P(sk_b), P(seed_b), 3, BIG, stream))
+        dlib.check(L.dil_sign_dev(P(sig_b), P(att_b), P(sk_b), P(mu_b), 3, BIG, 0, 512, stream))
+        vdb_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd_b), P(pk_b), P(sig_b), P(mu_b), 3, BIG, 0, stream))
+        ok = ok and int(vd_b.abs().sum()) == 0
+        # the operations on (key, message): mu = SHAKE256(tr || M) on the device too (64-byte messages, one key for the batch)
+        blob = u8(VBATCH * 64)
+        offs = (torch.arange(VBATCH, device="cuda", dtype=torch.int64) * 64).contiguous()
+        lens = torch.full((VBATCH,), 64, dtype=torch.int32, device="cuda")
+        sig_m = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
+        sm_ms, _ = timed(lambda i: L.dil_sign_msg_dev(P(sig_m), P(att), P(sk), P(blob), blob.numel(), P(offs), P(lens), 3, VBATCH, 1, 512, stream))
+        vm_ms, _ = timed(lambda i: L.dil_verify_msg_dev(P(vd), P(pk), P(sig_m), P(blob), blob.numel(), P(offs), P(lens), 3, VBATCH, 1, stream))
+        ok = ok and int(vd.abs().sum()) == 0
+        per_s = lambda ms: VBATCH / (ms * 1e-3)  # noqa: E731
+        sec["scheme_level3_wire_format"] = {
+            "note": "pk/sk/sig bytes in HBM -> bytes in HBM; SHAKE, samplers, codecs, rejection loop all on the device; "
+                    "verification reads the packed fields inside the fused kernel (no int32 temporaries).  Rates are whole calls "
+                    "timed with HIP events around back-to-back calls on one stream (the median of three regions of >= 25 ms); the sign rates are therefore HOST-INCLUSIVE: "
+                    "dil_sign_dev synchronises the stream once per rejection round (an 8-byte count read back, ~10 us per round)",
+            "keygen_per_s": per_s(kg_ms), "sign_shared_key_per_s": per_s(sg_ms), "sign_distinct_keys_per_s": per_s(sgd_ms),
+            "verify_shared_pk_per_s": per_s(vf_ms), "verify_distinct_pk_per_s": per_s(vfd_ms),
+            "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "sample_in_ball_bits_kernel + "
+                                             "verify_wire_wpi_kernel<3>", "wire_bytes_per_verify": 30 * 1024 + 3200 + 61 + 1920 + 256 + 768},
+            "verify_expanded_keys": {"distinct_pk_per_s": per_s(vxd_ms), "shared_pk_per_s": per_s(vxs_ms),
+                                     "note": "A = ExpandA(rho) expanded once by the caller and kept across calls"},
+            "messages_64B_one_key": {"sign_msg_per_s": per_s(sm_ms), "verify_msg_per_s": per_s(vm_ms)},
+            "mean_sign_attempts": mean_att, "all_signatures_verify": ok, "batch": VBATCH,
+            "batch_65536": {"keygen_per_s": BIG / (kgb_ms * 1e-3), "sign_shared_key_per_s": BIG / (sgb_ms * 1e-3),
+                            "verify_shared_pk_per_s": BIG / (vfb_ms * 1e-3), "verify_distinct_pk_per_s": BIG / (vdb_ms * 1e-3)}}
+        # small-batch latency of one whole call (launch-bound): wall time per call incl. the host side
+        lat = {}
+        for nb in (1, 64, 1024):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(reps2):
-                rc2 |= vstep2(i)
+            reps = 20
+            for _ in range(reps):
+                L.dil_verify_sig_dev(P(vd), P(pk), P(sigd), P(mu), 3, nb, 0, stream)
             torch.cuda.synchronize()
-            dlib.check(rc2, "overlapped verify launches")
-            v2_ms = sharding.max_over_ranks((time.perf_counter() - t0) / reps2 * 1e3)
-            v2_gbs = VERIFY3_BYTES * VBATCH / (v2_ms * 1e-3) / 1e9
-            sec["roofline"].update({"achieved_overlapped": v2_gbs, "frac_overlapped": v2_gbs / HBM_PEAK_GBS,
-                                    "concurrent_launches_overlapped": 2, "overlapped_value": world * VBATCH / (v2_ms * 1e-3),
-                                    "timing": "frac = per-launch share of back-to-back launches on ONE stream (HIP events, the median of three regions); "
-                                              "frac_overlapped = the same launches alternating over two streams, host clock around "
-                                              "a synchronised region"})
-        # the same launches over ONE input set (360 MiB, partly served by the 256 MiB Infinity Cache), for context
-        l_ms, _ = timed(lambda i: L.dil_verify_core_dev(vptr[0][5], vptr[0][0], vptr[0][1], vptr[0][2], vptr[0][3], vptr[0][4], 3,
-                                                        VBATCH, 0, stream))
-        sec["llc_assisted_value"] = world * VBATCH / (l_ms * 1e-3)
-        # same pipeline with ONE public key for the whole batch (A, t1 staged in LDS): VALU-bound, reported beside it
-        s_ms, _ = timed(lambda i: L.dil_verify_core_dev(vptr[i % VSETS][5], vptr[0][0], vptr[i % VSETS][1], vptr[i % VSETS][2],
-                                                        vptr[0][3], vptr[i % VSETS][4], 3, VBATCH, 1, stream))
-        sec["shared_pk"] = {"value": VBATCH / (s_ms * 1e-3), "unit": "verify/s per GPU", "avg_launch_ms": s_ms,
-                            "bytes_per_verify": 15 * 1024, "kernel": "verify_shared_kernel<3,16>",
-                            "bound": "valu (key material LDS-resident)"}
-        # configs[2] and configs[4] of BASELINE.json (parity-test configs; timed here for the record only)
-        g2 = torch.Generator(device="cuda").manual_seed(5)
-        rnd = lambda *sh: torch.randint(0, 8380417, sh, dtype=torch.int32, device="cuda", generator=g2)  # noqa: E731
-        try:
-            A2 = [rnd(4096, 4, 4, 256) for _ in range(4)]           # 4 x 64 MiB of A: rotating, HBM-streaming
-            y2, wout = rnd(4096, 4, 256), torch.empty((4096, 4, 256), dtype=torch.int32, device="cuda")
-            m_ms, _ = timed(lambda i: L.dil_matvec_dev(P(wout), P(A2[i % 4]), P(y2), 2, 4096, 0, stream))
-            ms_ms, _ = timed(lambda i: L.dil_matvec_dev(P(wout), P(A2[0]), P(y2), 2, 4096, 1, stream))     # ONE matrix for the batch (report both)
-            # a real key and real challenges (phase 2 reads c s1 and c s2 off one transform, exact for valid inputs: DESIGN.md 4)
-            small = lambda lim, *sh: (torch.randint(-lim, lim + 1, sh, dtype=torch.int64, device="cuda", generator=g2) % 8380417).to(torch.int32)  # noqa: E731
-            A5, y5 = rnd(1, 8, 7, 256), small((1 << 19) - 1, 8192, 7, 256)
-            c5 = api.sample_in_ball(torch.randint(0, 256, (8192, 32), dtype=torch.uint8, device="cuda", generator=g2), 5)
-            s1h, s2h, t0h = small(2, 1, 7, 256), small(2, 1, 8, 256), small(4095, 1, 8, 256)
-            for t in (s1h, s2h, t0h):
-                api.ntt(t)
-            w1s = torch.empty((8192, 8, 256), dtype=torch.uint8, device="cuda")
-            w0s = torch.empty((8192, 8, 256), dtype=torch.int32, device="cuda")
-            z5 = torch.empty((8192, 7, 256), dtype=torch.int32, device="cuda")
-            h5 = torch.empty((8192, 8, 256), dtype=torch.uint8, device="cuda")
-            f5 = torch.empty((8192,), dtype=torch.int32, device="cuda")
-
-            def attempt(i):
-                return L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream) | \
-                    L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1, 0, stream)
-            (a_ms, _), sign_mhz = with_clock(lambda: timed(attempt), 5 * args.min_ms, "attempt")
-            # the same pair over TWO rotating sets of buffers (2 x 223 MB: past the 256 MiB Infinity Cache), as the headline and the
-            # verify leg are measured: the HBM-streaming figure.  (One set = 223 MB is largely cache-resident.)
-            y5b = small((1 << 19) - 1, 8192, 7, 256)
-            c5b = api.sample_in_ball(torch.randint(0, 256, (8192, 32), dtype=torch.uint8, device="cuda", generator=g2), 5)
-            rot = [(y5, c5, w1s, w0s, z5, h5), (y5b, c5b, torch.empty_like(w1s), torch.empty_like(w0s), torch.empty_like(z5), torch.empty_like(h5))]
-
-            def attempt_rot(i):
-                yy, cc, ww1, ww0, zz, hh = rot[i & 1]
-                return L.dil_sign_phase1_dev(P(ww1), P(ww0), P(A5), P(yy), 5, 8192, 1, stream) | \
-                    L.dil_sign_phase2_skey_dev(P(zz), P(hh), P(f5), P(cc), P(yy), P(ww0), P(ww1), P(s1h), P(s2h), P(t0h), 5, 8192, 1, 0, stream)
-            ar_ms, _ = timed(attempt_rot)
-            p1_ms, _ = timed(lambda i: L.dil_sign_phase1_dev(P(w1s), P(w0s), P(A5), P(y5), 5, 8192, 1, stream))
-            p2_ms, _ = timed(lambda i: L.dil_sign_phase2_skey_dev(P(z5), P(h5), P(f5), P(c5), P(y5), P(w0s), P(w1s), P(s1h), P(s2h), P(t0h), 5, 8192, 1,
-                                                                  0, stream))
-            sv = pmc_sign_valu()
-            sec["other_configs"] = {
-                "configs[2] level-2 A.y matvec batch=4096 distinct A (4 rotating matrices)": {
-                    "matvecs_per_s": 4096 / (m_ms * 1e-3), "ms": m_ms, "GBps": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9,
-                    "bytes_per_matvec": 24 * 1024, "frac_of_hbm_peak": 24 * 1024 * 4096 / (m_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "kernel": "matvec_wpi_kernel<4,4,2,OUT_W>"},
-                "configs[2] level-2 A.y matvec batch=4096 shared A (one matrix, LDS-resident)": {
-                    "matvecs_per_s": 4096 / (ms_ms * 1e-3), "ms": ms_ms, "bytes_per_matvec": 8 * 1024,
-                    "GBps": (8 * 1024 * 4096 + 16 * 1024) / (ms_ms * 1e-3) / 1e9,
-                    "frac_of_hbm_peak": (8 * 1024 * 4096 + 16 * 1024) / (ms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "kernel": "matvec_shared_kernel<4,4,2,OUT_W,16>", "bound": "valu / launch (32 MiB of traffic)"},
-                "configs[4] level-5 sign attempt (phase1+phase2) batch=8192 per GPU, shared key": {
-                    "attempts_per_s": 8192 / (a_ms * 1e-3), "ms": a_ms, "phase1_ms": p1_ms, "phase2_ms": p2_ms,
-                    "buffers": "one set (y, c, w1, w0, z, h = 223 MB): largely Infinity-Cache-resident, as in rounds 1-3",
-                    "hbm_streaming": {"attempts_per_s": 8192 / (ar_ms * 1e-3), "ms": ar_ms, "buffers": "two rotating sets (446 MB)",
-                                      "frac_of_hbm_peak": (46 * 1024) * 8192 / (ar_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                    "roofline": None if not sv else {
-                        "bound": "valu", "unit": "wave64 VALU instructions/s",
-                        "peak": VALU_PEAK, "peak_source": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (MI355X_MICROARCH.md)",
-                        "valu_insts_per_attempt": sv, "source": "profiles/pmc_summary.json (committed SQ_INSTS_VALU passes of these kernels / 8192)",
-                        "phase1_frac": sv["phase1"] * 8192 / (p1_ms * 1e-3) / VALU_PEAK,
-                        "phase2_frac": sv["phase2"] * 8192 / (p2_ms * 1e-3) / VALU_PEAK,
-                        "shader_mhz_observed": sign_mhz, "attempt_ms_beside_clock_probe": probe_effect.get("attempt", (None,))[0],
-                        "peak_at_observed_clock": None if not sign_mhz else VALU_PEAK * sign_mhz / 2400.0,
-                        "phase1_frac_at_observed_clock": None if not sign_mhz else sv["phase1"] * 8192 / (p1_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
-                        "phase2_frac_at_observed_clock": None if not sign_mhz else sv["phase2"] * 8192 / (p2_ms * 1e-3) / (VALU_PEAK * sign_mhz / 2400.0),
-                        "hbm": {"bytes_per_attempt": 45 * 1024 + 1024, "note": "y 7 + w0 8 + w1 2 + w1 packed 1 KiB (phase 1) and c 1 + y 7 + "
-                                "w0 8 + w1 2 + z 7 + h 2 KiB (phase 2): the int32 planes of the public entry points",
-                                "frac_of_hbm_peak": (46 * 1024) * 8192 / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                        "note": "the measured issue cost of this instruction mix is ~4.3 cycles (multiplies 4.4, adds 2.5), and the "
-                                "transform alone reaches 0.62-0.67 of this peak in a compute-only loop (profiles/r03c_tune_xchg.txt)"}}}
-        except Exception as e:  # noqa: BLE001
-            sec["other_configs"] = {"error": repr(e)}
-        # the whole scheme from wire bytes on the device (level 3, batch 8192 per GPU)
-        try:
-            g3 = torch.Generator(device="cuda").manual_seed(9 + rank)
-            u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g3)  # noqa: E731
-            seed, mu = u8(VBATCH, 32), u8(VBATCH, 64)
-            pkb, skb, sgb = api.pk_bytes(3), api.sk_bytes(3), api.sig_bytes(3)
-            pk = torch.empty((VBATCH, pkb), dtype=torch.uint8, device="cuda")
-            sk = torch.empty((VBATCH, skb), dtype=torch.uint8, device="cuda")
-            sig = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
-            sigd = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
-            att = torch.empty((VBATCH,), dtype=torch.int32, device="cuda")
-            vd = torch.empty((VBATCH,), dtype=torch.int32, device="cuda")
-            kg_ms, _ = timed(lambda i: L.dil_keygen_dev(P(pk), P(sk), P(seed), 3, VBATCH, stream))
-            sg_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, VBATCH, 1, 512, stream))
-            mean_att = float(att.float().mean())
-            sgd_ms, _ = timed(lambda i: L.dil_sign_dev(P(sigd), P(att), P(sk), P(mu), 3, VBATCH, 0, 512, stream))
-            vf_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
-            ok = int(vd.abs().sum()) == 0
-            vfd_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd), P(pk), P(sigd), P(mu), 3, VBATCH, 0, stream))
-            ok = ok and int(vd.abs().sum()) == 0
-            # the fused wire-format kernel alone (A expanded beforehand): bytes = 30 KiB A + packed z, t1, hints, c, w1
-            A3 = api.expand_a(pk[:, :32].contiguous(), 3)
-            w1p = torch.empty((VBATCH, 6 * 128), dtype=torch.uint8, device="cuda")
-            wk_ms, _ = timed(lambda i: L.dil_verify_wire_core_dev(P(w1p), P(vd), P(A3), P(pk), P(sigd), 3, VBATCH, 0, stream))
-            # verification against keys whose matrix was expanded once and is kept across calls (dil_verify_sig_expanded_dev)
-            vxd_ms, _ = timed(lambda i: L.dil_verify_sig_expanded_dev(P(vd), P(A3), P(pk), P(sigd), P(mu), 3, VBATCH, 0, stream))
-            ok = ok and int(vd.abs().sum()) == 0
-            vxs_ms, _ = timed(lambda i: L.dil_verify_sig_expanded_dev(P(vd), P(A3), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
-            ok = ok and int(vd.abs().sum()) == 0
-            # the same at 8 x the batch (65536 per GPU): the latency-bound hash kernels are amortised
-            BIG = 8 * VBATCH
-            mu_b = u8(BIG, 64)
-            sig_b = torch.empty((BIG, sgb), dtype=torch.uint8, device="cuda")
-            att_b = torch.empty((BIG,), dtype=torch.int32, device="cuda")
-            vd_b = torch.empty((BIG,), dtype=torch.int32, device="cuda")
-            sgb_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig_b), P(att_b), P(sk), P(mu_b), 3, BIG, 1, 512, stream))
-            vfb_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd_b), P(pk), P(sig_b), P(mu_b), 3, BIG, 1, stream))
-            ok = ok and int(vd_b.abs().sum()) == 0
-            seed_b = u8(BIG, 32)
-            pk_b = torch.empty((BIG, pkb), dtype=torch.uint8, device="cuda")
-            sk_b = torch.empty((BIG, skb), dtype=torch.uint8, device="cuda")
-            kgb_ms, _ = timed(lambda i: L.dil_keygen_dev(P(pk_b), P(sk_b), P(seed_b), 3, BIG, stream))
-            dlib.check(L.dil_sign_dev(P(sig_b), P(att_b), P(sk_b), P(mu_b), 3, BIG, 0, 512, stream))
-            vdb_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd_b), P(pk_b), P(sig_b), P(mu_b), 3, BIG, 0, stream))
-            ok = ok and int(vd_b.abs().sum()) == 0
-            # the operations on (key, message): mu = SHAKE256(tr || M) on the device too (64-byte messages, one key for the batch)
-            blob = u8(VBATCH * 64)
-            offs = (torch.arange(VBATCH, device="cuda", dtype=torch.int64) * 64).contiguous()
-            lens = torch.full((VBATCH,), 64, dtype=torch.int32, device="cuda")
-            sig_m = torch.empty((VBATCH, sgb), dtype=torch.uint8, device="cuda")
-            sm_ms, _ = timed(lambda i: L.dil_sign_msg_dev(P(sig_m), P(att), P(sk), P(blob), blob.numel(), P(offs), P(lens), 3, VBATCH, 1, 512, stream))
-            vm_ms, _ = timed(lambda i: L.dil_verify_msg_dev(P(vd), P(pk), P(sig_m), P(blob), blob.numel(), P(offs), P(lens), 3, VBATCH, 1, stream))
-            ok = ok and int(vd.abs().sum()) == 0
-            per_s = lambda ms: VBATCH / (ms * 1e-3)  # noqa: E731
-            sec["scheme_level3_wire_format"] = {
-                "note": "pk/sk/sig bytes in HBM -> bytes in HBM; SHAKE, samplers, codecs, rejection loop all on the device; "
-                        "verification reads the packed fields inside the fused kernel (no int32 temporaries).  Rates are whole calls "
-                        "timed with HIP events around back-to-back calls on one stream (the median of three regions of >= 25 ms); the sign rates are therefore HOST-INCLUSIVE: "
-                        "dil_sign_dev synchronises the stream once per rejection round (an 8-byte count read back, ~10 us per round)",
-                "keygen_per_s": per_s(kg_ms), "sign_shared_key_per_s": per_s(sg_ms), "sign_distinct_keys_per_s": per_s(sgd_ms),
-                "verify_shared_pk_per_s": per_s(vf_ms), "verify_distinct_pk_per_s": per_s(vfd_ms),
-                "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "sample_in_ball_bits_kernel + "
-                                                 "verify_wire_wpi_kernel<3>", "wire_bytes_per_verify": 30 * 1024 + 3200 + 61 + 1920 + 256 + 768},
-                "verify_expanded_keys": {"distinct_pk_per_s": per_s(vxd_ms), "shared_pk_per_s": per_s(vxs_ms),
-                                         "note": "A = ExpandA(rho) expanded once by the caller and kept across calls"},
-                "messages_64B_one_key": {"sign_msg_per_s": per_s(sm_ms), "verify_msg_per_s": per_s(vm_ms)},
-                "mean_sign_attempts": mean_att, "all_signatures_verify": ok, "batch": VBATCH,
-                "batch_65536": {"keygen_per_s": BIG / (kgb_ms * 1e-3), "sign_shared_key_per_s": BIG / (sgb_ms * 1e-3),
-                                "verify_shared_pk_per_s": BIG / (vfb_ms * 1e-3), "verify_distinct_pk_per_s": BIG / (vdb_ms * 1e-3)}}
-            # small-batch latency of one whole call (launch-bound): wall time per call incl. the host side
-            lat = {}
-            for nb in (1, 64, 1024):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                reps = 20
-                for _ in range(reps):
-                    L.dil_verify_sig_dev(P(vd), P(pk), P(sigd), P(mu), 3, nb, 0, stream)
-                torch.cuda.synchronize()
-                lat[f"verify_sig_batch_{nb}_ms"] = (time.perf_counter() - t0) / reps * 1e3
-            for name, call in (("keygen_batch_1_ms", lambda: L.dil_keygen_dev(P(pk), P(sk), P(seed), 3, 1, stream)),
-                               ("sign_batch_1_ms", lambda: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, 1, 1, 512, stream))):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(20):
-                    call()
-                torch.cuda.synchronize()
-                lat[name] = (time.perf_counter() - t0) / 20 * 1e3
-            # the drop-in surface's batch-of-one call (libdil256_ref.so ntt() = dil_ntt_host(a, 1)): resident mailbox wave vs a launch
-            # per call; host wall time per call, ctypes' ~1 us included in both
-            import ctypes as _C
-            one = np.arange(256, dtype=np.int32)
-            onep = one.ctypes.data_as(_C.POINTER(_C.c_int32))
-            for mode, key, reps in ((1, "ntt_host_batch_1_us", 5000), (0, "ntt_host_batch_1_launch_path_us", 300)):
-                L.dil_set_option(b"host_mailbox", mode)
-                for _ in range(20):
-                    L.dil_ntt_host(onep, 1)
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    L.dil_ntt_host(onep, 1)
-                lat[key] = (time.perf_counter() - t0) / reps * 1e6
-            L.dil_set_option(b"host_mailbox", 0)
+            lat[f"verify_sig_batch_{nb}_ms"] = (time.perf_counter() - t0) / reps * 1e3
+        for name, call in (("keygen_batch_1_ms", lambda: L.dil_keygen_dev(P(pk), P(sk), P(seed), 3, 1, stream)),
+                           ("sign_batch_1_ms", lambda: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, 1, 1, 512, stream))):
             torch.cuda.synchronize()
-            sec["scheme_level3_wire_format"]["latency"] = lat
-        except Exception as e:  # noqa: BLE001
-            sec["scheme_level3_wire_format"] = {"error": repr(e)}
-        # ---- BASELINE configs[4] as north_star describes it: ONE batch of level-5 signing work, 8192 items per GPU, sharded by
-        # contiguous slices over the ranks (sharding.run_sharded), HIP compute on every rank, then the one collective of the
-        # design: the gather of the (z, h, flag) result slabs over RCCL/xGMI -- timed separately.
-        try:
-            sec["configs4_sharded"] = bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api)
-        except Exception as e:  # noqa: BLE001
-            sec["configs4_sharded"] = {"error": repr(e)}
-        out["secondary"] = sec
-
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            try:
-                out["cpu_baseline"]["all_threads"] = cpu_baseline_all_threads(1.0 / out["cpu_baseline"]["value"])
-            except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"]["all_threads"] = {"error": repr(e)}
-            if not args.no_secondary:
-                out["secondary"]["cpu_baseline"] = cpu_baseline_verify()
-                try:
-                    out["secondary"]["cpu_baseline"]["all_threads"] = cpu_baseline_verify_all_threads()
-                except Exception as e:  # noqa: BLE001
-                    out["secondary"]["cpu_baseline"]["all_threads"] = {"error": repr(e)}
-        print(json.dumps(out))
-    sharding.barrier()
-    if world > 1:
-        torch.distributed.destroy_process_group()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                call()
+            torch.cuda.synchronize()
+            lat[name] = (time.perf_counter() - t0) / 20 * 1e3
+        # the drop-in surface's batch-of-one call (libdil256_ref.so ntt() = dil_ntt_host(a, 1)): resident mailbox wave vs a launch
+        # per call; host wall time per call, ctypes' ~1 us included in both
+        import ctypes as _C
+        one = np.arange(256, dtype=np.int32)
+        onep = one.ctypes.data_as(_C.POINTER(_C.c_int32))
+        for mode, key, reps in ((1, "ntt_host_batch_1_us", 5000), (0, "ntt_host_batch_1_launch_path_us", 300)):
+            L.dil_set_option(b"host_mailbox", mode)
+            for _ in range(20):
+                L.dil_ntt_host(onep, 1)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                L.dil_ntt_host(onep, 1)
+            lat[key] = (time.perf_counter() - t0) / reps * 1e6
+        L.dil_set_option(b"host_mailbox", 0)
+        torch.cuda.synchronize()
+        sec["scheme_level3_wire_format"]["latency"] = lat
+    except Exception as e:  # noqa: BLE001
+        sec["scheme_level3_wire_format"] = {"error": repr(e)}
 
 
-def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
+def leg_end_to_end(cx):
+    """"exclude H2D/D2H from kernel figures but report end-to-end separately".  The reference's calling convention for the
+    path is caller-owned HOST arrays (reference_code/ref_ntt.h:30-36, hardware_code/ntt2x2.h:30-34); these are the same two workloads
+    through the host-pointer entry points (csrc/capi.hip: chunks round-robin over streams, H2D -> kernel -> D2H), with the caller's
+    buffers pageable and page-locked, against the link's own copy rate measured here.  PCIe-bound by two orders of magnitude: never `value`."""
+    api = cx.api
+
+    def med(f, reps=5):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    out = {}
+    nbytes = 256 << 20
+    hbuf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    dbuf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+
+    def h2d():
+        dbuf.copy_(hbuf, non_blocking=True)
+        torch.cuda.synchronize()
+
+    def d2h():
+        hbuf.copy_(dbuf, non_blocking=True)
+        torch.cuda.synchronize()
+    h2d(), d2h()
+    link = {"h2d_GBps": nbytes / med(h2d) / 1e9, "d2h_GBps": nbytes / med(d2h) / 1e9,
+            "how": "256 MiB page-locked <-> device copies (torch), median of 5; the two directions are separate links (full duplex)"}
+    del hbuf, dbuf
+    out["pcie"] = link
+    one_way = min(link["h2d_GBps"], link["d2h_GBps"])
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 8380417, (BATCH, 256), dtype=np.int32)
+    ntt = {"workload": "BASELINE configs[1] through dil_ntt_host + dil_invntt_host: 65536 polynomials, 64 MiB up and 64 MiB down per call",
+           "options": {k: api.get_option(k) for k in ("host_chunk", "host_chunk_pinned", "host_streams")}}
+    for kind in ("pageable", "page_locked"):
+        keep = torch.from_numpy(a.copy()).pin_memory() if kind == "page_locked" else None
+        x = keep.numpy() if keep is not None else a.copy()
+        api.ntt(x), api.invntt(x)
+        assert (x == a).all(), "host round trip is not the identity"
+        tf, ti = med(lambda: api.ntt(x)), med(lambda: api.invntt(x))
+        gb = BATCH * 1024 / ((tf + ti) / 2) / 1e9
+        ntt[kind] = {"value": 2 * BATCH / (tf + ti), "unit": "NTT/s", "fwd_ms": tf * 1e3, "inv_ms": ti * 1e3,
+                     "GBps_each_way": gb, "frac_of_pcie": gb / one_way,
+                     "note": "frac_of_pcie = bytes one way / call time, over the slower direction's copy rate: 1.0 = both directions "
+                             "fully overlapped at link rate"}
+    # the batch at which a host caller is better off here than on the CPU: per-call wall time of dil_ntt_host, pageable buffer
+    sweep = {}
+    for b in (1, 4, 16, 64, 256, 1024, 4096, 16384, 65536):
+        xb = a[:b].copy()
+        api.ntt(xb)
+        reps = 200 if b <= 1024 else 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            api.ntt(xb)
+        sweep[str(b)] = b / ((time.perf_counter() - t0) / reps)
+    ntt["batch_sweep_NTT_per_s"] = sweep
+    out["ntt"] = ntt
+    # configs[3]: host A / z / c / t1 / h -> w1
+    A, z, c, t1_, h = synth_verify(VBATCH, 901)
+    h2 = np.ascontiguousarray(h.reshape(VBATCH, -1))
+    up = A.nbytes + z.nbytes + c.nbytes + t1_.nbytes + h2.nbytes
+    ver = {"workload": "BASELINE configs[3] through dil_verify_core_host: 8192 level-3 items, a key per item", "bytes_up": int(up),
+           "bytes_down": int(VBATCH * 6 * 256)}
+    for kind in ("pageable", "page_locked"):
+        arrs = [A, z, c, t1_, h2]
+        keep = None
+        if kind == "page_locked":
+            keep = [torch.from_numpy(x).pin_memory() for x in arrs]
+            arrs = [k.numpy() for k in keep]
+        w1 = api.verify_core(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], 3)
+        t = med(lambda: api.verify_core(arrs[0], arrs[1], arrs[2], arrs[3], arrs[4], 3, out=w1.reshape(VBATCH, -1)), 3)
+        ver[kind] = {"value": VBATCH / t, "unit": "verify/s", "ms": t * 1e3, "GBps_up": up / t / 1e9, "frac_of_pcie": up / t / 1e9 / link["h2d_GBps"]}
+    out["verify"] = ver
+    return out
+
+
+def bench_configs4_sharded(cx):
     """level-5 sign inner loop (phase 1 + phase 2, one signing key) and the whole signing loop on one batch of
     8192 x world items: every rank builds the SAME batch (same seed), run_sharded hands it its contiguous slice, the
     HIP kernels run on the slice, gather_slabs all-gathers the result slabs"""
+    L, P, stream, rank, world, timed, sharding, api = cx.L, cx.P, cx.stream, cx.rank, cx.world, cx.timed, cx.sharding, cx.api
     per, K5, L5 = 8192, 8, 7
     total = per * world
     gq = torch.Generator(device="cuda").manual_seed(4242)          # same on every rank: one logical batch
@@ -873,6 +955,84 @@ def bench_configs4_sharded(L, P, stream, rank, world, timed, sharding, api):
     vd = api.verify_sig(pk, gsig[lo:lo + 2048].contiguous(), mu[lo:lo + 2048].contiguous(), 5, shared_pk=True)
     out["gathered_signatures_verify"] = int(vd.abs().sum()) == 0
     return out
+
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--prewarm-ms", type=float, default=200.0,
+                    help="untimed: keep launching steps for this long before the W warm-up steps, so that the GPU has "
+                         "left its idle power state (short runs measured 10 %% low without it)")
+    ap.add_argument("--rotate", type=int, default=8, help="distinct resident batches the steps rotate over")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps alternate over (step i runs on stream i %% S; a batch always stays on one "
+                         "stream).  2 keeps a second launch in flight, which fills the dispatch gap and the ramp/tail of "
+                         "every kernel: +15 %% over one stream")
+    ap.add_argument("--region-ms", type=float, default=50.0,
+                    help="a timed region of the headline is a whole number of K-step groups at least this long")
+    ap.add_argument("--regions", type=int, default=7, help="timed regions of the headline (at least)")
+    ap.add_argument("--total-ms", type=float, default=400.0, help="the headline's regions add up to at least this much")
+    ap.add_argument("--min-ms", type=float, default=25.0,
+                    help="every secondary leg is timed for at least this long, whatever --steps says")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-verify-overlap", action="store_true",
+                    help="skip the two-stream leg of the secondary verify core (profiling runs: keeps rocprofv3's average "
+                         "duration of verify_wpi_kernel a single-kernel figure)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) legs")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    cx = Bench(args)
+    rank, world = cx.rank, cx.world
+    out = leg_headline(cx)
+    if world > 1:
+        leg_distributed(cx, out)
+    if not args.no_secondary:
+        sec = leg_verify_core(cx)
+        leg_other_configs(cx, sec)
+        leg_scheme(cx, sec)
+        # BASELINE configs[4] as north_star describes it: ONE batch of level-5 signing work, 8192 items per GPU, sharded by contiguous
+        # slices over the ranks (sharding.run_sharded), HIP compute on every rank, then the one collective of the design: the gather of
+        # the (z, h, flag) result slabs over RCCL/xGMI -- timed separately.
+        try:
+            sec["configs4_sharded"] = bench_configs4_sharded(cx)
+        except Exception as e:  # noqa: BLE001
+            sec["configs4_sharded"] = {"error": repr(e)}
+        out["secondary"] = sec
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        try:
+            out["end_to_end"] = leg_end_to_end(cx)
+        except Exception as e:  # noqa: BLE001
+            out["end_to_end"] = {"error": repr(e)}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"]["all_threads"] = cpu_baseline_all_threads(1.0 / out["cpu_baseline"]["value"])
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"]["all_threads"] = {"error": repr(e)}
+            if not args.no_secondary:
+                out["secondary"]["cpu_baseline"] = cpu_baseline_verify()
+                try:
+                    out["secondary"]["cpu_baseline"]["all_threads"] = cpu_baseline_verify_all_threads()
+                except Exception as e:  # noqa: BLE001
+                    out["secondary"]["cpu_baseline"]["all_threads"] = {"error": repr(e)}
+            sweep = out.get("end_to_end", {}).get("ntt", {}).get("batch_sweep_NTT_per_s")
+            if sweep:       # the batch from which one dil_ntt_host call beats the CPU reference on this box
+                first = lambda rate: next((int(b) for b, v in sweep.items() if v > rate), None)  # noqa: E731
+                allt = out["cpu_baseline"].get("all_threads", {}).get("value")
+                out["end_to_end"]["ntt"]["crossover_batch"] = {"vs_one_cpu_thread": first(out["cpu_baseline"]["value"]),
+                                                               "vs_all_cpu_threads": first(allt) if allt else None}
+        print(json.dumps(out))
+    cx.sharding.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

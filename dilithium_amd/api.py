@@ -172,8 +172,14 @@ def matvec(A, y, level, shared_A=False, out=None):
 
 
 def verify_core(A, z, c, t1, h, level, shared_pk=False, out=None):
-    """w1 = UseHint(h, INTT(A o NTT(z) - NTT(c) o NTT(t1 2^13))) -> uint8 [B,K,256]"""
+    """w1 = UseHint(h, INTT(A o NTT(z) - NTT(c) o NTT(t1 2^13))) -> uint8 [B,K,256]; numpy operands take the host-pointer entry point"""
     K, Lv = _kl(level)
+    if not _is_tensor(z):
+        B = z.size // (Lv * N)
+        w1 = out if out is not None else np.empty((B, K * N), dtype=np.uint8)
+        _lib.check(_lib.load().dil_verify_core_host(_np8(w1), _np(A), _np(z), _np(c), _np(t1), _np8(h.reshape(B, K * N)), level, B, int(shared_pk)),
+                   "dil_verify_core_host")
+        return w1.reshape(B, K, N)
     B = z.numel() // (Lv * N)
     w1 = out if out is not None else torch.empty((B, K, N), dtype=torch.uint8, device=z.device)
     _lib.check(_lib.load().dil_verify_core_dev(_dev(w1, torch.uint8), _dev(A, torch.int32), _dev(z, torch.int32),

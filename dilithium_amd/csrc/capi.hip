@@ -41,6 +41,10 @@ const OptName* option_table(int* n)
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
         {"packed_y", "DIL_PACKED_Y", &cfg.packed_y},
+        {"host_chunk", "DIL_HOST_CHUNK", &cfg.host_chunk},
+        {"host_chunk_pinned", "DIL_HOST_CHUNK_PINNED", &cfg.host_chunk_pinned},
+        {"host_streams", "DIL_HOST_STREAMS", &cfg.host_streams},
+        {"host_pin", "DIL_HOST_PIN", &cfg.host_pin},
         {"host_mailbox", "DIL_HOST_MAILBOX", &cfg.host_mailbox},
         {"mailbox_idle_us", "DIL_MAILBOX_IDLE_US", &cfg.mailbox_idle_us},
         {"fuse_challenge", "DIL_FUSE_CHALLENGE", &cfg.fuse_challenge},
@@ -97,8 +101,8 @@ void destroy_device(Device& d)
     d.aux.destroy();
     if (d.hp.ready) {
         for (int i = 0; i < HOST_STREAMS; i++) {
-            (void)hipFree(d.hp.dev[i]);
-            (void)hipStreamDestroy(d.hp.stream[i]);
+            if (d.hp.dev[i]) (void)hipFree(d.hp.dev[i]);
+            if (d.hp.stream[i]) (void)hipStreamDestroy(d.hp.stream[i]);
         }
         d.hp = HostPipe{};
     }
@@ -372,21 +376,56 @@ int ensure_scratch(Device& d, size_t bytes)
 // so that the copies are true asynchronous DMA.
 // Locking: these entry points share the device's staging buffers, so they are serialised by the device's
 // `host_mu` -- a lock of their own; initialisation (Device::mu) and every *_dev entry point are never blocked by it.
-constexpr size_t HOST_CHUNK = 16384;     // polynomials per chunk (16 MiB)
+// Chunk size and stream count are options (host_chunk in KiB = polynomials, host_streams; swept in profiles/r05_host_pipe.txt).
+// (profiles/r05g_host_pipe.txt: pageable buffers are staged by the runtime -- streams do not matter, large chunks do: 25.8 M NTT/s at
+//  16 MiB; page-locked buffers overlap the two directions across streams, best with small chunks: 32.9 M NTT/s at 1 MiB x 4 streams;
+//  the link itself moves 57 GB/s each way.)
+static size_t host_chunk_polys(bool pinned = false)
+{
+    const int v = pinned ? dil::rt::cfg.host_chunk_pinned.load(std::memory_order_relaxed) : dil::rt::cfg.host_chunk.load(std::memory_order_relaxed);
+    return (size_t)std::min(std::max(v, 64), 1 << 20);
+}
+static bool is_page_locked(const void* h)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, h) != hipSuccess) {
+        (void)hipGetLastError();                      // an ordinary malloc'ed pointer is "invalid value" to the runtime: pageable
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+static int host_stream_count() { return std::min(std::max(dil::rt::cfg.host_streams.load(std::memory_order_relaxed), 1), HOST_STREAMS); }
 
-int ensure_pipe(Device& d)
+int ensure_pipe(Device& d, size_t bytes_per_stream)
 {
     dil::rt::HostPipe& hp = d.hp;
-    if (hp.ready) return 0;
-    for (int i = 0; i < HOST_STREAMS; i++) {
-        DIL_TRY(hipStreamCreateWithFlags(&hp.stream[i], hipStreamNonBlocking));
-        DIL_TRY(hipMalloc(reinterpret_cast<void**>(&hp.dev[i]), HOST_CHUNK * 1024));
+    if (!hp.ready) {
+        for (int i = 0; i < HOST_STREAMS; i++) DIL_TRY(hipStreamCreateWithFlags(&hp.stream[i], hipStreamNonBlocking));
+        hp.ready = true;
     }
-    const char* e = getenv("DIL_HOST_PIN");
-    hp.pin = (e && atoi(e) != 0) ? 1 : 0;
-    hp.ready = true;
+    if (hp.dev_bytes < bytes_per_stream) {
+        for (int i = 0; i < HOST_STREAMS; i++) {
+            if (hp.dev[i]) DIL_TRY(hipFree(hp.dev[i]));
+            hp.dev[i] = nullptr;
+        }
+        hp.dev_bytes = 0;
+        for (int i = 0; i < HOST_STREAMS; i++) DIL_TRY(hipMalloc(reinterpret_cast<void**>(&hp.dev[i]), bytes_per_stream));
+        hp.dev_bytes = bytes_per_stream;
+    }
     return 0;
 }
+// page-lock a caller's buffer for the duration of a call (option host_pin); a buffer that cannot be registered is simply copied pageable
+struct PinGuard {
+    void* p = nullptr;
+    PinGuard(const void* h, size_t bytes)
+    {
+        if (dil::rt::cfg.host_pin.load(std::memory_order_relaxed) && h && bytes &&
+            hipHostRegister(const_cast<void*>(h), bytes, hipHostRegisterDefault) == hipSuccess)
+            p = const_cast<void*>(h);
+        else (void)hipGetLastError();
+    }
+    ~PinGuard() { if (p) (void)hipHostUnregister(p); }
+};
 
 template <class F>
 int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, tables, stream) -> int
@@ -395,6 +434,9 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     DIL_ENTER(d, T);
     std::lock_guard<std::mutex> lk(d.host_mu);
     int rc;
+    PinGuard pin(h, batch > 4096 ? batch * 1024 : 0);        // (option host_pin; not worth a registration for a small batch)
+    const size_t HOST_CHUNK = host_chunk_polys(batch > 4096 && (pin.p || is_page_locked(h)));
+    const int NS = host_stream_count();
     if (batch <= HOST_CHUNK) {
         const size_t bytes = batch * 1024;
         rc = ensure_scratch(d, bytes);
@@ -406,26 +448,84 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
         DIL_TRY(hipMemcpy(h, d.scratch, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
-    rc = ensure_pipe(d);
+    rc = ensure_pipe(d, HOST_CHUNK * 1024);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
-    bool pinned = false;
-    if (hp.pin) pinned = hipHostRegister(h, batch * 1024, hipHostRegisterDefault) == hipSuccess;
     int err = 0;
     size_t c = 0;
     for (size_t off = 0; off < batch && !err; off += HOST_CHUNK, c++) {
-        const int s = (int)(c % HOST_STREAMS);
+        const int s = (int)(c % NS);
         const size_t n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
         int32_t* hc = h + off * 256;
-        err = (int)hipMemcpyAsync(hp.dev[s], hc, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
-        if (!err) err = fn(hp.dev[s], n, T, hp.stream[s]);
-        if (!err) err = (int)hipMemcpyAsync(hc, hp.dev[s], n * 1024, hipMemcpyDeviceToHost, hp.stream[s]);
+        int32_t* dc = reinterpret_cast<int32_t*>(hp.dev[s]);
+        err = (int)hipMemcpyAsync(dc, hc, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
+        if (!err) err = fn(dc, n, T, hp.stream[s]);
+        if (!err) err = (int)hipMemcpyAsync(hc, dc, n * 1024, hipMemcpyDeviceToHost, hp.stream[s]);
     }
-    for (int i = 0; i < HOST_STREAMS; i++) {
+    for (int i = 0; i < NS; i++) {
         const hipError_t e = hipStreamSynchronize(hp.stream[i]);
         if (!err && e != hipSuccess) err = (int)e;
     }
-    if (pinned) (void)hipHostUnregister(h);
+    return err;
+}
+
+// The verify core from HOST operands (the reference's calling convention for the path: caller-owned host arrays, ref_ntt.h:30-36):
+// items in chunks round-robin over the streams, each chunk  H2D (A, z, c, t1, h) -> fused kernel -> D2H (w1)  on its own stream.
+// A key shared by the batch goes up once.  Chunk = as many items as fit the staging buffer of host_chunk KiB.
+int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1, const uint8_t* h, int level, size_t batch,
+                     int shared_pk)
+{
+    if (batch == 0) return 0;
+    if (level != 2 && level != 3 && level != 5) return (int)hipErrorInvalidValue;
+    DIL_ENTER(d, T);
+    std::lock_guard<std::mutex> lk(d.host_mu);
+    const size_t K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
+    const size_t bA = K * L * 1024, bz = L * 1024, bc = 1024, bt = K * 1024, bh = K * 256, bw = K * 256;
+    const size_t key_bytes = bA + bt, item_in = bz + bc + bh + (shared_pk ? 0 : key_bytes), item_all = item_in + bw;
+    const int NS = host_stream_count();
+    const size_t budget = std::max(host_chunk_polys(), (size_t)65536) * 1024;      // upload-dominated: 64 MiB chunks reach 0.88-0.95 of the link
+    const size_t per_chunk = std::max<size_t>(1, (budget - (shared_pk ? key_bytes : 0)) / item_all);
+    int rc = ensure_pipe(d, std::max(budget, item_all + key_bytes));
+    if (rc) return rc;
+    dil::rt::HostPipe& hp = d.hp;
+    const size_t nk = shared_pk ? 1 : batch;
+    PinGuard pA(A, nk * bA), pz(z, batch * bz), pc(c, batch * bc), pt(t1, nk * bt), ph(h, batch * bh), pw(w1, batch * bw);
+    int err = 0;
+    bool key_up[HOST_STREAMS] = {};
+    size_t ck = 0;
+    for (size_t off = 0; off < batch && !err; off += per_chunk, ck++) {
+        const int s = (int)(ck % NS);
+        const size_t n = std::min(per_chunk, batch - off);
+        hipStream_t st = hp.stream[s];
+        uint8_t* base = hp.dev[s];
+        // staging layout: [A | t1 of the shared key] then per chunk A, t1 (a key per item), z, c, h, w1 -- every block 1 KiB aligned
+        int32_t* dA = reinterpret_cast<int32_t*>(base);
+        int32_t* dt = reinterpret_cast<int32_t*>(base + (shared_pk ? bA : n * bA));
+        uint8_t* q = base + (shared_pk ? key_bytes : n * key_bytes);
+        int32_t* dz = reinterpret_cast<int32_t*>(q);
+        int32_t* dc = reinterpret_cast<int32_t*>(q + n * bz);
+        uint8_t* dh = q + n * (bz + bc);
+        uint8_t* dw = dh + n * bh;
+        if (shared_pk) {
+            if (!key_up[s]) {                        // once per stream's staging buffer
+                err = (int)hipMemcpyAsync(dA, A, bA, hipMemcpyHostToDevice, st);
+                if (!err) err = (int)hipMemcpyAsync(dt, t1, bt, hipMemcpyHostToDevice, st);
+                key_up[s] = true;
+            }
+        } else {
+            err = (int)hipMemcpyAsync(dA, A + off * (bA / 4), n * bA, hipMemcpyHostToDevice, st);
+            if (!err) err = (int)hipMemcpyAsync(dt, t1 + off * (bt / 4), n * bt, hipMemcpyHostToDevice, st);
+        }
+        if (!err) err = (int)hipMemcpyAsync(dz, z + off * (bz / 4), n * bz, hipMemcpyHostToDevice, st);
+        if (!err) err = (int)hipMemcpyAsync(dc, c + off * (bc / 4), n * bc, hipMemcpyHostToDevice, st);
+        if (!err) err = (int)hipMemcpyAsync(dh, h + off * bh, n * bh, hipMemcpyHostToDevice, st);
+        if (!err) err = (int)dil::launch_verify(level, dw, dA, dz, dc, dt, dh, n, shared_pk, T, st);
+        if (!err) err = (int)hipMemcpyAsync(w1 + off * bw, dw, n * bw, hipMemcpyDeviceToHost, st);
+    }
+    for (int i = 0; i < NS; i++) {
+        const hipError_t e = hipStreamSynchronize(hp.stream[i]);
+        if (!err && e != hipSuccess) err = (int)e;
+    }
     return err;
 }
 
@@ -671,6 +771,11 @@ int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const i
 {
     DIL_ENTER(d, T);
     return (int)dil::launch_verify(level, w1, A, z, c, t1, h, batch, shared_pk, T, S(stream));
+}
+int dil_verify_core_host(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1, const uint8_t* h, int level,
+                         size_t batch, int shared_pk)
+{
+    return host_verify_core(w1, A, z, c, t1, h, level, batch, shared_pk);
 }
 int dil_sign_phase1_dev(uint8_t* w1, int32_t* w0, const int32_t* A, const int32_t* y, int level, size_t batch,
                         int shared_key, void* stream)

@@ -40,6 +40,10 @@ struct Config {
     std::atomic<int> host_mailbox{0};      // DIL_HOST_MAILBOX: 1 = the *_host entry points serve batch == 1 through the resident mailbox wave
                                            // (libdil256_ref.so turns it on: its ntt() / invntt() / ... are batch-of-one calls)
     std::atomic<int> mailbox_idle_us{200}; // DIL_MAILBOX_IDLE_US: the mailbox wave retires after this long without a request
+    std::atomic<int> host_chunk{16384};    // DIL_HOST_CHUNK: polynomials (KiB) per chunk of the *_host pipelines, pageable caller buffers
+    std::atomic<int> host_chunk_pinned{1024};  // DIL_HOST_CHUNK_PINNED: the same when the caller's buffer is page-locked (true asynchronous DMA: small chunks overlap better)
+    std::atomic<int> host_streams{4};      // DIL_HOST_STREAMS: streams the chunks go round (1 .. 8)
+    std::atomic<int> host_pin{0};          // DIL_HOST_PIN: 1 = the caller's buffers are page-locked for the duration of a *_host call
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
 };
 extern Config cfg;
@@ -73,12 +77,12 @@ struct AuxStream {
 };
 
 // staging of the *_host transform entry points (capi.hip)
-constexpr int HOST_STREAMS = 3;
+constexpr int HOST_STREAMS = 8;            // upper bound; option host_streams picks how many a call uses
 struct HostPipe {
-    hipStream_t stream[HOST_STREAMS] = {nullptr, nullptr, nullptr};
-    int32_t* dev[HOST_STREAMS] = {nullptr, nullptr, nullptr};
+    hipStream_t stream[HOST_STREAMS] = {};
+    uint8_t* dev[HOST_STREAMS] = {};       // one staging buffer per stream
+    size_t dev_bytes = 0;                  // size of each
     bool ready = false;
-    int pin = -1;
 };
 
 // the host mailbox of the batch-of-one drop-in calls (kernels.hpp Mailbox; capi.hip mailbox_call)

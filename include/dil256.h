@@ -152,6 +152,12 @@ int dil_matvec_dev(int32_t* w, const int32_t* A, const int32_t* y, int level, si
 int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1,
                         const uint8_t* h, int level, size_t batch, int shared_pk, void* stream);
 
+/* The same from HOST arrays (the reference's calling convention for this path is caller-owned host buffers, reference_code/ref_ntt.h:30-36):
+ * synchronous; items in chunks round-robin over `host_streams` streams, each chunk H2D -> fused kernel -> D2H (options host_chunk,
+ * host_streams, host_pin).  PCIe-bound: 45 KiB up and 1.5 KiB down per level-3 item. */
+int dil_verify_core_host(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1, const uint8_t* h, int level,
+                         size_t batch, int shared_pk);
+
 /* ---- H10: sign inner loop (combined_top.v:1830-2229) --------------------------------------
  * phase 1 (FSM1 + DECOMP): w = INTT(A o NTT(y)); (w1, w0) = Decompose(w); w0 as residue in [0,q).
  * phase 2 (FSM2): z = y + c*s1, r0 = w0 - c*s2, ct0 = c*t0, h = MakeHint(r0 + ct0, w1);

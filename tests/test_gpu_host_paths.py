@@ -1,0 +1,60 @@
+"""The host-pointer pipelines (csrc/capi.hip host_inplace / host_verify_core: chunks round-robin over streams, H2D -> kernel -> D2H) under
+every setting of their options -- host_chunk (KiB per chunk), host_streams (1 .. 8), host_pin (caller's buffers page-locked) -- against
+the oracle and the device-pointer entry points.  The reference's calling convention for the path is caller-owned HOST arrays
+(reference_code/ref_ntt.h:30-36, hardware_code/ntt2x2.h:30-34); bench.py's `end_to_end` block times these calls."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Q, N, splitmix64_polys
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def host_opts(gpu):
+    from dilithium_amd import api
+    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin")}
+    yield lambda **kw: [api.set_option(k, v) for k, v in kw.items()]
+    for k, v in saved.items():
+        api.set_option(k, v)
+
+
+@pytest.mark.parametrize("chunk,streams,pin", [(64, 1, 0), (64, 3, 1), (100, 8, 0), (16384, 3, 0), (1024, 2, 1)])
+def test_ntt_host_chunked(gpu, oracle, host_opts, chunk, streams, pin):
+    from dilithium_amd import api
+    host_opts(host_chunk=chunk, host_streams=streams, host_pin=pin)
+    n = 3 * chunk + 17 if chunk < 4096 else 20000
+    a = splitmix64_polys(n, seed=chunk + streams)
+    x = a.copy()
+    api.ntt(x)
+    idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 97)), [n - 1, chunk - 1 if chunk < n else 0, min(chunk, n - 1)]]))
+    assert (x[idx] == oracle.ntt(a[idx])).all()
+    api.invntt(x)
+    assert (x == a).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("chunk,streams,pin", [(128, 3, 0), (300, 1, 1), (16384, 3, 0)])
+def test_verify_core_host_vs_device_and_oracle(gpu, oracle, host_opts, level, shared, chunk, streams, pin):
+    from dilithium_amd import api
+    K, L = {2: (4, 4), 3: (6, 5), 5: (8, 7)}[level]
+    n = 77
+    nk = 1 if shared else n
+    rng = np.random.default_rng(level * 10 + chunk)
+    A = splitmix64_polys(nk * K * L, seed=level).reshape(nk, K, L, N)
+    g1 = 1 << (17 if level == 2 else 19)
+    z = np.mod(rng.integers(-g1 + 1, g1 + 1, (n, L, N)), Q).astype(np.int32)
+    c = np.zeros((n, N), np.int32)
+    for i in range(n):
+        pos = rng.choice(N, 39, replace=False)
+        c[i, pos] = np.where(rng.random(39) < 0.5, 1, Q - 1)
+    t1 = rng.integers(0, 1024, (nk, K, N)).astype(np.int32)
+    h = (rng.random((n, K, N)) < 0.03).astype(np.uint8)
+    host_opts(host_chunk=chunk, host_streams=streams, host_pin=pin)
+    w1 = api.verify_core(A, z, c, t1, h.reshape(n, K * N), level, shared_pk=shared)
+    cu = lambda x: gpu.from_numpy(x).cuda()  # noqa: E731
+    dev = api.verify_core(cu(A), cu(z), cu(c), cu(t1), cu(h), level, shared_pk=shared).cpu().numpy()
+    assert (w1.reshape(dev.shape) == dev).all()
+    Ab, tb = (np.broadcast_to(A, (n, K, L, N)), np.broadcast_to(t1, (n, K, N))) if shared else (A, t1)
+    assert (dev == oracle.verify_core(level, np.ascontiguousarray(Ab), z, c, np.ascontiguousarray(tb), h)).all()
