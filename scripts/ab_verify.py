@@ -22,6 +22,8 @@ ap.add_argument("--kind", default="verify", choices=["verify", "matvec", "sign1"
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--generic", action="store_true", help="sign2: the entry point for arbitrary residues even where the small-key one exists")
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--sets", type=int, default=4, help="rotating input sets (4 x 360 MiB at level 3: past the 256 MiB Infinity Cache for real; "
+                "two sets, the default of rounds 2-4, are LLC-assisted -- profiles/r05i_rotating_sets.txt)")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 KL = {2: (4, 4), 3: (6, 5), 5: (8, 7)}
@@ -32,7 +34,7 @@ torch.cuda.init()
 g = torch.Generator(device="cuda").manual_seed(0)
 rnd = lambda *s: torch.randint(0, Q, s, dtype=torch.int32, device="cuda", generator=g)  # noqa: E731
 sets = []
-for _ in range(2):
+for _ in range(a.sets):
     t1 = torch.randint(0, 1024, (n, K, 256), dtype=torch.int32, device="cuda", generator=g)
     h = (torch.rand((n, K, 256), device="cuda", generator=g) < 0.03).to(torch.uint8)
     sets.append((rnd(n, K, L, 256), rnd(n, L, 256), rnd(n, 256), t1, h))
@@ -91,7 +93,7 @@ E.dil_event_create(C.byref(e1))
 
 def run(L_, reps):
     for i in range(reps):
-        A, z, c, t1, h = sets[i & 1]
+        A, z, c, t1, h = sets[i % len(sets)]
         sh = 1 if a.shared else 0
         if a.kind == "ntt":
             b = nttb[i & 7]

@@ -1,0 +1,222 @@
+// tune_verify_mem.hip -- the memory side of the fused level-3 verify core (pipelines.hip verify_wpi_kernel) as a skeleton: the same
+// operands in the same order from the same five arrays, a key per item, persistent waves, one row of A ahead -- and a checksum instead
+// of the arithmetic.  Under four rotating input sets the real kernel runs at its memory-only time (68.2 vs 67.5 us, profiles/
+// r05j_ab_verify_sets.txt) = 5.6 TB/s, where a plain read-only stream reaches 6.4-7.2 TB/s on this chip (profiles/r01_membench.txt):
+// which property of the access pattern costs the difference?
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/tune_verify_mem.hip -o scripts/bin/tune_verify_mem
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int K = 6, L = 5;
+
+__device__ __forceinline__ int4 ld4(const int32_t* p, bool nt)
+{
+    int4 v;
+    if (nt) {
+        v.x = __builtin_nontemporal_load(p);
+        v.y = __builtin_nontemporal_load(p + 1);
+        v.z = __builtin_nontemporal_load(p + 2);
+        v.w = __builtin_nontemporal_load(p + 3);
+    } else {
+        v = *reinterpret_cast<const int4*>(p);
+    }
+    return v;
+}
+__device__ __forceinline__ int32_t ld1(const int32_t* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ int32_t fold(int4 v) { return v.x ^ v.y ^ v.z ^ v.w; }
+
+// SMALL4: z / c / t1 as one dwordx4 per lane and polynomial (else four strided dwords, as the transforms want them)
+// NT_SMALL: non-temporal policy for z / c / t1 / h too        AHEAD: rows of A in flight beyond the current one (1 = the kernel)
+// WPS: waves per SIMD asked of the allocator                  CONTIG: a workgroup walks a contiguous run of items
+template <bool SMALL4, bool NT_SMALL, int AHEAD, int WPS, bool CONTIG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void skel(uint8_t* __restrict__ w1, const int32_t* __restrict__ A,
+                                                                                           const int32_t* __restrict__ z, const int32_t* __restrict__ c,
+                                                                                           const int32_t* __restrict__ t1, const uint8_t* __restrict__ h,
+                                                                                           size_t batch)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    size_t it, step, end;
+    if (CONTIG) {
+        const size_t per = (batch + gridDim.x - 1) / gridDim.x;
+        it = (size_t)blockIdx.x * per + wv;
+        end = std::min(batch, (size_t)(blockIdx.x + 1) * per);
+        step = 4;
+    } else {
+        it = (size_t)blockIdx.x * 4 + wv;
+        end = batch;
+        step = nwaves;
+    }
+    auto small = [&](const int32_t* p) -> int32_t {
+        if (SMALL4) return fold(ld4(p + 4 * lane, NT_SMALL));
+        int32_t s = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) s ^= ld1(p + lane + 64 * m, NT_SMALL);
+        return s;
+    };
+    int32_t zc[L + 1];
+    auto load_zc = [&](size_t i) {
+#pragma unroll
+        for (int l = 0; l < L; l++) zc[l] = small(z + (i * L + l) * 256);
+        zc[L] = small(c + i * 256);
+    };
+    if (it < end) load_zc(it);
+    for (; it < end; it += step) {
+        const int32_t* Ait = A + it * (size_t)(K * L) * 256;
+        const int32_t* t1it = t1 + it * (size_t)K * 256;
+        const uint8_t* hit = h + it * K * 256;
+        int4 Ar[AHEAD][L];
+#pragma unroll
+        for (int a = 0; a < AHEAD; a++)
+#pragma unroll
+            for (int l = 0; l < L; l++) Ar[a][l] = ld4(Ait + (size_t)(a * L + l) * 256 + 4 * lane, true);
+        int32_t tn = small(t1it);
+        uint32_t hn = reinterpret_cast<const uint32_t*>(hit)[lane];
+        int32_t acc = 0;
+#pragma unroll
+        for (int l = 0; l <= L; l++) acc ^= zc[l];
+        const size_t itn = it + step;
+        if (itn < end) load_zc(itn);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            int32_t r = acc ^ tn ^ (int32_t)hn;
+#pragma unroll
+            for (int l = 0; l < L; l++) r ^= fold(Ar[0][l]);
+#pragma unroll
+            for (int a = 0; a + 1 < AHEAD; a++)
+#pragma unroll
+                for (int l = 0; l < L; l++) Ar[a][l] = Ar[a + 1][l];
+            if (k + AHEAD < K) {
+#pragma unroll
+                for (int l = 0; l < L; l++) Ar[AHEAD - 1][l] = ld4(Ait + (size_t)((k + AHEAD) * L + l) * 256 + 4 * lane, true);
+            }
+            if (k + 1 < K) {
+                tn = small(t1it + (k + 1) * 256);
+                hn = reinterpret_cast<const uint32_t*>(hit + (k + 1) * 256)[lane];
+            }
+            reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 256)[lane] = (uint32_t)r;
+        }
+    }
+}
+
+// references in the same run: a plain grid-stride read of the same bytes (what the chip gives a read-only stream today), and the
+// matrix stream alone in the kernel's order (an item's 30 KiB per wave, 5 KiB at a time)
+__global__ __launch_bounds__(256) void plain_read(uint32_t* __restrict__ out, const int4* __restrict__ p, size_t nvec)
+{
+    int32_t s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) s ^= fold(ld4(reinterpret_cast<const int32_t*>(p + i), true));
+    if (s == 0x12345678) out[threadIdx.x] = (uint32_t)s;
+}
+template <int ROWS_PER_ITEM>
+__global__ __launch_bounds__(256) void a_only(uint32_t* __restrict__ out, const int32_t* __restrict__ A, size_t batch)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    int32_t s = 0;
+    for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
+        const int32_t* Ait = A + it * (size_t)(ROWS_PER_ITEM * L) * 256;
+        int4 cur[L];
+#pragma unroll
+        for (int l = 0; l < L; l++) cur[l] = ld4(Ait + l * 256 + 4 * lane, true);
+        for (int k = 0; k < ROWS_PER_ITEM; k++) {
+            int4 nx[L];
+            if (k + 1 < ROWS_PER_ITEM) {
+#pragma unroll
+                for (int l = 0; l < L; l++) nx[l] = ld4(Ait + (size_t)((k + 1) * L + l) * 256 + 4 * lane, true);
+            }
+#pragma unroll
+            for (int l = 0; l < L; l++) s ^= fold(cur[l]);
+#pragma unroll
+            for (int l = 0; l < L; l++) cur[l] = nx[l];
+        }
+    }
+    if (s == 0x12345678) out[threadIdx.x] = (uint32_t)s;
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const size_t n = 8192, NS = 4;
+    const size_t bA = n * K * L * 1024, bz = n * L * 1024, bc = n * 1024, bt = n * K * 1024, bh = n * K * 256;
+    int32_t *A, *z, *c, *t1;
+    uint8_t *h, *w1;
+    CK(hipMalloc(&A, NS * bA)); CK(hipMalloc(&z, NS * bz)); CK(hipMalloc(&c, NS * bc)); CK(hipMalloc(&t1, NS * bt)); CK(hipMalloc(&h, NS * bh));
+    CK(hipMalloc(&w1, NS * bh));
+    CK(hipMemset(A, 1, NS * bA)); CK(hipMemset(z, 2, NS * bz)); CK(hipMemset(c, 3, NS * bc)); CK(hipMemset(t1, 4, NS * bt)); CK(hipMemset(h, 0, NS * bh));
+    const double bytes = (double)(bA + bz + bc + bt + 2 * bh);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#define RUN(label, KERN, BPC)                                                                                                      \
+    {                                                                                                                              \
+        auto go = [&](int i) {                                                                                                     \
+            const size_t s = i % NS;                                                                                               \
+            KERN<<<cus * BPC, 256>>>(w1 + s * bh, A + s * (bA / 4), z + s * (bz / 4), c + s * (bc / 4), t1 + s * (bt / 4), h + s * bh, n); \
+        };                                                                                                                         \
+        for (int i = 0; i < 40; i++) go(i);                                                                                        \
+        CK(hipDeviceSynchronize());                                                                                                \
+        std::vector<float> t;                                                                                                      \
+        for (int rep = 0; rep < 5; rep++) {                                                                                        \
+            CK(hipEventRecord(e0));                                                                                                \
+            for (int i = 0; i < 200; i++) go(i);                                                                                   \
+            CK(hipEventRecord(e1));                                                                                                \
+            CK(hipEventSynchronize(e1));                                                                                           \
+            float ms;                                                                                                              \
+            CK(hipEventElapsedTime(&ms, e0, e1));                                                                                  \
+            t.push_back(ms / 200 * 1e3f);                                                                                          \
+        }                                                                                                                          \
+        std::sort(t.begin(), t.end());                                                                                             \
+        printf("%-86s %7.2f us  %6.0f GB/s  %.3f of 8 TB/s\n", label, t[2], bytes / t[2] / 1e3, bytes / t[2] / 1e3 / 8000);        \
+    }
+    {
+        auto tm = [&](const char* label, auto go, double by) {
+            for (int i = 0; i < 20; i++) go(i);
+            CK(hipDeviceSynchronize());
+            std::vector<float> t;
+            for (int rep = 0; rep < 5; rep++) {
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 100; i++) go(i);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                t.push_back(ms / 100 * 1e3f);
+            }
+            std::sort(t.begin(), t.end());
+            printf("%-86s %7.2f us  %6.0f GB/s  %.3f of 8 TB/s\n", label, t[2], by / t[2] / 1e3, by / t[2] / 1e3 / 8000);
+        };
+        for (int bpc : {4, 8, 16})
+            tm(bpc == 4 ? "plain grid-stride nt read of one set's A (240 MiB), 4 blocks/CU" : bpc == 8 ? "  8 blocks/CU" : "  16 blocks/CU",
+               [&](int i) { plain_read<<<cus * bpc, 256>>>(reinterpret_cast<uint32_t*>(w1), reinterpret_cast<const int4*>(A + (i % NS) * (bA / 4)), bA / 16); }, (double)bA);
+        tm("the matrix stream alone, kernel order (item = 30 KiB per wave, a 5-KiB row ahead), 3 blocks/CU",
+           [&](int i) { a_only<K><<<cus * 3, 256>>>(reinterpret_cast<uint32_t*>(w1), A + (i % NS) * (bA / 4), n); }, (double)bA);
+        tm("  the same bytes as 49152 items of one row (5 KiB per wave and trip)",
+           [&](int i) { a_only<1><<<cus * 3, 256>>>(reinterpret_cast<uint32_t*>(w1), A + (i % NS) * (bA / 4), n * K); }, (double)bA);
+        tm("  6 blocks/CU", [&](int i) { a_only<K><<<cus * 6, 256>>>(reinterpret_cast<uint32_t*>(w1), A + (i % NS) * (bA / 4), n); }, (double)bA);
+    }
+    // warm
+    RUN("(warm-up)", (skel<false, false, 1, 3, false>), 3)
+    RUN("as the kernel: strided dwords (default policy) for z c t1, A nt x4 one row ahead, 3 waves/SIMD", (skel<false, false, 1, 3, false>), 3)
+    RUN("  + nt on z c t1", (skel<false, true, 1, 3, false>), 3)
+    RUN("  z c t1 as dwordx4", (skel<true, false, 1, 3, false>), 3)
+    RUN("  z c t1 as dwordx4 + nt", (skel<true, true, 1, 3, false>), 3)
+    RUN("  A two rows ahead", (skel<false, false, 2, 3, false>), 3)
+    RUN("  A two rows ahead, small x4 nt", (skel<true, true, 2, 3, false>), 3)
+    RUN("  A three rows ahead, small x4 nt", (skel<true, true, 3, 3, false>), 3)
+    RUN("  contiguous run of items per workgroup", (skel<false, false, 1, 3, true>), 3)
+    RUN("  contiguous + small x4 nt + A two ahead", (skel<true, true, 2, 3, true>), 3)
+    RUN("  2 waves/SIMD", (skel<false, false, 1, 2, false>), 2)
+    RUN("  2 waves/SIMD, small x4 nt, A two ahead", (skel<true, true, 2, 2, false>), 2)
+    RUN("  4 waves/SIMD", (skel<false, false, 1, 4, false>), 4)
+    RUN("  4 waves/SIMD, small x4 nt", (skel<true, true, 1, 4, false>), 4)
+    RUN("  6 waves/SIMD, small x4 nt", (skel<true, true, 1, 6, false>), 6)
+    RUN("  8 waves/SIMD, small x4 nt", (skel<true, true, 1, 8, false>), 8)
+    return 0;
+}
