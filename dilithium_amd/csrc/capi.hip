@@ -47,6 +47,7 @@ const OptName* option_table(int* n)
         {"host_pin", "DIL_HOST_PIN", &cfg.host_pin},
         {"host_mailbox", "DIL_HOST_MAILBOX", &cfg.host_mailbox},
         {"mailbox_idle_us", "DIL_MAILBOX_IDLE_US", &cfg.mailbox_idle_us},
+        {"mailbox_resident_us", "DIL_MAILBOX_RESIDENT_US", &cfg.mailbox_resident_us},
         {"fuse_challenge", "DIL_FUSE_CHALLENGE", &cfg.fuse_challenge},
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
@@ -285,8 +286,9 @@ int mailbox_start(Device& d, const dil::Tables& T)          // (re)launch the re
     dil::rt::MailboxHost& m = d.mbox;
     __atomic_store_n(&m.host->state, (uint32_t)dil::MB_ALIVE, __ATOMIC_RELEASE);
     const uint64_t ticks = (uint64_t)std::max(1, dil::rt::cfg.mailbox_idle_us.load(std::memory_order_relaxed)) * 100;   // 100 MHz
+    const uint64_t resident = (uint64_t)std::max(1, dil::rt::cfg.mailbox_resident_us.load(std::memory_order_relaxed)) * 100;
     m.launches++;
-    return (int)dil::launch_mailbox(m.dev, __atomic_load_n(&m.host->done_seq, __ATOMIC_ACQUIRE), ticks, T, m.stream);
+    return (int)dil::launch_mailbox(m.dev, __atomic_load_n(&m.host->done_seq, __ATOMIC_ACQUIRE), ticks, resident, T, m.stream);
 }
 // one request: in0 (and in1) are copied into the mailbox, the wave is woken (or launched), `out` receives the 1 KiB result
 int mailbox_call(int op, int mapping, const int32_t* in0, const int32_t* in1, int32_t* out)
@@ -312,9 +314,7 @@ int mailbox_call(int op, int mapping, const int32_t* in0, const int32_t* in1, in
     dil::Mailbox* mb = m.host;
     memcpy(mb->in0, in0, 1024);
     if (in1) memcpy(mb->in1, in1, 1024);
-    mb->op = (uint32_t)op;
-    mb->mapping = (uint32_t)mapping;
-    const uint32_t seq = ++m.seq;
+    const uint32_t seq = dil::mb_header(++m.seq, (uint32_t)op, (uint32_t)mapping);     // one word: never torn against the wave's poll
     __atomic_store_n(&mb->req_seq, seq, __ATOMIC_RELEASE);
     __atomic_thread_fence(__ATOMIC_SEQ_CST);                  // the request is out before `state` is read (see mailbox_kernel's retirement)
     m.calls++;
@@ -329,9 +329,9 @@ int mailbox_call(int op, int mapping, const int32_t* in0, const int32_t* in1, in
                 return rc;
             }
         }
-        if ((spins & 1023) == 1023 && now_us() - t0 > 2e6) {   // 2 s without an answer: never again (the launch path still works)
-            m.broken = true;
-            return (int)hipErrorLaunchTimeOut;
+        if ((spins & 1023) == 1023 && now_us() - t0 > 2e6) {   // 2 s without an answer (e.g. a saturated GPU that cannot schedule the wave):
+            m.broken = true;                                   // never again -- and THIS call takes the launch path too, which still works
+            return MB_FALLBACK;                                // (a late device write to mb->out lands in the mailbox, not in the caller's buffer)
         }
         __builtin_ia32_pause();
     }
@@ -343,11 +343,9 @@ void mailbox_destroy(Device& d)
     dil::rt::MailboxHost& m = d.mbox;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.host) return;
-    if (mb_read(&m.host->state) != (uint32_t)dil::MB_DEAD) {     // ask the wave to leave, then wait for its stream
-        m.host->op = (uint32_t)dil::MB_QUIT;
-        __atomic_store_n(&m.host->req_seq, ++m.seq, __ATOMIC_RELEASE);
-    }
-    (void)hipStreamSynchronize(m.stream);
+    if (mb_read(&m.host->state) != (uint32_t)dil::MB_DEAD)       // ask the wave to leave, then wait for its stream
+        __atomic_store_n(&m.host->req_seq, dil::mb_header(++m.seq, (uint32_t)dil::MB_QUIT, 0), __ATOMIC_RELEASE);
+    if (!m.broken) (void)hipStreamSynchronize(m.stream);          // (a wedged wave -- what `broken` records -- would hang this for ever)
     (void)hipStreamDestroy(m.stream);
     (void)hipHostFree(m.host);
     m.host = m.dev = nullptr;

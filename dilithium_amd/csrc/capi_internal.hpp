@@ -40,6 +40,7 @@ struct Config {
     std::atomic<int> host_mailbox{0};      // DIL_HOST_MAILBOX: 1 = the *_host entry points serve batch == 1 through the resident mailbox wave
                                            // (libdil256_ref.so turns it on: its ntt() / invntt() / ... are batch-of-one calls)
     std::atomic<int> mailbox_idle_us{200}; // DIL_MAILBOX_IDLE_US: the mailbox wave retires after this long without a request
+    std::atomic<int> mailbox_resident_us{20000};   // DIL_MAILBOX_RESIDENT_US: ... and after this long in all, busy or not (a device-wide sync of another thread waits at most this long)
     std::atomic<int> host_chunk{16384};    // DIL_HOST_CHUNK: polynomials (KiB) per chunk of the *_host pipelines, pageable caller buffers
     std::atomic<int> host_chunk_pinned{1024};  // DIL_HOST_CHUNK_PINNED: the same when the caller's buffer is page-locked (true asynchronous DMA: small chunks overlap better)
     std::atomic<int> host_streams{4};      // DIL_HOST_STREAMS: streams the chunks go round (1 .. 8)

@@ -288,18 +288,17 @@ __global__ __launch_bounds__(256) void bram_mul_kernel(int32_t* ram, const int32
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mb_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void mb_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// the request header (req_seq, op, mapping: one 16-byte piece of one cache line) in ONE system-scope load = one PCIe read: the host
-// stores op / mapping before req_seq, so a header that shows the new sequence number carries its operation too -- a round trip
-// less per call than polling the word and then fetching the rest
-__device__ __forceinline__ uint4 mb_load_header(const Mailbox* mb)
+// the request header (sequence number, op, mapping in ONE 32-bit word: kernels.hpp mb_header) in one system-scope load = one PCIe read
+// that cannot be torn; wave-uniform
+__device__ __forceinline__ uint32_t mb_load_header(const Mailbox* mb)
 {
-    uint4 h;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(h) : "v"(&mb->req_seq) : "memory");
-    return h;
+    uint32_t h;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(h) : "v"(&mb->req_seq) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
 }
 
 __global__ __launch_bounds__(64) void mailbox_kernel(Mailbox* mb, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab,
-                                                     uint32_t last_done, uint64_t idle_ticks)
+                                                     uint32_t last_done, uint64_t idle_ticks, uint64_t max_resident_ticks)
 {
     const int lane = threadIdx.x & 63;
     TwRegs twf, twi;
@@ -307,20 +306,23 @@ __global__ __launch_bounds__(64) void mailbox_kernel(Mailbox* mb, const uint32_t
     twi.load(inv_tab, lane);
     const LaneMasks lm(lane);
     uint32_t done = last_done, served = 0;
-    uint64_t t_last = wall_clock64();                   // 100 MHz, independent of the shader clock
+    const uint64_t t_start = wall_clock64();            // 100 MHz, independent of the shader clock
+    uint64_t t_last = t_start;
     for (;;) {
-        uint4 hdr = mb_load_header(mb);
-        uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.x);
-        if (seq == done) {
-            if (wall_clock64() - t_last < idle_ticks) continue;
+        uint32_t hdr = mb_load_header(mb);
+        if (hdr == done) {
+            // Retire after `idle_ticks` without a request -- and, busy or not, after `max_resident_ticks` in all: a caller issuing
+            // requests back to back would otherwise keep the wave resident for ever and starve every other thread's device-wide
+            // synchronisation (hipFree, hipMalloc, hipDeviceSynchronize); the next call relaunches it (~40 us, once per residency).
+            const uint64_t now = wall_clock64();
+            if (now - t_last < idle_ticks && now - t_start < max_resident_ticks) continue;
             // retire -- unless a request slips in: announce, look once more (a PCIe read cannot overtake the posted write before
             // it, so either this read sees the request or the host, which reads `state` after posting, sees EXITING / DEAD)
             if (lane == 0) mb_store(&mb->state, MB_EXITING);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             hdr = mb_load_header(mb);
-            seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.x);
-            if (seq == done) {
+            if (hdr == done) {
                 if (lane == 0) {
                     mb_store(&mb->served, served);
                     mb_store(&mb->state, MB_DEAD);
@@ -329,12 +331,12 @@ __global__ __launch_bounds__(64) void mailbox_kernel(Mailbox* mb, const uint32_t
             }
             if (lane == 0) mb_store(&mb->state, MB_ALIVE);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // the payload was written before req_seq
-        const uint32_t op = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr.y);
-        const int mapping = __builtin_amdgcn_readfirstlane((int)hdr.z);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // the payload was written before the header
+        const uint32_t op = (hdr >> 2) & 63u;
+        const int mapping = (int)(hdr & 3u);
         if (op == MB_QUIT) {
             if (lane == 0) {
-                mb_store(&mb->done_seq, seq);
+                mb_store(&mb->done_seq, hdr);
                 mb_store(&mb->state, MB_DEAD);
             }
             return;
@@ -364,8 +366,8 @@ __global__ __launch_bounds__(64) void mailbox_kernel(Mailbox* mb, const uint32_t
         served++;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) mb_store(&mb->done_seq, seq);
-        done = seq;
+        if (lane == 0) mb_store(&mb->done_seq, hdr);
+        done = hdr;
         t_last = wall_clock64();
     }
 }
@@ -392,9 +394,9 @@ hipError_t launch_clock_probe(uint64_t* out4, uint64_t spin_ticks, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, const Tables& t, hipStream_t s)
+hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, uint64_t max_resident_ticks, const Tables& t, hipStream_t s)
 {
-    hipLaunchKernelGGL(mailbox_kernel, 1, 64, 0, s, mb_dev, t.fwd, t.inv, last_done, idle_ticks);
+    hipLaunchKernelGGL(mailbox_kernel, 1, 64, 0, s, mb_dev, t.fwd, t.inv, last_done, idle_ticks, max_resident_ticks);
     return hipGetLastError();
 }
 

@@ -52,15 +52,18 @@ hipError_t launch_ntt_traffic(bool inverse, int32_t* polys, size_t batch, const 
 // next call; `state` closes the race between "retiring" and "a request just arrived" (capi.hip mailbox_call).
 enum { MB_FWD = 0, MB_INV = 1, MB_PW_MUL = 2, MB_BRAM_FWD = 3, MB_BRAM_INV = 4, MB_BRAM_MUL = 5, MB_QUIT = 6 };
 enum { MB_DEAD = 0, MB_ALIVE = 1, MB_EXITING = 2 };
+// The request header is ONE 32-bit word -- sequence number << 8 | op << 2 | mapping -- so that the wave's poll can never see a new
+// sequence number with the previous request's operation (a 16-byte PCIe read is not guaranteed to be untorn against the host's stores).
+__host__ __device__ inline uint32_t mb_header(uint32_t seq, uint32_t op, uint32_t mapping) { return (seq << 8) | (op << 2) | (mapping & 3u); }
 struct Mailbox {
     // host -> device (one cache line)
-    uint32_t req_seq, op, mapping, pad0[13];
+    uint32_t req_seq, pad0[15];           // mb_header(seq, op, mapping)
     // device -> host (one cache line)
     uint32_t done_seq, state, served, pad1[13];
     int32_t in0[256], in1[256], out[256];
 };
 hipError_t launch_clock_probe(uint64_t* out4, uint64_t spin_ticks, hipStream_t s);   // bench.py: effective shader clock
-hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, const Tables& t, hipStream_t s);
+hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_ticks, uint64_t max_resident_ticks, const Tables& t, hipStream_t s);
 
 hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t* b, const int32_t* acc, size_t batch,
                             const Tables& t, hipStream_t s);

@@ -1456,6 +1456,9 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
                         int32_t* w0_scratch, int y_fmt, bool small_key)
 {
     if (batch == 0) return hipSuccess;
+    // a speculative round is spec_n items x S attempts, entry = item * S + attempt; the kernel reads an item's earlier attempts one per
+    // lane, so S cannot exceed the wave width (scheme.hip's s_max = 64 is that bound)
+    if (km.spec_n && (km.S > 64 || (size_t)km.spec_n * km.S != batch)) return hipErrorInvalidValue;
     if (y_fmt == Y_PACKED && !(use_wpi(batch, t) && small_key)) return hipErrorInvalidValue;      // packed y: the signing loop's wave-per-item shapes only
     if (use_wpi(batch, t) && w0_scratch) {      // the signing loop's early-exit form (w0 is its own scratch, reused for r0)
         if (w0_scratch != w0) return hipErrorInvalidValue;

@@ -624,7 +624,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
     // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
     // speculate for free
-    const int s_max = 64;
+    const int s_max = 64;           // also the wave width: phase 2 reads an item's earlier attempts one per lane (launch_sign2 refuses more)
     const int opt_cap = dil::rt::cfg.sign_cap.load(std::memory_order_relaxed);
     const int sign_waste = dil::rt::cfg.sign_waste.load(std::memory_order_relaxed);
     const bool sign_early = dil::rt::cfg.sign_early.load(std::memory_order_relaxed) != 0;

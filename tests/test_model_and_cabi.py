@@ -152,6 +152,44 @@ def test_use_hint_half_bucket_form_over_the_whole_field():
             assert (n == want).all(), (level, hint)
 
 
+def test_decompose_w0res_over_the_whole_field():
+    """pipeline_common.hpp decompose_w0res<LEVEL> (sign phase 1's output stage; phase 2's exact small-integer paths rely on it): w1 =
+    HighBits(a) and w0 = LowBits(a) AS A RESIDUE, computed without the centring step of Decompose -- the kernel's 32-bit operations
+    restated in numpy -- against Decompose + canonicalisation (the oracle's orc_decompose formulas, pinned to the RTL threshold map by
+    tests/test_oracle.py) for EVERY a in [0, q), both gamma2 values, including the wrap where a1 = 44 | 16 becomes 0"""
+    import numpy as np
+    q = 8380417
+    a = np.arange(q, dtype=np.int64)
+    for level in (2, 3):                 # (level 5 shares level 3's gamma2)
+        g2 = (q - 1) // 88 if level == 2 else (q - 1) // 32
+        # reference: Decompose, then LowBits as a residue
+        t = (a + 127) >> 7
+        if level == 2:
+            t = (t * 11275 + (1 << 23)) >> 24
+            t = t ^ (((43 - t) >> 63) & t)
+        else:
+            t = ((t * 1025 + (1 << 21)) >> 22) & 15
+        a0 = a - t * 2 * g2
+        a0 = a0 - ((((q - 1) // 2 - a0) >> 63) & q)                # centred into (-gamma2, gamma2] (and a - q for the wrapped bucket)
+        want_w0 = np.where(a0 < 0, a0 + q, a0)
+        # the kernel: uint32 / int32 arithmetic
+        au = a.astype(np.uint32)
+        tk = (au + np.uint32(127)) >> np.uint32(7)
+        if level == 2:
+            tk = (tk * np.uint32(11275) + np.uint32(1 << 23)) >> np.uint32(24)
+            sg = ((np.int32(43) - tk.astype(np.int32)) >> 31).astype(np.uint32)           # sgn(43 - t): all-ones where t > 43
+            tk = tk ^ (sg & tk)
+        else:
+            tk = ((tk * np.uint32(1025) + np.uint32(1 << 21)) >> np.uint32(22)) & np.uint32(15)
+        r = au.astype(np.int32) - tk.astype(np.int32) * np.int32(2 * g2)
+        w0 = (r + ((r >> 31) & np.int32(q))).astype(np.uint32)
+        assert (tk.astype(np.int64) == t).all(), level
+        assert (w0.astype(np.int64) == want_w0).all(), level
+        assert int(w0.max()) < q
+        wrapped = a >= q - g2                     # the last half bucket: a1 = 44 | 16 -> 0, LowBits = a - q, residue = a itself
+        assert (t[wrapped] == 0).all() and (want_w0[wrapped] == a[wrapped]).all()
+
+
 def test_every_option_is_documented_and_round_trips_without_gpu(lib):
     """dil_set_option / dil_get_option (include/dil256.h): every name in the library's option table is described in the header or
     in INTEGRATION.md, reads back what was set, and an unknown name is refused -- all without a GPU"""
