@@ -45,6 +45,7 @@ struct Config {
     std::atomic<int> host_chunk_pinned{1024};  // DIL_HOST_CHUNK_PINNED: the same when the caller's buffer is page-locked (true asynchronous DMA: small chunks overlap better)
     std::atomic<int> host_streams{4};      // DIL_HOST_STREAMS: streams the chunks go round (1 .. 8)
     std::atomic<int> host_pin{0};          // DIL_HOST_PIN: 1 = the caller's buffers are page-locked for the duration of a *_host call
+    std::atomic<int> multi_group_at_1{0};  // DIL_MULTI_GROUP_AT_1 (tests): 1 | 2 = a one-device dil_*_multi_dev job goes through the grouped collective code
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
 };
 extern Config cfg;

@@ -215,8 +215,14 @@ int gather_slabs(void* const* bufs, size_t item_bytes, size_t batch, int root, i
     std::lock_guard<std::mutex> lk(m.mu);
     if (m.G != G) return (int)hipErrorInvalidValue;
     if (root >= G) return (int)hipErrorInvalidValue;
-    if (G > 1 && batch > 0 && item_bytes > 0) {
-        const bool equal = batch % (size_t)G == 0;
+    // Option multi_group_at_1 (tests only): send a ONE-device job through the grouped code below instead of the trivial collective --
+    // 1: GroupStart, the in-place ncclAllGather, GroupEnd, drain; 2: the ragged form, one ncclBroadcast per slab inside the group.  On a
+    // one-GPU box this is the only way any of the group code runs before a multi-GPU node sees it.  (ncclSend / ncclRecv of the
+    // gather-to-a-root form need two ranks: they execute for the first time there.)
+    int force = 0;
+    if (G == 1 && dil_get_option("multi_group_at_1", &force) != 0) force = 0;
+    if ((G > 1 || force) && batch > 0 && item_bytes > 0) {
+        const bool equal = batch % (size_t)G == 0 && force != 2;
         DIL_NCCL(m.rccl.GroupStart(), "ncclGroupStart");
         ncclResult_t bad = ncclSuccess;                  // first failure inside the group; the group is closed either way
         const char* bad_what = "";
@@ -293,6 +299,26 @@ hipStream_t dev_stream(int g) { return g_multi.stream[(size_t)g]; }
 }  // namespace
 
 extern "C" {
+
+// What the collective layer is bound to: NCCL_VERSION_CODE of the RCCL in use (major * 10000 + minor * 100 + patch), the path of the
+// library (as the dynamic linker reports it), communicators alive.  0 on success; RCCL is bound on first use (DIL_ERR_RCCL if absent).
+int dil_multi_info(int* rccl_version, char* path, size_t path_len, int* ndev)
+{
+    std::lock_guard<std::mutex> lk(g_multi.mu);
+    if (!g_multi.rccl.load()) {
+        const char* dl = dlerror();
+        snprintf(g_multi.last_error, sizeof(g_multi.last_error), "%s%s%s", g_multi.rccl.why, dl ? ": " : "", dl ? dl : "");
+        return DIL_ERR_RCCL;
+    }
+    if (rccl_version) *rccl_version = g_multi.rccl.version;
+    if (ndev) *ndev = g_multi.G;
+    if (path && path_len) {
+        path[0] = 0;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(g_multi.rccl.AllGather), &info) && info.dli_fname) snprintf(path, path_len, "%s", info.dli_fname);
+    }
+    return 0;
+}
 
 const char* dil_multi_last_error(void)
 {

@@ -45,6 +45,7 @@ SIGNATURES = {
     "dil_bram_mul_host": [_i32p, _i32p, _sz, C.c_int],
     "dil_matvec_dev": [_vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_verify_core_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_multi_info": [C.POINTER(C.c_int), C.c_char_p, _sz, C.POINTER(C.c_int)],
     "dil_verify_core_host": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int],
     "dil_sign_phase1_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase2_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],

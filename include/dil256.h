@@ -324,6 +324,8 @@ int dil_verify_sig_multi_host(int32_t* verdict, const uint8_t* pk, const uint8_t
 int dil_multi_init(int ndev);
 int dil_multi_shutdown(void);
 const char* dil_multi_last_error(void);
+/* which RCCL the collectives are bound to: NCCL_VERSION_CODE (major * 10000 + minor * 100 + patch), the library's path, devices of the live communicators (0: none) */
+int dil_multi_info(int* rccl_version, char* path, size_t path_len, int* ndev);
 int dil_gather_slabs_multi_dev(void* const* bufs, size_t item_bytes, size_t batch, int gather_root, int ndev);
 int dil_ntt_multi_dev(int32_t* const* polys /* in/out: full-size, slab in place */, size_t batch, int inverse, int gather_root, int ndev);
 int dil_sign_multi_dev(uint8_t* const* sig, int32_t* const* attempts /* or NULL */, const uint8_t* const* sk, const uint8_t* const* mu,

@@ -24,18 +24,30 @@ python - "$OUT/scale_lines.jsonl" "$OUT/scale_curve.json" "$NGPU" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
 base = next((r for r in rows if r["n_gpus"] == 1), None)
-curve = []
+curve, bad = [], []
 for r in rows:
     n = r["n_gpus"]
     c4 = r.get("secondary", {}).get("configs4_sharded", {})
+    dist = r.get("distributed") or {}
+    # at N = 1 there is no process group: one rank, one device by construction
+    nranks = dist.get("rccl_nranks", 1 if n == 1 else None)
+    devices = dist.get("distinct_devices", 1 if n == 1 else None)
     per_gpu = r["value"] / n
     curve.append({"n_gpus": n, "value": r["value"], "unit": r["unit"], "per_gpu_value": per_gpu,
-                  "per_gpu_vs_n1": per_gpu / base["value"] if base else None, "ms_per_step": r["ms_per_step"],
-                  "configs4_attempt_ms_per_rank_slice": c4.get("attempt_ms_per_rank_slice"), "configs4_attempts_per_s": c4.get("attempts_per_s"),
+                  "per_gpu_vs_n1": per_gpu / base["value"] if base else None,
+                  "kernel_ms": r["ms_per_step"],                     # one step (fwd + inv launch) on every GPU's own batch: flat in N if the path shards cleanly
+                  "configs4_kernel_ms": c4.get("attempt_ms_per_rank_slice"), "configs4_attempts_per_s": c4.get("attempts_per_s"),
                   "final_gather_ms": c4.get("final_gather_ms"), "final_gather_bytes": c4.get("final_gather_bytes"),
                   "final_gather_GBps_per_gpu_received": c4.get("final_gather_GBps_per_gpu_received"),
-                  "xgmi_bound_GBps_per_gpu": c4.get("xgmi_bound_GBps_per_gpu"), "distributed": r.get("distributed")})
+                  "xgmi_bound_GBps_per_gpu": c4.get("xgmi_bound_GBps_per_gpu"),
+                  "rccl_nranks": nranks, "distinct_devices": devices, "backend": dist.get("backend"), "rccl_version": dist.get("rccl_version"),
+                  "librccl": dist.get("librccl")})
+    if nranks != n or devices != n or (n > 1 and dist.get("backend") != "nccl"):
+        bad.append(f"N={n}: rccl_nranks={nranks} distinct_devices={devices} backend={dist.get('backend')}")
 json.dump({"visible_gpus": int(sys.argv[3]), "note": "efficiency is the driver's to compute; per_gpu_vs_n1 is the flatness of the per-GPU rate",
-           "curve": curve}, open(sys.argv[2], "w"), indent=1)
-print(json.dumps([{k: c[k] for k in ("n_gpus", "value", "per_gpu_vs_n1", "final_gather_ms")} for c in curve]))
+           "valid": not bad, "refused": bad, "curve": curve}, open(sys.argv[2], "w"), indent=1)
+print(json.dumps([{k: c[k] for k in ("n_gpus", "value", "per_gpu_vs_n1", "kernel_ms", "final_gather_ms", "rccl_nranks", "distinct_devices")} for c in curve]))
+if bad:
+    print("REFUSED: a row whose RCCL job is not N ranks on N distinct devices is not a scaling curve:", "; ".join(bad))
+    sys.exit(1)
 PY

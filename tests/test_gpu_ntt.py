@@ -202,6 +202,33 @@ def test_bram_api_vs_reference_golden(gpu, golden, mapping):
     assert (host(t) == canon(golden[f"bram_mul_{mapping}"])).all()
 
 
+@pytest.mark.parametrize("mapping", [NATURAL, AFTER_NTT, AFTER_INVNTT])
+def test_bram_all_ops_4096_random_and_edge_rows_vs_oracle(gpu, oracle, mapping):
+    """all 9 (op x mapping) combinations of the hardware-model API (hardware_code/ntt2x2.h:30-34) well beyond the 16 polynomials of the
+    goldens: 4096 seeded-random `bram`s plus the 21 edge rows of the golden set (ramp, zeros, all q-1, all -(q-1), ones, unit impulses,
+    signed rows), every output row, against the oracle's bram model -- which tests/test_oracle.py pins live against the compiled
+    reference (oracle/_ref/libref.so) on every mapping"""
+    from dilithium_amd import api
+    edge = [np.arange(N), np.zeros(N), np.full(N, Q - 1), np.full(N, -(Q - 1)), np.full(N, 1)]
+    for idx in (0, 1, 2, 63, 64, 127, 128, 255):
+        e = np.zeros(N)
+        e[idx] = 1
+        edge.append(e)
+    ram = np.concatenate([np.array(edge, dtype=np.int32), splitmix64_polys(8, seed=31 + mapping, lo=-(Q - 1), hi=Q),
+                          splitmix64_polys(4096, seed=41 + mapping)])
+    mul = splitmix64_polys(ram.shape[0], seed=51 + mapping)
+    assert ram.shape[0] == 4096 + 21
+    t = dev(gpu, ram)
+    api.ntt2x2_fwdntt(t.view(-1, 64, 4), mapping)
+    assert (host(t) == canon(oracle.bram_fwdntt(ram, mapping))).all()
+    t = dev(gpu, ram)
+    api.ntt2x2_invntt(t.view(-1, 64, 4), mapping)
+    assert (host(t) == canon(oracle.bram_invntt(ram, mapping))).all()
+    t = dev(gpu, ram)
+    api.ntt2x2_mul(t.view(-1, 64, 4), dev(gpu, mul).view(-1, 64, 4), mapping)
+    assert (host(t) == canon(oracle.bram_mul(ram, mul, mapping))).all()
+
+
 def test_bram_polymul_chain_like_reference_test(gpu, oracle, golden):
     """ntt2x2_test.cpp:109-137 polymul(): fwd, fwd, mul, inv under AFTER_NTT == plain product;
     b = 31 a as in the reference's main (:171-172)"""

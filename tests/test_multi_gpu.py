@@ -177,6 +177,34 @@ def test_cpp_multi_dev_layer_rccl_gather(gpu, oracle, ndev, root, kat_msgs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n", [1024, 1025])
+def test_grouped_rccl_path_at_world_one(gpu, oracle, mode, n):
+    """csrc/multi_gpu.hip gather_slabs on ONE device, sent through the grouped code a multi-GPU job runs (option multi_group_at_1):
+    mode 1 = ncclGroupStart -> in-place ncclAllGather -> ncclGroupEnd -> drain; mode 2 = the ragged all-gather-v form, one ncclBroadcast
+    per slab inside the group -- on real RCCL, with the compute before it checked against the oracle.  (ncclSend / ncclRecv of the
+    gather-to-a-root form need two ranks and execute for the first time on a multi-GPU node.)"""
+    from dilithium_amd import api, lib as dlib
+    from oracle.oracle import splitmix64_polys
+    L_ = dlib.load()
+    saved = api.get_option("multi_group_at_1")
+    try:
+        api.set_option("multi_group_at_1", mode)
+        dlib.check(L_.dil_multi_init(1), "dil_multi_init")
+        a = splitmix64_polys(n, seed=900 + mode)
+        buf = gpu.from_numpy(a.copy()).cuda()
+        dlib.check(L_.dil_ntt_multi_dev(_ptrs([buf]), n, 0, -1, 1), "dil_ntt_multi_dev through the grouped path")
+        assert (buf.cpu().numpy() == oracle.ntt(a)).all()
+        ver, nd = C.c_int(0), C.c_int(-1)
+        path = C.create_string_buffer(512)
+        dlib.check(L_.dil_multi_info(C.byref(ver), path, 512, C.byref(nd)), "dil_multi_info")
+        assert ver.value >= 2700 and nd.value == 1 and b"rccl" in path.value.lower()
+    finally:
+        api.set_option("multi_group_at_1", saved)
+        L_.dil_multi_shutdown()
+
+
+@pytest.mark.gpu
 def test_cpp_multi_dev_bad_arguments(gpu):
     from dilithium_amd import lib as dlib
     L_ = dlib.load()
