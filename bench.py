@@ -718,6 +718,10 @@ def leg_scheme(cx, sec):
         ok = ok and int(vd.abs().sum()) == 0
         vxs_ms, _ = timed(lambda i: L.dil_verify_sig_expanded_dev(P(vd), P(A3), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
         ok = ok and int(vd.abs().sum()) == 0
+        # ... and whose t1^ = NTT(t1 2^13) is kept too (dil_expand_t1_dev + dil_verify_sig_expanded2_dev): K forward transforms fewer per verification
+        T3 = api.expand_t1(pk, 3)
+        vx2_ms, _ = timed(lambda i: L.dil_verify_sig_expanded2_dev(P(vd), P(A3), P(T3), P(pk), P(sigd), P(mu), 3, VBATCH, 0, stream))
+        ok = ok and int(vd.abs().sum()) == 0
         # the same at 8 x the batch (65536 per GPU): the latency-bound hash kernels are amortised
         BIG = 8 * VBATCH
         mu_b = u8(BIG, 64)
@@ -753,6 +757,7 @@ def leg_scheme(cx, sec):
             "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "sample_in_ball_bits_kernel + "
                                              "verify_wire_wpi_kernel<3>", "wire_bytes_per_verify": 30 * 1024 + 3200 + 61 + 1920 + 256 + 768},
             "verify_expanded_keys": {"distinct_pk_per_s": per_s(vxd_ms), "shared_pk_per_s": per_s(vxs_ms),
+                                     "distinct_pk_with_t1hat_per_s": per_s(vx2_ms),
                                      "note": "A = ExpandA(rho) expanded once by the caller and kept across calls"},
             "messages_64B_one_key": {"sign_msg_per_s": per_s(sm_ms), "verify_msg_per_s": per_s(vm_ms)},
             "mean_sign_attempts": mean_att, "all_signatures_verify": ok, "batch": VBATCH,

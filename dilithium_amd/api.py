@@ -427,6 +427,25 @@ def verify_sig_expanded(A, pk, sig, mu, level, shared_pk=False):
     return verdict
 
 
+def expand_t1(pk, level):
+    """t1^ = NTT(t1 2^13) of every key, int32 [B,K,256] canonical -- kept beside expand_a(rho) by a caller that verifies under the same keys again"""
+    K, _ = _kl(level)
+    B = pk.shape[0]
+    out = torch.empty((B, K, N), dtype=torch.int32, device=pk.device)
+    _lib.check(_lib.load().dil_expand_t1_dev(_dev(out, torch.int32), _dev(pk, torch.uint8), level, B, _stream()), "dil_expand_t1_dev")
+    return out
+
+
+def verify_sig_expanded2(A, t1hat, pk, sig, mu, level, shared_pk=False):
+    """verify_sig with A = expand_a(rho) AND t1^ = expand_t1(pk) of the keys kept by the caller"""
+    B = sig.shape[0]
+    verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
+    _lib.check(_lib.load().dil_verify_sig_expanded2_dev(_dev(verdict, torch.int32), _dev(A, torch.int32), _dev(t1hat, torch.int32),
+                                                        _dev(pk, torch.uint8), _dev(sig, torch.uint8), _dev(mu, torch.uint8), level, B,
+                                                        int(shared_pk), _stream()), "dil_verify_sig_expanded2_dev")
+    return verdict
+
+
 def verify_wire_core(A, pk, sig, level, shared_pk=False):
     """the fused wire-format verify kernel: (w1 packed uint8 [B, K*128|192], verdict int32 [B] with bits 2 | 4)"""
     K, _ = _kl(level)

@@ -156,7 +156,9 @@ hipError_t launch_z_norm(int32_t* verdict, const int32_t* z, int level, size_t b
 // ---- wire-format fused verify (wire_kernels.hip): packed z / t1 / hints / c in, packed w1 + verdict bits 2|4 out ----
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
-                              const Tables& t, hipStream_t s, int a_fmt = A_I32);
+                              const Tables& t, hipStream_t s, int a_fmt = A_I32,
+                              const int32_t* t1hat = nullptr);     // NTT(t1 2^13) per key, kept by the caller (a key per item): the kernel skips those K transforms
+hipError_t launch_expand_t1(int32_t* t1hat, const uint8_t* pk, size_t pk_stride, int level, size_t nkeys, const Tables& t, hipStream_t s);
 // set-up of a signing call in one launch: [ExpandA of few keys,] s1^ s2^ t0^ = NTT(unpack(sk)), rho' = SHAKE256(key || mu), attempts = 0
 hipError_t launch_sign_setup(int level, int32_t* A, bool expand_a_here, int32_t* s1h, int32_t* s2h, int32_t* t0h, const uint8_t* sk,
                              size_t nk, uint8_t* rp, int32_t* attempts, const uint8_t* mu, size_t key_stride, size_t batch, const Tables& t,

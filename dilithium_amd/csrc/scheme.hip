@@ -486,7 +486,8 @@ namespace {
 int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t* verdict, const uint8_t* pk, const uint8_t* sig,
                     const uint8_t* mu, int level, const LevelPar& p, size_t batch, int shared_pk, hipStream_t s,
                     const int32_t* A_ready = nullptr,      // A_ready: the caller's ExpandA(rho) of every key (dil_expand_a_dev), kept across calls
-                    AuxFork* mu_pending = nullptr)         // mu is still being computed on the helper stream: joined before its first use
+                    AuxFork* mu_pending = nullptr,         // mu is still being computed on the helper stream: joined before its first use
+                    const int32_t* t1hat_ready = nullptr)  // with A_ready: the keys' NTT(t1 2^13) too (dil_expand_t1_dev), a key per item
 {
     int rc;
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
@@ -508,7 +509,7 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         if (ws.rc) return ws.rc;
         if (A_ready) {               // the matrix is already there: SampleInBall, the fused kernel, the challenge hash
             DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
-            DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
+            DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s, dil::A_I32, t1hat_ready));
             return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
         }
         // Two independent Keccak jobs: ExpandA (nk * K * L sponges) and SampleInBall (batch sponges, one lane each).
@@ -605,6 +606,31 @@ int dil_verify_sig_expanded_dev(int32_t* verdict, const int32_t* A, const uint8_
     const int fuse = dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed);
     if (!fuse) return (int)hipErrorNotSupported;             // this entry point exists only in the fused form
     return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s, A));
+}
+
+// The same with t1^ = NTT(t1 2^13) of every key kept beside its matrix (dil_expand_t1_dev): the fused kernel runs L + 1 forward and K
+// inverse transforms per verification instead of L + 1 + K and K (VY_NTT_T1, combined_top.v:1259-1313, once per key).  t1hat is used
+// with a key per signature; with one key for the batch the shared-key kernel keeps t1^ in LDS anyway and t1hat is ignored.
+int dil_verify_sig_expanded2_dev(int32_t* verdict, const int32_t* A, const int32_t* t1hat, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu,
+                                 int level, size_t batch, int shared_pk, void* stream)
+{
+    LevelPar p;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    DIL_ENTER(dv, T);
+    if (batch == 0) return 0;
+    if (!A || !t1hat || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(t1hat)) & 15) || (reinterpret_cast<uintptr_t>(mu) & 7))
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = S(stream);
+    StreamScratch ws(dv, s);
+    if (!dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed)) return (int)hipErrorNotSupported;
+    return ws.close(verify_sig_core(dv, T, ws, verdict, pk, sig, mu, level, p, batch, shared_pk, s, A, nullptr, shared_pk ? nullptr : t1hat));
+}
+int dil_expand_t1_dev(int32_t* t1hat, const uint8_t* pk, int level, size_t nkeys, void* stream)
+{
+    DIL_ENTER(dv, T);
+    if (reinterpret_cast<uintptr_t>(t1hat) & 15) return (int)hipErrorInvalidValue;
+    return (int)dil::launch_expand_t1(t1hat, pk, dil_pk_bytes(level), level, nkeys, T, S(stream));
 }
 
 // ---- row N3: the whole signing rejection loop on the device ---------------------------------------

@@ -53,14 +53,18 @@ template <int LEVEL> struct WireSh { static constexpr int NW = 12; static conste
 #ifndef DIL_WW_WAVES
 #define DIL_WW_WAVES(LEVEL) 3      // waves per SIMD the register allocator aims for (168 VGPRs)
 #endif
-template <int LEVEL, int AF>
+// T1H: the caller keeps t1^ = NTT(t1 2^13) of every key beside its matrix (dil_expand_t1_dev: VY_NTT_T1 of combined_top.v:1259-1313 done
+// once per key instead of once per verification): the K transforms of t1 leave the kernel -- L + 1 forward and K inverse remain --
+// for 6 KiB of int32 per key in place of 1.9 KiB of packed t1.
+template <int LEVEL, int AF, bool T1H = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVES(LEVEL), DIL_WW_WAVES(LEVEL)))) void verify_wire_wpi_kernel(
     uint8_t* __restrict__ w1p_out, int32_t* __restrict__ verdict, const int32_t* __restrict__ A,
     const uint8_t* __restrict__ pk, size_t pk_stride, const uint8_t* __restrict__ sig, size_t sig_stride,
-    const uint32_t* __restrict__ cbits, size_t batch, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
+    const uint32_t* __restrict__ cbits, size_t batch, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab,
+    const int32_t* __restrict__ t1hat = nullptr)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-    constexpr bool DUAL = DIL_WW_DUAL(LEVEL);
+    constexpr bool DUAL = DIL_WW_DUAL(LEVEL) && !T1H;
     using W = Wire<LEVEL>;
     // per wave: L KiB of z^ | 64 dwords byte scratch | 64 dwords hint bitmap
     using XP = X10Pick<true>;
@@ -102,8 +106,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
         const uint8_t* t1it = pk + it * pk_stride + 32;
         ARow<L, AF> Ar;
         Ar.load(Ait, lane, true);
-        uint32_t tn[4];
-        plt.load(tn, t1it);
+        uint32_t tn[4] = {0, 0, 0, 0};
+        int4 thn = make_int4(0, 0, 0, 0);                       // T1H: row k + 1 of t1^, one row ahead like A
+        const int32_t* thit = T1H ? t1hat + it * (size_t)K * 256 : nullptr;
+        if constexpr (T1H) thn = ld_nt4(thit + 4 * lane);
+        else plt.load(tn, t1it);
         const bool bad = hints_to_bitmap<LEVEL>(bm, sc, hb0, hb1, lane);
         int32_t zmax = 0;
         int32_t ch[4];
@@ -170,6 +177,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
                 DIL_SCHED_FENCE_W();
                 ntt_inv_core(r, twi, lm);
             }
+            DIL_SCHED_FENCE_W();
+            } else if constexpr (T1H) {
+            th[0] = thn.x, th[1] = thn.y, th[2] = thn.z, th[3] = thn.w;
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
+#pragma unroll
+            for (int m = 0; m < 4; m++) r[m] = mont_red64(acc[m]);
+            if (k + 1 < K) {
+                Ar.load(Ait + (size_t)(k + 1) * L * PD, lane, true);
+                thn = ld_nt4(thit + (k + 1) * 256 + 4 * lane);
+            }
+            DIL_SCHED_FENCE_W();
+            ntt_inv_core(r, twi, lm);
             DIL_SCHED_FENCE_W();
             } else {
             t1_row(th, tn);
@@ -455,12 +475,54 @@ __global__ __launch_bounds__(64) void sign_setup_kernel(int32_t* __restrict__ A,
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
+// t1^[key][k] = NTT(t1[k] 2^13), canonical: one wave per polynomial, read from the packed public key (decoder.v:96-100)
+__global__ __launch_bounds__(256) void expand_t1_kernel(int32_t* __restrict__ t1hat, const uint8_t* __restrict__ pk, size_t pk_stride, int K, size_t npolys,
+                                                        const uint32_t* __restrict__ fwd_tab)
+{
+    const int lane = threadIdx.x & 63;
+    TwRegs tw;
+    tw.load(fwd_tab, lane);
+    const X10Dpp lm(lane);
+    const PackedLane<10> plt(lane);
+    for (size_t u = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); u < npolys; u += (size_t)gridDim.x * 4) {
+        const size_t key = u / (size_t)K;
+        const int k = (int)(u % (size_t)K);
+        uint32_t raw[4], f[4];
+        plt.load(raw, pk + key * pk_stride + 32 + (size_t)k * 320);
+        plt.fields(f, raw);
+        int32_t r[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) r[m] = (int32_t)(f[m] << 13);
+        ntt_fwd_core(r, tw, lm);
+        *reinterpret_cast<int4*>(t1hat + u * 256 + 4 * lane) = make_int4((int32_t)canon_any(r[0]), (int32_t)canon_any(r[1]), (int32_t)canon_any(r[2]),
+                                                                         (int32_t)canon_any(r[3]));
+    }
+}
+hipError_t launch_expand_t1(int32_t* t1hat, const uint8_t* pk, size_t pk_stride, int level, size_t nkeys, const Tables& t, hipStream_t s)
+{
+    if (nkeys == 0) return hipSuccess;
+    if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
+    const int K = level == 2 ? 4 : level == 3 ? 6 : 8;
+    const size_t npolys = nkeys * (size_t)K;
+    hipLaunchKernelGGL(expand_t1_kernel, grid_for((npolys + 3) / 4, t.num_cus * 8), 256, 0, s, t1hat, pk, pk_stride, K, npolys, t.fwd);
+    return hipGetLastError();
+}
+
 template <int LEVEL>
 static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                                            const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
-                                           const Tables& t, hipStream_t s, int a_fmt)
+                                           const Tables& t, hipStream_t s, int a_fmt, const int32_t* t1hat)
 {
     if (shared_pk && a_fmt != A_I32) return hipErrorInvalidValue;
+    if (t1hat && !shared_pk) {                    // keys whose t1^ the caller keeps beside A (a key per item; int32 A only)
+        if (a_fmt != A_I32) return hipErrorInvalidValue;
+        const int g = grid_for((batch + 3) / 4,
+                               t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_I32, true>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch("verify_wire_wpi", g, 4, batch);
+        hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_I32, true>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
+                           t.fwd, t.inv_pipe, t1hat);
+        return hipGetLastError();
+    }
     if (shared_pk) {
         constexpr int NW = WireNW<LEVEL>::N;
         const int g = grid_for((batch + NW - 1) / NW, t.num_cus);
@@ -472,26 +534,26 @@ static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const
                                t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_P24>, 256, t.wpi_blocks_per_cu, t.device));
         note_launch("verify_wire_wpi", g, 4, batch);
         hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_P24>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
-                           t.fwd, t.inv_pipe);
+                           t.fwd, t.inv_pipe, nullptr);
     } else {
         const int g = grid_for((batch + 3) / 4,
                                t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_I32>, 256, t.wpi_blocks_per_cu, t.device));
         note_launch("verify_wire_wpi", g, 4, batch);
         hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_I32>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
-                           t.fwd, t.inv_pipe);
+                           t.fwd, t.inv_pipe, nullptr);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_verify_wire(int level, uint8_t* w1p, int32_t* verdict, const int32_t* A, const uint8_t* pk, size_t pk_stride,
                               const uint8_t* sig, size_t sig_stride, const uint32_t* cbits, size_t batch, int shared_pk,
-                              const Tables& t, hipStream_t s, int a_fmt)
+                              const Tables& t, hipStream_t s, int a_fmt, const int32_t* t1hat)
 {
     if (batch == 0) return hipSuccess;
     switch (level) {
-    case 2: return launch_verify_wire_level<2>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
-    case 3: return launch_verify_wire_level<3>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
-    case 5: return launch_verify_wire_level<5>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt);
+    case 2: return launch_verify_wire_level<2>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt, t1hat);
+    case 3: return launch_verify_wire_level<3>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt, t1hat);
+    case 5: return launch_verify_wire_level<5>(w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch, shared_pk, t, s, a_fmt, t1hat);
     default: return hipErrorInvalidValue;
     }
 }

@@ -71,6 +71,8 @@ SIGNATURES = {
     "dil_sig_bytes": [C.c_int],
     "dil_verify_sig_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_verify_sig_expanded_dev": [_vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_verify_sig_expanded2_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
+    "dil_expand_t1_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_verify_wire_core_dev": [_vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
     "dil_mu_dev": [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _sz, _vp],

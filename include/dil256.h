@@ -253,6 +253,12 @@ int dil_verify_sig_dev(int32_t* verdict, const uint8_t* pk, const uint8_t* sig, 
 /* dil_verify_sig_dev against keys whose matrix A = ExpandA(rho) the caller expanded ONCE (dil_expand_a_dev on the keys' rho,
  * [batch|1][K][L][256] int32, 16-byte aligned) and keeps across calls: many signatures under few public keys.  pk is still
  * read for t1.  Same verdict bits.  (ExpandA is 2/3 of a distinct-key verification batch and 1/3 of a one-key batch.) */
+/* ... and with t1^ = NTT(t1 2^13) of every key kept too (rtl_src/combined_top.v:1259-1313 VY_NTT_T1, decoder.v:96-100, once per key):
+ * t1hat [nkeys][K][256] int32 canonical from dil_expand_t1_dev; the fused kernel skips those K forward transforms (a key per signature;
+ * with shared_pk the batch's one t1^ lives in LDS anyway and t1hat is not read). */
+int dil_expand_t1_dev(int32_t* t1hat, const uint8_t* pk /* [nkeys][pk_bytes] */, int level, size_t nkeys, void* stream);
+int dil_verify_sig_expanded2_dev(int32_t* verdict, const int32_t* A, const int32_t* t1hat, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu,
+                                 int level, size_t batch, int shared_pk, void* stream);
 int dil_verify_sig_expanded_dev(int32_t* verdict, const int32_t* A, const uint8_t* pk, const uint8_t* sig, const uint8_t* mu, int level,
                                 size_t batch, int shared_pk, void* stream);
 

@@ -206,3 +206,34 @@ def test_verify_sig_with_expanded_keys(gpu, level, kat_msgs):
     m = cu(gpu, rng.integers(0, 256, (2100, 64), dtype=np.uint8))
     s1, _ = api.sign(cu(gpu, sk[:1]), m, level, shared_sk=True)
     assert int(api.verify_sig_expanded(A[:1].contiguous(), pkd[:1], s1, m, level, shared_pk=True).abs().sum()) == 0
+    # ... and with t1^ = NTT(t1 2^13) kept too (dil_expand_t1_dev + dil_verify_sig_expanded2_dev): the same verdict words, and t1^ itself
+    # against the codec + transform entry points
+    th = api.expand_t1(pkd, level)
+    t1 = api.unpack(pkd, api.CODEC_T1, level, 32)
+    want = (t1 << 13).contiguous()
+    api.ntt(want)
+    assert gpu.equal(th, want)
+    v2 = api.verify_sig_expanded2(A, th, pkd, sgd, mud, level).cpu().numpy()
+    assert (v2 == v).all()
+    assert int(api.verify_sig_expanded2(A[:1].contiguous(), th[:1].contiguous(), pkd[:1], s1, m, level, shared_pk=True).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
+def test_expanded2_on_tampered_signatures_at_dispatch_size(gpu, level):
+    """dil_verify_sig_expanded2_dev == dil_verify_sig_dev on 2600 signatures under 2600 keys, every fourth one tampered in z, c~ or the hints"""
+    from dilithium_amd import api
+    n = 2600
+    rng = np.random.default_rng(70 + level)
+    seed = cu(gpu, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    mu = cu(gpu, rng.integers(0, 256, (n, 64), dtype=np.uint8))
+    pk, sk = api.keygen(seed, level)
+    sig, _ = api.sign(sk, mu, level)
+    bad = sig.clone()
+    idx = np.arange(0, n, 4)
+    pos = rng.integers(0, sig.shape[1], idx.size)
+    for i, p_ in zip(idx, pos):
+        bad[int(i), int(p_)] ^= 1 << int(rng.integers(0, 8))
+    A, th = api.expand_a(pk[:, :32].contiguous(), level), api.expand_t1(pk, level)
+    want = api.verify_sig(pk, bad, mu, level)
+    assert gpu.equal(api.verify_sig_expanded2(A, th, pk, bad, mu, level), want)
+    assert int((want != 0).sum()) >= idx.size * 9 // 10 and int(want[1::4].abs().sum()) == 0
