@@ -686,11 +686,7 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
                            reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
         return hipGetLastError();
     }
-#ifdef DIL_EA_OLD
-    hipLaunchKernelGGL(expand_a_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
-#else
     hipLaunchKernelGGL(expand_a_fast_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
-#endif
     return hipGetLastError();
 }
 

@@ -39,15 +39,6 @@ __device__ __forceinline__ int resolve_row(int mapping, int addr)
     return addr;
 }
 
-// exchange policy of the standalone transforms (A/B hook: -DDIL_NTT_XPOL=2 = all three exchanges through LDS)
-#if defined(DIL_NTT_XPOL) && DIL_NTT_XPOL == 2
-#define DIL_NTT_XDECL(name)                                                        \
-    __shared__ __attribute__((aligned(16))) uint32_t name##_buf[4 * 256];          \
-    const XAllLds name(name##_buf + (threadIdx.x >> 6) * 256, lane)
-#else
-#define DIL_NTT_XDECL(name) const LaneMasks& name = lm
-#endif
-
 // LAYOUT = LAYOUT_POLY : plain data_t[256] in reference order (ref_ntt.h API)
 // LAYOUT = LAYOUT_BRAM : `bram` rows behind `mapping`; the transform leaves its output rows at
 //                        the model's post-transform permutation (ntt2x2_test.cpp:55,76,129-132)
@@ -82,28 +73,20 @@ __device__ __forceinline__ int inv_out_off(int i, int mapping)
 // HBM traffic: 1 KiB in (4 coalesced 256-B dword loads per wave) + 1 KiB out (one 1-KiB
 // dwordx4 store per wave) per polynomial.
 // ---------------------------------------------------------------------------------------
-// A/B hooks of the launch shape (profiles/r04o_ab_ntt_shapes_prio.txt: 1 / 2 / 4 waves per workgroup x 4 ... 16 workgroups per CU, with
-// and without s_setprio 3 around the loop's memory instructions -- 50.9-53.5 us per forward + inverse pair, all within +-1.5 % of
-// the shipped shape; with r01_tune_ntt.txt, r03e_tune_ntt2.txt and r04i_* the shape, prefetch depth, exchange policy and product form
-// of this kernel are exhausted: it runs at 0.91 of its own loads and stores)
-#ifndef DIL_NTT_WPB
-#define DIL_NTT_WPB 4          // waves per workgroup of the standalone transforms (the blocks-per-CU option scales by 4 / WPB)
-#endif
-#ifndef DIL_NTT_PRIO
-#define DIL_NTT_PRIO 0         // s_setprio around the memory instructions of the persistent loop
-#endif
-#if DIL_NTT_PRIO
-#define NTT_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define NTT_PRIO(p) ((void)0)
-#endif
+// Frozen in round 5.  Launch shape (1 / 2 / 4 waves per workgroup x 4 ... 16 workgroups per CU), s_setprio around the memory instructions,
+// prefetch depth, chunking, the exchange policy and the product form were swept in rounds 1-4 (profiles/r01_tune_ntt.txt,
+// r03e_tune_ntt2.txt, r04i_*, r04o_ab_ntt_shapes_prio.txt: all within +-1.5 % of this shape); round 5 measured the two memory-side
+// forms left -- one dwordx4 load per lane with the transposition through LDS, and the same slot filled by global_load_lds_dwordx4 --
+// and both lose with the arithmetic on (26.3 / 26.5 vs 25.95 us per 65536 polynomials, profiles/r05_ntt_x4.txt).  The kernel runs at
+// 0.91 of its own loads and stores; the A/B hooks are gone.
+constexpr int NTT_WPB = 4;          // waves per workgroup of the standalone transforms
 template <int LAYOUT>
-__global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_fwd_kernel(int32_t* __restrict__ polys, size_t batch,
+__global__ __launch_bounds__(64 * NTT_WPB) void ntt_fwd_kernel(int32_t* __restrict__ polys, size_t batch,
                                                        const uint32_t* __restrict__ tw_tab, int mapping)
 {
     const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * DIL_NTT_WPB + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * DIL_NTT_WPB;
+    const size_t wave = (size_t)blockIdx.x * NTT_WPB + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * NTT_WPB;
     if (wave >= batch) return;
     int off[4];
 #pragma unroll
@@ -111,7 +94,7 @@ __global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_fwd_kernel(int32_t* __re
     const int out_off = fwd_out_row_off<LAYOUT>(lane, mapping);
     TwRegs tw;
     const LaneMasks lm(lane);
-    DIL_NTT_XDECL(xp);
+    const LaneMasks& xp = lm;
     if (LAYOUT == LAYOUT_BRAM && mapping == MAP_AFTER_INVNTT) {
         // this mapping puts the lane's 4 inputs at 16 (lane>>2) + 4 m + (lane&3): 16-byte pieces 64 B apart for every
         // load instruction.  Read the wave's 1 KiB with one dwordx4 per lane instead and transpose inside each quad.
@@ -134,27 +117,24 @@ __global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_fwd_kernel(int32_t* __re
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
         const size_t pn = p + nwaves;
-        NTT_PRIO(3);
         if (pn < batch) {
 #pragma unroll
             for (int m = 0; m < 4; m++) nxt[m] = ld_s(polys + pn * 256 + off[m]);
         }
-        NTT_PRIO(0);
         ntt_fwd_core(r, tw, xp);
         const uint32_t o0 = canon_any(r[0]), o1 = canon_any(r[1]), o2 = canon_any(r[2]), o3 = canon_any(r[3]);
-        NTT_PRIO(3);
         st_nt4(polys + p * 256 + out_off, o0, o1, o2, o3);
     }
 }
 
 // H3/H5/H6 inverse NTT (x 256^-1), batched, in place.  Inputs in (-q, q) (or canonical).
 template <int LAYOUT>
-__global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_inv_kernel(int32_t* __restrict__ polys, size_t batch,
+__global__ __launch_bounds__(64 * NTT_WPB) void ntt_inv_kernel(int32_t* __restrict__ polys, size_t batch,
                                                        const uint32_t* __restrict__ tw_tab, int mapping)
 {
     const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * DIL_NTT_WPB + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * DIL_NTT_WPB;
+    const size_t wave = (size_t)blockIdx.x * NTT_WPB + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * NTT_WPB;
     if (wave >= batch) return;
     const int in_off = inv_in_row_off<LAYOUT>(lane, mapping);
     int off[4];
@@ -164,13 +144,11 @@ __global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_inv_kernel(int32_t* __re
     TwRegs tw;
     tw.load(tw_tab, lane);
     const LaneMasks lm(lane);
-    DIL_NTT_XDECL(xp);
+    const LaneMasks& xp = lm;
     for (size_t p = wave; p < batch; p += nwaves) {
         int32_t r[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
         const size_t pn = p + nwaves;
-        NTT_PRIO(3);
         if (pn < batch) nxt = ld_nt4(polys + pn * 256 + in_off);
-        NTT_PRIO(0);
         ntt_inv_core(r, tw, xp);
         if (LAYOUT == LAYOUT_BRAM && mapping == MAP_NATURAL) {
             // outputs of this (op, mapping) land at 16 (lane>>2) + 4 m + (lane&3): transpose inside each quad and
@@ -229,11 +207,11 @@ __global__ __launch_bounds__(256) void pointwise_kernel(int32_t* c, const int32_
 // wave and polynomial; inverse: mirrored -- so that the bench line carries, beside the 8 TB/s spec, what this access pattern
 // reaches on the box it runs on.  Scrambles the buffer (a lane's four strided values leave as one row); scratch data only.
 template <bool INVERSE>
-__global__ __launch_bounds__(64 * DIL_NTT_WPB) void ntt_traffic_kernel(int32_t* __restrict__ polys, size_t batch)
+__global__ __launch_bounds__(64 * NTT_WPB) void ntt_traffic_kernel(int32_t* __restrict__ polys, size_t batch)
 {
     const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * DIL_NTT_WPB + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * DIL_NTT_WPB;
+    const size_t wave = (size_t)blockIdx.x * NTT_WPB + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * NTT_WPB;
     if (wave >= batch) return;
     if (!INVERSE) {
         int32_t nxt[4];
@@ -404,14 +382,14 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
                       const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = grid_for((batch + DIL_NTT_WPB - 1) / DIL_NTT_WPB, t.num_cus * t.ntt_blocks_per_cu * 4 / DIL_NTT_WPB);
+    const int grid = grid_for((batch + NTT_WPB - 1) / NTT_WPB, t.num_cus * t.ntt_blocks_per_cu * 4 / NTT_WPB);
     const uint32_t* tab = inverse ? t.inv : t.fwd;   // standalone flavour of the inverse table
     if (!inverse) {
-        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_POLY>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
-        else hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_BRAM>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
+        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_POLY>, grid, 64 * NTT_WPB, 0, s, polys, batch, tab, mapping);
+        else hipLaunchKernelGGL(ntt_fwd_kernel<LAYOUT_BRAM>, grid, 64 * NTT_WPB, 0, s, polys, batch, tab, mapping);
     } else {
-        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_POLY>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
-        else hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_BRAM>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch, tab, mapping);
+        if (layout == LAYOUT_POLY) hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_POLY>, grid, 64 * NTT_WPB, 0, s, polys, batch, tab, mapping);
+        else hipLaunchKernelGGL(ntt_inv_kernel<LAYOUT_BRAM>, grid, 64 * NTT_WPB, 0, s, polys, batch, tab, mapping);
     }
     return hipGetLastError();
 }
@@ -419,9 +397,9 @@ hipError_t launch_ntt(bool inverse, int layout, int mapping, int32_t* polys, siz
 hipError_t launch_ntt_traffic(bool inverse, int32_t* polys, size_t batch, const Tables& t, hipStream_t s)
 {
     if (batch == 0) return hipSuccess;
-    const int grid = grid_for((batch + DIL_NTT_WPB - 1) / DIL_NTT_WPB, t.num_cus * t.ntt_blocks_per_cu * 4 / DIL_NTT_WPB);      // the transforms' own launch shape
-    if (inverse) hipLaunchKernelGGL(ntt_traffic_kernel<true>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch);
-    else hipLaunchKernelGGL(ntt_traffic_kernel<false>, grid, 64 * DIL_NTT_WPB, 0, s, polys, batch);
+    const int grid = grid_for((batch + NTT_WPB - 1) / NTT_WPB, t.num_cus * t.ntt_blocks_per_cu * 4 / NTT_WPB);      // the transforms' own launch shape
+    if (inverse) hipLaunchKernelGGL(ntt_traffic_kernel<true>, grid, 64 * NTT_WPB, 0, s, polys, batch);
+    else hipLaunchKernelGGL(ntt_traffic_kernel<false>, grid, 64 * NTT_WPB, 0, s, polys, batch);
     return hipGetLastError();
 }
 

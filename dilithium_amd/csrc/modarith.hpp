@@ -43,14 +43,17 @@ __device__ __forceinline__ int32_t sgn(int32_t x)
     return m;
 }
 
-// Two forms of the constant product, chosen per translation unit (-DDIL_MAD64 or a #define before the first include):
+// Two forms of the constant product, chosen per translation unit (constexpr MAD64 below):
 //   0  v_mul_lo_u32 + 2 x v_mul_hi_i32 + v_sub          (4 instructions, ~15.7 issue cycles; needs wq = wt q^-1)
 //   1  p = y wt as v_mad_i64_i32, m = lo32(p) q^-1, hi32(p - m q) as a second v_mad_i64_i32   (3 instructions, ~14.8 cycles)
 // Same integer either way (p - m q has a zero low word, so its high word is hi(p) - hi(m q)).  Measured (profiles/r04c_*):
 // the VALU-bound fused pipelines gain 2-2.6 % with form 1, the HBM-bound standalone transforms LOSE 5 % (the 64-bit pairs
 // cost registers there), so pipelines.hip / wire_kernels.hip select 1 and kernels.hip keeps 0.
-#ifndef DIL_MAD64
-#define DIL_MAD64 0
+// One form per translation unit: pipelines.hip and wire_kernels.hip define DIL_PRODUCT_MAD64 before they include this header.
+#ifdef DIL_PRODUCT_MAD64
+constexpr bool MAD64 = true;
+#else
+constexpr bool MAD64 = false;
 #endif
 // (the instruction also writes a carry mask: it goes to a scratch SGPR pair of the compiler's choosing; VCC measured the same)
 __device__ __forceinline__ int64_t mad64(int32_t a, int32_t b, int64_t c)     // a * b + c, one v_mad_i64_i32
@@ -79,39 +82,39 @@ __device__ __forceinline__ int64_t mul64_s(int32_t a, uint32_t b_scalar)       /
 // Any int32 y; |result| < q (|y * wt| < 2^31 * q/2).
 __device__ __forceinline__ int32_t mont_tw(int32_t y, int32_t wt, uint32_t wq)
 {
-#if DIL_MAD64
-    const int64_t p = mul64(y, wt);
-    const int32_t m = (int32_t)((uint32_t)p * QINV);
-    return (int32_t)(mad64(m, -Q, p) >> 32);
-#else
-    const int32_t m = (int32_t)((uint32_t)y * wq);
-    return mulhi_i32(y, wt) - mulhi_i32(m, Q);
-#endif
+    if constexpr (MAD64) {
+        const int64_t p = mul64(y, wt);
+        const int32_t m = (int32_t)((uint32_t)p * QINV);
+        return (int32_t)(mad64(m, -Q, p) >> 32);
+    } else {
+        const int32_t m = (int32_t)((uint32_t)y * wq);
+        return mulhi_i32(y, wt) - mulhi_i32(m, Q);
+    }
 }
 // the same with a wave-uniform constant as the SCALAR operand of the multiplies (ntt_core.hpp TwLdsC: the uniform pass)
 __device__ __forceinline__ int32_t mont_tw_s(int32_t y, uint32_t wt, uint32_t wq)
 {
-#if DIL_MAD64
-    const int64_t p = mul64_s(y, wt);
-    const int32_t m = (int32_t)((uint32_t)p * QINV);
-    return (int32_t)(mad64(m, -Q, p) >> 32);
-#else
-    int32_t m, h;
-    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"(y), "s"(wq));
-    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(h) : "v"(y), "s"(wt));
-    return h - mulhi_i32(m, Q);
-#endif
+    if constexpr (MAD64) {
+        const int64_t p = mul64_s(y, wt);
+        const int32_t m = (int32_t)((uint32_t)p * QINV);
+        return (int32_t)(mad64(m, -Q, p) >> 32);
+    } else {
+        int32_t m, h;
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m) : "v"(y), "s"(wq));
+        asm("v_mul_hi_i32 %0, %1, %2" : "=v"(h) : "v"(y), "s"(wt));
+        return h - mulhi_i32(m, Q);
+    }
 }
 
 // p * 2^-32 mod q for |p| < 2^31 * q;  |result| < q.
 __device__ __forceinline__ int32_t mont_red64(int64_t p)
 {
     const int32_t m = (int32_t)((uint32_t)p * QINV);
-#if DIL_MAD64
-    return (int32_t)(mad64(m, -Q, p) >> 32);
-#else
-    return (int32_t)(p >> 32) - mulhi_i32(m, Q);
-#endif
+    if constexpr (MAD64) {
+        return (int32_t)(mad64(m, -Q, p) >> 32);
+    } else {
+        return (int32_t)(p >> 32) - mulhi_i32(m, Q);
+    }
 }
 
 // a * b * 2^-32 mod q (generic Montgomery product; v_mad_i64_i32 gives the 64-bit product)

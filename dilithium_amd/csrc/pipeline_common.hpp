@@ -15,23 +15,17 @@ namespace dil {
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // (1:0) exchange of the transforms inside the wave-per-item pipelines (ntt_core.hpp): through LDS where the kernel's
-// LDS budget has the 1 KiB per wave to spare (USE = true), else in registers.  -DDIL_X10_LDS=0 builds the in-register
-// form everywhere for A/B runs.
-#ifndef DIL_X10_LDS
-#define DIL_X10_LDS 1
-#endif
+// LDS budget has the 1 KiB per wave to spare (USE = true), else in registers.
 template <bool USE>
 struct X10Pick {
     using type = X10Dpp;
     static constexpr int DW = 0;
 };
-#if DIL_X10_LDS
 template <>
 struct X10Pick<true> {
     using type = X10Lds;
     static constexpr int DW = 256;          // LDS dwords per wave
 };
-#endif
 
 // ---------------------------------------------------------------------------------------
 // Dilithium element-wise tail: Decompose / UseHint / MakeHint / norm checks
@@ -258,9 +252,6 @@ struct PipeTables<true> {
     __device__ __forceinline__ static Fwd fwd(const uint32_t* lds, const uint32_t* __restrict__ f, int lane) { return Fwd(lds, f, lane); }
     __device__ __forceinline__ static Inv inv(const uint32_t* lds, const uint32_t* __restrict__ i, int lane) { return Inv(lds + TWC_DWORDS, i, lane); }
 };
-#ifndef DIL_TWC
-#define DIL_TWC 1
-#endif
 
 // Byte planes (h, w1) move as whole dwords: 64 lanes x 4 bytes = one coalesced 256-B row per
 // instruction.  global_store_byte / global_load_ubyte of 64-byte runs measured 2x the whole

@@ -2,9 +2,7 @@
 // mat-vec (H9), verify core (H8), sign inner loop phases 1 and 2 (H10).
 //   rtl_src/combined_top.v:1207-1469 (verify), :1850-1933 (mat-vec / FSM1), :1946-2229 (FSM2)
 // Two shapes: workgroup-per-item (small batches, low latency) and wave-per-item (large batches).
-#ifndef DIL_MAD64
-#define DIL_MAD64 1        // the constant products as two v_mad_i64_i32 (modarith.hpp): these kernels are VALU-bound
-#endif
+#define DIL_PRODUCT_MAD64   // the constant products as two v_mad_i64_i32 (modarith.hpp MAD64): these kernels are VALU-bound
 #include "launch_util.hpp"
 #include "pipeline_common.hpp"
 #include "wire_common.hpp"
@@ -270,18 +268,11 @@ struct YSrc<LEVEL, Y_PACKED> {
 // BASELINE configs[2] (level 2, 4096 items) 20.2 -> 18.0 us; four rows are no better (profiles/r03q_ab_mr.txt).  (The fused
 // VERIFY kernels did not gain from the same ring -- profiles/r03k_ab_vw.txt; the wire-format one spills with it at level 5,
 // 128 -> 191 us, profiles/r03r_rows_keygen_wire.txt -- and keep one buffer.)
-#ifndef DIL_MV_ROWS
 #define DIL_MV_ROWS(K) 2
-#endif
-#ifndef DIL_KG_ROWS
 #define DIL_KG_ROWS(K) 1          // keygen's fused kernel (24-bit packed matrix): two rows in flight change nothing (profiles/r03r_rows_keygen_wire.txt)
-#endif
 // mat-vec / sign phase 1, wave-per-item.  Per item: issue row-0 loads | L forward NTTs on registers
 // loaded during the PREVIOUS item's row phase, y^ -> this wave's LDS slice | issue the NEXT item's y
 // loads | K rows: MAC from LDS, prefetch row k+1, INTT, (Decompose), store.
-#ifndef DIL_MVW_DUAL
-#define DIL_MVW_DUAL 1      // the L forward transforms side by side, the K inverse ones in pairs (rows k, k + 1 of the two-row ring)
-#endif
 template <int K, int L, int LEVEL, int OUT, int AF, int YF>
 __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
@@ -289,7 +280,7 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
     KeyMap km, const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     using XP = X10Pick<true>;
-    using PT = PipeTables<DIL_TWC>;
+    using PT = PipeTables<true>;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     PT::stage(lds, fwd_tab, inv_tab);
@@ -318,18 +309,12 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
         for (int j = 0; j < NR; j++) Ar[j].load(Ait + (size_t)j * L * PD, lane, !shared_A && km.S == 1);
 #pragma unroll
         for (int l = 0; l < L; l++) ys.value(yr.v[l]);
-#if DIL_MVW_DUAL
         ntt_fwd_coreN<L>(yr.v, twf, lm);
-#else
-#pragma unroll
-        for (int l = 0; l < L; l++) ntt_fwd_core(yr.v[l], twf, lm);
-#endif
 #pragma unroll
         for (int l = 0; l < L; l++) *reinterpret_cast<int4*>(yl + l * 256 + 4 * lane) = make_int4(yr.v[l][0], yr.v[l][1], yr.v[l][2], yr.v[l][3]);
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) load_y(itn);
-#if DIL_MVW_DUAL
         if constexpr (NR == 2 && K % 2 == 0) {
             // rows k and k + 1 sit in the ring's two buffers: both multiply-accumulates, then both inverse transforms side by side
 #pragma unroll
@@ -351,7 +336,6 @@ __global__ __launch_bounds__(256) void matvec_wpi_kernel(
             }
             continue;
         }
-#endif
         constexpr int ROW_UNROLL = NR > 1 ? K : 1;           // the ring's slot index must be static
 #pragma unroll ROW_UNROLL
         for (int k = 0; k < K; k++) {
@@ -479,23 +463,12 @@ __global__ __launch_bounds__(256) void keygen_wpi_kernel(
 #endif
 // waves per SIMD the register allocator aims for: 4 at level 2 (118 VGPRs), 3 at levels 3 / 5 (138 / 168 VGPRs; forcing 4
 // there was measured slower in both rounds -- the HBM stream is throughput-limited, more waves only add pressure)
-#ifndef DIL_VW_WAVES
 #define DIL_VW_WAVES(LEVEL) ((LEVEL) == 2 ? 4 : 3)
-#endif
 // exchange policy of the VALU-bound kernels: all three exchanges of a transform through a 1-KiB per-wave LDS buffer (ntt_core.hpp XAllLds)
 struct S2X {
     using type = XAllLds;
     static constexpr int DW = 256;
 };
-#ifndef DIL_VW_TWC
-#define DIL_VW_TWC 1        // compact twiddle tables (ntt_core.hpp TwLdsC)
-#endif
-#ifndef DIL_VW_XALL
-#define DIL_VW_XALL 0       // 1: all three exchanges of a transform through the wave's LDS buffer (0: only the (1:0) one)
-#endif
-#ifndef DIL_VW_DUAL
-#define DIL_VW_DUAL 2       // 1: the z-phase's L + 1 forward transforms side by side; 2: and NTT(t1[k+1] 2^13) beside INTT(row k)
-#endif
 template <int LEVEL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVES(LEVEL), DIL_VW_WAVES(LEVEL)))) void verify_wpi_kernel(
     uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
@@ -503,12 +476,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
     const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_tab)
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
-#if DIL_VW_XALL
-    using XP = S2X;
-#else
     using XP = X10Pick<true>;
-#endif
-    using PT = PipeTables<DIL_VW_TWC>;
+    using PT = PipeTables<true>;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + 4 * L * 256 + 4 * 64 + 4 * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     PT::stage(lds, fwd_tab, inv_tab);
@@ -539,12 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
         load_strided<false>(tn, t1it, lane);
         hn = load_row_u8(hit, lane);
         // z-phase
-#if DIL_VW_DUAL
         ntt_fwd_coreN<L + 1>(zc, twf, lm);
-#else
-#pragma unroll
-        for (int l = 0; l <= L; l++) VW_FWD(zc[l], twf, lm);
-#endif
 #pragma unroll
         for (int l = 0; l < L; l++) *reinterpret_cast<int4*>(zl + l * 256 + 4 * lane) = make_int4(zc[l][0], zc[l][1], zc[l][2], zc[l][3]);
         int32_t ch[4] = {zc[L][0], zc[L][1], zc[L][2], zc[L][3]};
@@ -552,20 +516,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
         // next item's time-domain inputs: a whole row phase to land
         const size_t itn = it + nwaves;
         if (itn < batch) load_zc(itn);
-#if DIL_VW_DUAL == 2
         // row k's INTT runs beside row k + 1's NTT(t1 2^13): th is always one row ahead
         int32_t th[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
         load_strided<false>(tn, t1it + 256, lane);
         VW_FWD(th, twf, lm);
-#endif
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, zl, lane);
             uint32_t hb[4];
             unpack_row_u8(hb, hn, sc, lane);
-#if DIL_VW_DUAL == 2
 #pragma unroll
             for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
@@ -582,25 +543,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
                 VW_INV(r, twi, lm);
             }
             DIL_SCHED_FENCE();
-#else
-            int32_t th[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
-            if (k + 1 < K) {
-                VW_ALOAD(Ar, Ait + (size_t)(k + 1) * L * 256, lane, true);
-                load_strided<false>(tn, t1it + (k + 1) * 256, lane);
-                hn = load_row_u8(hit + (k + 1) * 256, lane);
-            }
-            DIL_SCHED_FENCE();     // keep the stages from being interleaved (register pressure, not ILP, is the limit)
-            VW_FWD(th, twf, lm);
-            DIL_SCHED_FENCE();
-#pragma unroll
-            for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
-            int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
-            DIL_SCHED_FENCE();
-            VW_INV(r, twi, lm);
-            DIL_SCHED_FENCE();
-#endif
             const size_t o = (it * K + k) * 256;
             uint32_t wb[4];
 #pragma unroll
@@ -620,12 +562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
 // and six at every level and key form -- level 5, 8192 attempts, one key: 53.2 us at four, 55.3 at five, 53.8 at six; a key per
 // attempt: 64.1 / 64.9 / 76.4 (spills) -- profiles/r04e_ab_s2_waves_prefetch.txt.  A row-ahead prefetch of w0 / y / w1 does not pay
 // (vmcnt retires in order: waiting for the row's key operand then waits for the prefetch too).
-#ifndef DIL_S2_DUAL
-#define DIL_S2_DUAL 1
-#endif
-#ifndef DIL_S2_ATTR
 #define DIL_S2_ATTR __attribute__((amdgpu_waves_per_eu(4)))
-#endif
 template <int LEVEL, int YF, bool SH, bool SMALL>
 __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
     int32_t* __restrict__ z_out, uint8_t* __restrict__ h_out, int32_t* __restrict__ flags_out,
@@ -637,7 +574,7 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     constexpr bool STAGED = SH && SMALL;        // the paired key rows live in LDS
     using XP = S2X;
-    using PT = PipeTables<DIL_TWC>;
+    using PT = PipeTables<true>;
     constexpr int PAIR_AT = PT::DWORDS + 4 * 64 + 4 * XP::DW;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (STAGED ? L * 256 : 0)];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
@@ -692,12 +629,7 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
                 a[0] = mont_mul(ch[0], a2.x); a[1] = mont_mul(ch[1], a2.y); a[2] = mont_mul(ch[2], a2.z); a[3] = mont_mul(ch[3], a2.w);
             }
             int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
-#if DIL_S2_DUAL
             ntt_inv_core2(a, b, twi, lm);           // the row's two transforms side by side (ntt_core.hpp)
-#else
-            ntt_inv_core(a, twi, lm);
-            ntt_inv_core(b, twi, lm);
-#endif
             int32_t cs1[4] = {0, 0, 0, 0};
             if (!SMALL && zrow) {                   // generic: c s1[k] has a transform of its own
                 cs1[0] = mont_mul(ch[0], a1.x); cs1[1] = mont_mul(ch[1], a1.y); cs1[2] = mont_mul(ch[2], a1.z); cs1[3] = mont_mul(ch[3], a1.w);
@@ -765,7 +697,7 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using XP = S2X;
-    using PT = PipeTables<DIL_TWC>;
+    using PT = PipeTables<true>;
     constexpr int PAIR_AT = PT::DWORDS + 4 * 64 + 4 * XP::DW;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PAIR_AT + (SH ? L * 256 : 0)];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
@@ -985,26 +917,17 @@ __device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a
 // LDS slice -- that slice (L KiB per wave) was what capped the workgroup at 12 waves = 3 per SIMD at level 5, and three waves per
 // SIMD issue no more than two (scripts/tune_xchg.hip, profiles/r03c_tune_xchg.txt: 785 / 785 / 689 cycles per transform at 2 / 3 /
 // 4 waves).  Now 16 waves = 4 per SIMD at every level, no ds_write of y^ and half the ds_read_b128 of the multiply-accumulate.
-#ifndef DIL_MVS_XEMIT
-#define DIL_MVS_XEMIT 1         // output rows through one LDS transposition (pipeline_common.hpp emit_w1w0_row_t)
-#endif
-#if DIL_MVS_XEMIT
 #define MVS_XB xb
-#else
-#define MVS_XB nullptr
-#endif
 #ifndef MVS_FWD         // hook points of the A/B builds (variants.hpp)
 #define MVS_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
 #define MVS_INV(r, tw, x) ntt_inv_core(r, tw, x)
 #endif
-#ifndef DIL_MVS_PFN
 // Level 5: nothing is prefetched.  Three of the seven polynomials would fit beside seven transforms in flight under 128 VGPRs and
 // make the kernel 2 % faster on its own (45.5 vs 46.1 us) -- but with them bench.py's attempt (phase 1, then phase 2, over ONE set of
 // buffers: 223 MB, Infinity-Cache-resident) takes 134.7 instead of 103.9 us, while the same pair over two rotating sets (HBM-streaming)
 // is unchanged (105.9 vs 106.6): profiles/r04q_ab_pf.txt, r04r_ab_pair.txt.  Unexplained; the cache-resident regime is the one the
 // signing loop's narrow rounds run in, so the prefetch stays off where it was off.
 #define DIL_MVS_PFN(L) ((L) <= 5 ? (L) : 0)
-#endif
 #ifndef MVS_FWDN
 #define MVS_FWDN(v, tw, x) ntt_fwd_coreN<L>(v, tw, x)
 #endif
@@ -1012,18 +935,13 @@ __device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a
 #define MVS_FWD2(a, b, tw, x) ntt_fwd_core2(a, b, tw, x)
 #define MVS_INV2(a, b, tw, x) ntt_inv_core2(a, b, tw, x)
 #endif
-#ifndef DIL_MVS_DUAL
-#define DIL_MVS_DUAL 2          // 1: two polynomials per transform pass (ntt_core.hpp ntt_*_core2); 2: and all L forward transforms at once
-#endif
 #ifndef MVS_AREAD
 #define MVS_AREAD(p) (*reinterpret_cast<const int4*>(p))
 #endif
 #ifndef MVS_EMIT
 #define MVS_EMIT(call, w0, o, r, lane) call
 #endif
-#ifndef DIL_MVS_WGS
 #define DIL_MVS_WGS 1          // 16-wave workgroups per CU the shared-key kernels are built for (8 waves per SIMD need <= 64 VGPRs)
-#endif
 template <int K, int L, int LEVEL, int OUT, int NW, int YF>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS_WGS * NW / 4))) void matvec_shared_kernel(
     int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out, int32_t* __restrict__ w0_out,
@@ -1036,7 +954,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
     // Round 4: compact twiddle tables (5.25 KiB) and the byte-plane scratch aliased onto the wave's exchange buffer (both are
     // wave-private and used in turn): level 5 is 5.25 + 56 + 16 = 77.25 KiB per workgroup, so TWO 16-wave workgroups share a CU.
     using XP = S2X;
-    using PT = PipeTables<DIL_TWC>;
+    using PT = PipeTables<true>;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + K * L * 256 + NW * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     PT::stage(lds, fwd_tab, inv_tab);
@@ -1069,7 +987,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
 #pragma unroll
             for (int m = 0; m < 4; m++) yh[l][m] = yr.v[l][m];
         }
-#if DIL_MVS_DUAL == 2
         if constexpr (PF > 0 && PF < L) {
             // two groups: the prefetched polynomials are transformed while the others' loads are in flight
             int32_t (&ga)[PF][4] = reinterpret_cast<int32_t (&)[PF][4]>(yh[0]);
@@ -1085,22 +1002,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
             for (int l = 0; l < L; l++) ys.value(yh[l]);
             MVS_FWDN(yh, twf, lm);
         }
-#else
-#pragma unroll
-        for (int l = 0; l < L; l++) ys.value(yh[l]);
-#if DIL_MVS_DUAL
-#pragma unroll
-        for (int l = 0; l + 1 < L; l += 2) MVS_FWD2(yh[l], yh[l + 1], twf, lm);
-        if (L & 1) MVS_FWD(yh[L - 1], twf, lm);
-#else
-#pragma unroll
-        for (int l = 0; l < L; l++) MVS_FWD(yh[l], twf, lm);
-#endif
-#endif
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) load_y(itn);
-#if DIL_MVS_DUAL
         static_assert(K % 2 == 0, "rows are processed in pairs");
         for (int k = 0; k < K; k += 2) {
             int64_t acc[4] = {0, 0, 0, 0}, acd[4] = {0, 0, 0, 0};
@@ -1126,7 +1030,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
             MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k + 1) * 256, rd, sc, lane, MVS_XB)), w0_out, (it * K + k + 1) * 256, rd, lane);
         }
         if (false)
-#endif
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1150,9 +1053,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
 // workgroup by its first K waves (VY_NTT_T1, combined_top.v:1259) -- cheaper than a second launch.
 // z^ stays in registers (a lane multiplies the coefficients it transformed itself), as y^ in matvec_shared_kernel: no per-wave
 // LDS slice, 16 waves per workgroup at every level (level 5 was 11), and all three exchanges through LDS.
-#ifndef DIL_VS_DUAL
-#define DIL_VS_DUAL 1
-#endif
 template <int LEVEL, int NW>
 __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
     uint8_t* __restrict__ w1_out, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
@@ -1161,7 +1061,7 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
 {
     constexpr int K = Par<LEVEL>::K, L = Par<LEVEL>::L;
     using XP = S2X;
-    using PT = PipeTables<DIL_TWC>;
+    using PT = PipeTables<true>;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + (K * L + K) * 256 + NW * 64 + NW * XP::DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     PT::stage(lds, fwd_tab, inv_tab);
@@ -1209,21 +1109,14 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
             }
         }
         int32_t ch[4] = {cr[0], cr[1], cr[2], cr[3]};
-#if DIL_VS_DUAL
         ntt_fwd_coreN<L>(zh, twf, lm);                  // the L forward transforms side by side; c joins the first inverse pair's slot
         ntt_fwd_core(ch, twf, lm);
-#else
-#pragma unroll
-        for (int l = 0; l < L; l++) ntt_fwd_core(zh[l], twf, lm);
-        ntt_fwd_core(ch, twf, lm);
-#endif
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
         if (itn < batch) {
             if (PFZ) zr.load(z + itn * L * 256, lane);
             load_strided<false>(cr, c + itn * 256, lane);
         }
-#if DIL_VS_DUAL
         static_assert(K % 2 == 0, "rows are processed in pairs");
         for (int k = 0; k < K; k += 2) {                // rows k, k + 1: both multiply-accumulates, then both inverse transforms side by side
             int64_t acc[4] = {0, 0, 0, 0}, acd[4] = {0, 0, 0, 0};
@@ -1262,7 +1155,6 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
             if (k + 2 < K) hn = load_row_u8(hit + (k + 2) * 256, lane);
         }
         if (false)
-#endif
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1297,9 +1189,7 @@ __global__ __launch_bounds__(64 * NW) void verify_shared_kernel(
 // LDS budget (160 KiB): tables 16 KiB + key + NW * L KiB of per-wave vector slices
 template <int LEVEL> struct SharedNW;
 // (y^ / z^ live in registers, the workgroup is 16 waves at every level: tables 16 + key K L (+ K) + 16 x 1.25 KiB)
-#ifndef DIL_MVS_NW
 #define DIL_MVS_NW 16
-#endif
 template <> struct SharedNW<2> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = DIL_MVS_NW; };
 template <> struct SharedNW<3> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = DIL_MVS_NW; };
 template <> struct SharedNW<5> { static constexpr int MATVEC = DIL_MVS_NW, VERIFY = DIL_MVS_NW; };   // 16 + 56 + 8 + 16 x 1.25 = 100 KiB

@@ -9,9 +9,7 @@
 // instead of 45 KiB plus the codec kernels' own read + write of the same fields.  The ||z|| < gamma1 - beta check
 // (norm_check.v:84-105) and the hint-encoding validation ride along (z is in registers anyway).
 // Same arithmetic as verify_wpi_kernel / verify_shared_kernel (pipelines.hip): combined_top.v:1207-1469.
-#ifndef DIL_MAD64
-#define DIL_MAD64 1        // the constant products as two v_mad_i64_i32 (modarith.hpp): these kernels are VALU-bound
-#endif
+#define DIL_PRODUCT_MAD64   // the constant products as two v_mad_i64_i32 (modarith.hpp MAD64): these kernels are VALU-bound
 #include <algorithm>
 #include "launch_util.hpp"
 #include "wire_common.hpp"
@@ -24,35 +22,19 @@ namespace dil {
 #define DIL_SCHED_FENCE_W() __builtin_amdgcn_sched_barrier(0)
 // shape of verify_wire_shared_kernel per level: waves per workgroup, exchange policy (all through LDS, or in registers where
 // the 15 LDS addresses would push a 16-wave workgroup past its 128 registers), prefetch of the next item's packed z
-#ifndef DIL_VWS_SHAPE
-#define DIL_VWS_SHAPE 0
-#endif
 template <int LEVEL> struct WireSh;
-#if DIL_VWS_SHAPE == 0
-#ifndef DIL_VWS_DUAL
 #define DIL_VWS_DUAL 1      // transforms side by side (forward: all L; inverse: row pairs)
-#endif
 template <> struct WireSh<2> { static constexpr int NW = 16; static constexpr bool PFZ = false, DUAL = DIL_VWS_DUAL; using X = XAllLds; };
 template <> struct WireSh<3> { static constexpr int NW = 16; static constexpr bool PFZ = false, DUAL = DIL_VWS_DUAL; using X = X10Dpp; };
 template <> struct WireSh<5> { static constexpr int NW = 12; static constexpr bool PFZ = false, DUAL = DIL_VWS_DUAL; using X = XAllLds; };   // 12 waves: up to 168 VGPRs
-#else        // A/B: every level at 12 waves with prefetch and LDS exchanges
-template <int LEVEL> struct WireSh { static constexpr int NW = 12; static constexpr bool PFZ = true, DUAL = true; using X = XAllLds; };
-#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // distinct public keys: wave per item, A streamed from HBM (expanded by expand_a_kernel), everything else packed
 // ---------------------------------------------------------------------------------------------------------
-#ifndef DIL_WW_TWC
-#define DIL_WW_TWC 1        // compact twiddle tables
-#endif
-#ifndef DIL_WW_DUAL
 // forward transforms in pairs, NTT(t1[k+1] 2^13) beside INTT(row k): level 3 83.8 -> 81.2 us, level 2 65.5 -> 62.1 us per 8192; not at
 // level 5, where the second chain's registers spill under the 168-VGPR cap (126.5 -> 130.2 us): profiles/r04l_ab_wire_matvec.txt
 #define DIL_WW_DUAL(LEVEL) ((LEVEL) != 5)
-#endif
-#ifndef DIL_WW_WAVES
 #define DIL_WW_WAVES(LEVEL) 3      // waves per SIMD the register allocator aims for (168 VGPRs)
-#endif
 // T1H: the caller keeps t1^ = NTT(t1 2^13) of every key beside its matrix (dil_expand_t1_dev: VY_NTT_T1 of combined_top.v:1259-1313 done
 // once per key instead of once per verification): the K transforms of t1 leave the kernel -- L + 1 forward and K inverse remain --
 // for 6 KiB of int32 per key in place of 1.9 KiB of packed t1.
@@ -68,7 +50,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
     using W = Wire<LEVEL>;
     // per wave: L KiB of z^ | 64 dwords byte scratch | 64 dwords hint bitmap
     using XP = X10Pick<true>;
-    using PT = PipeTables<DIL_WW_TWC>;
+    using PT = PipeTables<true>;
     constexpr int WAVE_DW = L * 256 + 64 + 64 + XP::DW;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + 4 * WAVE_DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
@@ -231,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void verify_wire_shared_kernel(
     // workgroup at every level -- as verify_shared_kernel / matvec_shared_kernel (pipelines.hip)
     constexpr int XDW = 256;
     constexpr int WAVE_DW = 64 + 64 + XDW;           // byte scratch | hint bitmap | exchange buffer
-    using PT = PipeTables<DIL_WW_TWC>;
+    using PT = PipeTables<true>;
     __shared__ __attribute__((aligned(16))) uint32_t lds[PT::DWORDS + (K * L + K) * 256 + NW * WAVE_DW];
     const int lane = threadIdx.x & 63, wv = wave_in_block();
     PT::stage(lds, fwd_tab, inv_tab);
