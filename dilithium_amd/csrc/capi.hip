@@ -41,6 +41,7 @@ const OptName* option_table(int* n)
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},
         {"packed_y", "DIL_PACKED_Y", &cfg.packed_y},
+        {"w0w1_plane", "DIL_W0W1_PLANE", &cfg.w0w1_plane},
         {"multi_group_at_1", "DIL_MULTI_GROUP_AT_1", &cfg.multi_group_at_1},
         {"host_chunk", "DIL_HOST_CHUNK", &cfg.host_chunk},
         {"host_chunk_pinned", "DIL_HOST_CHUNK_PINNED", &cfg.host_chunk_pinned},

@@ -46,6 +46,7 @@ struct Config {
     std::atomic<int> host_streams{4};      // DIL_HOST_STREAMS: streams the chunks go round (1 .. 8)
     std::atomic<int> host_pin{0};          // DIL_HOST_PIN: 1 = the caller's buffers are page-locked for the duration of a *_host call
     std::atomic<int> multi_group_at_1{0};  // DIL_MULTI_GROUP_AT_1 (tests): 1 | 2 = a one-device dil_*_multi_dev job goes through the grouped collective code
+    std::atomic<int> w0w1_plane{1};        // DIL_W0W1_PLANE: 1 = inside the signing loop phase 1 hands w1 to phase 2 in the top byte of the w0 dwords (0: a byte plane of its own)
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
 };
 extern Config cfg;

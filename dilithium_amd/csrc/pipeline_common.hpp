@@ -362,10 +362,14 @@ __device__ __forceinline__ void emit_w1w0_row_t(uint8_t* __restrict__ w1p_row, u
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const uint4 q = *reinterpret_cast<const uint4*>(xb + 4 * lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    st_nt4(w0_row + 4 * lane, q.x & 0xFFFFFFu, q.y & 0xFFFFFFu, q.z & 0xFFFFFFu, q.w & 0xFFFFFFu);
     // bytes 3 of (q.x, q.y, q.z, q.w) -> one dword (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c = 0)
     const uint32_t b = __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0703u) | __builtin_amdgcn_perm(q.w, q.z, 0x07030c0cu);
-    reinterpret_cast<uint32_t*>(w1_row)[lane] = b;
+    if (w1_row) {          // the public planes: w0 int32, w1 bytes
+        st_nt4(w0_row + 4 * lane, q.x & 0xFFFFFFu, q.y & 0xFFFFFFu, q.z & 0xFFFFFFu, q.w & 0xFFFFFFu);
+        reinterpret_cast<uint32_t*>(w1_row)[lane] = b;
+    } else {               // inside the signing loop (W0W1 plane, see emit_matvec_row): the transposed dwords leave as they are
+        st_nt4(w0_row + 4 * lane, q.x, q.y, q.z, q.w);
+    }
     if (w1p_row) {
         if (W1Pack<LEVEL>::BITS == 4) {
             uint32_t n = (b | (b >> 4)) & 0x00FF00FFu;
@@ -385,7 +389,10 @@ __device__ __forceinline__ void emit_w1w0_row_t(uint8_t* __restrict__ w1p_row, u
 // Output stage of one mat-vec row: r[] = INTT output (|r| < q, strided order) ->
 //   OUT_W   : w row, canonical int32             (matvec)
 //   OUT_W1W0: w1 = HighBits as bytes, w0 = LowBits as residue in [0,q)  (sign phase 1, DECOMP :1946); if w_out is not
-//             null in this mode it is the PACKED w1 plane ([rows][W1Pack::ROW_BYTES] bytes)
+//             null in this mode it is the PACKED w1 plane ([rows][W1Pack::ROW_BYTES] bytes).
+//             w1_out == nullptr: the signing loop's private W0W1 plane -- one dword per coefficient, w0 | w1 << 24 (w0 < 2^23,
+//             w1 < 2^6), written where w0 goes: FSM2 of the reference reads w0 / w1 straight from BRAM, never re-encoded
+//             (combined_top.v:1946-2229); phase 2 gets both from ONE strided load and no byte plane crosses HBM
 template <int LEVEL, int OUT>
 __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uint8_t* __restrict__ w1_out,
                                                 int32_t* __restrict__ w0_out, size_t o, const int32_t (&r)[4],
@@ -395,8 +402,8 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
     // the INTT's strided order (lane + 64 m) into row order (4 lane + j): OUT_W leaves as ONE 1-KiB dwordx4 store per wave
     // instead of four 256-byte dword stores, OUT_W1W0 takes the one-transposition stage above
     if (OUT != OUT_W && xbuf) {
-        emit_w1w0_row_t<LEVEL>(w_out ? reinterpret_cast<uint8_t*>(w_out) + (o >> 8) * W1Pack<LEVEL>::ROW_BYTES : nullptr, w1_out + o,
-                               w0_out + o, r, xbuf, lane);
+        emit_w1w0_row_t<LEVEL>(w_out ? reinterpret_cast<uint8_t*>(w_out) + (o >> 8) * W1Pack<LEVEL>::ROW_BYTES : nullptr,
+                               w1_out ? w1_out + o : nullptr, w0_out + o, r, xbuf, lane);
         return;
     }
     uint32_t wb[4], ov[4];
@@ -411,6 +418,10 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
     }
     if (OUT != OUT_W && w_out)       // sign phase 1: w1 ALSO leaves packed (the challenge hash's input) -- no pack_w1 launch
         store_row_w1_packed<LEVEL>(reinterpret_cast<uint8_t*>(w_out) + (o >> 8) * W1Pack<LEVEL>::ROW_BYTES, wb, scratch, lane);
+    if (OUT != OUT_W && !w1_out) {   // W0W1 plane
+#pragma unroll
+        for (int m = 0; m < 4; m++) ov[m] |= wb[m] << 24;
+    }
     int32_t* dst = (OUT == OUT_W ? w_out : w0_out) + o;
     if (xbuf) {
 #pragma unroll
@@ -422,7 +433,7 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
 #pragma unroll
         for (int m = 0; m < 4; m++) st_nt(dst + lane + 64 * m, (int32_t)ov[m]);
     }
-    if (OUT != OUT_W) store_row_u8(w1_out + o, wb, scratch, lane);
+    if (OUT != OUT_W && w1_out) store_row_u8(w1_out + o, wb, scratch, lane);
 }
 
 // strided load of one polynomial (natural order) into NTT-input registers.

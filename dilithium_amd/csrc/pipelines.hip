@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
             int32_t wv0[4], yv[4];
             uint32_t wv1[4], hv[4];
             load_strided(wv0, w0 + o, lane);
-            const uint32_t w1p = load_row_u8(w1 + o, lane);
+            const uint32_t w1p = w1 ? load_row_u8(w1 + o, lane) : 0u;         // (w1 == nullptr: the loop's W0W1 plane, w0 | w1 << 24)
             if (zrow) ys.raw(yv, y, it * L + k, lane);
             if (k + 1 < K) {
                 if (!STAGED && k + 1 < L) n1 = *reinterpret_cast<const int4*>(s1 + (k + 1) * 256 + 4 * lane);
@@ -650,7 +650,15 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_wpi_kernel(
 #pragma unroll
                 for (int m = 0; m < 4; m++) a[m] = small_exact(a[m]);
             }
-            unpack_row_u8(wv1, w1p, sc, lane);
+            if (w1) {
+                unpack_row_u8(wv1, w1p, sc, lane);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    wv1[m] = (uint32_t)wv0[m] >> 24;
+                    wv0[m] &= 0xFFFFFF;
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 uint64_t hm;
@@ -705,6 +713,7 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
     if (SH) SmallPair::stage_key<L>(reinterpret_cast<int32_t*>(lds + PAIR_AT), s1hat, s2hat);
     __syncthreads();
     const int32_t* s12 = reinterpret_cast<const int32_t*>(lds + PAIR_AT);
+    const uint32_t W0MASK = w1 ? 0xFFFFFFFFu : 0xFFFFFFu;      // w1 == nullptr: w0 is the loop's W0W1 plane (w0 | w1 << 24, emit_matvec_row)
     const typename PT::Fwd twf = PT::fwd(lds, fwd_tab, lane);
     const typename PT::Inv twi = PT::inv(lds, inv_tab, lane);
     const typename XP::type lm(lds + PT::DWORDS + 4 * 64 + wv * XP::DW, lane);
@@ -782,9 +791,9 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
             }
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const uint32_t r0 = canon_pm2q(wv0[m] - a[m]);
+                const uint32_t r0 = canon_pm2q((int32_t)((uint32_t)wv0[m] & W0MASK) - a[m]);
                 rej |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
-                w0[o + lane + 64 * m] = (int32_t)r0;
+                w0[o + lane + 64 * m] = (int32_t)(r0 | ((uint32_t)wv0[m] & ~W0MASK));      // (the W0W1 plane keeps w1 in its top byte)
             }
             if (__ballot(rej)) {
                 bits = 2;
@@ -810,9 +819,9 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
             bool rej = false;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const uint32_t r0 = canon_pm2q(wv0[m] - a[m]);
+                const uint32_t r0 = canon_pm2q((int32_t)((uint32_t)wv0[m] & W0MASK) - a[m]);
                 rej |= norm_reject(r0, Par<LEVEL>::GAMMA2 - Par<LEVEL>::BETA);
-                w0[o + lane + 64 * m] = (int32_t)r0;
+                w0[o + lane + 64 * m] = (int32_t)(r0 | ((uint32_t)wv0[m] & ~W0MASK));      // (the W0W1 plane keeps w1 in its top byte)
             }
             if (__ballot(rej)) {
                 bits = 2;
@@ -856,12 +865,20 @@ __global__ __launch_bounds__(256) DIL_S2_ATTR void sign2_early_wpi_kernel(
                 int32_t r0v[4];
                 uint32_t wv1[4], hv[4];
                 load_strided(r0v, w0 + o, lane);          // this lane's own stores of stage (A)
-                const uint32_t w1p = load_row_u8(w1 + o, lane);
+                const uint32_t w1p = w1 ? load_row_u8(w1 + o, lane) : 0u;
                 if (k + 1 < K) kn = *reinterpret_cast<const int4*>(t0 + (k + 1) * 256 + 4 * lane);
                 int32_t b[4] = {mont_mul(ch[0], b0.x), mont_mul(ch[1], b0.y), mont_mul(ch[2], b0.z), mont_mul(ch[3], b0.w)};
                 ntt_inv_core(b, twi, lm);
                 bool rej = false;
-                unpack_row_u8(wv1, w1p, sc, lane);
+                if (w1) {
+                    unpack_row_u8(wv1, w1p, sc, lane);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        wv1[m] = (uint32_t)r0v[m] >> 24;
+                        r0v[m] &= 0xFFFFFF;
+                    }
+                }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const uint32_t ct0 = canon_small(b[m]);
@@ -1350,6 +1367,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
     // lane, so S cannot exceed the wave width (scheme.hip's s_max = 64 is that bound)
     if (km.spec_n && (km.S > 64 || (size_t)km.spec_n * km.S != batch)) return hipErrorInvalidValue;
     if (y_fmt == Y_PACKED && !(use_wpi(batch, t) && small_key)) return hipErrorInvalidValue;      // packed y: the signing loop's wave-per-item shapes only
+    if (!w1 && !use_wpi(batch, t)) return hipErrorInvalidValue;        // w1 == nullptr = the loop's W0W1 plane in w0: the wave-per-item kernels only
     if (use_wpi(batch, t) && w0_scratch) {      // the signing loop's early-exit form (w0 is its own scratch, reused for r0)
         if (w0_scratch != w0) return hipErrorInvalidValue;
 #define DIL_S2E2(LV, YF, SH)                                                                                                     \

@@ -214,6 +214,7 @@ struct AttemptScratch {
     bool fuse_challenge = true;  // c~ and c by one launch (hash_kernels.hip challenge_sample_kernel)
     bool packed_y = false;       // the signing loop: y stays ExpandMask's raw stream in rounds large enough for the wave-per-item kernels
     bool small_key = false;      // s1^ s2^ t0^ decoded from secret-key bytes, c from SampleInBall: phase 2 may use its small-product forms
+    bool w0w1 = false;           // the signing loop: between phase 1 and phase 2 w0 and w1 travel as ONE dword per coefficient (w0 | w1 << 24) -- no w1 byte plane
     int alloc(StreamScratch& ws, int level, int K, int L, size_t batch)
     {
         y = ws.take<int32_t>(batch * L * 256);
@@ -284,15 +285,17 @@ int sign_attempt_impl(const dil::Tables& T, const AttemptScratch& t, uint8_t* ct
     const int y_fmt = (t.packed_y && dil::fused_wpi_shape(batch, T)) ? dil::Y_PACKED : dil::Y_I32;
     if (y_fmt == dil::Y_PACKED) DIL_TRY(dil::launch_expand_mask_packed(reinterpret_cast<uint8_t*>(t.y), rhoprime, kappa, level, batch, s));
     else DIL_TRY(dil::launch_expand_mask(t.y, rhoprime, kappa, level, batch, s));
-    // phase 1 writes w1 twice: as a byte plane (phase 2 reads it per coefficient) and packed (the challenge hash's input)
-    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, t.w1, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt, y_fmt));
+    // phase 1 writes w1 packed (the challenge hash's input) and, for phase 2, either as a byte plane of its own (the public form) or -- in
+    // the signing loop's wave-per-item rounds -- in the top byte of the w0 dwords (pipeline_common.hpp emit_matvec_row: the W0W1 plane)
+    uint8_t* w1_plane = (t.w0w1 && dil::fused_wpi_shape(batch, T)) ? nullptr : t.w1;
+    DIL_TRY(dil::launch_matvec(level, dil::OUT_W1W0, nullptr, w1_plane, t.w0, A, t.y, batch, shared_key, T, s, km, t.w1p, t.a_fmt, y_fmt));
     if (t.fuse_challenge) {
         DIL_TRY(dil::launch_challenge_sample(ctilde, t.c, mu, t.w1p, level, batch, s));
     } else {
         DIL_TRY(dil::launch_challenge_hash(ctilde, nullptr, mu, t.w1p, level, nullptr, batch, s));
         DIL_TRY(dil::launch_sample_in_ball(t.c, ctilde, level, batch, s));
     }
-    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, t.w1, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
+    DIL_TRY(dil::launch_sign2(level, z, h, flags, t.c, t.y, t.w0, w1_plane, s1hat, s2hat, t0hat, batch, shared_key, T, s, km,
                               early_exit ? t.w0 : nullptr, y_fmt, t.small_key));
     return 0;
 }
@@ -700,6 +703,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         att.a_fmt = matrix_format(nk, p.K, p.L);
         att.packed_y = dil::rt::cfg.packed_y.load(std::memory_order_relaxed) != 0;
         att.fuse_challenge = dil::rt::cfg.fuse_challenge.load(std::memory_order_relaxed) != 0;
+        att.w0w1 = dil::rt::cfg.w0w1_plane.load(std::memory_order_relaxed) != 0;
         att.small_key = true;            // s1^ s2^ t0^ come from unpack(sk) and c from SampleInBall: the small-product kernels are exact (pipelines.hip)
         const bool few = nk * p.K * p.L <= dil::EA_TWO_LANE_MAX;            // (then the matrix format is int32)
         if (!few) DIL_TRY(dil::launch_expand_a(A, sk, skb, level, nk, s, att.a_fmt));

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 OPTION_SETS = {
     "sign_skip=0": {"sign_skip": 0},
     "packed_y=0": {"packed_y": 0},
+    "w0w1_plane=0": {"w0w1_plane": 0},
     "fuse_challenge=0": {"fuse_challenge": 0},
     "a24=0,fuse_keygen=0": {"a24": 0, "fuse_keygen": 0},
     "coop_max=0": {"coop_max": 0},                       # round 5: the lane-per-sponge / two-lane Keccak forms everywhere
