@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small fixed workloads for rocprofv3 (kernel trace or --pmc passes):
-   prof_target.py ntt | verify | verify_rot | verify_shared | sign | hash | scheme | all   [reps]"""
+   prof_target.py ntt | verify | verify_rot | verify_shared | sign | signloop | hash | scheme | all   [reps]"""
 import os
 import sys
 
@@ -71,6 +71,12 @@ def main():
         for _ in range(reps):
             w1, w0 = api.sign_phase1(A, y, 5, shared_key=True)
             api.sign_phase2(c, y, w0, w1, s1h, s2h, t0h, 5, shared_key=True, small_key=True)
+    if what == "signloop":          # the whole signing loop, level 5, 8192 messages, one key (configs[4]'s loop): options from the environment
+        u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g)  # noqa: E731
+        pk, sk = api.keygen(u8(1, 32), 5)
+        mu = u8(8192, 64)
+        for _ in range(reps):
+            api.sign(sk, mu, 5, shared_sk=True)
     if what in ("hash", "scheme"):
         n = 8192
         u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g)  # noqa: E731

@@ -87,6 +87,43 @@ __global__ __launch_bounds__(256) void ntt_var(int32_t* __restrict__ polys, size
     }
 }
 
+// LDS-DMA with D polynomials in flight beyond the current one (D + 1 slots of 1 KiB per wave): prefetch depth without VGPRs.
+// gfx9 retires VMEM operations in issue order on one counter: after DMA(p) were issued D stores and D DMAs, so vmcnt(2 D) = "DMA(p) landed".
+template <int D, bool COMPUTE, int WPB>
+__global__ __launch_bounds__(64 * WPB) void ntt_dma_deep(int32_t* __restrict__ polys, size_t batch, const uint32_t* __restrict__ tw_tab)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t slots[WPB * (D + 1) * 256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = (size_t)blockIdx.x * WPB + wv, nwaves = (size_t)gridDim.x * WPB;
+    if (wave >= batch) return;
+    TwRegs tw;
+    if (COMPUTE) tw.load(tw_tab, lane);
+    const LaneMasks lm(lane);
+    uint32_t* slot = slots + wv * (D + 1) * 256;
+    using lds_ptr = __attribute__((address_space(3))) uint32_t*;
+    auto dma = [&](size_t p, int s) { __builtin_amdgcn_global_load_lds(polys + p * 256 + 4 * lane, (lds_ptr)(slot + s * 256), 16, 0, 2); };
+#pragma unroll
+    for (int d = 0; d < D; d++)
+        if (wave + d * nwaves < batch) dma(wave + d * nwaves, d);
+    int s = 0;
+    for (size_t p = wave; p < batch; p += nwaves) {
+        const size_t pn = p + (size_t)D * nwaves;
+        const int sn = s + D > D ? s + D - (D + 1) : s + D;
+        if (pn < batch) dma(pn, sn);
+        // wave-uniform tail: fewer operations behind DMA(p) when no more DMAs are issued -- wait for everything there
+        if (pn < batch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int32_t r[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) r[m] = (int32_t)slot[s * 256 + lane + 64 * m];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (COMPUTE) ntt_fwd_core(r, tw, lm);
+        st_nt4(polys + p * 256 + 4 * lane, COMPUTE ? canon_any(r[0]) : (uint32_t)r[0], COMPUTE ? canon_any(r[1]) : (uint32_t)r[1],
+               COMPUTE ? canon_any(r[2]) : (uint32_t)r[2], COMPUTE ? canon_any(r[3]) : (uint32_t)r[3]);
+        s = s == D ? 0 : s + 1;
+    }
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -120,6 +157,9 @@ int main()
     check("dword loads", [&] { ntt_var<LD_DWORD, true, true><<<cus * 8, 256>>>(d, batch, d_tab); });
     check("dwordx4 + LDS transposition", [&] { ntt_var<LD_X4_LDS, true, true><<<cus * 8, 256>>>(d, batch, d_tab); });
     check("LDS-DMA", [&] { ntt_var<LD_DMA, true, true><<<cus * 8, 256>>>(d, batch, d_tab); });
+    check("LDS-DMA 2 ahead", [&] { ntt_dma_deep<2, true, 4><<<cus * 8, 256>>>(d, batch, d_tab); });
+    check("LDS-DMA 3 ahead", [&] { ntt_dma_deep<3, true, 4><<<cus * 6, 256>>>(d, batch, d_tab); });
+    check("LDS-DMA 4 ahead, 8 waves", [&] { ntt_dma_deep<4, true, 8><<<cus * 3, 512>>>(d, batch, d_tab); });
     for (size_t b = 0; b < NB; b++) CK(hipMemcpy(d + b * batch * 256, h.data(), batch * 1024, hipMemcpyHostToDevice));
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -154,5 +194,31 @@ int main()
     TIME("transform     LDS-DMA default policy                     8 blocks/CU", (ntt_var<LD_DMA, true, false>), 8)
     TIME("transform     LDS-DMA nt                                 6 blocks/CU", (ntt_var<LD_DMA, true, true>), 6)
     TIME("transform     LDS-DMA nt                                 4 blocks/CU", (ntt_var<LD_DMA, true, true>), 4)
+#define TIMED(label, KERN, BPC, TPB)                                                                  \
+    {                                                                                                  \
+        std::vector<float> t;                                                                          \
+        for (int rep = 0; rep < 5; rep++) {                                                            \
+            for (int i = 0; i < 16; i++) KERN<<<cus * BPC, TPB>>>(d + (i % NB) * batch * 256, batch, d_tab); \
+            CK(hipEventRecord(a));                                                                     \
+            for (int i = 0; i < 256; i++) KERN<<<cus * BPC, TPB>>>(d + (i % NB) * batch * 256, batch, d_tab); \
+            CK(hipEventRecord(b));                                                                     \
+            CK(hipEventSynchronize(b));                                                                \
+            float ms;                                                                                  \
+            CK(hipEventElapsedTime(&ms, a, b));                                                        \
+            t.push_back(ms / 256 * 1e3f);                                                              \
+        }                                                                                              \
+        std::sort(t.begin(), t.end());                                                                 \
+        printf("%-70s %7.2f us  %7.1f GB/s  %.3f of 8 TB/s\n", label, t[2], 2048.0 * batch / t[2] / 1e3, 2048.0 * batch / t[2] / 1e3 / 8000); \
+    }
+    TIMED("traffic only  LDS-DMA 2 ahead                            8 blocks/CU", (ntt_dma_deep<2, false, 4>), 8, 256)
+    TIMED("traffic only  LDS-DMA 3 ahead                            6 blocks/CU", (ntt_dma_deep<3, false, 4>), 6, 256)
+    TIMED("transform     LDS-DMA 2 ahead                            8 blocks/CU", (ntt_dma_deep<2, true, 4>), 8, 256)
+    TIMED("transform     LDS-DMA 2 ahead                            6 blocks/CU", (ntt_dma_deep<2, true, 4>), 6, 256)
+    TIMED("transform     LDS-DMA 3 ahead                            8 blocks/CU", (ntt_dma_deep<3, true, 4>), 8, 256)
+    TIMED("transform     LDS-DMA 3 ahead                            6 blocks/CU", (ntt_dma_deep<3, true, 4>), 6, 256)
+    TIMED("transform     LDS-DMA 3 ahead                            4 blocks/CU", (ntt_dma_deep<3, true, 4>), 4, 256)
+    TIMED("transform     LDS-DMA 4 ahead, 8 waves per block         4 blocks/CU", (ntt_dma_deep<4, true, 8>), 4, 512)
+    TIMED("transform     LDS-DMA 4 ahead, 8 waves per block         3 blocks/CU", (ntt_dma_deep<4, true, 8>), 3, 512)
+    TIMED("transform     LDS-DMA 6 ahead                            4 blocks/CU", (ntt_dma_deep<6, true, 4>), 4, 256)
     return 0;
 }
