@@ -356,10 +356,15 @@ __global__ __launch_bounds__(64) void sample_in_ball_bits_kernel(uint32_t* __res
 // `a_blocks` workgroups expand the matrix and whose other workgroups sample the challenges, side by side on different CUs.
 __global__ __launch_bounds__(64) void expand_a_sib_kernel(int32_t* __restrict__ A, const uint64_t* __restrict__ rho, size_t rho_stride_words,
                                                           int K, int L, size_t nkeys, unsigned a_blocks, uint32_t* __restrict__ cbits,
-                                                          const uint8_t* __restrict__ ctilde, size_t ct_stride, int tau, size_t nitems)
+                                                          const uint8_t* __restrict__ ctilde, size_t ct_stride, int tau, size_t nitems, int coop_a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[SibLds<64>::BYTES];
-    if (blockIdx.x < a_blocks)
+    if (blockIdx.x < a_blocks && coop_a) {     // few keys under many signatures: a polynomial per workgroup, its sponge spread over the wave
+        const size_t p = blockIdx.x, key = p / (size_t)(K * L);
+        const int ij = (int)(p % (size_t)(K * L)), i = ij / L, j = ij % L;
+        coop::expand_a_body(A + p * 256, reinterpret_cast<const uint32_t*>(rho + key * rho_stride_words), (uint32_t)j | ((uint32_t)i << 8),
+                            reinterpret_cast<uint32_t*>(lds));
+    } else if (blockIdx.x < a_blocks)
         expand_a_body<true>(A, rho, rho_stride_words, K, L, nkeys, blockIdx.x, reinterpret_cast<uint32_t*>(lds));
     else
         sample_in_ball_bits_body<64>(cbits, ctilde, ct_stride, tau, nitems, blockIdx.x - a_blocks, reinterpret_cast<int8_t*>(lds),
@@ -575,10 +580,13 @@ hipError_t launch_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride
     const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
     if (coop_wanted(nkeys * (size_t)(K * L) + nitems))
         return launch_coop_expand_a_sib(A, rho, rho_stride_bytes, nkeys, K, L, cbits, ctilde, ct_stride, tau, nitems, s);
-    const unsigned a_blocks = (unsigned)((2 * nkeys * (size_t)(K * L) + 63) / 64);
+    // (many signatures under few keys: the matrix still takes the one-sponge-per-wavefront form -- 17 instead of 47 us for one key --
+    //  beside SampleInBall's lane-per-item workgroups)
+    const int coop_a = coop_wanted(nkeys * (size_t)(K * L));
+    const unsigned a_blocks = coop_a ? (unsigned)(nkeys * (size_t)(K * L)) : (unsigned)((2 * nkeys * (size_t)(K * L) + 63) / 64);
     const unsigned c_blocks = (unsigned)((nitems + 63) / 64);
     hipLaunchKernelGGL(expand_a_sib_kernel, a_blocks + c_blocks, 64, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L,
-                       nkeys, a_blocks, cbits, ctilde, ct_stride, tau, nitems);
+                       nkeys, a_blocks, cbits, ctilde, ct_stride, tau, nitems, coop_a);
     return hipGetLastError();
 }
 
