@@ -11,6 +11,11 @@ namespace dil {
 // permutations: 2752 sponges 43 vs 54 us, 4096 54 vs 54 (profiles/r05a_keccak_coop.txt).  0: never.
 std::atomic<int> coop_max_sponges{3072};
 bool coop_wanted(size_t sponges) { return sponges > 0 && sponges <= (size_t)coop_max_sponges.load(std::memory_order_relaxed); }
+// SampleInBall is ONE permutation and then a sampler that the cooperative form runs in parallel (ballots + a lane per sign) where the
+// lane-per-item form walks 60-odd bytes serially: alone it wins up to ~10000 items (4096: 12.9 vs 24.8 us, 8192: 21 vs 25, 16384: 37 vs
+// 26; scripts/bench_sib_forms.py) -- but it is eight times the issue slots, and beside a throughput-bound neighbour (ExpandA of 8192 keys
+// on the other stream) the call gets SLOWER from 8192 items on (281.7 vs 274.6 us): the bound is 1.5 x coop_max.
+bool coop_wanted_sib(size_t items) { return items > 0 && 2 * items <= 3 * (size_t)coop_max_sponges.load(std::memory_order_relaxed); }
 
 __global__ __launch_bounds__(64) void coop_shake256_kernel(uint32_t* __restrict__ out, int out_words, const uint32_t* __restrict__ in, int in_words)
 {

@@ -755,7 +755,7 @@ hipError_t launch_sample_in_ball(int32_t* c, const uint8_t* ctilde, int level, s
     if (nitems == 0) return hipSuccess;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
-    if (coop_wanted(nitems)) return launch_coop_sample_in_ball(c, nullptr, ctilde, 32, tau, nitems, s);
+    if (coop_wanted_sib(nitems)) return launch_coop_sample_in_ball(c, nullptr, ctilde, 32, tau, nitems, s);
     hipLaunchKernelGGL(sample_in_ball_kernel, (int)((nitems + 63) / 64), 64, 0, s, c, reinterpret_cast<const uint64_t*>(ctilde), tau, nitems);
     return hipGetLastError();
 }

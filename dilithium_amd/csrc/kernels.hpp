@@ -115,6 +115,7 @@ hipError_t launch_sign2(int level, int32_t* z, uint8_t* h, int32_t* flags, const
 // ---- the same operations with one sponge per wavefront (coop_kernels.hip): what the launchers below run for calls with few sponges ----
 extern std::atomic<int> coop_max_sponges;          // option "coop_max": a call with at most this many sponges runs them one per wavefront (0: never)
 bool coop_wanted(size_t sponges);
+bool coop_wanted_sib(size_t items);                // SampleInBall's own (1.5 x) bound
 hipError_t launch_coop_shake256(uint64_t* out, int out_bytes, const uint64_t* in, int in_bytes, size_t batch, hipStream_t s);
 hipError_t launch_coop_challenge_hash(uint8_t* out32, int32_t* verdict, const uint8_t* mu, const uint8_t* w1p, int w1_words, const uint8_t* expect,
                                       size_t expect_stride, size_t batch, hipStream_t s);

@@ -578,7 +578,7 @@ hipError_t launch_expand_a_sib(int32_t* A, const uint8_t* rho, size_t rho_stride
     if ((rho_stride_bytes & 7) || (reinterpret_cast<uintptr_t>(rho) & 7)) return hipErrorInvalidValue;
     const int K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
-    if (coop_wanted(nkeys * (size_t)(K * L) + nitems))
+    if (coop_wanted(nkeys * (size_t)(K * L)) && coop_wanted_sib(nitems))       // both jobs one sponge per wavefront
         return launch_coop_expand_a_sib(A, rho, rho_stride_bytes, nkeys, K, L, cbits, ctilde, ct_stride, tau, nitems, s);
     // (many signatures under few keys: the matrix still takes the one-sponge-per-wavefront form -- 17 instead of 47 us for one key --
     //  beside SampleInBall's lane-per-item workgroups)
@@ -595,7 +595,7 @@ hipError_t launch_sample_in_ball_bits(uint32_t* cbits, const uint8_t* ctilde, si
     if (nitems == 0) return hipSuccess;
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const int tau = level == 2 ? 39 : level == 3 ? 49 : 60;
-    if (coop_wanted(nitems)) return launch_coop_sample_in_ball(nullptr, cbits, ctilde, ct_stride, tau, nitems, s);
+    if (coop_wanted_sib(nitems)) return launch_coop_sample_in_ball(nullptr, cbits, ctilde, ct_stride, tau, nitems, s);
     hipLaunchKernelGGL(sample_in_ball_bits_kernel, (int)((nitems + 63) / 64), 64, 0, s, cbits, ctilde, ct_stride, tau, nitems);
     return hipGetLastError();
 }
