@@ -87,6 +87,35 @@ __global__ __launch_bounds__(256) void ntt_var(int32_t* __restrict__ polys, size
     }
 }
 
+// The shipped shape with the co-resident workgroups of a CU started out of phase: all 32 waves of a CU otherwise run load burst ->
+// transform -> store burst in lockstep for the eight polynomials each of them owns.  slot = blockIdx / 256 (2048 blocks: the g-th
+// workgroup of its CU), delay = slot * STEP * 64 cycles (s_sleep).
+template <int STEP>
+__global__ __launch_bounds__(256) void ntt_stagger(int32_t* __restrict__ polys, size_t batch, const uint32_t* __restrict__ tw_tab)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = (size_t)blockIdx.x * 4 + wv, nwaves = (size_t)gridDim.x * 4;
+    if (wave >= batch) return;
+    TwRegs tw;
+    tw.load(tw_tab, lane);
+    const LaneMasks lm(lane);
+    const int slot = (int)(blockIdx.x >> 8) * 4 + wv * (STEP < 0 ? 1 : 0);
+    for (int i = 0; i < slot * (STEP < 0 ? -STEP : STEP); i++) __builtin_amdgcn_s_sleep(1);
+    int32_t nx[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) nx[m] = ld_nt(polys + wave * 256 + lane + 64 * m);
+    for (size_t p = wave; p < batch; p += nwaves) {
+        int32_t r[4] = {nx[0], nx[1], nx[2], nx[3]};
+        const size_t pn = p + nwaves;
+        if (pn < batch) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) nx[m] = ld_nt(polys + pn * 256 + lane + 64 * m);
+        }
+        ntt_fwd_core(r, tw, lm);
+        st_nt4(polys + p * 256 + 4 * lane, canon_any(r[0]), canon_any(r[1]), canon_any(r[2]), canon_any(r[3]));
+    }
+}
+
 // LDS-DMA with D polynomials in flight beyond the current one (D + 1 slots of 1 KiB per wave): prefetch depth without VGPRs.
 // gfx9 retires VMEM operations in issue order on one counter: after DMA(p) were issued D stores and D DMAs, so vmcnt(2 D) = "DMA(p) landed".
 template <int D, bool COMPUTE, int WPB>
@@ -220,5 +249,11 @@ int main()
     TIMED("transform     LDS-DMA 4 ahead, 8 waves per block         4 blocks/CU", (ntt_dma_deep<4, true, 8>), 4, 512)
     TIMED("transform     LDS-DMA 4 ahead, 8 waves per block         3 blocks/CU", (ntt_dma_deep<4, true, 8>), 3, 512)
     TIMED("transform     LDS-DMA 6 ahead                            4 blocks/CU", (ntt_dma_deep<6, true, 4>), 4, 256)
+    TIMED("transform     shipped shape, co-resident workgroups 0.1 us apart   8 blocks/CU", (ntt_stagger<1>), 8, 256)
+    TIMED("transform     shipped shape, 0.2 us apart                          8 blocks/CU", (ntt_stagger<2>), 8, 256)
+    TIMED("transform     shipped shape, 0.4 us apart                          8 blocks/CU", (ntt_stagger<4>), 8, 256)
+    TIMED("transform     shipped shape, 0.8 us apart                          8 blocks/CU", (ntt_stagger<8>), 8, 256)
+    TIMED("transform     shipped shape, every wave 0.1 us apart               8 blocks/CU", (ntt_stagger<-1>), 8, 256)
+    TIMED("transform     shipped shape, no delay (reference)                  8 blocks/CU", (ntt_stagger<0>), 8, 256)
     return 0;
 }
