@@ -3,10 +3,10 @@
 #   pass 1 (gcc runtime):   oracle/dil_oracle.c, dilithium_amd/csrc/ref_api.cpp      -> the oracle / KAT / drop-in CPU tests
 #   pass 2 (clang runtime): the HOST code of libdil256.so (capi.hip, scheme.hip, multi_gpu.hip ... compiled by hipcc with
 #                           -fsanitize=address,undefined; device code unchanged)     -> the C-ABI / options / sharding CPU tests
-# usage: scripts/san_check.sh [logfile]      (default profiles/r04_sanitizers.txt)
+# usage: scripts/san_check.sh [logfile]      (default profiles/r05_sanitizers.txt)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$ROOT/profiles/r04_sanitizers.txt}
+LOG=${1:-$ROOT/profiles/r05_sanitizers.txt}
 SAN=$ROOT/oracle/_san
 mkdir -p $SAN
 cd $ROOT
@@ -27,7 +27,7 @@ P1=${PIPESTATUS[0]}
 
 say "== pass 2: hipcc host code with clang's -fsanitize=address,undefined: libdil256.so (capi / scheme / multi_gpu host paths)"
 SRC=""
-for f in kernels pipelines hash_kernels codec_kernels  wire_kernels capi scheme multi_gpu; do SRC="$SRC dilithium_amd/csrc/$f.hip"; done
+for f in kernels pipelines hash_kernels coop_kernels codec_kernels wire_kernels capi scheme multi_gpu; do SRC="$SRC dilithium_amd/csrc/$f.hip"; done
 hipcc --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wall -pthread $SANFLAGS -fno-sanitize=vptr,function -shared-libsan $SRC -o $SAN/libdil256.so >> $LOG 2>&1 \
     || { say "libdil256 san build FAILED"; exit 1; }
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
