@@ -105,6 +105,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
     }
 }
 
+// K waves share an item: wave k owns row k of A (5 KiB), one of the L + 1 time-domain polynomials (z_0 .. z_{L-1}, c), t1[k], h[k], w1[k]
+// -- per wave and trip the "one-row item" of a_only<1>; the item's transformed z^ would meet in LDS, so a workgroup barrier per item
+// (BARRIER) stands in for that hand-over.  PF: the next item's row is loaded before the barrier.
+template <bool BARRIER, int WGS_ITEMS>
+__global__ __launch_bounds__(64 * K) void skel_rows(uint8_t* __restrict__ w1, const int32_t* __restrict__ A, const int32_t* __restrict__ z,
+                                                    const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint8_t* __restrict__ h, size_t batch)
+{
+    __shared__ int32_t share[K * 64];
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    auto row = [&](size_t it, int4 (&a)[L], int32_t& zc, int32_t& tn, uint32_t& hn) {
+#pragma unroll
+        for (int l = 0; l < L; l++) a[l] = ld4(A + (it * K + k) * (size_t)L * 256 + l * 256 + 4 * lane, true);
+        const int32_t* zp = k < L ? z + (it * L + k) * 256 : c + it * 256;        // (K = L + 1 at level 3)
+        zc = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) zc ^= zp[lane + 64 * m];
+        tn = 0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) tn ^= t1[(it * K + k) * 256 + lane + 64 * m];
+        hn = reinterpret_cast<const uint32_t*>(h + (it * K + k) * 256)[lane];
+    };
+    int4 a[L];
+    int32_t zc, tn;
+    uint32_t hn;
+    size_t it = blockIdx.x;
+    if (it < batch) row(it, a, zc, tn, hn);
+    for (; it < batch; it += gridDim.x) {
+        int32_t r = zc ^ tn ^ (int32_t)hn;
+#pragma unroll
+        for (int l = 0; l < L; l++) r ^= fold(a[l]);
+        const size_t itn = it + gridDim.x;
+        if (itn < batch) row(itn, a, zc, tn, hn);
+        if (BARRIER) {
+            share[k * 64 + lane] = r;
+            __syncthreads();
+            r ^= share[((k + 1) % K) * 64 + lane];
+            __syncthreads();
+        }
+        reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 256)[lane] = (uint32_t)r;
+    }
+}
+
 // references in the same run: a plain grid-stride read of the same bytes (what the chip gives a read-only stream today), and the
 // matrix stream alone in the kernel's order (an item's 30 KiB per wave, 5 KiB at a time)
 __global__ __launch_bounds__(256) void plain_read(uint32_t* __restrict__ out, const int4* __restrict__ p, size_t nvec)
@@ -218,5 +260,33 @@ int main()
     RUN("  4 waves/SIMD, small x4 nt", (skel<true, true, 1, 4, false>), 4)
     RUN("  6 waves/SIMD, small x4 nt", (skel<true, true, 1, 6, false>), 6)
     RUN("  8 waves/SIMD, small x4 nt", (skel<true, true, 1, 8, false>), 8)
+#define RUNR(label, KERN, BLOCKS)                                                                                                  \
+    {                                                                                                                              \
+        auto go = [&](int i) {                                                                                                     \
+            const size_t s = i % NS;                                                                                               \
+            KERN<<<BLOCKS, 64 * K>>>(w1 + s * bh, A + s * (bA / 4), z + s * (bz / 4), c + s * (bc / 4), t1 + s * (bt / 4), h + s * bh, n); \
+        };                                                                                                                         \
+        for (int i = 0; i < 40; i++) go(i);                                                                                        \
+        CK(hipDeviceSynchronize());                                                                                                \
+        std::vector<float> t;                                                                                                      \
+        for (int rep = 0; rep < 5; rep++) {                                                                                        \
+            CK(hipEventRecord(e0));                                                                                                \
+            for (int i = 0; i < 200; i++) go(i);                                                                                   \
+            CK(hipEventRecord(e1));                                                                                                \
+            CK(hipEventSynchronize(e1));                                                                                           \
+            float ms;                                                                                                              \
+            CK(hipEventElapsedTime(&ms, e0, e1));                                                                                  \
+            t.push_back(ms / 200 * 1e3f);                                                                                          \
+        }                                                                                                                          \
+        std::sort(t.begin(), t.end());                                                                                             \
+        printf("%-86s %7.2f us  %6.0f GB/s  %.3f of 8 TB/s\n", label, t[2], bytes / t[2] / 1e3, bytes / t[2] / 1e3 / 8000);        \
+    }
+    RUNR("K waves share an item (a row each), no barrier, 2 workgroups per CU", (skel_rows<false, 0>), cus * 2)
+    RUNR("  3 workgroups per CU", (skel_rows<false, 0>), cus * 3)
+    RUNR("  4 workgroups per CU", (skel_rows<false, 0>), cus * 4)
+    RUNR("  with a workgroup barrier pair per item, 2 per CU", (skel_rows<true, 0>), cus * 2)
+    RUNR("  with a workgroup barrier pair per item, 3 per CU", (skel_rows<true, 0>), cus * 3)
+    RUNR("  with a workgroup barrier pair per item, 4 per CU", (skel_rows<true, 0>), cus * 4)
+    RUNR("  with a workgroup barrier pair per item, 5 per CU", (skel_rows<true, 0>), cus * 5)
     return 0;
 }
