@@ -17,9 +17,9 @@ api.init(0)
 eng = dk.OracleEngine(Oracle())
 cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
 OPTS = {"a24": (0, 1, 2), "fuse_keygen": (0, 1), "fuse_wire": (0, 1), "aux_overlap": (0, 1), "fused_mode": (0, 1, 2), "sign_early": (0, 1),
-        "sign_skip": (0, 1, 2, 3), "packed_y": (0, 1), "fuse_challenge": (0, 1)}
+        "sign_skip": (0, 1, 2, 3), "packed_y": (0, 1), "fuse_challenge": (0, 1), "coop_max": (0, 700, 3072, 1 << 30), "w0w1_plane": (0, 1)}
 DEFAULTS = {"a24": 1, "fuse_keygen": 1, "fuse_wire": 1, "aux_overlap": 1, "fused_mode": 0, "sign_early": 1, "sign_skip": 3, "packed_y": 1,
-            "fuse_challenge": 1}
+            "fuse_challenge": 1, "coop_max": 3072, "w0w1_plane": 1}
 t0 = time.time()
 cases = sigs = checked = 0
 while time.time() - t0 < budget:
