@@ -1,7 +1,7 @@
 // coop_bodies.hpp -- the SHAKE-bound operations of the scheme with ONE sponge per wavefront (keccak_coop.hpp), as device functions
 // for a workgroup of one wave: kernels of their own (coop_kernels.hip) and roles inside the composite launches (wire_kernels.hip,
 // codec_kernels.hip).  The launchers pick these forms while a call has fewer sponges than about three per SIMD (option coop_max):
-// a permutation then takes 2.8 us instead of the 5.9 / 9.7 us of the two-lane / lane-per-sponge forms (profiles/r05a_keccak_coop.txt),
+// a permutation then takes 2.4 us instead of the 5.9 / 9.7 us of the two-lane / lane-per-sponge forms (profiles/r05d_keccak_coop_asm.txt),
 // and the byte stream of a sponge is spread over the lanes, so absorbing is one coalesced load per block and the samplers test a
 // whole block of candidates at once (ballot + prefix count) instead of walking it byte by byte.
 //   H(mu || w1), SampleInBall   gen_c.v:163-196,318-339          ExpandMask   expandmask_ext.v:98,131-185, rejection_y.v:97-99

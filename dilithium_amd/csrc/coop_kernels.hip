@@ -1,14 +1,15 @@
 // coop_kernels.hip -- the SHAKE-bound kernels in their one-sponge-per-wavefront form (keccak_coop.hpp, coop_bodies.hpp): what the launchers
 // of hash_kernels.hip / wire_kernels.hip / codec_kernels.hip run while a call has few sponges (option coop_max; see coop_wanted()).
-// One workgroup = one wave = one sponge.  Parity: the same tests as the lane-per-sponge forms (tests/test_gpu_hash.py runs every entry
-// point on both sides of the threshold and with the option forced either way).
+// One workgroup = one wave = one sponge.  Parity: tests/test_gpu_coop.py runs every entry point with the option forced both ways
+// (cooperative at every size / never) at 1 ... 49152 sponges against each other, hashlib and the host samplers; tests/test_gpu_options.py
+// re-runs the scheme-level KAT tests with coop_max = 0 and 2^30.
 #include "coop_bodies.hpp"
 #include "kernels.hpp"
 
 namespace dil {
 
 // A call with at most this many sponges runs them one per wavefront.  Crossover against the two-lane form for a chain of eight
-// permutations: 2752 sponges 43 vs 54 us, 4096 54 vs 54 (profiles/r05a_keccak_coop.txt).  0: never.
+// permutations: 2752 sponges 43 vs 54 us, 4096 53 vs 54 (profiles/r05d_keccak_coop_asm.txt).  0: never.
 std::atomic<int> coop_max_sponges{3072};
 bool coop_wanted(size_t sponges) { return sponges > 0 && sponges <= (size_t)coop_max_sponges.load(std::memory_order_relaxed); }
 // SampleInBall is ONE permutation and then a sampler that the cooperative form runs in parallel (ballots + a lane per sign) where the

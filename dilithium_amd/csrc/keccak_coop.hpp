@@ -2,7 +2,7 @@
 // (narrow signing rounds, single signatures / verifications / key generations).  What the reference does with one
 // state per Keccak core and a round per cycle (rtl_src/keccak_datapath.vhd:97,116-117; three cores, combined_top.v:225-231;
 // the challenge path gen_c.v:163-196,318-339).  keccak.hpp's lane-per-sponge forms run a 120..182-instruction round as one
-// dependent chain per lane; here a round is ~30 instructions:
+// dependent chain per lane; here a round is 29 VALU instructions + one LDS gather (2.36 us per permutation, profiles/r05d_keccak_coop_asm.txt):
 //
 //   lane L = 32 h + l : dword h (0 = low, 1 = high half) of state word w,  l = w (w < 15) or w + 1 (w >= 15), w = x + 5 y
 //   -> row 0 of a half-wave holds the planes y = 0, 1, 2 as three groups of five lanes, row 1 the planes y = 3, 4
@@ -15,7 +15,7 @@
 //   chi    the x + 1, x + 2 neighbours by DPP, one v_bitop3_b32
 //   iota   the round constants sit one per lane in a VGPR that shifts down one lane per round (DPP wave_shl:1)
 //
-// Written from FIPS 202; checked against the lane-per-sponge form and hashlib (tests/test_gpu_hash.py).
+// Written from FIPS 202; checked against a host model (scripts/tune_keccak_coop.hip), the lane-per-sponge forms and hashlib (tests/test_gpu_coop.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
