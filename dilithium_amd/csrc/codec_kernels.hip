@@ -516,7 +516,8 @@ hipError_t launch_keygen_finish(uint8_t* sk, size_t sk_bytes, const uint8_t* pk,
     if (h_blocks + p_blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(h_blocks + p_blocks);
     if (eta_bits == 3) hipLaunchKernelGGL(keygen_finish_kernel<3>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys, coop_h);
-    else if (eta_bits == 4) hipLaunchKernelGGL(keygen_finish_kernel<4>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks, nkeys, coop_h);
+    else if (eta_bits == 4) hipLaunchKernelGGL(keygen_finish_kernel<4>, grid, 64, 0, s, sk, sk_bytes, pk, pk_bytes, e, s1, s2, L, K, eta, h_blocks,
+             nkeys, coop_h);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(64) void coop_challenge_hash_kernel(uint32_t* __res
     coop::challenge_hash_body(out32, verdict, mu, w1p, w1_words, expect, expect_stride, blockIdx.x);
 }
 
-__global__ __launch_bounds__(64) void coop_challenge_sample_kernel(uint32_t* __restrict__ ctilde_out, int32_t* __restrict__ c_out, const uint32_t* __restrict__ mu,
+__global__ __launch_bounds__(64) void coop_challenge_sample_kernel(uint32_t* __restrict__ ctilde_out, int32_t* __restrict__ c_out,
+                             const uint32_t* __restrict__ mu,
                                                                    const uint32_t* __restrict__ w1p, int w1_words, int tau)
 {
     __shared__ __attribute__((aligned(16))) coop::SibShared sh;
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(64) void coop_sample_in_ball_kernel(void* __restric
 }
 
 template <int B, bool RAW>
-__global__ __launch_bounds__(64) void coop_expand_mask_kernel(void* __restrict__ y, const uint32_t* __restrict__ rhoprime, const uint32_t* __restrict__ kappa, int L)
+__global__ __launch_bounds__(64) void coop_expand_mask_kernel(void* __restrict__ y, const uint32_t* __restrict__ rhoprime,
+                             const uint32_t* __restrict__ kappa, int L)
 {
     __shared__ uint32_t stream[8 * B + 2];
     const size_t p = blockIdx.x, item = p / (size_t)L;
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(64) void coop_expand_a_kernel(int32_t* __restrict__
 }
 
 template <int ETA>
-__global__ __launch_bounds__(64) void coop_expand_s_kernel(int32_t* __restrict__ s1, int32_t* __restrict__ s2, int L, int K, const uint8_t* __restrict__ rhoprime,
+__global__ __launch_bounds__(64) void coop_expand_s_kernel(int32_t* __restrict__ s1, int32_t* __restrict__ s2, int L, int K,
+                             const uint8_t* __restrict__ rhoprime,
                                                            size_t rp_stride)
 {
     __shared__ uint32_t blk[36];
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(64) void coop_expand_s_kernel(int32_t* __restrict__
     coop::expand_s_body<ETA>(out, rhoprime + item * rp_stride, (uint32_t)j, blk);
 }
 
-__global__ __launch_bounds__(64) void coop_mu_kernel(uint32_t* __restrict__ mu, const uint8_t* __restrict__ tr, size_t tr_stride, const uint8_t* __restrict__ msgs,
+__global__ __launch_bounds__(64) void coop_mu_kernel(uint32_t* __restrict__ mu, const uint8_t* __restrict__ tr, size_t tr_stride,
+                             const uint8_t* __restrict__ msgs,
                                                      size_t msgs_bytes, const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ lengths,
                                                      int32_t* __restrict__ bad)
 {
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(64) void coop_mu_kernel(uint32_t* __restrict__ mu, 
 
 // Composite launches of the few-key paths, as in wire_kernels.hip / hash_kernels.hip: independent latency-bound jobs side by side in ONE launch.
 //   verification: A = ExpandA(rho) of the key(s) beside c = SampleInBall(c~) of the signatures
-__global__ __launch_bounds__(64) void coop_expand_a_sib_kernel(int32_t* __restrict__ A, const uint32_t* __restrict__ rho, size_t rho_stride_dwords, int K, int L,
+__global__ __launch_bounds__(64) void coop_expand_a_sib_kernel(int32_t* __restrict__ A, const uint32_t* __restrict__ rho, size_t rho_stride_dwords,
+                             int K, int L,
                                                                unsigned a_blocks, uint32_t* __restrict__ cbits, const uint8_t* __restrict__ ctilde,
                                                                size_t ct_stride, int tau)
 {
@@ -146,7 +151,8 @@ hipError_t launch_coop_challenge_hash(uint8_t* out32, int32_t* verdict, const ui
                                       size_t expect_stride, size_t batch, hipStream_t s)
 {
     if (!grid_ok(batch)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(coop_challenge_hash_kernel, (unsigned)batch, 64, 0, s, reinterpret_cast<uint32_t*>(out32), verdict, reinterpret_cast<const uint32_t*>(mu),
+    hipLaunchKernelGGL(coop_challenge_hash_kernel, (unsigned)batch, 64, 0, s, reinterpret_cast<uint32_t*>(out32), verdict,
+                       reinterpret_cast<const uint32_t*>(mu),
                        reinterpret_cast<const uint32_t*>(w1p), w1_words, expect, expect_stride);
     return hipGetLastError();
 }
@@ -209,10 +215,12 @@ hipError_t launch_coop_expand_a_s(int32_t* A, const uint8_t* rho, size_t rho_str
     const size_t a_blocks = nkeys * (size_t)(K * L), s_blocks = nkeys * (size_t)(L + K);
     if (!grid_ok(a_blocks + s_blocks)) return hipErrorInvalidValue;
     if (eta == 2)
-        hipLaunchKernelGGL(coop_expand_a_s_kernel<2>, (unsigned)(a_blocks + s_blocks), 64, 0, s, A, reinterpret_cast<const uint32_t*>(rho), rho_stride_bytes / 4, K, L,
+        hipLaunchKernelGGL(coop_expand_a_s_kernel<2>, (unsigned)(a_blocks + s_blocks), 64, 0, s, A, reinterpret_cast<const uint32_t*>(rho),
+                           rho_stride_bytes / 4, K, L,
                            (unsigned)a_blocks, s1, s2, rhoprime, rp_stride);
     else
-        hipLaunchKernelGGL(coop_expand_a_s_kernel<4>, (unsigned)(a_blocks + s_blocks), 64, 0, s, A, reinterpret_cast<const uint32_t*>(rho), rho_stride_bytes / 4, K, L,
+        hipLaunchKernelGGL(coop_expand_a_s_kernel<4>, (unsigned)(a_blocks + s_blocks), 64, 0, s, A, reinterpret_cast<const uint32_t*>(rho),
+                           rho_stride_bytes / 4, K, L,
                            (unsigned)a_blocks, s1, s2, rhoprime, rp_stride);
     return hipGetLastError();
 }

@@ -677,7 +677,8 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
     if (level != 2 && level != 3 && level != 5) return hipErrorInvalidValue;
     const size_t total = nitems * (size_t)(K * L);
     if (a_fmt == A_P24) {        // packed output: always the throughput kernel (callers ask for it only on large batches)
-        hipLaunchKernelGGL(expand_a_fast_kernel<true>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
+        hipLaunchKernelGGL(expand_a_fast_kernel<true>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A,
+                           reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
         return hipGetLastError();
     }
     if (coop_wanted(total)) return launch_coop_expand_a(A, rho, rho_stride_bytes, K, L, nitems, s);      // a sponge per wavefront
@@ -686,7 +687,8 @@ hipError_t launch_expand_a(int32_t* A, const uint8_t* rho, size_t rho_stride_byt
                            reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(expand_a_fast_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho), rho_stride_bytes / 8, K, L, nitems);
+    hipLaunchKernelGGL(expand_a_fast_kernel<false>, (int)((total + HASH_BS - 1) / HASH_BS), HASH_BS, 0, s, A, reinterpret_cast<const uint64_t*>(rho),
+                       rho_stride_bytes / 8, K, L, nitems);
     return hipGetLastError();
 }
 

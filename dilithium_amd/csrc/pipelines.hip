@@ -1044,7 +1044,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
             MVS_INV2(r, rd, twi, lm);
             DIL_SCHED_FENCE();
             MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, MVS_XB)), w0_out, (it * K + k) * 256, r, lane);
-            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k + 1) * 256, rd, sc, lane, MVS_XB)), w0_out, (it * K + k + 1) * 256, rd, lane);
+            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k + 1) * 256, rd, sc, lane, MVS_XB)), w0_out,
+                     (it * K + k + 1) * 256, rd, lane);
         }
         if (false)
         for (int k = 0; k < K; k++) {
