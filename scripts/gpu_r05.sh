@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-5 GPU visit (round 4: gpu_r04.sh): parity tests (+ the persistent-loop step log), kernel-coverage trace, smoke, bench, rocprofv3 kernel stats of the
 # same bench command, HBM-traffic PMC passes (each its own run; kernel trace only).
-#   gpurun --timeout 2400 -- bash scripts/gpu_r05.sh [tag] [what...]     what: tests cover smoke bench prof pmc signpmc looppmc   (default: all)
+#   gpurun --timeout 2400 -- bash scripts/gpu_r05.sh [tag] [what...]     what: tests cover smoke bench prof pmc signpmc looppmc verifyprof   (default: all)
 TAG=${1:-r05z}; shift
-WHAT=${@:-tests cover smoke bench prof pmc signpmc looppmc}
+WHAT=${@:-tests cover smoke bench prof pmc signpmc looppmc verifyprof}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -103,4 +103,13 @@ if has looppmc; then      # VALU instructions of the signing loop's own phase 1 
       python $GRAFT_REPO_ROOT/scripts/rocpd_stats.py $OUT/${TAG}_lpmc$v/p_results.db | grep -E "sign2_early|matvec_shared|kernel " | grep -v "at::" | cut -c1-190; done; } > $OUT/${TAG}_signloop_pmc.txt 2>&1
   rm -rf $OUT/${TAG}_lpmc*/
   cat $OUT/${TAG}_signloop_pmc.txt
+fi
+if has verifyprof; then   # the verify leg ALONE over four rotating input sets: the average duration bench.py's secondary roofline must agree with
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_vprof -o v -- python $GRAFT_REPO_ROOT/scripts/prof_target.py verify_rot 200 > $OUT/${TAG}_vprof.log 2>&1
+  echo "verifyprof exit $?"
+  cd $GRAFT_REPO_ROOT
+  python scripts/rocpd_stats.py $OUT/${TAG}_vprof/v_results.db $OUT/${TAG}_kernel_stats_verify_4sets.txt > /dev/null 2>&1
+  rm -rf $OUT/${TAG}_vprof
+  head -4 $OUT/${TAG}_kernel_stats_verify_4sets.txt | cut -c1-170
 fi

@@ -37,16 +37,16 @@ def main():
                 api.verify_core(A, z, c, t1, h, 3, out=w1)
             if what not in ("verify", "ntt+verify"):
                 api.verify_core(A[:1], z, c, t1[:1], h, 3, shared_pk=True, out=w1)
-    if what == "verify_rot":        # two input sets alternating: HBM-streaming like bench.py's secondary metric
+    if what == "verify_rot":        # FOUR input sets rotating (1.44 GB): HBM-streaming like bench.py's secondary metric (two are LLC-assisted)
         n, K, L = 8192, 6, 5
         sets = []
-        for _ in range(2):
+        for _ in range(4):
             t1 = torch.randint(0, 1024, (n, K, 256), dtype=torch.int32, device="cuda", generator=g)
             h = (torch.rand((n, K, 256), device="cuda", generator=g) < 0.03).to(torch.uint8)
             sets.append((rnd(n, K, L, 256), rnd(n, L, 256), rnd(n, 256), t1, h))
         w1 = torch.empty((n, K, 256), dtype=torch.uint8, device="cuda")
-        for i in range(2 * reps + 2):
-            A, z, c, t1, h = sets[i % 2]
+        for i in range(4 * reps + 4):
+            A, z, c, t1, h = sets[i % 4]
             api.verify_core(A, z, c, t1, h, 3, out=w1)
     if what == "wire" or bench:     # the fused wire-format verify kernel, distinct pk (bench.py's verify_wire_core leg)
         n = 8192
