@@ -131,7 +131,9 @@ __device__ __forceinline__ uint32_t permute_c(uint32_t v, const Lane& k)
 // The same 24 rounds by hand: 29 VALU instructions per round.  What the compiler cannot do: fold the row shifts into the xors
 // (v_xor_b32_dpp), select the wrapped x + 1 neighbour with v_cndmask_b32_dpp under a loop-invariant VCC (= lanes with x != 4), place the
 // independent instructions into the wait states the DPP / v_permlane reads need after a VALU write, and run the iota bookkeeping under
-// the gather's LDS round trip.
+// the gather's LDS round trip.  (The one v_cndmask_b32_dpp per round is NOT the 23-cycle instruction profiles/r01_ubench_valu_rates.txt shows
+// for VCC-form selects in a dependent chain: with VCC loop-invariant, mov_dpp + v_bfi_b32 in its place measured 1-3 % slower,
+// profiles/r05o_keccak_coop_bfi.txt.)
 __device__ __forceinline__ uint32_t permute(uint32_t v, const Lane& k)
 {
     uint32_t rc = k.rc0, p, q, cm, cp, t, u, d, own, par, b, b1, b2, ri;
