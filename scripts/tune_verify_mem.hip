@@ -147,6 +147,38 @@ __global__ __launch_bounds__(64 * K) void skel_rows(uint8_t* __restrict__ w1, co
     }
 }
 
+// One RECORD per item (an API change: SURVEY 8(d) fixes separate operand arrays): [A 30 KiB | z 5 | c 1 | t1 6 | h 1.5 KiB] contiguous,
+// 44544 B, read front to back by the item's wave in 5-KiB pieces; w1 to its own array.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void skel_aos(uint8_t* __restrict__ w1, const int32_t* __restrict__ rec, size_t batch)
+{
+    constexpr int REC_DW = (K * L + L + 1 + K) * 256 + K * 64;      // dwords per record
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    for (size_t it = (size_t)blockIdx.x * 4 + wv; it < batch; it += nwaves) {
+        const int32_t* p = rec + it * (size_t)REC_DW;
+        int32_t acc = 0;
+        int4 cur[L];
+#pragma unroll
+        for (int l = 0; l < L; l++) cur[l] = ld4(p + l * 256 + 4 * lane, true);
+        constexpr int PIECES = (K * L + L + 1 + K) / L;             // 8 pieces of 5 KiB (+ 2 polynomials + the hints)
+        for (int q = 0; q < PIECES; q++) {
+            int4 nx[L];
+            if (q + 1 < PIECES) {
+#pragma unroll
+                for (int l = 0; l < L; l++) nx[l] = ld4(p + (size_t)((q + 1) * L + l) * 256 + 4 * lane, true);
+            }
+#pragma unroll
+            for (int l = 0; l < L; l++) acc ^= fold(cur[l]);
+#pragma unroll
+            for (int l = 0; l < L; l++) cur[l] = nx[l];
+            if (q < K) reinterpret_cast<uint32_t*>(w1 + (it * K + q) * 256)[lane] = (uint32_t)acc;
+        }
+        const int4 t0 = ld4(p + (size_t)(PIECES * L) * 256 + 4 * lane, true), t1v = ld4(p + (size_t)(PIECES * L + 1) * 256 + 4 * lane, true);
+        const int32_t hh = p[(K * L + L + 1 + K) * 256 + lane];
+        if ((acc ^ fold(t0) ^ fold(t1v) ^ hh) == 0x12345678) w1[it] = 1;
+    }
+}
+
 // references in the same run: a plain grid-stride read of the same bytes (what the chip gives a read-only stream today), and the
 // matrix stream alone in the kernel's order (an item's 30 KiB per wave, 5 KiB at a time)
 __global__ __launch_bounds__(256) void plain_read(uint32_t* __restrict__ out, const int4* __restrict__ p, size_t nvec)
@@ -280,6 +312,32 @@ int main()
         }                                                                                                                          \
         std::sort(t.begin(), t.end());                                                                                             \
         printf("%-86s %7.2f us  %6.0f GB/s  %.3f of 8 TB/s\n", label, t[2], bytes / t[2] / 1e3, bytes / t[2] / 1e3 / 8000);        \
+    }
+    {
+        int32_t* rec;
+        const size_t rec_b = ((size_t)(K * L + L + 1 + K) * 1024 + K * 256);
+        CK(hipMalloc(&rec, NS * n * rec_b));
+        CK(hipMemset(rec, 5, NS * n * rec_b));
+        auto tm2 = [&](const char* label, int bpc) {
+            auto go = [&](int i) { skel_aos<<<cus * bpc, 256>>>(w1 + (i % NS) * bh, rec + (i % NS) * (n * rec_b / 4), n); };
+            for (int i = 0; i < 40; i++) go(i);
+            CK(hipDeviceSynchronize());
+            std::vector<float> t;
+            for (int rep = 0; rep < 5; rep++) {
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 200; i++) go(i);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                t.push_back(ms / 200 * 1e3f);
+            }
+            std::sort(t.begin(), t.end());
+            printf("%-86s %7.2f us  %6.0f GB/s  %.3f of 8 TB/s\n", label, t[2], bytes / t[2] / 1e3, bytes / t[2] / 1e3 / 8000);
+        };
+        tm2("one contiguous 44.5-KiB record per item (AoS), wave per item, 3 blocks/CU", 3);
+        tm2("  4 blocks/CU", 4);
+        CK(hipFree(rec));
     }
     RUNR("K waves share an item (a row each), no barrier, 2 workgroups per CU", (skel_rows<false, 0>), cus * 2)
     RUNR("  3 workgroups per CU", (skel_rows<false, 0>), cus * 3)
