@@ -3,6 +3,11 @@
 // of the arithmetic.  Under four rotating input sets the real kernel runs at its memory-only time (68.2 vs 67.5 us, profiles/
 // r05j_ab_verify_sets.txt) = 5.6 TB/s, where a plain read-only stream reaches 6.4-7.2 TB/s on this chip (profiles/r01_membench.txt):
 // which property of the access pattern costs the difference?
+// Answer (profiles/r05k_verify_mem_skeleton.txt): none of the read side's.  Without the w1 stores the same reads take 59.3 us = 6.37 TB/s,
+// the plain read-only rate of this chip; the 12.6 MB of w1 (3.5 % of the bytes) cost the other 6 us (9 %), 4.5 us of them even when the
+// rows land in an L2-resident window, and no store form moves it (WR variants: per item, nt / sc0 / sc1 policies, 128-B rows, x2 / x4 by
+// fewer lanes, two or three rows per instruction: 63.3 - 66.6 us).  WR variants that leave some lane's result unused let the compiler
+// drop loads (an early run "found" 51 us that way): every form below keeps every lane of every row live.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/tune_verify_mem.hip -o scripts/bin/tune_verify_mem
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -34,7 +39,7 @@ __device__ __forceinline__ int32_t fold(int4 v) { return v.x ^ v.y ^ v.z ^ v.w; 
 // SMALL4: z / c / t1 as one dwordx4 per lane and polynomial (else four strided dwords, as the transforms want them)
 // NT_SMALL: non-temporal policy for z / c / t1 / h too        AHEAD: rows of A in flight beyond the current one (1 = the kernel)
 // WPS: waves per SIMD asked of the allocator                  CONTIG: a workgroup walks a contiguous run of items
-template <bool SMALL4, bool NT_SMALL, int AHEAD, int WPS, bool CONTIG>
+template <bool SMALL4, bool NT_SMALL, int AHEAD, int WPS, bool CONTIG, int WR = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void skel(uint8_t* __restrict__ w1, const int32_t* __restrict__ A,
                                                                                            const int32_t* __restrict__ z, const int32_t* __restrict__ c,
                                                                                            const int32_t* __restrict__ t1, const uint8_t* __restrict__ h,
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
         int32_t tn = small(t1it);
         uint32_t hn = reinterpret_cast<const uint32_t*>(hit)[lane];
         int32_t acc = 0;
+        uint32_t rows[K] = {};
 #pragma unroll
         for (int l = 0; l <= L; l++) acc ^= zc[l];
         const size_t itn = it + step;
@@ -100,7 +106,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
                 tn = small(t1it + (k + 1) * 256);
                 hn = reinterpret_cast<const uint32_t*>(hit + (k + 1) * 256)[lane];
             }
-            reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 256)[lane] = (uint32_t)r;
+            uint32_t* wp = reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 256) + lane;
+            if (WR == 1) *wp = (uint32_t)r;
+            else if (WR == 3) __builtin_nontemporal_store((uint32_t)r, wp);
+            else if (WR == 4) reinterpret_cast<uint32_t*>(w1 + ((it & 1023) * K + k) * 256)[lane] = (uint32_t)r;   // 1.5 MiB, L2-resident
+            else if (WR == 5) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(wp), "v"(r) : "memory");
+            else if (WR == 6) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(wp), "v"(r) : "memory");
+            else if (WR == 7) asm volatile("global_store_dword %0, %1, off nt" ::"v"(wp), "v"(r) : "memory");
+            else if (WR == 8) asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(wp), "v"(r) : "memory");
+            // (the narrower forms gather their dwords from the other lanes, as the real re-layout would: every lane's r stays live)
+            else if (WR == 10) {
+                const uint32_t a = __shfl((uint32_t)r, (2 * lane) & 63), b = __shfl((uint32_t)r, (2 * lane + 1) & 63);
+                if (lane < 32) *reinterpret_cast<uint2*>(w1 + (it * K + k) * 256 + 8 * lane) = make_uint2(a, b);
+            } else if (WR == 11) {
+                uint32_t q[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) q[j] = __shfl((uint32_t)r, (4 * lane + j) & 63);
+                if (lane < 16) *reinterpret_cast<uint4*>(w1 + (it * K + k) * 256 + 16 * lane) = make_uint4(q[0], q[1], q[2], q[3]);
+            } else if (WR == 12) *reinterpret_cast<uint16_t*>(w1 + (it * K + k) * 128 + 2 * lane) = (uint16_t)r;
+            else if (WR == 13) {          // two rows per store instruction: 512 B as dwordx2 from 64 lanes, every other row
+                if (k & 1) *reinterpret_cast<uint2*>(w1 + (it * K + k - 1) * 256 + 8 * lane) = make_uint2(rows[k - 1], (uint32_t)r);
+                else rows[k] = (uint32_t)r;
+            } else if (WR == 14) {        // three rows per store instruction (768 B as dwordx3... as x4 of which one is padding: dwordx3)
+                if (k % 3 == 2) {
+                    uint32_t* o = reinterpret_cast<uint32_t*>(w1 + (it * K + k - 2) * 256) + 3 * lane;
+                    *reinterpret_cast<uint3*>(o) = make_uint3(rows[k - 2], rows[k - 1], (uint32_t)r);
+                } else rows[k] = (uint32_t)r;
+            } else if (WR == 9) {
+                const uint32_t a = (uint32_t)r ^ __shfl((uint32_t)r, lane ^ 32);
+                if (lane < 32) *reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 128 + 4 * lane) = a;   // 128 B per row (packed)
+            }
+            else rows[k] = (uint32_t)r;
+        }
+        if (WR == 2) {                 // the item's K rows of w1 in one go (1.5 KiB contiguous)
+#pragma unroll
+            for (int k = 0; k < K; k++) reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 256)[lane] = rows[k];
+        } else if (WR == 0) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) x = x * 31u + rows[k];     // (a plain xor would cancel the K copies of acc and with them the z / c loads)
+            if (x == 0x12345678u) w1[it] = 1;
         }
     }
 }
@@ -278,6 +323,20 @@ int main()
     // warm
     RUN("(warm-up)", (skel<false, false, 1, 3, false>), 3)
     RUN("as the kernel: strided dwords (default policy) for z c t1, A nt x4 one row ahead, 3 waves/SIMD", (skel<false, false, 1, 3, false>), 3)
+    RUN("  no w1 stores at all (reads only)", (skel<false, false, 1, 3, false, 0>), 3)
+    RUN("  w1 stored once per item (1.5 KiB) instead of once per row", (skel<false, false, 1, 3, false, 2>), 3)
+    RUN("  w1 rows to a 1.5-MiB window that stays in L2 (no DRAM writes)", (skel<false, false, 1, 3, false, 4>), 3)
+    RUN("  w1 rows with __builtin_nontemporal_store", (skel<false, false, 1, 3, false, 3>), 3)
+    RUN("  w1 rows with global_store_dword nt", (skel<false, false, 1, 3, false, 7>), 3)
+    RUN("  w1 rows with global_store_dword sc1", (skel<false, false, 1, 3, false, 6>), 3)
+    RUN("  w1 rows with global_store_dword sc0 sc1", (skel<false, false, 1, 3, false, 5>), 3)
+    RUN("  w1 rows with global_store_dword sc0 sc1 nt", (skel<false, false, 1, 3, false, 8>), 3)
+    RUN("  w1 rows packed to 128 B (half the lanes store a dword)", (skel<false, false, 1, 3, false, 9>), 3)
+    RUN("  w1 rows packed to 128 B (64 lanes store a ushort)", (skel<false, false, 1, 3, false, 12>), 3)
+    RUN("  256-B rows stored by 32 lanes as dwordx2", (skel<false, false, 1, 3, false, 10>), 3)
+    RUN("  256-B rows stored by 16 lanes as dwordx4", (skel<false, false, 1, 3, false, 11>), 3)
+    RUN("  two rows per store (512 B as dwordx2 of 64 lanes)", (skel<false, false, 1, 3, false, 13>), 3)
+    RUN("  three rows per store (768 B as dwordx3 of 64 lanes)", (skel<false, false, 1, 3, false, 14>), 3)
     RUN("  + nt on z c t1", (skel<false, true, 1, 3, false>), 3)
     RUN("  z c t1 as dwordx4", (skel<true, false, 1, 3, false>), 3)
     RUN("  z c t1 as dwordx4 + nt", (skel<true, true, 1, 3, false>), 3)
