@@ -8,7 +8,7 @@
 //     config.h:29-51        BRAM<T>, bram, enum OPERATION, enum MAPPING
 //     ntt2x2.h:30-34        ntt2x2_fwdntt, ntt2x2_mul, ntt2x2_invntt
 //     address_encoder_decoder.h   resolve_address
-//     util.h:40-50          reshape, compare_array, compare_bram_array, print_reshaped_array, print_index_reshaped_array
+//     util.h:31-50          print_array<T>, reshape, compare_array, compare_bram_array, print_reshaped_array, print_index_reshaped_array
 //     ram_util.h:29-33      read_ram, write_ram, get_twiddle_factors
 // compiles against this header and links against libdil256_ref.so + libdil256.so instead:
 // same names, same C++ linkage, same in-place / caller-owns-buffers contract.  Every call runs
@@ -20,6 +20,7 @@
 #define DIL256_REF_HPP
 
 #include <stdint.h>
+#include <stdio.h>
 
 typedef int32_t data_t;
 typedef int64_t data2_t;
@@ -58,6 +59,16 @@ int compare_array(data_t* a, data_t* b, int bound);
 int compare_bram_array(bram* ram, data_t array[DILITHIUM_N], const char* string, enum MAPPING mapping, int print_out);
 void print_reshaped_array(bram* ram, int bound, const char* string);
 void print_index_reshaped_array(bram* ram, int index);
+// util.h:31-40 is a header template there, so it is one here: "<label> :" and the first `bound` entries as "%3u, " on one line
+// (the report format is the surface; no arithmetic)
+template <typename T>
+void print_array(T* a, int bound, const char* string)
+{
+    fputs(string, stdout);
+    fputs(" :", stdout);
+    for (T* p = a; p != a + bound; ++p) printf("%3u, ", *p);
+    putchar('\n');
+}
 
 void read_ram(data_t data_out[4], const bram* ram, const unsigned ram_i);
 void write_ram(bram* ram, const unsigned ram_i, const data_t data_in[4]);

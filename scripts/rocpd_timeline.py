@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
-"""Print the kernel timeline (start offset, duration, gap to previous) of the LAST `count` dispatches in a rocprofv3 rocpd DB.
-usage: rocpd_timeline.py <results.db> <count> [out.txt]"""
+"""Timeline of the LAST burst of kernels in a rocprofv3 rocpd database: start offset, duration and the idle gap before each
+launch -- where a multi-launch call (the signing loop's rounds) spends time that no kernel accounts for.
+usage: rocpd_timeline.py <results.db> [gap_us_that_separates_calls = 300]"""
 import sqlite3
 import sys
 
-db = sqlite3.connect(sys.argv[1])
-n = int(sys.argv[2])
-rows = db.execute("select name, start, end, grid_x, workgroup_x from kernels order by start desc limit ?", (n,)).fetchall()[::-1]
-t0 = rows[0][1]
-prev_end = t0
-lines = [f"{'t_us':>10s} {'dur_us':>9s} {'gap_us':>8s} {'grid':>9s}  kernel"]
-for name, st, en, gx, wx in rows:
-    short = name.replace("void dil::", "").replace("dil::", "").split("(")[0][:60]
-    lines.append(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:9.1f} {(st - prev_end) / 1e3:8.1f} {gx:9d}  {short}")
-    prev_end = en
-lines.append(f"span {(rows[-1][2] - t0) / 1e3:.1f} us, busy {sum(r[2] - r[1] for r in rows) / 1e3:.1f} us")
-out = "\n".join(lines)
-print(out)
-if len(sys.argv) > 3:
-    open(sys.argv[3], "w").write(out + "\n")
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    sep = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 300e3
+    rows = db.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
+    rows = [r for r in rows if "at::" not in r[0]]
+    cut = 0
+    for i in range(1, len(rows)):
+        if rows[i][1] - rows[i - 1][2] > sep:
+            cut = i
+    burst = rows[cut:]
+    t0 = burst[0][1]
+    busy = 0
+    gaps = 0
+    prev_end = t0
+    print(f"{'t_us':>8s} {'gap_us':>7s} {'dur_us':>8s} {'grid':>8s}  kernel")
+    for name, st, en, gx, wx in burst:
+        gap = st - prev_end
+        print(f"{(st - t0) / 1e3:8.1f} {gap / 1e3:7.1f} {(en - st) / 1e3:8.1f} {gx:8d}  {name[:110]}")
+        busy += en - st
+        gaps += max(gap, 0)
+        prev_end = max(prev_end, en)
+    print(f"launches {len(burst)}  span {(prev_end - t0) / 1e3:.1f} us  kernels {busy / 1e3:.1f} us  idle between launches {gaps / 1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

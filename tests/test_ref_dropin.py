@@ -53,6 +53,18 @@ def test_ref_library_exports_reference_symbols(oracle):
             assert ra(m, a) == oracle.lib.orc_resolve_address(m, a)
 
 
+def test_header_alone_gives_print_array(tmp_path):
+    """util.h:31-40's header template comes with dil256_ref.hpp itself: a TU that includes nothing of the reference compiles,
+    and the line it prints is the reference's ("<label> :" + "%3u, " per entry)"""
+    src = tmp_path / "pa.cpp"
+    src.write_text('#include "dil256_ref.hpp"\nint main() { data_t a[5] = {1, 22, 333, 4444, 8380416}; unsigned char b[2] = {7, 255};\n'
+                   '  print_array(a, 5, "r_gold"); print_array(b, 2, "u8"); return 0; }\n')
+    exe = tmp_path / "pa"
+    subprocess.check_call(["g++", "-O1", "-Wall", "-Wno-format", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert out == "r_gold :  1,  22, 333, 4444, 8380416, \nu8 :  7, 255, \n"
+
+
 def _ref_lib():
     from oracle import oracle as orc
     p = os.path.join(os.path.dirname(orc.__file__), "_ref", "libref.so")
