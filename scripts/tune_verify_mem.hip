@@ -3,11 +3,13 @@
 // of the arithmetic.  Under four rotating input sets the real kernel runs at its memory-only time (68.2 vs 67.5 us, profiles/
 // r05j_ab_verify_sets.txt) = 5.6 TB/s, where a plain read-only stream reaches 6.4-7.2 TB/s on this chip (profiles/r01_membench.txt):
 // which property of the access pattern costs the difference?
-// Answer (profiles/r05k_verify_mem_skeleton.txt): none of the read side's.  Without the w1 stores the same reads take 59.3 us = 6.37 TB/s,
-// the plain read-only rate of this chip; the 12.6 MB of w1 (3.5 % of the bytes) cost the other 6 us (9 %), 4.5 us of them even when the
-// rows land in an L2-resident window, and no store form moves it (WR variants: per item, nt / sc0 / sc1 policies, 128-B rows, x2 / x4 by
-// fewer lanes, two or three rows per instruction: 63.3 - 66.6 us).  WR variants that leave some lane's result unused let the compiler
-// drop loads (an early run "found" 51 us that way): every form below keeps every lane of every row live.
+// Answer (profiles/r05k_verify_mem_skeleton.txt): none of the read side's.  Without the w1 stores the same reads take 58.8 us = 6.4 TB/s,
+// the plain read-only rate of this chip; the 12.6 MB of w1 (3.5 % of the bytes) cost the other 6.7 us (10 %).  The cost follows the bytes
+// stored (0.8 MB: +1.2 us, 2.1 MB: +2.6 us, 12.6 MB: +6.7 us -- a written byte costs about three read ones in this stream), most of it
+// even when the rows land in an L2-resident window, and neither the store form (per item, nt / sc0 / sc1 policies, 128-B rows, x2 / x4 by
+// fewer lanes, two or three rows per instruction: 63.3 - 66.6 us) nor its place in the wave's instruction stream (every row held back until
+// the wave's last load has returned: 65.3 us) moves it.  WR variants that leave some lane's result unused let the compiler drop loads
+// (an early run "found" 51 us that way): every form below keeps every lane of every row live.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/tune_verify_mem.hip -o scripts/bin/tune_verify_mem
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -72,7 +74,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
         zc[L] = small(c + i * 256);
     };
     if (it < end) load_zc(it);
-    for (; it < end; it += step) {
+    uint32_t keep[3][K] = {};          // WR == 15: every row of the wave's (at most three) items held back until its last load has returned
+    size_t kept_it[3] = {};
+    int trip = 0;
+    for (; it < end; it += step, trip++) {
         const int32_t* Ait = A + it * (size_t)(K * L) * 256;
         const int32_t* t1it = t1 + it * (size_t)K * 256;
         const uint8_t* hit = h + it * K * 256;
@@ -109,6 +114,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
             uint32_t* wp = reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 256) + lane;
             if (WR == 1) *wp = (uint32_t)r;
             else if (WR == 3) __builtin_nontemporal_store((uint32_t)r, wp);
+            else if (WR == 16) { if (k == 0 && trip == 0) *wp = (uint32_t)r; else rows[k] = (uint32_t)r; }    // one row per wave and launch
+            else if (WR == 17) { if (k == 0) *wp = (uint32_t)r; else rows[k] = (uint32_t)r; }                 // one row per item
             else if (WR == 4) reinterpret_cast<uint32_t*>(w1 + ((it & 1023) * K + k) * 256)[lane] = (uint32_t)r;   // 1.5 MiB, L2-resident
             else if (WR == 5) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(wp), "v"(r) : "memory");
             else if (WR == 6) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(wp), "v"(r) : "memory");
@@ -138,15 +145,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
             }
             else rows[k] = (uint32_t)r;
         }
+        if (WR == 15) {
+#pragma unroll
+            for (int t = 0; t < 3; t++)
+                if (t == trip) {
+                    kept_it[t] = it;
+#pragma unroll
+                    for (int k = 0; k < K; k++) keep[t][k] = rows[k];
+                }
+        }
         if (WR == 2) {                 // the item's K rows of w1 in one go (1.5 KiB contiguous)
 #pragma unroll
             for (int k = 0; k < K; k++) reinterpret_cast<uint32_t*>(w1 + (it * K + k) * 256)[lane] = rows[k];
-        } else if (WR == 0) {
+        } else if (WR == 0 || WR == 16 || WR == 17) {
             uint32_t x = 0;
 #pragma unroll
             for (int k = 0; k < K; k++) x = x * 31u + rows[k];     // (a plain xor would cancel the K copies of acc and with them the z / c loads)
             if (x == 0x12345678u) w1[it] = 1;
         }
+    }
+    if (WR == 15) {
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (t < trip) {
+#pragma unroll
+                for (int k = 0; k < K; k++) reinterpret_cast<uint32_t*>(w1 + (kept_it[t] * K + k) * 256)[lane] = keep[t][k];
+            }
     }
 }
 
@@ -325,6 +349,9 @@ int main()
     RUN("as the kernel: strided dwords (default policy) for z c t1, A nt x4 one row ahead, 3 waves/SIMD", (skel<false, false, 1, 3, false>), 3)
     RUN("  no w1 stores at all (reads only)", (skel<false, false, 1, 3, false, 0>), 3)
     RUN("  w1 stored once per item (1.5 KiB) instead of once per row", (skel<false, false, 1, 3, false, 2>), 3)
+    RUN("  every w1 row held in registers until the wave's last load is back, stored then", (skel<false, false, 1, 3, false, 15>), 3)
+    RUN("  ONE row stored per wave and launch (0.8 MB), the others only summed", (skel<false, false, 1, 3, false, 16>), 3)
+    RUN("  one row of the six stored per item (2.1 MB)", (skel<false, false, 1, 3, false, 17>), 3)
     RUN("  w1 rows to a 1.5-MiB window that stays in L2 (no DRAM writes)", (skel<false, false, 1, 3, false, 4>), 3)
     RUN("  w1 rows with __builtin_nontemporal_store", (skel<false, false, 1, 3, false, 3>), 3)
     RUN("  w1 rows with global_store_dword nt", (skel<false, false, 1, 3, false, 7>), 3)
