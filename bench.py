@@ -804,8 +804,9 @@ def leg_scheme(cx, sec):
 def leg_end_to_end(cx):
     """"exclude H2D/D2H from kernel figures but report end-to-end separately".  The reference's calling convention for the
     path is caller-owned HOST arrays (reference_code/ref_ntt.h:30-36, hardware_code/ntt2x2.h:30-34); these are the same two workloads
-    through the host-pointer entry points (csrc/capi.hip: chunks round-robin over streams, H2D -> kernel -> D2H), with the caller's
-    buffers pageable and page-locked, against the link's own copy rate measured here.  PCIe-bound by two orders of magnitude: never `value`."""
+    through the host-pointer entry points (csrc/capi.hip: chunks of H2D -> kernel -> D2H; a helper thread downloads a pageable buffer, a
+    page-locked one gets one stream per direction), with the caller's buffers pageable and page-locked, against the link's own copy rate
+    measured here -- one direction at a time, and both at once in the best pattern found (scripts/bench_pcie_duplex.py).  PCIe-bound by two orders of magnitude: never `value`."""
     api = cx.api
 
     def med(f, reps=5):
@@ -829,15 +830,29 @@ def leg_end_to_end(cx):
         hbuf.copy_(dbuf, non_blocking=True)
         torch.cuda.synchronize()
     h2d(), d2h()
-    link = {"h2d_GBps": nbytes / med(h2d) / 1e9, "d2h_GBps": nbytes / med(d2h) / 1e9,
-            "how": "256 MiB page-locked <-> device copies (torch), median of 5; the two directions are separate links (full duplex)"}
-    del hbuf, dbuf
+    hbuf2 = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    dbuf2 = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    s_up, s_dn = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def both(chunk=8 << 20):
+        for off in range(0, nbytes, chunk):
+            with torch.cuda.stream(s_up):
+                dbuf[off:off + chunk].copy_(hbuf[off:off + chunk], non_blocking=True)
+            with torch.cuda.stream(s_dn):
+                hbuf2[off:off + chunk].copy_(dbuf2[off:off + chunk], non_blocking=True)
+        torch.cuda.synchronize()
+    both()
+    link = {"h2d_GBps": nbytes / med(h2d) / 1e9, "d2h_GBps": nbytes / med(d2h) / 1e9, "duplex_GBps_each_way": nbytes / med(both) / 1e9,
+            "how": "256 MiB page-locked <-> device copies (torch), median of 5, one direction at a time; duplex = both directions at once as "
+                   "8-MiB copies on one stream per direction, the best pattern found (two whole-buffer copies side by side share the "
+                   "one-way rate: profiles/r05t_pcie_duplex.txt)"}
+    del hbuf, dbuf, hbuf2, dbuf2
     out["pcie"] = link
     one_way = min(link["h2d_GBps"], link["d2h_GBps"])
     rng = np.random.default_rng(3)
     a = rng.integers(0, 8380417, (BATCH, 256), dtype=np.int32)
     ntt = {"workload": "BASELINE configs[1] through dil_ntt_host + dil_invntt_host: 65536 polynomials, 64 MiB up and 64 MiB down per call",
-           "options": {k: api.get_option(k) for k in ("host_chunk", "host_chunk_pinned", "host_streams")}}
+           "options": {k: api.get_option(k) for k in ("host_chunk", "host_chunk_pinned", "host_streams", "host_threads", "host_duplex")}}
     for kind in ("pageable", "page_locked"):
         keep = torch.from_numpy(a.copy()).pin_memory() if kind == "page_locked" else None
         x = keep.numpy() if keep is not None else a.copy()
@@ -846,9 +861,9 @@ def leg_end_to_end(cx):
         tf, ti = med(lambda: api.ntt(x)), med(lambda: api.invntt(x))
         gb = BATCH * 1024 / ((tf + ti) / 2) / 1e9
         ntt[kind] = {"value": 2 * BATCH / (tf + ti), "unit": "NTT/s", "fwd_ms": tf * 1e3, "inv_ms": ti * 1e3,
-                     "GBps_each_way": gb, "frac_of_pcie": gb / one_way,
-                     "note": "frac_of_pcie = bytes one way / call time, over the slower direction's copy rate: 1.0 = both directions "
-                             "fully overlapped at link rate"}
+                     "GBps_each_way": gb, "frac_of_pcie": gb / one_way, "frac_of_duplex_link": gb / link["duplex_GBps_each_way"],
+                     "note": "frac_of_pcie = bytes one way / call time, over the slower direction's copy rate alone: 1.0 = both directions "
+                             "fully overlapped at the one-way rate; frac_of_duplex_link = over what the link gave each way with both busy"}
     # the batch at which a host caller is better off here than on the CPU: per-call wall time of dil_ntt_host, pageable buffer
     sweep = {}
     for b in (1, 4, 16, 64, 256, 1024, 4096, 16384, 65536):

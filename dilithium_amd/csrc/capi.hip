@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -47,6 +48,8 @@ const OptName* option_table(int* n)
         {"host_chunk_pinned", "DIL_HOST_CHUNK_PINNED", &cfg.host_chunk_pinned},
         {"host_streams", "DIL_HOST_STREAMS", &cfg.host_streams},
         {"host_pin", "DIL_HOST_PIN", &cfg.host_pin},
+        {"host_duplex", "DIL_HOST_DUPLEX", &cfg.host_duplex},
+        {"host_threads", "DIL_HOST_THREADS", &cfg.host_threads},
         {"host_mailbox", "DIL_HOST_MAILBOX", &cfg.host_mailbox},
         {"mailbox_idle_us", "DIL_MAILBOX_IDLE_US", &cfg.mailbox_idle_us},
         {"mailbox_resident_us", "DIL_MAILBOX_RESIDENT_US", &cfg.mailbox_resident_us},
@@ -106,6 +109,8 @@ void destroy_device(Device& d)
         for (int i = 0; i < HOST_STREAMS; i++) {
             if (d.hp.dev[i]) (void)hipFree(d.hp.dev[i]);
             if (d.hp.stream[i]) (void)hipStreamDestroy(d.hp.stream[i]);
+            if (d.hp.up_done[i]) (void)hipEventDestroy(d.hp.up_done[i]);
+            if (d.hp.dn_done[i]) (void)hipEventDestroy(d.hp.dn_done[i]);
         }
         d.hp = HostPipe{};
     }
@@ -368,18 +373,17 @@ int ensure_scratch(Device& d, size_t bytes)
     return 0;
 }
 
-// host wrapper: the reference's callers hold HOST buffers.  Small batches: copy in, run, copy
-// out on the default stream.  Large batches: chunks of HOST_CHUNK polynomials round-robin over
-// HOST_STREAMS streams, each chunk H2D -> kernel -> D2H on its own stream, so the PCIe transfers of
-// one chunk overlap the kernel and the opposite-direction transfer of its neighbours.  With
-// DIL_HOST_PIN=1 the caller's buffer is page-locked (hipHostRegister) for the duration of the call
-// so that the copies are true asynchronous DMA.
+// host wrapper: the reference's callers hold HOST buffers.  Small batches (< 8 MiB): copy in, run, copy out on the default stream.
+// Larger ones go through NS staging buffers in chunks of H2D -> kernel -> D2H, in the pattern that gets both directions of the link
+// busy at once for the kind of memory the caller holds (profiles/r05t_*.txt):
+//   pageable      the runtime stages such copies itself and blocks the copying thread meanwhile: the calling thread uploads and launches
+//                 (stream 0), a helper thread downloads (stream 1).  64 MiB + 64 MiB: 2.56 -> 1.82 ms.  (host_threads = 1: one thread)
+//   page-locked   (by the caller, or for the call by DIL_HOST_PIN=1): stream 0 carries every upload, stream 1 kernels and downloads --
+//                 one stream per direction and 8-MiB chunks is the one pattern tried in which the link runs duplex (43 - 47 GB/s each way
+//                 of 57; two big copies side by side share 57).  2.03 -> 1.80 ms.  (host_duplex = 0: chunks round-robin over NS streams)
 // Locking: these entry points share the device's staging buffers, so they are serialised by the device's
 // `host_mu` -- a lock of their own; initialisation (Device::mu) and every *_dev entry point are never blocked by it.
-// Chunk size and stream count are options (host_chunk in KiB = polynomials, host_streams; swept in profiles/r05_host_pipe.txt).
-// (profiles/r05g_host_pipe.txt: pageable buffers are staged by the runtime -- streams do not matter, large chunks do: 25.8 M NTT/s at
-//  16 MiB; page-locked buffers overlap the two directions across streams, best with small chunks: 32.9 M NTT/s at 1 MiB x 4 streams;
-//  the link itself moves 57 GB/s each way.)
+// Chunk size and buffer count are options (host_chunk / host_chunk_pinned in KiB = polynomials, host_streams).
 static size_t host_chunk_polys(bool pinned = false)
 {
     const int v = pinned ? dil::rt::cfg.host_chunk_pinned.load(std::memory_order_relaxed) : dil::rt::cfg.host_chunk.load(std::memory_order_relaxed);
@@ -401,6 +405,10 @@ int ensure_pipe(Device& d, size_t bytes_per_stream)
     dil::rt::HostPipe& hp = d.hp;
     if (!hp.ready) {
         for (int i = 0; i < HOST_STREAMS; i++) DIL_TRY(hipStreamCreateWithFlags(&hp.stream[i], hipStreamNonBlocking));
+        for (int i = 0; i < HOST_STREAMS; i++) {
+            DIL_TRY(hipEventCreateWithFlags(&hp.up_done[i], hipEventDisableTiming));
+            DIL_TRY(hipEventCreateWithFlags(&hp.dn_done[i], hipEventDisableTiming));
+        }
         hp.ready = true;
     }
     if (hp.dev_bytes < bytes_per_stream) {
@@ -435,9 +443,21 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     std::lock_guard<std::mutex> lk(d.host_mu);
     int rc;
     PinGuard pin(h, batch > 4096 ? batch * 1024 : 0);        // (option host_pin; not worth a registration for a small batch)
-    const size_t HOST_CHUNK = host_chunk_polys(batch > 4096 && (pin.p || is_page_locked(h)));
+    // Which pipeline, which chunk (profiles/r05t_host_batch_sweep.txt):
+    //   pageable     helper thread from two chunks of the option's size (16 MiB) up; a call of fewer than four such chunks is cut in four (>= 2 MiB each:
+    //                below that a copy is latency)
+    //   page-locked  one stream per direction pays from eight chunks of the option's size (64 MiB) up; smaller calls go round-robin over the
+    //                streams in 1-MiB chunks (16 MiB: 0.50 vs 0.56 ms)
+    //   below 8 MiB in all: one upload, one launch, one download
+    const bool locked = batch > 4096 && (pin.p || is_page_locked(h));
+    const size_t opt_chunk = host_chunk_polys(locked);
+    const bool duplex = locked && dil::rt::cfg.host_duplex.load(std::memory_order_relaxed) && batch >= 8 * opt_chunk;
+    const bool helper_thread = !locked && dil::rt::cfg.host_threads.load(std::memory_order_relaxed) >= 2 && batch >= 2 * opt_chunk;
+    const size_t HOST_CHUNK = locked ? ((duplex || !dil::rt::cfg.host_duplex.load(std::memory_order_relaxed)) ? opt_chunk : std::min<size_t>(opt_chunk, 1024))
+                              : (!helper_thread || batch >= 4 * opt_chunk) ? opt_chunk
+                                                                         : std::min(opt_chunk, std::max<size_t>(2048, (batch / 4 + 63) & ~(size_t)63));
     const int NS = host_stream_count();
-    if (batch <= HOST_CHUNK) {
+    if (batch <= HOST_CHUNK || batch < std::min<size_t>(8192, 2 * opt_chunk)) {
         const size_t bytes = batch * 1024;
         rc = ensure_scratch(d, bytes);
         if (rc) return rc;
@@ -453,6 +473,89 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     dil::rt::HostPipe& hp = d.hp;
     int err = 0;
     size_t c = 0;
+    if (duplex) {
+        // Page-locked buffers: the link carries both directions at once only in ONE pattern of those tried (scripts/bench_pcie_duplex.py,
+        // profiles/r05t_pcie_duplex.txt): one stream per direction, chunks of 4 - 16 MiB -- 43 - 47 GB/s each way, where two large
+        // copies side by side share 57 GB/s and several streams per direction fall back to ~32.  So: stream 0 carries every upload,
+        // stream 1 the kernels and downloads, NS staging buffers go round between them on events.
+        hipStream_t up = hp.stream[0], dn = hp.stream[1];
+        for (size_t off = 0; off < batch && !err; off += HOST_CHUNK, c++) {
+            const int b = (int)(c % NS);
+            const size_t n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
+            int32_t* hc = h + off * 256;
+            int32_t* dc = reinterpret_cast<int32_t*>(hp.dev[b]);
+            if (c >= (size_t)NS) err = (int)hipStreamWaitEvent(up, hp.dn_done[b], 0);        // the buffer's previous chunk has left
+            if (!err) err = (int)hipMemcpyAsync(dc, hc, n * 1024, hipMemcpyHostToDevice, up);
+            if (!err) err = (int)hipEventRecord(hp.up_done[b], up);
+            if (!err) err = (int)hipStreamWaitEvent(dn, hp.up_done[b], 0);
+            if (!err) err = fn(dc, n, T, dn);
+            if (!err) err = (int)hipMemcpyAsync(hc, dc, n * 1024, hipMemcpyDeviceToHost, dn);
+            if (!err) err = (int)hipEventRecord(hp.dn_done[b], dn);
+        }
+        for (int i = 0; i < 2; i++) {
+            const hipError_t e = hipStreamSynchronize(hp.stream[i]);
+            if (!err && e != hipSuccess) err = (int)e;
+        }
+        return err;
+    }
+    if (helper_thread) {
+        // Pageable buffers: the runtime stages the copy and BLOCKS the copying thread meanwhile, so one thread gets upload and download one
+        // after the other (27 GB/s each way).  A second thread takes the downloads: 37.8 GB/s each way at 8-MiB chunks -- the rate of the
+        // page-locked pipeline above (scripts/tune_pageable_duplex.hip, profiles/r05t_pageable_duplex.txt).  The calling thread uploads
+        // and launches on stream 0; the helper waits for a chunk's event and downloads on stream 1; NS staging buffers go round.
+        hipStream_t up = hp.stream[0], dn = hp.stream[1];
+        const size_t nch = (batch + HOST_CHUNK - 1) / HOST_CHUNK;
+        std::atomic<size_t> uploaded{0}, downloaded{0};
+        std::atomic<int> err_dn{0};
+        std::atomic<bool> stop{false};
+        const int dev_id = d.id;
+        auto download = [&] {
+            if (hipSetDevice(dev_id) != hipSuccess) { err_dn.store((int)hipErrorInvalidDevice); return; }
+            for (size_t k = 0; k < nch; k++) {
+                while (uploaded.load(std::memory_order_acquire) <= k) {
+                    if (stop.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                const int b = (int)(k % NS);
+                const size_t off = k * HOST_CHUNK, n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
+                hipError_t e = hipStreamWaitEvent(dn, hp.up_done[b], 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(h + off * 256, hp.dev[b], n * 1024, hipMemcpyDeviceToHost, dn);
+                if (e == hipSuccess) e = hipEventRecord(hp.dn_done[b], dn);
+                if (e != hipSuccess) { err_dn.store((int)e); return; }
+                downloaded.store(k + 1, std::memory_order_release);
+            }
+            const hipError_t e = hipStreamSynchronize(dn);
+            if (e != hipSuccess) err_dn.store((int)e);
+        };
+        std::thread helper;
+        try {
+            helper = std::thread(download);
+        } catch (const std::exception&) {                // no thread to be had: the one-thread pipeline below
+        }
+        for (size_t k = 0; helper.joinable() && k < nch && !err; k++) {
+            const int b = (int)(k % NS);
+            const size_t off = k * HOST_CHUNK, n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
+            int32_t* dc = reinterpret_cast<int32_t*>(hp.dev[b]);
+            if (k >= (size_t)NS) {                       // the buffer's previous chunk: its download queued (host side), then done (device side)
+                while (downloaded.load(std::memory_order_acquire) + NS <= k && !err_dn.load(std::memory_order_relaxed)) std::this_thread::yield();
+                if (err_dn.load(std::memory_order_relaxed)) break;
+                err = (int)hipStreamWaitEvent(up, hp.dn_done[b], 0);
+            }
+            if (!err) err = (int)hipMemcpyAsync(dc, h + off * 256, n * 1024, hipMemcpyHostToDevice, up);
+            if (!err) err = fn(dc, n, T, up);
+            if (!err) err = (int)hipEventRecord(hp.up_done[b], up);
+            if (!err) uploaded.store(k + 1, std::memory_order_release);
+        }
+        if (helper.joinable()) {
+            if (err || err_dn.load()) stop.store(true);
+            helper.join();
+            const hipError_t e = hipStreamSynchronize(up);
+            if (!err) err = err_dn.load();
+            if (!err && e != hipSuccess) err = (int)e;
+            if (err) (void)hipStreamSynchronize(dn);
+            return err;
+        }
+    }
     for (size_t off = 0; off < batch && !err; off += HOST_CHUNK, c++) {
         const int s = (int)(c % NS);
         const size_t n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;

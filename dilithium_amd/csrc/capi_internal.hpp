@@ -41,9 +41,12 @@ struct Config {
                                            // (libdil256_ref.so turns it on: its ntt() / invntt() / ... are batch-of-one calls)
     std::atomic<int> mailbox_idle_us{200}; // DIL_MAILBOX_IDLE_US: the mailbox wave retires after this long without a request
     std::atomic<int> mailbox_resident_us{20000};   // DIL_MAILBOX_RESIDENT_US: ... and after this long in all, busy or not (a device-wide sync of another thread waits at most this long)
-    std::atomic<int> host_chunk{16384};    // DIL_HOST_CHUNK: polynomials (KiB) per chunk of the *_host pipelines, pageable caller buffers
-    std::atomic<int> host_chunk_pinned{1024};  // DIL_HOST_CHUNK_PINNED: the same when the caller's buffer is page-locked (true asynchronous DMA: small chunks overlap better)
+    std::atomic<int> host_chunk{8192};     // DIL_HOST_CHUNK: polynomials (KiB) per chunk of the *_host pipelines, pageable caller buffers
+    std::atomic<int> host_threads{2};      // DIL_HOST_THREADS: 2 = a pageable caller buffer is uploaded by the calling thread and downloaded by a second one (the runtime
+                                           // blocks the thread that copies pageable memory: one thread gets the two directions one after the other)
+    std::atomic<int> host_chunk_pinned{8192};  // DIL_HOST_CHUNK_PINNED: the same when the caller's buffer is page-locked (true asynchronous DMA: small chunks overlap better)
     std::atomic<int> host_streams{4};      // DIL_HOST_STREAMS: streams the chunks go round (1 .. 8)
+    std::atomic<int> host_duplex{1};       // DIL_HOST_DUPLEX: 1 = page-locked caller buffers: ONE stream carries every upload, one the kernels + downloads (0: chunks round-robin over host_streams)
     std::atomic<int> host_pin{0};          // DIL_HOST_PIN: 1 = the caller's buffers are page-locked for the duration of a *_host call
     std::atomic<int> multi_group_at_1{0};  // DIL_MULTI_GROUP_AT_1 (tests): 1 | 2 = a one-device dil_*_multi_dev job goes through the grouped collective code
     std::atomic<int> w0w1_plane{1};        // DIL_W0W1_PLANE: 1 = inside the signing loop phase 1 hands w1 to phase 2 in the top byte of the w0 dwords (0: a byte plane of its own)
@@ -85,6 +88,7 @@ struct HostPipe {
     hipStream_t stream[HOST_STREAMS] = {};
     uint8_t* dev[HOST_STREAMS] = {};       // one staging buffer per stream
     size_t dev_bytes = 0;                  // size of each
+    hipEvent_t up_done[HOST_STREAMS] = {}, dn_done[HOST_STREAMS] = {};   // per staging buffer: its upload landed / its download left
     bool ready = false;
 };
 

@@ -1,5 +1,7 @@
-"""The host-pointer pipelines (csrc/capi.hip host_inplace / host_verify_core: chunks round-robin over streams, H2D -> kernel -> D2H) under
-every setting of their options -- host_chunk (KiB per chunk), host_streams (1 .. 8), host_pin (caller's buffers page-locked) -- against
+"""The host-pointer pipelines (csrc/capi.hip host_inplace / host_verify_core: chunks of H2D -> kernel -> D2H; a helper thread for the
+downloads of a pageable buffer, one stream per direction for a page-locked one, or round-robin over streams) under every setting of
+their options -- host_chunk / host_chunk_pinned (KiB per chunk), host_streams (1 .. 8 staging buffers), host_pin, host_duplex,
+host_threads -- against
 the oracle and the device-pointer entry points.  The reference's calling convention for the path is caller-owned HOST arrays
 (reference_code/ref_ntt.h:30-36, hardware_code/ntt2x2.h:30-34); bench.py's `end_to_end` block times these calls."""
 import numpy as np
@@ -13,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def host_opts(gpu):
     from dilithium_amd import api
-    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin")}
+    saved = {k: api.get_option(k) for k in ("host_chunk", "host_chunk_pinned", "host_streams", "host_pin", "host_duplex", "host_threads")}
     yield lambda **kw: [api.set_option(k, v) for k, v in kw.items()]
     for k, v in saved.items():
         api.set_option(k, v)
@@ -28,6 +30,30 @@ def test_ntt_host_chunked(gpu, oracle, host_opts, chunk, streams, pin):
     x = a.copy()
     api.ntt(x)
     idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 97)), [n - 1, chunk - 1 if chunk < n else 0, min(chunk, n - 1)]]))
+    assert (x[idx] == oracle.ntt(a[idx])).all()
+    api.invntt(x)
+    assert (x == a).all()
+
+
+@pytest.mark.parametrize("threads,duplex,pin,locked", [(2, 1, 0, False), (1, 1, 0, False), (2, 1, 1, False), (2, 0, 1, False), (2, 1, 0, True),
+                                                       (2, 0, 0, True)])
+@pytest.mark.parametrize("chunk,bufs", [(64, 1), (64, 2), (100, 4), (600, 2), (8192, 3)])
+def test_ntt_host_two_threads_and_one_stream_per_direction(gpu, oracle, host_opts, threads, duplex, pin, locked, chunk, bufs):
+    """the two pipelines of round 5 -- a helper thread downloading a pageable buffer's chunks, one stream per direction for a page-locked
+    one -- with the staging ring wrapping several times (7+ chunks over 1 .. 4 buffers) and a ragged last chunk, against the oracle and the
+    round trip; `locked`: the caller's buffer is page-locked already (torch pin_memory), pin: the library registers it for the call"""
+    from dilithium_amd import api
+    host_opts(host_chunk=chunk, host_chunk_pinned=chunk, host_streams=bufs, host_pin=pin, host_duplex=duplex, host_threads=threads)
+    n = 9 * chunk + 17 if chunk < 4096 else 20011         # (chunk 600: 5417 polynomials, past the 4096 below which a page-locked buffer
+    a = splitmix64_polys(n, seed=chunk + bufs)            #  is not treated as one, and >= 8 chunks: the one-stream-per-direction pipeline)
+    if locked:
+        keep = gpu.empty((n, N), dtype=gpu.int32).pin_memory()
+        x = keep.numpy()
+        x[:] = a
+    else:
+        x = a.copy()
+    api.ntt(x)
+    idx = np.unique(np.concatenate([np.arange(0, n, max(1, n // 97)), [n - 1, chunk - 1, min(chunk, n - 1), n - 17, n - 18]]))
     assert (x[idx] == oracle.ntt(a[idx])).all()
     api.invntt(x)
     assert (x == a).all()
