@@ -84,3 +84,56 @@ def test_verify_core_host_vs_device_and_oracle(gpu, oracle, host_opts, level, sh
     assert (w1.reshape(dev.shape) == dev).all()
     Ab, tb = (np.broadcast_to(A, (n, K, L, N)), np.broadcast_to(t1, (n, K, N))) if shared else (A, t1)
     assert (dev == oracle.verify_core(level, np.ascontiguousarray(Ab), z, c, np.ascontiguousarray(tb), h)).all()
+
+
+def test_host_pipelines_from_concurrent_threads(gpu, oracle):
+    """three host threads in the *_host transforms at once (pageable buffers large enough for the helper-thread pipeline, a page-locked one,
+    small ones on the one-shot path) beside a fourth on the device-pointer scheme calls: the host entry points of a device serialise on
+    their own lock, the helper thread of one call never serves another, every result is the oracle's"""
+    import threading
+    from dilithium_amd import api
+    torch = gpu
+    errors = []
+    n = 20000
+    srcs = [splitmix64_polys(n, seed=40 + i) for i in range(3)]
+    keep = torch.empty((n, N), dtype=torch.int32).pin_memory()
+    idx = np.arange(0, n, 211)
+    want = [oracle.ntt(s[idx]) for s in srcs]
+
+    def host_worker(i):
+        try:
+            x = keep.numpy() if i == 2 else srcs[i].copy()
+            for rep in range(5):
+                x[:] = srcs[i]
+                api.ntt(x)
+                assert (x[idx] == want[i]).all(), ("forward", i, rep)
+                api.invntt(x)
+                assert (x == srcs[i]).all(), ("round trip", i, rep)
+                y = srcs[i][:50 + rep].copy()
+                api.ntt(y)
+                api.invntt(y)
+                assert (y == srcs[i][:50 + rep]).all(), ("small", i, rep)
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    def dev_worker():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                g = torch.Generator(device="cuda").manual_seed(1)
+                u8 = lambda *sh: torch.randint(0, 256, sh, dtype=torch.uint8, device="cuda", generator=g)  # noqa: E731
+                seed, mu = u8(300, 32), u8(300, 64)
+                for _ in range(5):
+                    pk, sk = api.keygen(seed, 3)
+                    sig, _ = api.sign(sk, mu, 3)
+                    assert int(api.verify_sig(pk, sig, mu, 3).abs().sum()) == 0
+                st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(("dev", repr(e)))
+
+    ths = [threading.Thread(target=host_worker, args=(i,)) for i in range(3)] + [threading.Thread(target=dev_worker)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
