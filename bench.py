@@ -1014,9 +1014,16 @@ def main():
     if world > 1:
         leg_distributed(cx, out)
     if not args.no_secondary:
-        sec = leg_verify_core(cx)
-        leg_other_configs(cx, sec)
-        leg_scheme(cx, sec)
+        # (a secondary leg that fails leaves its error in the line: the headline above is printed whatever happens below)
+        try:
+            sec = leg_verify_core(cx)
+        except Exception as e:  # noqa: BLE001
+            sec = {"error": repr(e)}
+        for name, leg in (("other_configs", leg_other_configs), ("scheme_level3_wire_format", leg_scheme)):
+            try:
+                leg(cx, sec)
+            except Exception as e:  # noqa: BLE001
+                sec[name + "_error"] = repr(e)
         # BASELINE configs[4] as north_star describes it: ONE batch of level-5 signing work, 8192 items per GPU, sharded by contiguous
         # slices over the ranks (sharding.run_sharded), HIP compute on every rank, then the one collective of the design: the gather of
         # the (z, h, flag) result slabs over RCCL/xGMI -- timed separately.
