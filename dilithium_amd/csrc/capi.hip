@@ -435,6 +435,30 @@ struct PinGuard {
     ~PinGuard() { if (p) (void)hipHostUnregister(p); }
 };
 
+// Which pipeline a host-pointer transform call takes, and in which chunks (profiles/r05t_host_batch_sweep.txt):
+//   pageable     helper thread from two chunks of the option's size (16 MiB) up; a call of fewer than four such chunks is cut in four (>= 2 MiB
+//                each: below that a copy is latency); without the helper thread, chunks round-robin over the streams
+//   page-locked  one stream per direction pays from eight chunks of the option's size (64 MiB) up; smaller calls go round-robin over the
+//                streams in 1-MiB chunks (16 MiB: 0.50 vs 0.56 ms)
+//   below 8 MiB in all (or one chunk): one upload, one launch, one download
+enum { HOST_PIPE_ONE_SHOT = 0, HOST_PIPE_ROUND_ROBIN = 1, HOST_PIPE_DUPLEX = 2, HOST_PIPE_HELPER_THREAD = 3 };
+struct HostPlan {
+    int pipeline;
+    size_t chunk;      // polynomials per chunk
+};
+static HostPlan host_plan(size_t batch, bool locked)
+{
+    const size_t opt_chunk = host_chunk_polys(locked);
+    const bool want_duplex = dil::rt::cfg.host_duplex.load(std::memory_order_relaxed) != 0;
+    const bool duplex = locked && want_duplex && batch >= 8 * opt_chunk;
+    const bool helper_thread = !locked && dil::rt::cfg.host_threads.load(std::memory_order_relaxed) >= 2 && batch >= 2 * opt_chunk;
+    const size_t chunk = locked ? ((duplex || !want_duplex) ? opt_chunk : std::min<size_t>(opt_chunk, 1024))
+                         : (!helper_thread || batch >= 4 * opt_chunk) ? opt_chunk
+                                                                    : std::min(opt_chunk, std::max<size_t>(2048, (batch / 4 + 63) & ~(size_t)63));
+    if (batch <= chunk || batch < std::min<size_t>(8192, 2 * opt_chunk)) return {HOST_PIPE_ONE_SHOT, batch};
+    return {duplex ? HOST_PIPE_DUPLEX : helper_thread ? HOST_PIPE_HELPER_THREAD : HOST_PIPE_ROUND_ROBIN, chunk};
+}
+
 template <class F>
 int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, tables, stream) -> int
 {
@@ -443,21 +467,12 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     std::lock_guard<std::mutex> lk(d.host_mu);
     int rc;
     PinGuard pin(h, batch > 4096 ? batch * 1024 : 0);        // (option host_pin; not worth a registration for a small batch)
-    // Which pipeline, which chunk (profiles/r05t_host_batch_sweep.txt):
-    //   pageable     helper thread from two chunks of the option's size (16 MiB) up; a call of fewer than four such chunks is cut in four (>= 2 MiB each:
-    //                below that a copy is latency)
-    //   page-locked  one stream per direction pays from eight chunks of the option's size (64 MiB) up; smaller calls go round-robin over the
-    //                streams in 1-MiB chunks (16 MiB: 0.50 vs 0.56 ms)
-    //   below 8 MiB in all: one upload, one launch, one download
     const bool locked = batch > 4096 && (pin.p || is_page_locked(h));
-    const size_t opt_chunk = host_chunk_polys(locked);
-    const bool duplex = locked && dil::rt::cfg.host_duplex.load(std::memory_order_relaxed) && batch >= 8 * opt_chunk;
-    const bool helper_thread = !locked && dil::rt::cfg.host_threads.load(std::memory_order_relaxed) >= 2 && batch >= 2 * opt_chunk;
-    const size_t HOST_CHUNK = locked ? ((duplex || !dil::rt::cfg.host_duplex.load(std::memory_order_relaxed)) ? opt_chunk : std::min<size_t>(opt_chunk, 1024))
-                              : (!helper_thread || batch >= 4 * opt_chunk) ? opt_chunk
-                                                                         : std::min(opt_chunk, std::max<size_t>(2048, (batch / 4 + 63) & ~(size_t)63));
+    const HostPlan plan = host_plan(batch, locked);
+    const size_t HOST_CHUNK = plan.chunk;
+    const bool duplex = plan.pipeline == HOST_PIPE_DUPLEX, helper_thread = plan.pipeline == HOST_PIPE_HELPER_THREAD;
     const int NS = host_stream_count();
-    if (batch <= HOST_CHUNK || batch < std::min<size_t>(8192, 2 * opt_chunk)) {
+    if (plan.pipeline == HOST_PIPE_ONE_SHOT) {
         const size_t bytes = batch * 1024;
         rc = ensure_scratch(d, bytes);
         if (rc) return rc;
@@ -845,6 +860,14 @@ int dil_clock_probe_dev(uint64_t* out4, unsigned spin_us, void* stream)
     DIL_ENTER(d, T);
     if (!out4) return (int)hipErrorInvalidValue;
     return (int)dil::launch_clock_probe(out4, (uint64_t)spin_us * 100, S(stream));
+}
+
+int dil_host_plan(size_t batch, int page_locked, int* pipeline, size_t* chunk_polys)
+{
+    const HostPlan plan = host_plan(batch, batch > 4096 && page_locked != 0);
+    if (pipeline) *pipeline = plan.pipeline;
+    if (chunk_polys) *chunk_polys = plan.chunk;
+    return 0;
 }
 
 int dil_mailbox_stats(uint64_t* calls, uint64_t* launches, int* alive)

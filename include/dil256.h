@@ -203,6 +203,13 @@ int dil_sign_phase2_early_dev(int32_t* z, uint8_t* h, int32_t* flags, const int3
  * items > grid * items_per_block; the parity tests assert exactly that.  Runtime utility without a reference counterpart. */
 int dil_launch_info(const char* family, int* grid, int* items_per_block, size_t* items, size_t* launches);
 
+/* What a host-pointer transform call (dil_ntt_host, dil_invntt_host, dil_bram_*_host) of `batch` polynomials would do under the current
+ * options, for a pageable (0) or page-locked (1) caller buffer: *pipeline = 0 one upload / launch / download, 1 chunks round-robin over the
+ * streams, 2 one stream per direction (page-locked buffers from 64 MiB), 3 calling thread uploads + helper thread downloads (pageable
+ * buffers from 16 MiB); *chunk_polys = polynomials per chunk.  Pure host logic (no device needed); the reference's calling convention is
+ * caller-owned host arrays (reference_code/ref_ntt.h:30-36).  Runtime utility without a reference counterpart. */
+int dil_host_plan(size_t batch, int page_locked, int* pipeline, size_t* chunk_polys);
+
 /* ---- SHAKE-bound samplers on the device ---------------------------------
  * (round-3 v3.1 conventions, the ones the reference's KAT files obey; all buffers 8-byte aligned)
  * shake256:        out[i] = SHAKE256(in[i]); one input length for the batch; in_bytes, out_bytes % 8 == 0

@@ -212,3 +212,49 @@ def test_every_option_is_documented_and_round_trips_without_gpu(lib):
     v = C.c_int(0)
     assert lib.dil_get_option(b"no_such_option", C.byref(v)) != 0
     assert lib.dil_set_option(b"no_such_option", 1) != 0
+
+
+def test_host_pipeline_plan_without_gpu(lib):
+    """dil_host_plan: which of the host pipelines a dil_ntt_host-style call takes and in which chunks, by batch size, kind of caller
+    memory and options (csrc/capi.hip host_plan; measured thresholds in profiles/r05t_host_batch_sweep.txt) -- pure host logic"""
+    import ctypes as C
+    ONE_SHOT, ROUND_ROBIN, DUPLEX, HELPER = 0, 1, 2, 3
+    names = ("host_chunk", "host_chunk_pinned", "host_streams", "host_threads", "host_duplex")
+    saved = {}
+    for n in names:
+        v = C.c_int(0)
+        assert lib.dil_get_option(n.encode(), C.byref(v)) == 0
+        saved[n] = v.value
+
+    def plan(batch, locked):
+        p, c = C.c_int(-1), C.c_size_t(0)
+        assert lib.dil_host_plan(C.c_size_t(batch), locked, C.byref(p), C.byref(c)) == 0
+        return p.value, c.value
+
+    try:
+        for n, v in (("host_chunk", 8192), ("host_chunk_pinned", 8192), ("host_threads", 2), ("host_duplex", 1)):
+            assert lib.dil_set_option(n.encode(), v) == 0
+        # pageable: one shot below 8 MiB, one thread round-robin up to 16 MiB, helper thread from there; four chunks until 32 MiB
+        assert plan(1, 0) == (ONE_SHOT, 1) and plan(8191, 0) == (ONE_SHOT, 8191) and plan(8192, 0) == (ONE_SHOT, 8192)
+        assert plan(12000, 0) == (ROUND_ROBIN, 8192)
+        assert plan(16384, 0) == (HELPER, 4096) and plan(20000, 0) == (HELPER, 5056) and plan(32768, 0) == (HELPER, 8192)
+        assert plan(65536, 0) == (HELPER, 8192) and plan(1 << 20, 0) == (HELPER, 8192)
+        # page-locked: (a buffer of 4096 polynomials or fewer is not treated as one) round-robin in 1-MiB chunks, duplex from 64 MiB
+        assert plan(4096, 1) == (ONE_SHOT, 4096)
+        assert plan(8192, 1) == (ROUND_ROBIN, 1024) and plan(65535, 1) == (ROUND_ROBIN, 1024)
+        assert plan(65536, 1) == (DUPLEX, 8192) and plan(1 << 20, 1) == (DUPLEX, 8192)
+        # the options take the pipelines away
+        assert lib.dil_set_option(b"host_threads", 1) == 0 and plan(65536, 0) == (ROUND_ROBIN, 8192)
+        assert lib.dil_set_option(b"host_duplex", 0) == 0 and plan(65536, 1) == (ROUND_ROBIN, 8192)
+        # small chunks (what the GPU tests use to wrap the staging ring): every chunk is within the staging buffer of its size
+        assert lib.dil_set_option(b"host_threads", 2) == 0 and lib.dil_set_option(b"host_duplex", 1) == 0
+        assert lib.dil_set_option(b"host_chunk", 64) == 0 and lib.dil_set_option(b"host_chunk_pinned", 600) == 0
+        assert plan(593, 0) == (HELPER, 64) and plan(127, 0) == (ONE_SHOT, 127) and plan(128, 0) == (HELPER, 64)
+        assert plan(5417, 1) == (DUPLEX, 600) and plan(4799, 1) == (ROUND_ROBIN, 600)
+        for batch in (100, 1000, 5000, 20011, 70000, 300000):
+            for locked in (0, 1):
+                p, c = plan(batch, locked)
+                assert 1 <= c <= batch and (p == ONE_SHOT) == (c == batch)
+    finally:
+        for n, v in saved.items():
+            lib.dil_set_option(n.encode(), v)
