@@ -644,6 +644,37 @@ int dil_expand_t1_dev(int32_t* t1hat, const uint8_t* pk, int level, size_t nkeys
 // produces.  The pending set shrinks geometrically while S grows, so the loop needs ~5 rounds
 // instead of the ~35 the unluckiest signature of a large batch takes.
 namespace {
+constexpr int SIGN_S_MAX = 64;      // attempts per item and round; also the wave width: phase 2 reads an item's earlier attempts one per lane (launch_sign2 refuses more)
+// Entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches speculate for free
+// (a round never uses more than batch * SIGN_S_MAX entries: a single signature gets 64 entries, not 16384).
+// Default width: about one expected signature's worth of attempts per item in the first round (mean attempts 4.3 / 5.1 /
+// 3.9 at levels 2 / 3 / 5), between 16384 and 32768 entries -- below that the round's kernels sit on their latency
+// floors anyway, above it the speculation wastes more than a saved round is worth (scripts/bench_sign_cap.py,
+// profiles/r02_sign_round.txt: level 3, 8192 messages 1.69 -> 1.57 ms with 24576 entries; 65536 messages: width = batch)
+size_t sign_round_cap(int level, size_t batch)
+{
+    const int opt_cap = dil::rt::cfg.sign_cap.load(std::memory_order_relaxed);
+    const size_t s0 = level == 2 ? 4 : level == 3 ? 3 : 2;
+    const size_t dflt_cap = std::min<size_t>(std::max<size_t>(batch * s0, 16384), 32768);
+    return std::min<size_t>(std::max<size_t>(batch, opt_cap > 0 ? (size_t)opt_cap : dflt_cap), batch * (size_t)SIGN_S_MAX);
+}
+// Attempts per pending item this round: as many as fit in `cap` entries, but only while the work expected to be
+// wasted on attempts after an item's first success, n * (1 - (1-p)^(S-1)) entries with p ~ 0.2, stays below the
+// work a saved round's fixed latency is worth (option sign_waste entries; matters for batches >> 16384).
+int sign_round_width(size_t pending, size_t cap, int attempts_left)
+{
+    const int sign_waste = dil::rt::cfg.sign_waste.load(std::memory_order_relaxed);
+    const int s_lim = (int)std::min<size_t>(std::min<size_t>(cap / pending, (size_t)SIGN_S_MAX), (size_t)attempts_left);
+    int S_ = 1;
+    double keep = 1.0;                       // (1-p)^(S-1)
+    while (S_ < s_lim) {
+        keep *= 0.8;
+        if ((double)pending * (1.0 - keep) > (double)sign_waste) break;
+        S_++;
+    }
+    return S_;
+}
+
 int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu,
               int level, const LevelPar& p, size_t batch, int shared_sk, int max_attempts, hipStream_t s)
 {
@@ -651,21 +682,9 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     if (batch == 1) shared_sk = 1;
     const size_t skb = dil_sk_bytes(level), sgb = dil_sig_bytes(level), zb = (size_t)p.L * 32 * p.zbits;
     const size_t nk = shared_sk ? 1 : batch, sk_stride = shared_sk ? 0 : skb;
-    // entries kept in flight per round: the hash kernels are latency-bound below ~1 wave per SIMD, so small batches
-    // speculate for free
-    const int s_max = 64;           // also the wave width: phase 2 reads an item's earlier attempts one per lane (launch_sign2 refuses more)
-    const int opt_cap = dil::rt::cfg.sign_cap.load(std::memory_order_relaxed);
-    const int sign_waste = dil::rt::cfg.sign_waste.load(std::memory_order_relaxed);
     const bool sign_early = dil::rt::cfg.sign_early.load(std::memory_order_relaxed) != 0;
     const int sign_skip = dil::rt::cfg.sign_skip.load(std::memory_order_relaxed);       // bit 0: drop superseded attempts, bit 1: work queue
-    // (a round never uses more than batch * s_max entries: a single signature gets 64 entries, not 16384)
-    // default width: about one expected signature's worth of attempts per item in the first round (mean attempts 4.3 / 5.1 /
-    // 3.9 at levels 2 / 3 / 5), between 16384 and 32768 entries -- below that the round's kernels sit on their latency
-    // floors anyway, above it the speculation wastes more than a saved round is worth (scripts/bench_sign_cap.py,
-    // profiles/r02_sign_round.txt: level 3, 8192 messages 1.69 -> 1.57 ms with 24576 entries; 65536 messages: width = batch)
-    const size_t s0 = level == 2 ? 4 : level == 3 ? 3 : 2;
-    const size_t dflt_cap = std::min<size_t>(std::max<size_t>(batch * s0, 16384), 32768);
-    const size_t cap = std::min<size_t>(std::max<size_t>(batch, opt_cap > 0 ? (size_t)opt_cap : dflt_cap), batch * (size_t)s_max);
+    const size_t cap = sign_round_cap(level, batch);
     ws.secret = true;            // s1^ s2^ t0^, key, rho', y, rejected z: wiped on close when option `zeroize` is set
     // per key
     int32_t* A = ws.take<int32_t>(nk * p.K * p.L * 256);
@@ -719,19 +738,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     size_t n = batch;
     int a0 = 0;                                          // attempts every pending item has already failed
     while (n > 0 && a0 < max_attempts) {
-        // Attempts per pending item this round: as many as fit in `cap` entries, but only while the work expected to be
-        // wasted on attempts after an item's first success, n * (1 - (1-p)^(S-1)) entries with p ~ 0.2, stays below the
-        // work a saved round's fixed latency is worth (option sign_waste entries; matters for batches >> 16384).
-        int S_ = 1;
-        {
-            const int s_lim = (int)std::min<size_t>(std::min<size_t>(cap / n, (size_t)s_max), (size_t)(max_attempts - a0));
-            double keep = 1.0;                       // (1-p)^(S-1)
-            while (S_ < s_lim) {
-                keep *= 0.8;
-                if ((double)n * (1.0 - keep) > (double)sign_waste) break;
-                S_++;
-            }
-        }
+        const int S_ = sign_round_width(n, cap, max_attempts - a0);
         const size_t E = n * (size_t)S_;
         const bool direct = !idx_cur && S_ == 1;         // first round of a full batch: the caller's arrays as they are
         const uint8_t *mur = direct ? mu : mu_c, *rpr = direct ? rp : rp_c;
@@ -778,6 +785,18 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     return n == 0 ? 0 : DIL_ERR_UNFINISHED;
 }
 }  // namespace
+
+int dil_sign_round_plan(int level, size_t batch, size_t pending, int attempts_done, int max_attempts, int* attempts_per_item, size_t* entries)
+{
+    LevelPar p;
+    int rc;
+    if ((rc = level_par(level, &p))) return rc;
+    if (batch == 0 || pending == 0 || pending > batch || attempts_done < 0 || max_attempts <= attempts_done) return (int)hipErrorInvalidValue;
+    const int S_ = sign_round_width(pending, sign_round_cap(level, batch), max_attempts - attempts_done);
+    if (attempts_per_item) *attempts_per_item = S_;
+    if (entries) *entries = pending * (size_t)S_;
+    return 0;
+}
 
 int dil_sign_dev(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu, int level, size_t batch, int shared_sk,
                  int max_attempts, void* stream)

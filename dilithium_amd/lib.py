@@ -55,6 +55,7 @@ SIGNATURES = {
     "dil_sign_phase2_skey_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, C.c_int, _vp],
     "dil_launch_info": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz), C.POINTER(_sz)],
     "dil_host_plan": [_sz, C.c_int, C.POINTER(C.c_int), C.POINTER(_sz)],
+    "dil_sign_round_plan": [C.c_int, _sz, _sz, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(_sz)],
     "dil_shake256_dev": [_vp, _sz, _vp, _sz, _sz, _vp],
     "dil_expand_a_dev": [_vp, _vp, C.c_int, _sz, _vp],
     "dil_expand_mask_dev": [_vp, _vp, _vp, C.c_int, _sz, _vp],

@@ -210,6 +210,12 @@ int dil_launch_info(const char* family, int* grid, int* items_per_block, size_t*
  * caller-owned host arrays (reference_code/ref_ntt.h:30-36).  Runtime utility without a reference counterpart. */
 int dil_host_plan(size_t batch, int page_locked, int* pipeline, size_t* chunk_polys);
 
+/* The signing loop's speculation rule as a pure function (no device needed): a call of `batch` messages at `level` with `pending`
+ * messages still unsigned after `attempts_done` attempts each runs *attempts_per_item speculative attempts (kappa = attempts_done * L,
+ * ...) for every pending message in its next round = *entries entries in flight (options sign_cap, sign_waste).  The reference's FSM
+ * retries one signature at a time (rtl_src/combined_top.v:1694-2229); the first accepted attempt of an item is the one it would produce. */
+int dil_sign_round_plan(int level, size_t batch, size_t pending, int attempts_done, int max_attempts, int* attempts_per_item, size_t* entries);
+
 /* ---- SHAKE-bound samplers on the device ---------------------------------
  * (round-3 v3.1 conventions, the ones the reference's KAT files obey; all buffers 8-byte aligned)
  * shake256:        out[i] = SHAKE256(in[i]); one input length for the batch; in_bytes, out_bytes % 8 == 0

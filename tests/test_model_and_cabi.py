@@ -258,3 +258,46 @@ def test_host_pipeline_plan_without_gpu(lib):
     finally:
         for n, v in saved.items():
             lib.dil_set_option(n.encode(), v)
+
+
+def test_sign_round_plan_without_gpu(lib):
+    """dil_sign_round_plan: the signing loop's speculation rule (csrc/scheme.hip sign_round_cap / sign_round_width) as the host sees it:
+    S attempts per pending message so that a round keeps about `cap` entries in flight, never more than 64 per message (phase 2 reads an
+    item's earlier attempts one per lane) nor than max_attempts allows, and only while the expected waste stays under option sign_waste"""
+    import ctypes as C
+
+    def plan(level, batch, pending, done=0, max_attempts=512):
+        s, e = C.c_int(-1), C.c_size_t(0)
+        rc = lib.dil_sign_round_plan(level, C.c_size_t(batch), C.c_size_t(pending), done, max_attempts, C.byref(s), C.byref(e))
+        assert rc == 0, (level, batch, pending, rc)
+        assert e.value == pending * s.value and 1 <= s.value <= 64
+        return s.value
+
+    saved = {}
+    for n in ("sign_cap", "sign_waste"):
+        v = C.c_int(0)
+        assert lib.dil_get_option(n.encode(), C.byref(v)) == 0
+        saved[n] = v.value
+    try:
+        assert lib.dil_set_option(b"sign_cap", 0) == 0 and lib.dil_set_option(b"sign_waste", 6144) == 0
+        # the level-3 call of 8192 messages in profiles/r05s_sign_timeline.txt: 24576 / 21695 / 24288 / 2752 entries
+        assert plan(3, 8192, 8192) == 3 and plan(3, 8192, 4339, 3) == 5 and plan(3, 8192, 1518, 8) == 16 and plan(3, 8192, 43, 24) == 64
+        # first rounds: 4 / 3 / 2 attempts per message at levels 2 / 3 / 5 (about one expected signature's worth), capped at 32768 entries
+        assert plan(2, 8192, 8192) == 4 and plan(5, 8192, 8192) == 2 and plan(3, 16384, 16384) == 2 and plan(3, 65536, 65536) == 1
+        # small batches speculate for free: 16384 entries in flight, 64 attempts per message at most
+        assert plan(3, 1, 1) == 64 and plan(3, 100, 100) == 64 and plan(3, 256, 256) == 64 and plan(3, 1024, 1024) == 16
+        # max_attempts bounds the width of the last rounds
+        assert plan(3, 1, 1, 0, 5) == 5 and plan(3, 8192, 43, 500, 512) == 12
+        # the waste rule: a huge pending set stops widening once the attempts expected to be thrown away pass sign_waste
+        assert lib.dil_set_option(b"sign_cap", 1 << 20) == 0
+        assert plan(3, 65536, 65536) == 1 and plan(3, 65536, 20000) == 2 and plan(3, 65536, 6000) >= 8
+        assert lib.dil_set_option(b"sign_waste", 1 << 30) == 0 and plan(3, 65536, 65536) == 16
+        # an explicit cap
+        assert lib.dil_set_option(b"sign_cap", 16384) == 0 and plan(3, 8192, 8192) == 2
+        # refused: nothing pending, more pending than messages, no attempts left
+        s, e = C.c_int(0), C.c_size_t(0)
+        for args in ((3, 8192, 0, 0, 512), (3, 10, 11, 0, 512), (3, 10, 5, 7, 7), (4, 10, 5, 0, 512)):
+            assert lib.dil_sign_round_plan(args[0], C.c_size_t(args[1]), C.c_size_t(args[2]), args[3], args[4], C.byref(s), C.byref(e)) != 0
+    finally:
+        for n, v in saved.items():
+            lib.dil_set_option(n.encode(), v)
