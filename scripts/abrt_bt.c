@@ -1,0 +1,81 @@
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+static struct sigaction theirs, theirs_segv;
+static int have_segv;
+static int have_theirs;
+static int (*real_sigaction)(int, const struct sigaction*, struct sigaction*);
+static void ours(int sig, siginfo_t* si, void* uc)
+{
+    void* bt[64];
+    int n = backtrace(bt, 64);
+    char msg[160];
+    int len = snprintf(msg, sizeof msg, "\n==== signal %d in tid %ld (si_code %d, addr %p) native backtrace ====\n", sig, (long)syscall(SYS_gettid),
+                       si ? si->si_code : 0, si ? si->si_addr : 0);
+    if (write(2, msg, len) < 0) {}
+    backtrace_symbols_fd(bt, n, 2);
+    struct sigaction* t = sig == SIGSEGV ? &theirs_segv : &theirs;
+    int have = sig == SIGSEGV ? have_segv : have_theirs;
+    if (have && (t->sa_flags & SA_SIGINFO) && t->sa_sigaction) t->sa_sigaction(sig, si, uc);
+    else if (have && t->sa_handler != SIG_DFL && t->sa_handler != SIG_IGN) t->sa_handler(sig);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void install(void)
+{
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = ours;
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+    real_sigaction(SIGABRT, &sa, 0);
+    real_sigaction(SIGSEGV, &sa, 0);
+}
+int sigaction(int sig, const struct sigaction* act, struct sigaction* old)
+{
+    if (!real_sigaction) real_sigaction = dlsym(RTLD_NEXT, "sigaction");
+    if ((sig == SIGABRT || sig == SIGSEGV) && act) {
+        if (sig == SIGSEGV) { if (old) *old = theirs_segv; theirs_segv = *act; have_segv = 1; install(); return 0; }
+        if (old) *old = theirs;
+        theirs = *act;
+        have_theirs = 1;
+        install();
+        return 0;
+    }
+    return real_sigaction(sig, act, old);
+}
+__attribute__((constructor)) static void init(void)
+{
+    if (!real_sigaction) real_sigaction = dlsym(RTLD_NEXT, "sigaction");
+    void* warm[4];
+    backtrace(warm, 4);          /* loads libgcc_s now: the handler must not allocate */
+    install();
+}
+
+struct tramp { void* (*fn)(void*); void* arg; };
+static void* start_with_altstack(void* p)
+{
+    struct tramp t = *(struct tramp*)p;
+    free(p);
+    stack_t ss;
+    ss.ss_sp = malloc(1 << 16);
+    ss.ss_size = 1 << 16;
+    ss.ss_flags = 0;
+    if (ss.ss_sp) sigaltstack(&ss, 0);
+    return t.fn(t.arg);
+}
+int pthread_create(pthread_t* th, const pthread_attr_t* attr, void* (*fn)(void*), void* arg)
+{
+    static int (*real)(pthread_t*, const pthread_attr_t*, void* (*)(void*), void*);
+    if (!real) real = dlsym(RTLD_NEXT, "pthread_create");
+    struct tramp* t = malloc(sizeof *t);
+    t->fn = fn;
+    t->arg = arg;
+    return real(th, attr, start_with_altstack, t);
+}
