@@ -183,6 +183,86 @@ def cpu_baseline_verify_all_threads(target_s=4.0):
                                       f"{'%.2f CPUs' % quota if quota else 'none'} ({qsrc})"}
 
 
+def _cpu_threads():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def _cpu_leg(make_work, units_per_call, unit, what, target_s=3.0, target_all_s=3.0):
+    """One thread, then every visible hardware thread, of an oracle batch call (ctypes drops the GIL in the foreign call): make_work(i)
+    returns thread i's closure over its own inputs; time-bounded, quota-aware like the NTT leg.  kind 'port': the reference has no
+    software form of the fused op-graphs (they are RTL: combined_top.v), the oracle's C restatement is what a CPU runs."""
+    import threading
+    w0 = make_work(0)
+    w0()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < target_s:
+        w0()
+        n += units_per_call
+    dt = time.perf_counter() - t0
+    out = {"value": n / dt, "unit": unit, "cores": 1, "kind": "port", "sample": f"{n} {what} (oracle C restatement) in {dt:.1f} s, 1 thread"}
+    nthreads = _cpu_threads()
+    works = [make_work(i % 8) for i in range(nthreads)]
+    done = [0] * nthreads
+    deadline = [0.0]
+
+    def run(i):
+        k = 0
+        while time.perf_counter() < deadline[0]:
+            works[i]()
+            k += units_per_call
+        done[i] = k
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(nthreads)]
+    t0 = time.perf_counter()
+    deadline[0] = t0 + target_all_s
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    quota, qsrc = cpu_quota()
+    out["all_threads"] = {"value": sum(done) / dt, "unit": unit, "threads": nthreads, "cores": round(quota, 2) if quota else nthreads, "kind": "port",
+                          "sample": f"{sum(done)} {what} on {nthreads} threads in {dt:.1f} s; CPU quota: "
+                                    f"{'%.2f CPUs' % quota if quota else 'none'} ({qsrc})"}
+    return out
+
+
+def cpu_baseline_matvec(target_s=3.0):
+    """BASELINE configs[2] on the host: level-2 (K = L = 4) A.y, a matrix per item (combined_top.v:1850-1933), oracle orc_matvec"""
+    from oracle.oracle import Oracle, splitmix64_polys
+    o = Oracle()
+    n = 64
+
+    def make(i):
+        A = splitmix64_polys(n * 16, seed=500 + i).reshape(n, 4, 4, 256)
+        y = splitmix64_polys(n * 4, seed=600 + i).reshape(n, 4, 256)
+        return lambda: o.matvec(4, 4, A, y)
+    return _cpu_leg(make, n, "matvec/s", "level-2 mat-vecs, a matrix per item", target_s, target_s)
+
+
+def cpu_baseline_sign_attempt(target_s=3.0):
+    """BASELINE configs[4]'s unit on the host: one level-5 sign attempt = phase 1 (w = A.y, decompose) + phase 2 (z, r0 / hint checks) under
+    one key (combined_top.v:1830-2229), oracle orc_sign_phase1 + orc_sign_phase2"""
+    from oracle.oracle import Oracle, splitmix64_polys, Q
+    o = Oracle()
+    n, K, L = 16, 8, 7
+
+    def make(i):
+        rng = np.random.default_rng(700 + i)
+        A = splitmix64_polys(K * L, seed=800 + i).reshape(1, K, L, 256)
+        y = np.mod(rng.integers(-(1 << 19) + 1, (1 << 19) + 1, (n, L, 256)), Q).astype(np.int32)
+        c = np.zeros((n, 256), np.int32)
+        c[:, ::5] = 1
+        c[:, 1::7] = Q - 1
+        s1, s2, t0 = (splitmix64_polys(m, seed=900 + i + j).reshape(1, m, 256) for j, m in enumerate((L, K, K)))
+
+        def work():
+            w1, w0 = o.sign_phase1(5, A, y)
+            o.sign_phase2(5, c, y, w0, w1, s1, s2, t0)
+        return work
+    return _cpu_leg(make, n, "attempt/s", "level-5 sign attempts (phase 1 + phase 2), one key", target_s, target_s)
+
+
 def synth_verify(n, seed):
     from oracle.oracle import splitmix64_polys, Q, N
     K, L, tau, g1 = 6, 5, 49, 1 << 19
@@ -1037,19 +1117,39 @@ def main():
             out["end_to_end"] = leg_end_to_end(cx)
         except Exception as e:  # noqa: BLE001
             out["end_to_end"] = {"error": repr(e)}
+    if not args.no_secondary and "roofline" in out.get("secondary", {}):
+        # the second half of BASELINE.json's metric (Dilithium-3 verifies/s) inside the blocks the driver's record keeps: `roofline.verify_core`
+        # (+ the same scalars flat, `verify_core_*`, should a reader keep only scalars); op-graph: rtl_src/combined_top.v:1207-1469
+        sec = out["secondary"]
+        vr = sec["roofline"]
+        vc = {"metric": sec["metric"], "value": sec["value"], "unit": sec["unit"], "kernel": vr["kernel"], "bound": vr["bound"],
+              "achieved": vr["achieved"], "peak": vr["peak"], "frac": vr["frac"], "avg_launch_ms": vr["avg_launch_ms"],
+              "algorithmic_bytes_per_launch": VERIFY3_BYTES * VBATCH, "traffic": vr.get("traffic"),
+              "rotating_input_sets": sec["config"]["rotating_input_sets"], "batch": VBATCH,
+              "workload": "BASELINE configs[3]: level-3 verify core, batch 8192, a key per item"}
+        out["roofline"]["verify_core"] = vc
+        for k in ("value", "frac", "achieved", "avg_launch_ms", "traffic", "rotating_input_sets"):
+            out["roofline"]["verify_core_" + k] = vc[k]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            cb = out["cpu_baseline"]
             try:
-                out["cpu_baseline"]["all_threads"] = cpu_baseline_all_threads(1.0 / out["cpu_baseline"]["value"])
+                cb["all_threads"] = cpu_baseline_all_threads(1.0 / cb["value"])
+                cb["all_threads_value"], cb["all_threads_cores"] = cb["all_threads"]["value"], cb["all_threads"]["cores"]
             except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"]["all_threads"] = {"error": repr(e)}
+                cb["all_threads"] = {"error": repr(e)}
             if not args.no_secondary:
-                out["secondary"]["cpu_baseline"] = cpu_baseline_verify()
-                try:
-                    out["secondary"]["cpu_baseline"]["all_threads"] = cpu_baseline_verify_all_threads()
-                except Exception as e:  # noqa: BLE001
-                    out["secondary"]["cpu_baseline"]["all_threads"] = {"error": repr(e)}
+                legs = (("verify_core", lambda: dict(cpu_baseline_verify(), all_threads=cpu_baseline_verify_all_threads())),
+                        ("matvec", cpu_baseline_matvec), ("sign_attempt", cpu_baseline_sign_attempt))
+                for name, leg in legs:       # CPU figures of the other BASELINE configs (every GPU rate has its host rate beside it)
+                    try:
+                        cb[name] = leg()
+                        cb[name + "_value"] = cb[name]["value"]
+                        cb[name + "_all_threads_value"] = cb[name]["all_threads"]["value"]
+                    except Exception as e:  # noqa: BLE001
+                        cb[name] = {"error": repr(e)}
+                out["secondary"]["cpu_baseline"] = cb.get("verify_core")
             sweep = out.get("end_to_end", {}).get("ntt", {}).get("batch_sweep_NTT_per_s")
             if sweep:       # the batch from which one dil_ntt_host call beats the CPU reference on this box
                 first = lambda rate: next((int(b) for b, v in sweep.items() if v > rate), None)  # noqa: E731

@@ -309,6 +309,40 @@ void orc_butterfly_rtl(int mode, uint32_t aj, uint32_t ajlen, uint32_t zeta, uin
     }
 }
 
+/* The 2x2 unit as the reference's C++ hardware model composes it          */
+/* (hardware_code/butterfly_unit.h:112-196 `buttefly_circuit`, the model of */
+/* butterfly2x2.v): two butterflies (a,b | w[0]) (c,d | w[1]), the lane       */
+/* exchange b <-> c, two butterflies (a',b' | w[2]) (c',d' | w[3]).  In       */
+/* MUL mode the unit multiplies four lanes by four constants: the first two  */
+/* multipliers take lanes b, d; lanes a, c are switched onto the second two  */
+/* multipliers (:153-158) and switched back at the output (:180-187), so     */
+/* out = {w[2] a, w[0] b, w[3] c, w[1] d}.  Built here from the RTL butterfly */
+/* op set above on canonical residues; mode numbering = enum OPERATION       */
+/* (config.h:39-44): 0 forward, 1 inverse, 2 mul.  The C++ unit's inverse     */
+/* butterfly computes (ajlen - aj) * zeta (butterfly_unit.h:48-52), the RTL's */
+/* (aj - ajlen) * (q - zeta) (butterfly.v:186): the same product, so the     */
+/* same w feeds both.                                                        */
+void orc_butterfly_circuit(int mode, const int32_t in[4], const int32_t w[4], int32_t out[4])
+{
+    uint32_t a = (uint32_t)orc_canon(in[0]), b = (uint32_t)orc_canon(in[1]), c = (uint32_t)orc_canon(in[2]), d = (uint32_t)orc_canon(in[3]);
+    uint32_t z[4];
+    for (int i = 0; i < 4; i++) z[i] = (uint32_t)orc_canon(w[i]);
+    uint32_t a1, b1, c1, d1, a3, b3, c3, d3, unused;
+    if (mode == 2) {
+        orc_butterfly_rtl(2, b, z[0], 0, 0, &unused, &b1);       /* first pair of multipliers: lanes b, d */
+        orc_butterfly_rtl(2, d, z[1], 0, 0, &unused, &d1);
+        orc_butterfly_rtl(2, a, z[2], 0, 0, &unused, &b3);       /* lanes a, c switched onto the second pair */
+        orc_butterfly_rtl(2, c, z[3], 0, 0, &unused, &d3);
+        out[0] = (int32_t)b3; out[1] = (int32_t)b1; out[2] = (int32_t)d3; out[3] = (int32_t)d1;
+        return;
+    }
+    orc_butterfly_rtl(mode, a, b, z[0], 0, &a1, &b1);
+    orc_butterfly_rtl(mode, c, d, z[1], 0, &c1, &d1);
+    orc_butterfly_rtl(mode, a1, c1, z[2], 0, &a3, &b3);          /* lane exchange: (a1, c1) and (b1, d1) */
+    orc_butterfly_rtl(mode, b1, d1, z[3], 0, &c3, &d3);
+    out[0] = (int32_t)a3; out[1] = (int32_t)b3; out[2] = (int32_t)c3; out[3] = (int32_t)d3;
+}
+
 /* twiddle_resolver.v:106-130 (forward) / :87-105 (inverse): the ROM       */
 /* addresses of the (first-layer, first-layer, second-layer x2) twiddles  */
 /* of 2x2 step m of stage s (s = 0..3).                                    */

@@ -157,6 +157,15 @@ class Oracle:
             raise ValueError(f"bad level {level}")
         return p
 
+    def butterfly_circuit(self, data_in, w, mode):
+        """orc_butterfly_circuit on rows of 4 lanes / 4 twiddles: canonical outputs"""
+        data_in = np.ascontiguousarray(data_in, dtype=np.int32).reshape(-1, 4)
+        w = np.ascontiguousarray(w, dtype=np.int32).reshape(-1, 4)
+        out = np.empty_like(data_in)
+        for o_, i_, w_ in zip(out, data_in, w):
+            self.lib.orc_butterfly_circuit(int(mode), _p(i_), _p(w_), _p(o_))
+        return out
+
     def matvec(self, K, L, A, y, shared_A=False):
         y = np.ascontiguousarray(y, dtype=np.int32)
         A = np.ascontiguousarray(A, dtype=np.int32)
@@ -297,6 +306,22 @@ class Reference:
         for cr, ar, br in zip(c.reshape(-1, N), a.reshape(-1, N), b.reshape(-1, N)):
             self.f["pointwise_barrett"](_p(cr), _p(ar), _p(br))
         return c
+
+    def buttefly_circuit(self, data_in, w, mode):
+        """the reference's header template buttefly_circuit<data2_t, data_t> (butterfly_unit.h:112-196) through oracle/ref_shim.cpp: rows of
+        4 lanes and 4 twiddles -> rows of 4 raw outputs"""
+        data_in = np.ascontiguousarray(data_in, dtype=np.int32).reshape(-1, 4)
+        w = np.ascontiguousarray(w, dtype=np.int32).reshape(-1, 4)
+        out = np.empty_like(data_in)
+        for o_, i_, w_ in zip(out, data_in, w):
+            self.lib.ref_buttefly_circuit(_p(o_), _p(i_), _p(w_), int(mode))
+        return out
+
+    def butterfly(self, mode, zeta, aj, ajlen):
+        """butterfly<data2_t, data_t> (butterfly_unit.h:29-110), one call: (bj, bjlen) raw"""
+        bj, bl = C.c_int32(), C.c_int32()
+        self.lib.ref_butterfly(int(mode), C.byref(bj), C.byref(bl), int(zeta), int(aj), int(ajlen))
+        return bj.value, bl.value
 
     def bram_fwdntt(self, ram, mapping):
         ram = np.ascontiguousarray(ram, dtype=np.int32).copy()

@@ -15,23 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(autouse=True, scope="session")
-def _collect_garbage_between_tests_only():
-    """Python's cyclic collector runs between tests, never in the middle of one: finalizers of torch objects (device and page-locked
-    memory, events) then never run while a test is inside the HIP runtime.  On the MI355X boxes the whole-directory run of the GPU suite
-    died silently (SIGABRT / SIGSEGV inside a plain `torch.from_numpy(x).cuda()`) in 9 of 20 runs, always at one of a few test positions
-    -- allocation-count-driven -- while the same tests given as a file list never did (profiles/r05x_suite_crash.txt)."""
-    import gc
-    gc.disable()
-    yield
-    gc.enable()
+# (round 5 ran the cyclic collector only between tests to mask an intermittent crash; DIL_TEST_GC_BETWEEN=1 brings that back for A/B runs
+#  of scripts/stress_suite.sh -- the default is Python's own collector, as in any user process)
+if os.environ.get("DIL_TEST_GC_BETWEEN") == "1":
+    @pytest.fixture(autouse=True, scope="session")
+    def _collect_garbage_between_tests_only():
+        import gc
+        gc.disable()
+        yield
+        gc.enable()
 
-
-@pytest.fixture(autouse=True)
-def _gc_after_each_test():
-    yield
-    import gc
-    gc.collect()
+    @pytest.fixture(autouse=True)
+    def _gc_after_each_test():
+        yield
+        import gc
+        gc.collect()
 
 
 @pytest.fixture(scope="session")

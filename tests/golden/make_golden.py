@@ -11,6 +11,9 @@ What it writes (all data -- inputs and expected outputs; no reference source tex
                        (rho,key,tr,ctilde,seed,s1,s2,t0,t1,z,h) + derived expectations
                        (sign attempt counts, w1 of the verify core) from the KAT harness
   kat_msgs.npz         the 100 messages (identical for all levels)
+  butterfly_golden.npz inputs + raw outputs of the reference's header templates butterfly<> / buttefly_circuit<>
+                       (hardware_code/butterfly_unit.h, instantiated by oracle/ref_shim.cpp) in all three OPERATION modes
+                       (`python make_golden.py butterfly` writes only this file)
 """
 import os
 import shutil
@@ -26,8 +29,24 @@ from oracle import dilithium_kat as dk  # noqa: E402
 REF = "/root/reference"
 
 
+def butterfly_goldens(ref):
+    """4-lane rows: canonical lanes and twiddles, signed ones (the C++ unit works on signed data_t), the edge residues"""
+    rng = np.random.default_rng(20260929)
+    edge = np.array([0, 1, 2, Q - 1, Q - 2, (Q - 1) // 2, (Q + 1) // 2, -(Q - 1), -1], dtype=np.int32)
+    rows_in = np.concatenate([rng.integers(0, Q, (1500, 4)), rng.integers(-(Q - 1), Q, (500, 4)), rng.choice(edge, (600, 4))]).astype(np.int32)
+    rows_w = np.concatenate([rng.integers(0, Q, (1500, 4)), rng.integers(-(Q - 1), Q, (500, 4)), rng.choice(edge, (600, 4))]).astype(np.int32)
+    out = dict(data_in=rows_in, w=rows_w)
+    for mode in (0, 1, 2):
+        out[f"circuit_{mode}"] = ref.buttefly_circuit(rows_in, rows_w, mode)
+        out[f"butterfly_{mode}"] = np.array([ref.butterfly(mode, w[0], x[0], x[1]) for x, w in zip(rows_in, rows_w)], dtype=np.int32)
+    np.savez_compressed(f"{HERE}/butterfly_golden.npz", **out)
+
+
 def main():
     ref = Reference()
+    butterfly_goldens(ref)
+    if sys.argv[1:] == ["butterfly"]:
+        return
     shutil.copyfile(f"{REF}/zetas.txt", f"{HERE}/zetas_rom.txt")
 
     polys = [np.arange(N), np.zeros(N), np.full(N, Q - 1), np.full(N, -(Q - 1)), np.full(N, 1)]

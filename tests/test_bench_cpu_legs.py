@@ -22,3 +22,15 @@ def test_cpu_baseline_all_threads_is_time_bounded():
 def test_cpu_baseline_verify():
     b = bench.cpu_baseline_verify(target_s=0.5)
     assert b["unit"] == "verify/s" and b["value"] > 100
+
+
+def test_cpu_baseline_matvec_and_sign_attempt_are_bounded():
+    """the host figures of BASELINE configs[2] / configs[4] (every GPU rate has its host rate beside it)"""
+    t0 = time.perf_counter()
+    m = bench.cpu_baseline_matvec(target_s=0.3)
+    s = bench.cpu_baseline_sign_attempt(target_s=0.3)
+    assert time.perf_counter() - t0 < 40
+    assert m["unit"] == "matvec/s" and m["cores"] == 1 and m["kind"] == "port" and 1e3 < m["value"] < 1e7
+    assert s["unit"] == "attempt/s" and s["cores"] == 1 and 1e2 < s["value"] < 1e6
+    for b in (m, s):
+        assert b["all_threads"]["threads"] >= 1 and b["all_threads"]["value"] > 0

@@ -113,6 +113,39 @@ def test_rtl_butterfly_modes(oracle):
         assert bl.value == (a - b) % Q
 
 
+def test_butterfly_circuit_vs_reference_unit_goldens(oracle):
+    """the 2x2 unit: orc_butterfly_circuit (two RTL butterflies, lane exchange, two RTL butterflies; MUL mode: the a / c lanes switched onto
+    the second pair of multipliers and back) against raw outputs of the reference's OWN header templates buttefly_circuit<data2_t, data_t> and
+    butterfly<data2_t, data_t> (hardware_code/butterfly_unit.h:29-196, instantiated from where they lie by oracle/ref_shim.cpp;
+    tests/golden/make_golden.py butterfly) in all three OPERATION modes, on canonical, signed and edge lanes / twiddles.  The C++ unit works on
+    signed data_t with C's %, so its raw outputs are compared mod q."""
+    g = np.load(os.path.join(GOLDEN, "butterfly_golden.npz"))
+    x, w = g["data_in"], g["w"]
+    assert x.shape == (2600, 4)
+    for mode in (0, 1, 2):
+        assert (oracle.butterfly_circuit(x, w, mode) == canon(g[f"circuit_{mode}"])).all(), mode
+    # MUL mode is four products under the lane shuffle of butterfly_unit.h:153-187: out = {w2 a, w0 b, w3 c, w1 d}
+    prod = lambda a, b: np.mod(a.astype(np.int64) * b, Q).astype(np.int32)  # noqa: E731
+    want = np.stack([prod(x[:, 0], w[:, 2]), prod(x[:, 1], w[:, 0]), prod(x[:, 2], w[:, 3]), prod(x[:, 3], w[:, 1])], axis=1)
+    assert (canon(g["circuit_2"]) == want).all()
+    # one butterfly<> of the C++ unit == the RTL butterfly of the oracle (butterfly.v), forward and inverse, mod q
+    bj, bl = C.c_uint32(), C.c_uint32()
+    for mode in (0, 1):
+        for (a, b, _, _), (z, _, _, _), (rj, rl) in zip(canon(x)[:600], canon(w)[:600], canon(g[f"butterfly_{mode}"])[:600]):
+            oracle.lib.orc_butterfly_rtl(mode, int(a), int(b), int(z), 0, C.byref(bj), C.byref(bl))
+            assert (bj.value, bl.value) == (int(rj), int(rl)), (mode, a, b, z)
+
+
+@pytest.mark.skipif(not Reference.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_butterfly_circuit_vs_reference_unit_live(oracle):
+    r = Reference()
+    rng = np.random.default_rng(77)
+    x = rng.integers(-(Q - 1), Q, (3000, 4)).astype(np.int32)
+    w = rng.integers(-(Q - 1), Q, (3000, 4)).astype(np.int32)
+    for mode in (0, 1, 2):
+        assert (oracle.butterfly_circuit(x, w, mode) == canon(r.buttefly_circuit(x, w, mode))).all(), mode
+
+
 def test_twiddle_resolver_schedule(oracle):
     """twiddle_resolver.v addresses == the k-indices of ref_ntt2x2.cpp for every step"""
     out = (C.c_uint * 4)()
