@@ -440,7 +440,8 @@ def verify_sig_expanded2(A, t1hat, pk, sig, mu, level, shared_pk=False):
     """verify_sig with A = expand_a(rho) AND t1^ = expand_t1(pk) of the keys kept by the caller"""
     B = sig.shape[0]
     verdict = torch.empty((B,), dtype=torch.int32, device=sig.device)
-    _lib.check(_lib.load().dil_verify_sig_expanded2_dev(_dev(verdict, torch.int32), _dev(A, torch.int32), _dev(t1hat, torch.int32),
+    t1p = None if (t1hat is None and shared_pk) else _dev(t1hat, torch.int32)       # one key for the batch: t1^ is not read (include/dil256.h)
+    _lib.check(_lib.load().dil_verify_sig_expanded2_dev(_dev(verdict, torch.int32), _dev(A, torch.int32), t1p,
                                                         _dev(pk, torch.uint8), _dev(sig, torch.uint8), _dev(mu, torch.uint8), level, B,
                                                         int(shared_pk), _stream()), "dil_verify_sig_expanded2_dev")
     return verdict

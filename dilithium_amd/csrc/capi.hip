@@ -103,6 +103,7 @@ int init_device(Device& d, int id)
 void destroy_device(Device& d)
 {
     ::mailbox_destroy(d);
+    d.helper.stop();
     d.arenas.clear();
     d.aux.destroy();
     if (d.hp.ready) {
@@ -169,6 +170,54 @@ dil::Tables Device::tables() const
     t.fused_wgs_per_cu = pos(cfg.fused_wgs_per_cu.load(std::memory_order_relaxed), 4);
     t.fused_mode = cfg.fused_mode.load(std::memory_order_relaxed);
     return t;
+}
+
+bool HelperThread::submit(int device, std::function<void()> fn)
+{
+    std::unique_lock<std::mutex> lk(mu);
+    if (!started) {
+        try {
+            th = std::thread([this, device] {
+                (void)hipSetDevice(device);              // once: the thread serves this device for its whole life
+                std::unique_lock<std::mutex> l(mu);
+                for (;;) {
+                    cv.wait(l, [this] { return has_job || quit; });
+                    if (quit) return;
+                    std::function<void()> f = std::move(job);
+                    has_job = false;
+                    l.unlock();
+                    f();
+                    l.lock();
+                    job_done = true;
+                    cv.notify_all();
+                }
+            });
+        } catch (const std::exception&) {
+            return false;
+        }
+        started = true;
+    }
+    job = std::move(fn);
+    has_job = true;
+    job_done = false;
+    cv.notify_all();
+    return true;
+}
+void HelperThread::wait()
+{
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return job_done; });
+}
+void HelperThread::stop()
+{
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!started) return;
+        quit = true;
+        cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+    started = quit = has_job = false;
 }
 
 bool AuxStream::ensure()
@@ -295,7 +344,9 @@ int mailbox_start(Device& d, const dil::Tables& T)          // (re)launch the re
     const uint64_t ticks = (uint64_t)std::max(1, dil::rt::cfg.mailbox_idle_us.load(std::memory_order_relaxed)) * 100;   // 100 MHz
     const uint64_t resident = (uint64_t)std::max(1, dil::rt::cfg.mailbox_resident_us.load(std::memory_order_relaxed)) * 100;
     m.launches++;
-    return (int)dil::launch_mailbox(m.dev, __atomic_load_n(&m.host->done_seq, __ATOMIC_ACQUIRE), ticks, resident, T, m.stream);
+    const int rc = (int)dil::launch_mailbox(m.dev, __atomic_load_n(&m.host->done_seq, __ATOMIC_ACQUIRE), ticks, resident, T, m.stream);
+    if (rc) __atomic_store_n(&m.host->state, (uint32_t)dil::MB_DEAD, __ATOMIC_RELEASE);     // no wave was launched: nothing is resident
+    return rc;
 }
 // one request: in0 (and in1) are copied into the mailbox, the wave is woken (or launched), `out` receives the 1 KiB result
 int mailbox_call(int op, int mapping, const int32_t* in0, const int32_t* in1, int32_t* out)
@@ -345,19 +396,39 @@ int mailbox_call(int op, int mapping, const int32_t* in0, const int32_t* in1, in
     memcpy(out, mb->out, 1024);
     return 0;
 }
+// Tear the mailbox down -- but never under a wave that may still be resident.  The wave polls and writes the mapped page (1 KiB of
+// result + two words); freeing that page or destroying its stream while it runs is a device-side use-after-free (or a hang inside
+// hipHostFree).  So: ask the wave to leave, wait a BOUNDED time for the `state` word it writes last (MB_DEAD; the page is host memory, the
+// wait needs no runtime call), and only then synchronise the stream and free.  A wave that does not answer within the bound -- the state
+// `broken` records, or a GPU too busy to schedule it -- keeps its page and its stream: both are leaked on purpose (one page, one stream, once
+// per process).
 void mailbox_destroy(Device& d)
 {
     dil::rt::MailboxHost& m = d.mbox;
     std::lock_guard<std::mutex> lk(m.mu);
     if (!m.host) return;
-    if (mb_read(&m.host->state) != (uint32_t)dil::MB_DEAD)       // ask the wave to leave, then wait for its stream
+    bool dead = mb_read(&m.host->state) == (uint32_t)dil::MB_DEAD || m.launches == 0;
+    if (!dead) {
         __atomic_store_n(&m.host->req_seq, dil::mb_header(++m.seq, (uint32_t)dil::MB_QUIT, 0), __ATOMIC_RELEASE);
-    if (!m.broken) (void)hipStreamSynchronize(m.stream);          // (a wedged wave -- what `broken` records -- would hang this for ever)
-    (void)hipStreamDestroy(m.stream);
-    (void)hipHostFree(m.host);
+        const double bound_us = 2.0 * std::max(1, dil::rt::cfg.mailbox_resident_us.load(std::memory_order_relaxed)) + 2e5;   // the wave's own residency cap, twice, + 0.2 s
+        const double t0 = now_us();
+        for (uint64_t spins = 0; !dead; spins++) {
+            dead = mb_read(&m.host->state) == (uint32_t)dil::MB_DEAD;
+            if (!dead && (spins & 255) == 255 && now_us() - t0 > bound_us) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (dead) {
+        (void)hipStreamSynchronize(m.stream);        // the kernel's last instructions after its MB_DEAD store
+        (void)hipStreamDestroy(m.stream);
+        (void)hipHostFree(m.host);
+    } else {
+        m.leaked++;                                  // (dil_mailbox_stats reports it)
+    }
     m.host = m.dev = nullptr;
     m.stream = nullptr;
     m.broken = false;
+    m.launches = 0;
 }
 
 int ensure_scratch(Device& d, size_t bytes)
@@ -389,18 +460,25 @@ static size_t host_chunk_polys(bool pinned = false)
     const int v = pinned ? dil::rt::cfg.host_chunk_pinned.load(std::memory_order_relaxed) : dil::rt::cfg.host_chunk.load(std::memory_order_relaxed);
     return (size_t)std::min(std::max(v, 64), 1 << 20);
 }
-static bool is_page_locked(const void* h)
+static bool is_page_locked(const void* h, size_t bytes)          // both ends of the range: a partly registered buffer is pageable to us
 {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, h) != hipSuccess) {
-        (void)hipGetLastError();                      // an ordinary malloc'ed pointer is "invalid value" to the runtime: pageable
-        return false;
+    const char* ends[2] = {static_cast<const char*>(h), static_cast<const char*>(h) + (bytes ? bytes - 1 : 0)};
+    for (const char* p : ends) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();                  // an ordinary malloc'ed pointer is "invalid value" to the runtime: pageable
+            return false;                             // (that clears the runtime's per-thread last-error record, which this query itself has just set)
+        }
+        if (at.type != hipMemoryTypeHost) return false;
     }
-    return at.type == hipMemoryTypeHost;
+    return true;
 }
 static int host_stream_count() { return std::min(std::max(dil::rt::cfg.host_streams.load(std::memory_order_relaxed), 1), HOST_STREAMS); }
 
-int ensure_pipe(Device& d, size_t bytes_per_stream)
+// streams + events once; staging buffers only for the `nbuf` a call goes round, each grown to what the call needs -- and given back when a
+// run of 16 later calls needs less than a quarter of it, or not that buffer at all (one large dil_verify_core_host call must not hold
+// 8 x 64 MiB for the life of the process; calls of two sizes taking turns must not free and allocate every time)
+int ensure_pipe(Device& d, size_t bytes_per_buffer, int nbuf)
 {
     dil::rt::HostPipe& hp = d.hp;
     if (!hp.ready) {
@@ -411,14 +489,22 @@ int ensure_pipe(Device& d, size_t bytes_per_stream)
         }
         hp.ready = true;
     }
-    if (hp.dev_bytes < bytes_per_stream) {
-        for (int i = 0; i < HOST_STREAMS; i++) {
-            if (hp.dev[i]) DIL_TRY(hipFree(hp.dev[i]));
+    for (int i = 0; i < HOST_STREAMS; i++) {
+        const bool used = i < nbuf;
+        const bool regrow = used && hp.dev_bytes[i] < bytes_per_buffer;
+        const bool big = hp.dev[i] && hp.dev_bytes[i] > ((size_t)16 << 20) && (!used || hp.dev_bytes[i] > 4 * bytes_per_buffer);
+        hp.oversized[i] = big ? hp.oversized[i] + 1 : 0;
+        const bool shrink = hp.oversized[i] >= 16;
+        if ((regrow || shrink) && hp.dev[i]) {
+            DIL_TRY(hipFree(hp.dev[i]));            // (every stream of the pipe is idle between calls: each call ends in their synchronisation)
             hp.dev[i] = nullptr;
+            hp.dev_bytes[i] = 0;
+            hp.oversized[i] = 0;
         }
-        hp.dev_bytes = 0;
-        for (int i = 0; i < HOST_STREAMS; i++) DIL_TRY(hipMalloc(reinterpret_cast<void**>(&hp.dev[i]), bytes_per_stream));
-        hp.dev_bytes = bytes_per_stream;
+        if (used && !hp.dev[i]) {
+            DIL_TRY(hipMalloc(reinterpret_cast<void**>(&hp.dev[i]), bytes_per_buffer));
+            hp.dev_bytes[i] = bytes_per_buffer;
+        }
     }
     return 0;
 }
@@ -467,7 +553,7 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     std::lock_guard<std::mutex> lk(d.host_mu);
     int rc;
     PinGuard pin(h, batch > 4096 ? batch * 1024 : 0);        // (option host_pin; not worth a registration for a small batch)
-    const bool locked = batch > 4096 && (pin.p || is_page_locked(h));
+    const bool locked = batch > 4096 && (pin.p || is_page_locked(h, batch * 1024));
     const HostPlan plan = host_plan(batch, locked);
     const size_t HOST_CHUNK = plan.chunk;
     const bool duplex = plan.pipeline == HOST_PIPE_DUPLEX, helper_thread = plan.pipeline == HOST_PIPE_HELPER_THREAD;
@@ -483,7 +569,7 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
         DIL_TRY(hipMemcpy(h, d.scratch, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
-    rc = ensure_pipe(d, HOST_CHUNK * 1024);
+    rc = ensure_pipe(d, HOST_CHUNK * 1024, NS);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
     int err = 0;
@@ -523,9 +609,7 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
         std::atomic<size_t> uploaded{0}, downloaded{0};
         std::atomic<int> err_dn{0};
         std::atomic<bool> stop{false};
-        const int dev_id = d.id;
         auto download = [&] {
-            if (hipSetDevice(dev_id) != hipSuccess) { err_dn.store((int)hipErrorInvalidDevice); return; }
             for (size_t k = 0; k < nch; k++) {
                 while (uploaded.load(std::memory_order_acquire) <= k) {
                     if (stop.load(std::memory_order_relaxed)) return;
@@ -542,12 +626,8 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
             const hipError_t e = hipStreamSynchronize(dn);
             if (e != hipSuccess) err_dn.store((int)e);
         };
-        std::thread helper;
-        try {
-            helper = std::thread(download);
-        } catch (const std::exception&) {                // no thread to be had: the one-thread pipeline below
-        }
-        for (size_t k = 0; helper.joinable() && k < nch && !err; k++) {
+        const bool have_helper = d.helper.submit(d.id, download);    // false: no thread to be had -- the one-thread pipeline below
+        for (size_t k = 0; have_helper && k < nch && !err; k++) {
             const int b = (int)(k % NS);
             const size_t off = k * HOST_CHUNK, n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
             int32_t* dc = reinterpret_cast<int32_t*>(hp.dev[b]);
@@ -561,9 +641,9 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
             if (!err) err = (int)hipEventRecord(hp.up_done[b], up);
             if (!err) uploaded.store(k + 1, std::memory_order_release);
         }
-        if (helper.joinable()) {
+        if (have_helper) {
             if (err || err_dn.load()) stop.store(true);
-            helper.join();
+            d.helper.wait();                             // (the job holds references to this frame: it has returned before we do)
             const hipError_t e = hipStreamSynchronize(up);
             if (!err) err = err_dn.load();
             if (!err && e != hipSuccess) err = (int)e;
@@ -603,7 +683,7 @@ int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int3
     const int NS = host_stream_count();
     const size_t budget = std::max(host_chunk_polys(), (size_t)65536) * 1024;      // upload-dominated: 64 MiB chunks reach 0.88-0.95 of the link
     const size_t per_chunk = std::max<size_t>(1, (budget - (shared_pk ? key_bytes : 0)) / item_all);
-    int rc = ensure_pipe(d, std::max(budget, item_all + key_bytes));
+    int rc = ensure_pipe(d, std::max(budget, item_all + key_bytes), NS);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
     const size_t nk = shared_pk ? 1 : batch;

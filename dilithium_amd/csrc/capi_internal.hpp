@@ -8,7 +8,10 @@
 #include "kernels.hpp"
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 #define DIL_TRY(expr)                          \
     do {                                       \
@@ -86,10 +89,25 @@ struct AuxStream {
 constexpr int HOST_STREAMS = 8;            // upper bound; option host_streams picks how many a call uses
 struct HostPipe {
     hipStream_t stream[HOST_STREAMS] = {};
-    uint8_t* dev[HOST_STREAMS] = {};       // one staging buffer per stream
-    size_t dev_bytes = 0;                  // size of each
+    uint8_t* dev[HOST_STREAMS] = {};       // one staging buffer per stream, allocated when a call first uses that many (ensure_pipe)
+    size_t dev_bytes[HOST_STREAMS] = {};   // size of each
+    int oversized[HOST_STREAMS] = {};      // consecutive calls that needed less than a quarter of it (or not the buffer at all): given back after 16
     hipEvent_t up_done[HOST_STREAMS] = {}, dn_done[HOST_STREAMS] = {};   // per staging buffer: its upload landed / its download left
     bool ready = false;
+};
+
+// ONE parked helper thread per device for the pageable pipeline of the *_host entry points (the downloads of a call run on it): created on
+// the first call that needs it, bound to the device once, woken per call -- no thread creation and no fresh per-thread runtime state per call
+struct HelperThread {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread th;
+    std::function<void()> job;
+    bool has_job = false, job_done = false, quit = false, started = false;
+    bool submit(int device, std::function<void()> fn);   // false: no thread to be had (the caller runs its one-thread pipeline)
+    void wait();                                         // until the submitted job has returned
+    void stop();
+    ~HelperThread() { stop(); }
 };
 
 // the host mailbox of the batch-of-one drop-in calls (kernels.hpp Mailbox; capi.hip mailbox_call)
@@ -101,6 +119,7 @@ struct MailboxHost {
     uint32_t seq = 0;
     bool broken = false;            // a request timed out: the mailbox is not used again in this process
     uint64_t launches = 0, calls = 0;
+    uint64_t leaked = 0;            // mailboxes left behind by mailbox_destroy because their wave did not retire in time
 };
 
 struct Device {
@@ -114,6 +133,7 @@ struct Device {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     HostPipe hp;
+    HelperThread helper;            // (used under host_mu only)
     ArenaPool arenas;
     AuxStream aux;
     MailboxHost mbox;

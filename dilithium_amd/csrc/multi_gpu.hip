@@ -206,6 +206,38 @@ int multi_ensure(int ndev, int* G_out)
     return 0;
 }
 
+// The schedule of the final gather, device by device in issue order (one group): in-place all-gather of equal slabs; ragged slabs (by one
+// item) as all-gather-v = one broadcast per slab; gather to one root as its receives of every other slab and every other device's send of
+// its own.  Pure: no device, no RCCL.
+void gather_plan(size_t batch, size_t item_bytes, int root, int G, bool force_ragged, std::vector<dil_gather_op>& ops)
+{
+    ops.clear();
+    if (G < 1 || batch == 0 || item_bytes == 0) return;
+    const bool equal = batch % (size_t)G == 0 && !force_ragged;
+    for (int g = 0; g < G; g++) {
+        if (root < 0 && equal) {                     // the send slab sits at its own offset of the receive array
+            const size_t cnt = batch / (size_t)G * item_bytes;
+            ops.push_back({DIL_GATHER_ALLGATHER, g, -1, (size_t)g * cnt, cnt});
+        } else if (root < 0) {
+            for (int r = 0; r < G; r++) {
+                size_t lo, hi;
+                dil_shard_range(batch, r, G, &lo, &hi);
+                if (hi > lo) ops.push_back({DIL_GATHER_BROADCAST, g, r, lo * item_bytes, (hi - lo) * item_bytes});
+            }
+        } else if (g == root) {                      // the root receives every other slab ...
+            for (int r = 0; r < G; r++) {
+                size_t lo, hi;
+                dil_shard_range(batch, r, G, &lo, &hi);
+                if (r != root && hi > lo) ops.push_back({DIL_GATHER_RECV, g, r, lo * item_bytes, (hi - lo) * item_bytes});
+            }
+        } else {                                     // ... and every other device sends its own
+            size_t lo, hi;
+            dil_shard_range(batch, g, G, &lo, &hi);
+            if (hi > lo) ops.push_back({DIL_GATHER_SEND, g, root, lo * item_bytes, (hi - lo) * item_bytes});
+        }
+    }
+}
+
 // THE collective of the design: every device g holds items [lo_g, hi_g) of `bufs[g]` ([batch][item_bytes], device memory of
 // device g); afterwards every bufs[g] (root < 0) or bufs[root] alone holds all items.  Enqueued on the devices' streams, which
 // are then drained.
@@ -222,7 +254,8 @@ int gather_slabs(void* const* bufs, size_t item_bytes, size_t batch, int root, i
     int force = 0;
     if (G == 1 && dil_get_option("multi_group_at_1", &force) != 0) force = 0;
     if ((G > 1 || force) && batch > 0 && item_bytes > 0) {
-        const bool equal = batch % (size_t)G == 0 && force != 2;
+        std::vector<dil_gather_op> plan;
+        gather_plan(batch, item_bytes, root, G, force == 2, plan);
         DIL_NCCL(m.rccl.GroupStart(), "ncclGroupStart");
         ncclResult_t bad = ncclSuccess;                  // first failure inside the group; the group is closed either way
         const char* bad_what = "";
@@ -234,31 +267,22 @@ int gather_slabs(void* const* bufs, size_t item_bytes, size_t batch, int root, i
             bad_what = what;                                      \
         }                                                         \
     } while (0)
-        for (int g = 0; g < G; g++) {
+        for (const dil_gather_op& op : plan) {           // the schedule is pure host logic (gather_plan, exported as dil_multi_gather_plan and tested without a GPU)
+            const size_t g = (size_t)op.rank;
             char* mine = static_cast<char*>(bufs[g]);
-            if (root < 0 && equal) {                     // in-place all-gather: the send slab sits at its own offset of the receive array
-                const size_t cnt = batch / (size_t)G * item_bytes;
-                DIL_IN_GROUP(m.rccl.AllGather(mine + (size_t)g * cnt, mine, cnt, ncclUint8, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclAllGather");
-            } else if (root < 0) {                       // ragged by one item: all-gather-v = one broadcast per slab, all in ONE group
-                for (int r = 0; r < G; r++) {
-                    size_t lo, hi;
-                    dil_shard_range(batch, r, G, &lo, &hi);
-                    if (hi > lo)
-                        DIL_IN_GROUP(m.rccl.Broadcast(mine + lo * item_bytes, mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, r,
-                                                  m.comm[(size_t)g], m.stream[(size_t)g]), "ncclBroadcast");
-                }
-            } else if (g == root) {                      // gather to one root: it receives every other slab ...
-                for (int r = 0; r < G; r++) {
-                    size_t lo, hi;
-                    dil_shard_range(batch, r, G, &lo, &hi);
-                    if (r != root && hi > lo)
-                        DIL_IN_GROUP(m.rccl.Recv(mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, r, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclRecv");
-                }
-            } else {                                     // ... and every other device sends its own
-                size_t lo, hi;
-                dil_shard_range(batch, g, G, &lo, &hi);
-                if (hi > lo)
-                    DIL_IN_GROUP(m.rccl.Send(mine + lo * item_bytes, (hi - lo) * item_bytes, ncclUint8, root, m.comm[(size_t)g], m.stream[(size_t)g]), "ncclSend");
+            switch (op.kind) {
+            case DIL_GATHER_ALLGATHER:
+                DIL_IN_GROUP(m.rccl.AllGather(mine + op.offset, mine, op.bytes, ncclUint8, m.comm[g], m.stream[g]), "ncclAllGather");
+                break;
+            case DIL_GATHER_BROADCAST:
+                DIL_IN_GROUP(m.rccl.Broadcast(mine + op.offset, mine + op.offset, op.bytes, ncclUint8, op.peer, m.comm[g], m.stream[g]), "ncclBroadcast");
+                break;
+            case DIL_GATHER_RECV:
+                DIL_IN_GROUP(m.rccl.Recv(mine + op.offset, op.bytes, ncclUint8, op.peer, m.comm[g], m.stream[g]), "ncclRecv");
+                break;
+            default:
+                DIL_IN_GROUP(m.rccl.Send(mine + op.offset, op.bytes, ncclUint8, op.peer, m.comm[g], m.stream[g]), "ncclSend");
+                break;
             }
         }
 #undef DIL_IN_GROUP
@@ -317,6 +341,16 @@ int dil_multi_info(int* rccl_version, char* path, size_t path_len, int* ndev)
         Dl_info info;
         if (dladdr(reinterpret_cast<void*>(g_multi.rccl.AllGather), &info) && info.dli_fname) snprintf(path, path_len, "%s", info.dli_fname);
     }
+    return 0;
+}
+
+int dil_multi_gather_plan(size_t batch, size_t item_bytes, int gather_root, int ndev, int force_ragged, dil_gather_op* ops, size_t max_ops, size_t* n_ops)
+{
+    if (ndev < 1 || gather_root >= ndev || !n_ops) return (int)hipErrorInvalidValue;
+    std::vector<dil_gather_op> plan;
+    gather_plan(batch, item_bytes, gather_root, ndev, force_ragged != 0, plan);
+    *n_ops = plan.size();
+    for (size_t i = 0; ops && i < plan.size() && i < max_ops; i++) ops[i] = plan[i];
     return 0;
 }
 

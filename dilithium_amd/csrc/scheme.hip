@@ -622,8 +622,8 @@ int dil_verify_sig_expanded2_dev(int32_t* verdict, const int32_t* A, const int32
     if ((rc = level_par(level, &p))) return rc;
     DIL_ENTER(dv, T);
     if (batch == 0) return 0;
-    if (!A || !t1hat || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(t1hat)) & 15) || (reinterpret_cast<uintptr_t>(mu) & 7))
-        return (int)hipErrorInvalidValue;
+    if (!A || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(mu) & 7)) return (int)hipErrorInvalidValue;
+    if (!shared_pk && (!t1hat || (reinterpret_cast<uintptr_t>(t1hat) & 15))) return (int)hipErrorInvalidValue;     // (one key for the batch: t1hat is not read)
     hipStream_t s = S(stream);
     StreamScratch ws(dv, s);
     if (!dil::rt::cfg.fuse_wire.load(std::memory_order_relaxed)) return (int)hipErrorNotSupported;
@@ -631,8 +631,11 @@ int dil_verify_sig_expanded2_dev(int32_t* verdict, const int32_t* A, const int32
 }
 int dil_expand_t1_dev(int32_t* t1hat, const uint8_t* pk, int level, size_t nkeys, void* stream)
 {
+    LevelPar p;
+    if (int rc = level_par(level, &p)) return rc;
     DIL_ENTER(dv, T);
-    if (reinterpret_cast<uintptr_t>(t1hat) & 15) return (int)hipErrorInvalidValue;
+    if (nkeys == 0) return 0;
+    if (!t1hat || !pk || (reinterpret_cast<uintptr_t>(t1hat) & 15)) return (int)hipErrorInvalidValue;
     return (int)dil::launch_expand_t1(t1hat, pk, dil_pk_bytes(level), level, nkeys, T, S(stream));
 }
 

@@ -16,6 +16,11 @@ _u32p = C.POINTER(C.c_uint32)
 _vp = C.c_void_p
 _sz = C.c_size_t
 
+class GatherOp(C.Structure):
+    """include/dil256.h dil_gather_op"""
+    _fields_ = [("kind", C.c_int), ("rank", C.c_int), ("peer", C.c_int), ("offset", _sz), ("bytes", _sz)]
+
+
 # name -> (argtypes); every function returns int unless listed in _RESTYPE
 SIGNATURES = {
     "dil_init": [C.c_int],
@@ -46,6 +51,7 @@ SIGNATURES = {
     "dil_matvec_dev": [_vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_verify_core_dev": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_multi_info": [C.POINTER(C.c_int), C.c_char_p, _sz, C.POINTER(C.c_int)],
+    "dil_multi_gather_plan": [_sz, _sz, C.c_int, C.c_int, C.c_int, _vp, _sz, C.POINTER(_sz)],
     "dil_verify_core_host": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int],
     "dil_sign_phase1_dev": [_vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],
     "dil_sign_phase2_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _sz, C.c_int, _vp],

@@ -345,6 +345,21 @@ int dil_multi_shutdown(void);
 const char* dil_multi_last_error(void);
 /* which RCCL the collectives are bound to: NCCL_VERSION_CODE (major * 10000 + minor * 100 + patch), the library's path, devices of the live communicators (0: none) */
 int dil_multi_info(int* rccl_version, char* path, size_t path_len, int* ndev);
+/* The schedule of the final gather as pure host logic (no device, no RCCL needed: testable anywhere): the RCCL calls the *_multi_dev entry
+ * points issue inside ONE ncclGroupStart / ncclGroupEnd, in issue order, for `batch` items of `item_bytes` over ndev devices.
+ *   kind DIL_GATHER_ALLGATHER  device `rank` contributes [offset, offset + bytes) of its own full-size array, in place (equal slabs)
+ *        DIL_GATHER_BROADCAST  device `rank` takes part in the broadcast of [offset, offset + bytes) from device `peer` (ragged slabs)
+ *        DIL_GATHER_RECV       device `rank` (the root) receives [offset, offset + bytes) from device `peer`
+ *        DIL_GATHER_SEND       device `rank` sends its own slab [offset, offset + bytes) to device `peer` (the root)
+ * gather_root < 0: every device ends up with every item; gather_root = r: device r alone.  force_ragged != 0: the broadcast form even when
+ * the slabs are equal (what option multi_group_at_1 = 2 runs on one device).  Writes at most max_ops records, *n_ops = how many the
+ * schedule has.  There is no reference counterpart (the FPGA is one stream port, rtl_src/combined_top.v:36-41); contract: SURVEY 8(e). */
+enum { DIL_GATHER_ALLGATHER = 0, DIL_GATHER_BROADCAST = 1, DIL_GATHER_RECV = 2, DIL_GATHER_SEND = 3 };
+typedef struct dil_gather_op {
+    int kind, rank, peer;
+    size_t offset, bytes;
+} dil_gather_op;
+int dil_multi_gather_plan(size_t batch, size_t item_bytes, int gather_root, int ndev, int force_ragged, dil_gather_op* ops, size_t max_ops, size_t* n_ops);
 int dil_gather_slabs_multi_dev(void* const* bufs, size_t item_bytes, size_t batch, int gather_root, int ndev);
 int dil_ntt_multi_dev(int32_t* const* polys /* in/out: full-size, slab in place */, size_t batch, int inverse, int gather_root, int ndev);
 int dil_sign_multi_dev(uint8_t* const* sig, int32_t* const* attempts /* or NULL */, const uint8_t* const* sk, const uint8_t* const* mu,

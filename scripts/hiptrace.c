@@ -31,7 +31,29 @@ static inline Rec* put(const char* what, const void* a, const void* b, size_t n,
     r->t_ns = now_ns(); r->what = what; r->a = a; r->b = b; r->n = n; r->stream = stream; r->tid = my_tid; r->rc = -1;
     return r;
 }
-#define REAL(name) static int (*real)(); if (!real) real = (int (*)())dlsym(RTLD_NEXT, #name)
+/* the real entry point: torch brings its own libamdhip64.so in with a LOCAL dlopen, where RTLD_NEXT does not look -- find the loaded object by name */
+#include <link.h>
+static char hip_path[512];
+static int find_hip(struct dl_phdr_info* info, size_t size, void* data)
+{
+    (void)size; (void)data;
+    if (info->dlpi_name && strstr(info->dlpi_name, "libamdhip64")) { strncpy(hip_path, info->dlpi_name, sizeof hip_path - 1); return 1; }
+    return 0;
+}
+static void* resolve(const char* name)
+{
+    void* p = dlsym(RTLD_NEXT, name);
+    if (p) return p;
+    static void* h;
+    if (!h) {
+        dl_iterate_phdr(find_hip, 0);
+        h = dlopen(hip_path[0] ? hip_path : "libamdhip64.so", RTLD_NOW | (hip_path[0] ? RTLD_NOLOAD : 0));
+    }
+    p = h ? dlsym(h, name) : 0;
+    if (!p) { fprintf(stderr, "hiptrace: cannot resolve %s\n", name); abort(); }
+    return p;
+}
+#define REAL(name) static int (*real)(); if (!real) real = (int (*)())resolve(#name)
 
 int hipMemcpy(void* d, const void* s, size_t n, int kind) { REAL(hipMemcpy); Rec* r = put(kind == 1 ? "hipMemcpy H2D" : kind == 2 ? "hipMemcpy D2H" : "hipMemcpy", d, s, n, 0); return r->rc = real(d, s, n, kind); }
 int hipMemcpyAsync(void* d, const void* s, size_t n, int kind, void* st) { REAL(hipMemcpyAsync); Rec* r = put(kind == 1 ? "hipMemcpyAsync H2D" : kind == 2 ? "hipMemcpyAsync D2H" : "hipMemcpyAsync", d, s, n, st); return r->rc = real(d, s, n, kind, st); }

@@ -216,6 +216,18 @@ def test_verify_sig_with_expanded_keys(gpu, level, kat_msgs):
     v2 = api.verify_sig_expanded2(A, th, pkd, sgd, mud, level).cpu().numpy()
     assert (v2 == v).all()
     assert int(api.verify_sig_expanded2(A[:1].contiguous(), th[:1].contiguous(), pkd[:1], s1, m, level, shared_pk=True).abs().sum()) == 0
+    # one key for the batch: t1^ is documented as not read -- a NULL t1hat is accepted there (and only there)
+    assert int(api.verify_sig_expanded2(A[:1].contiguous(), None, pkd[:1], s1, m, level, shared_pk=True).abs().sum()) == 0
+    import ctypes as C
+    L = api._lib.load()
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    vd = gpu.empty((sgd.shape[0],), dtype=gpu.int32, device="cuda")
+    assert L.dil_verify_sig_expanded2_dev(P(vd), P(A), None, P(pkd), P(sgd), P(mud), level, sgd.shape[0], 0, None) != 0
+    # dil_expand_t1_dev validates before it computes strides: unknown level, NULL pointers
+    assert L.dil_expand_t1_dev(P(th), P(pkd), 4, 1, None) != 0
+    assert L.dil_expand_t1_dev(None, P(pkd), level, 1, None) != 0
+    assert L.dil_expand_t1_dev(P(th), None, level, 1, None) != 0
+    assert L.dil_expand_t1_dev(None, None, level, 0, None) == 0
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])

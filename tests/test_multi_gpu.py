@@ -90,6 +90,12 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["secondary"]["configs4_sharded"]["gathered_signatures_verify"] is True
+    # what makes a SCALE record checkable the day a multi-GPU node runs it: the collective backend's own count of the job's ranks (an
+    # all-reduce of ones over the process group -- RCCL's on a node, gloo's here) equals the world size, every rank reports where it sits
+    dist = d["distributed"]
+    assert dist["rccl_nranks"] == 2 and dist["world_size"] == 2 and len(dist["ranks"]) == 2 and dist["backend"] == "gloo"
+    assert sorted(r["rank"] for r in dist["ranks"]) == [0, 1]
+    assert dist["distinct_devices"] == 1                  # both ranks on the one GPU of this box: exactly what scripts/gpu_scale.sh refuses as a curve
 
 
 def _ptrs(tensors):

@@ -208,3 +208,112 @@ def test_multi_gpu_host_layer(gpu, oracle, kat_msgs):
     v = np.ones(100, np.int32)
     dlib.check(L.dil_verify_sig_multi_host(vp(v), vp(pk), vp(got), vp(mu), 3, 100, 0, 0))
     assert (v == 0).all()
+
+
+# ---- the schedule of the final gather (csrc/multi_gpu.hip gather_plan, exported as dil_multi_gather_plan), executed by a model of the
+# NCCL API's semantics: the Send / Recv pairing of the gather-to-a-root form has never run on hardware (no multi-GPU node in any round) --
+# here every call the library would issue inside its one group is issued against recording "communicators" over numpy buffers ----------
+class FakeRccl:
+    """G ranks, one byte buffer each; the group's calls in issue order; NCCL's rules: inside a group point-to-point calls match by (source,
+    destination) in FIFO order with equal counts; a collective must be called by EVERY rank with the same count (and root); nothing moves
+    before the group ends"""
+
+    def __init__(self, bufs):
+        self.bufs = bufs
+        self.G = len(bufs)
+        self.calls = []
+
+    def run(self, ops):
+        from collections import defaultdict, deque
+        sends, recvs = defaultdict(deque), defaultdict(deque)
+        bcasts, gathers = defaultdict(list), []
+        for op in ops:
+            self.calls.append((("allgather", "broadcast", "recv", "send")[op.kind], op.rank, op.peer, op.offset, op.bytes))
+            assert 0 <= op.rank < self.G and op.bytes > 0 and op.offset + op.bytes <= len(self.bufs[op.rank])
+            if op.kind == 3:
+                assert 0 <= op.peer < self.G and op.peer != op.rank
+                sends[(op.rank, op.peer)].append(op)
+            elif op.kind == 2:
+                assert 0 <= op.peer < self.G and op.peer != op.rank
+                recvs[(op.peer, op.rank)].append(op)
+            elif op.kind == 1:
+                bcasts[(op.peer, op.offset, op.bytes)].append(op.rank)
+            else:
+                gathers.append(op)
+        snapshot = [b.copy() for b in self.bufs]                       # group semantics: every transfer reads pre-group data
+        assert set(sends) == set(recvs), ("unmatched point-to-point calls: the group would hang", set(sends) ^ set(recvs))
+        for key in sends:
+            assert len(sends[key]) == len(recvs[key]), ("send / recv counts differ", key)
+            for s_, r_ in zip(sends[key], recvs[key]):
+                assert s_.bytes == r_.bytes, ("send / recv sizes differ: NCCL would corrupt or hang", key)
+                self.bufs[key[1]][r_.offset:r_.offset + r_.bytes] = snapshot[key[0]][s_.offset:s_.offset + s_.bytes]
+        for (root, off, n), ranks in bcasts.items():
+            assert sorted(ranks) == list(range(self.G)), ("a broadcast not entered by every rank hangs", root, off, ranks)
+            for g in range(self.G):
+                self.bufs[g][off:off + n] = snapshot[root][off:off + n]
+        if gathers:
+            assert sorted(o.rank for o in gathers) == list(range(self.G)) and len({o.bytes for o in gathers}) == 1
+            n = gathers[0].bytes
+            for o in gathers:
+                assert o.offset == o.rank * n                             # in place: the send slab at its own offset of the receive array
+                for g in range(self.G):
+                    self.bufs[g][o.rank * n:(o.rank + 1) * n] = snapshot[o.rank][o.offset:o.offset + n]
+
+
+def _gather_plan(batch, item_bytes, root, G, ragged=0):
+    import ctypes as C
+    from dilithium_amd import lib as dlib
+    L = dlib.load()
+    n = C.c_size_t()
+    assert L.dil_multi_gather_plan(batch, item_bytes, root, G, ragged, None, 0, C.byref(n)) == 0
+    ops = (dlib.GatherOp * max(1, n.value))()
+    assert L.dil_multi_gather_plan(batch, item_bytes, root, G, ragged, C.cast(ops, C.c_void_p), n.value, C.byref(n)) == 0
+    return list(ops)[:n.value]
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("batch", [1, 5, 8, 64, 8195])
+@pytest.mark.parametrize("root", [-1, 0, "last"])
+def test_final_gather_schedule_against_a_model_of_the_nccl_api(G, batch, root):
+    """every device's slab reaches every device (root < 0) or the root -- and only through calls NCCL can match: each non-root device sends
+    exactly its own shard once, the root posts exactly one receive per non-empty foreign shard at that shard's offset, sizes agree pairwise"""
+    root = G - 1 if root == "last" else root
+    item = 7                                                             # bytes per item, odd on purpose
+    rng = np.random.default_rng(G * 1000 + batch)
+    full = rng.integers(0, 256, batch * item, dtype=np.uint8)
+    for ragged in (0, 1):
+        bufs = []
+        for g in range(G):                                                # device g holds its own slab, junk elsewhere
+            lo, hi = sharding.shard_range(batch, g, G)
+            b = rng.integers(0, 256, batch * item, dtype=np.uint8)
+            b[lo * item:hi * item] = full[lo * item:hi * item]
+            bufs.append(b)
+        before = [b.copy() for b in bufs]
+        ops = _gather_plan(batch, item, root, G, ragged)
+        fake = FakeRccl(bufs)
+        fake.run(ops)
+        kinds = {c[0] for c in fake.calls}
+        if root < 0:
+            assert kinds <= ({"allgather"} if (batch % G == 0 and not ragged) else {"broadcast"})
+            for g in range(G):
+                assert (bufs[g] == full).all(), (g, "all-gather incomplete")
+        else:
+            assert kinds <= {"send", "recv"}
+            assert (bufs[root] == full).all(), "the root does not hold every item"
+            for g in range(G):
+                if g != root:
+                    assert (bufs[g] == before[g]).all(), "a non-root buffer was written"
+                    lo, hi = sharding.shard_range(batch, g, G)
+                    mine = [c for c in fake.calls if c[1] == g]
+                    assert mine == ([("send", g, root, lo * item, (hi - lo) * item)] if hi > lo else []), mine
+            assert sum(c[0] == "recv" for c in fake.calls) == sum(1 for g in range(G) if g != root and sharding.shard_range(batch, g, G)[1] > sharding.shard_range(batch, g, G)[0])
+
+
+def test_final_gather_schedule_rejects_bad_arguments():
+    import ctypes as C
+    from dilithium_amd import lib as dlib
+    L = dlib.load()
+    n = C.c_size_t()
+    assert L.dil_multi_gather_plan(8, 4, 2, 2, 0, None, 0, C.byref(n)) != 0          # root outside the job
+    assert L.dil_multi_gather_plan(8, 4, 0, 0, 0, None, 0, C.byref(n)) != 0
+    assert L.dil_multi_gather_plan(0, 4, -1, 4, 0, None, 0, C.byref(n)) == 0 and n.value == 0
