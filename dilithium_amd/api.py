@@ -106,6 +106,17 @@ def pointwise_barrett(c, a, b):
     return c
 
 
+def polymul(c, a, b):
+    """c = a * b in Z_q[x] / (x^256 + 1): the reference's polymul chain (ntt, ntt, pointwise_barrett, invntt; ntt2x2_test.cpp:109-137) as ONE
+    fused kernel; host arrays: one upload of a and b, one download of c.  c may alias a or b.  |a|, |b| < 2^26."""
+    L = _lib.load()
+    if _is_tensor(a):
+        _lib.check(L.dil_polymul_dev(_dev(c, torch.int32), _dev(a, torch.int32), _dev(b, torch.int32), _batch(a), _stream()), "dil_polymul_dev")
+    else:
+        _lib.check(L.dil_polymul_host(_np(c), _np(a), _np(b), _batch(a)), "dil_polymul_host")
+    return c
+
+
 def pointwise_acc(c, acc, a, b):
     """c = acc + a o b : the RTL's MULT mode is a multiply-accumulate (butterfly.v:144-150)"""
     _lib.check(_lib.load().dil_pointwise_acc_dev(_dev(c, torch.int32), _dev(acc, torch.int32), _dev(a, torch.int32),

@@ -747,6 +747,52 @@ int host_binary(int32_t* out, const int32_t* a, const int32_t* b, size_t batch, 
     return 0;
 }
 
+// c = a * b from HOST operands (dil_polymul_host): the chain's four calls would cross the link four times (2 + 2 + 3 + 2 KiB per product);
+// here a and b go up once, the fused kernel runs, c comes down -- 2 KiB up, 1 KiB down per product, chunks round-robin over the streams.
+int host_polymul(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
+{
+    if (batch == 0) return 0;
+    DIL_ENTER(d, T);
+    std::lock_guard<std::mutex> lk(d.host_mu);
+    const size_t CH = host_chunk_polys();
+    if (batch <= CH / 2 || batch < 4096) {
+        const size_t bytes = batch * 1024;
+        const int rc = ensure_scratch(d, 2 * bytes);
+        if (rc) return rc;
+        int32_t* da = static_cast<int32_t*>(d.scratch);
+        int32_t* db = da + batch * 256;
+        DIL_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+        DIL_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+        DIL_TRY(dil::launch_polymul(da, da, db, batch, T, 0));
+        DIL_TRY(hipStreamSynchronize(nullptr));
+        DIL_TRY(hipMemcpy(c, da, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    const int NS = host_stream_count();
+    const size_t chunk = CH / 2;                                   // a | b of a chunk share one staging buffer of the transforms' size
+    int rc = ensure_pipe(d, 2 * chunk * 1024, NS);
+    if (rc) return rc;
+    dil::rt::HostPipe& hp = d.hp;
+    PinGuard pa(a, batch * 1024), pb(b, batch * 1024), pc(c == a || c == b ? nullptr : c, batch * 1024);
+    int err = 0;
+    size_t k = 0;
+    for (size_t off = 0; off < batch && !err; off += chunk, k++) {
+        const int s = (int)(k % NS);
+        const size_t n = std::min(chunk, batch - off);
+        int32_t* da = reinterpret_cast<int32_t*>(hp.dev[s]);
+        int32_t* db = da + n * 256;
+        err = (int)hipMemcpyAsync(da, a + off * 256, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
+        if (!err) err = (int)hipMemcpyAsync(db, b + off * 256, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
+        if (!err) err = (int)dil::launch_polymul(da, da, db, n, T, hp.stream[s]);
+        if (!err) err = (int)hipMemcpyAsync(c + off * 256, da, n * 1024, hipMemcpyDeviceToHost, hp.stream[s]);
+    }
+    for (int i = 0; i < NS; i++) {
+        const hipError_t e = hipStreamSynchronize(hp.stream[i]);
+        if (!err && e != hipSuccess) err = (int)e;
+    }
+    return err;
+}
+
 }  // namespace
 
 extern "C" {
@@ -878,6 +924,23 @@ int dil_pointwise_host(int32_t* c, const int32_t* a, const int32_t* b, size_t ba
     return host_binary(c, a, b, batch, [batch](int32_t* da, int32_t* db, const dil::Tables& t) {
         return dil::launch_pointwise(dil::OP_MUL, da, da, db, nullptr, batch, t, 0);
     });
+}
+
+// c = a * b in Z_q[x] / (x^256 + 1): the reference's polymul chain (ntt, ntt, pointwise_barrett, invntt; ntt2x2_test.cpp:109-137) fused
+int dil_polymul_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream)
+{
+    DIL_ENTER(d, T);
+    if (batch && (!c || !a || !b)) return (int)hipErrorInvalidValue;
+    return (int)dil::launch_polymul(c, a, b, batch, T, S(stream));
+}
+int dil_polymul_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
+{
+    if (batch && (!c || !a || !b)) return (int)hipErrorInvalidValue;
+    if (batch == 1) {
+        const int rc = mailbox_call(dil::MB_POLYMUL, 0, a, b, c);
+        if (rc != MB_FALLBACK) return rc;
+    }
+    return host_polymul(c, a, b, batch);
 }
 
 // ---- bram (hardware-model API) -----------------------------------------------------------------

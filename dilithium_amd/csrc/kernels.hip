@@ -202,6 +202,57 @@ __global__ __launch_bounds__(256) void pointwise_kernel(int32_t* c, const int32_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The reference's polynomial product chain in ONE kernel: c = invntt(ntt(a) o ntt(b)) = a * b in Z_q[x] / (x^256 + 1)
+// (ntt2x2_test.cpp:109-137 `polymul`: two forward transforms, the pointwise product, the inverse transform; ref_ntt.cpp:28-87).
+// One wavefront owns a pair: both operands are transformed side by side in registers (ntt_fwd_core2: one set of twiddle reads, two
+// dependency chains), the forward transform leaves a lane holding the four outputs the inverse transform wants in that lane, so
+// the pointwise product is lane-local; one Montgomery product per coefficient (a^ b^ 2^-32, |.| < q: what the Gentleman-Sande
+// sums need) and the "pipeline" flavour of the inverse table, whose final constant 2^32 / 256 cancels it.  HBM traffic per product:
+// 2 KiB in, 1 KiB out -- against 9 KiB for the four launches of the chain (2 + 2 + 3 + 2).  c may alias a or b.
+// Forward twiddles in registers (used twice per pair), inverse ones in LDS (8 KiB per workgroup, staged once).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * NTT_WPB) void polymul_kernel(int32_t* c, const int32_t* a, const int32_t* b, size_t batch,
+                                                               const uint32_t* __restrict__ fwd_tab, const uint32_t* __restrict__ inv_pipe_tab)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_inv[TW_TABLE_DWORDS];
+    for (int i = threadIdx.x; i < TW_TABLE_DWORDS / 4; i += blockDim.x)
+        reinterpret_cast<uint4*>(s_inv)[i] = reinterpret_cast<const uint4*>(inv_pipe_tab)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * NTT_WPB + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * NTT_WPB;
+    if (wave >= batch) return;
+    TwRegs twf;
+    const TwLds twi{s_inv, lane};
+    const LaneMasks lm(lane);
+    int32_t na[4], nb[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        na[m] = ld_s(a + wave * 256 + lane + 64 * m);
+        nb[m] = ld_s(b + wave * 256 + lane + 64 * m);
+    }
+    twf.load(fwd_tab, lane);
+    for (size_t p = wave; p < batch; p += nwaves) {
+        int32_t ra[4] = {na[0], na[1], na[2], na[3]}, rb[4] = {nb[0], nb[1], nb[2], nb[3]};
+        const size_t pn = p + nwaves;
+        if (pn < batch) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                na[m] = ld_s(a + pn * 256 + lane + 64 * m);
+                nb[m] = ld_s(b + pn * 256 + lane + 64 * m);
+            }
+        }
+        ntt_fwd_core2(ra, rb, twf, lm);
+        int32_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = mont_mul(ra[j], rb[j]);        // |ra|, |rb| < 9 q: |product| < 2^31 q
+        ntt_inv_core(r, twi, lm);
+#pragma unroll
+        for (int m = 0; m < 4; m++) st_s(c + p * 256 + lane + 64 * m, (int32_t)canon_small(r[m]));
+    }
+}
+
 // The transforms' memory traffic WITHOUT the arithmetic (bench.py `roofline.achievable`): the same persistent grid, the same
 // prefetch distance, the same instructions to memory -- forward: four strided 256-byte dword loads, one 1-KiB dwordx4 store per
 // wave and polynomial; inverse: mirrored -- so that the bench line carries, beside the 8 TB/s spec, what this access pattern
@@ -336,6 +387,19 @@ __global__ __launch_bounds__(64) void mailbox_kernel(Mailbox* mb, const uint32_t
             ntt_inv_core(r, twi, lm);
 #pragma unroll
             for (int m = 0; m < 4; m++) mb->out[br ? inv_out_off<LAYOUT_BRAM>(lane + 64 * m, mapping) : lane + 64 * m] = (int32_t)canon_small(r[m]);
+        } else if (op == MB_POLYMUL) {                    // out = invntt(ntt(in0) o ntt(in1)): the reference's whole polymul chain in one request
+            int32_t rb[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                r[m] = mb->in0[lane + 64 * m];
+                rb[m] = mb->in1[lane + 64 * m];
+            }
+            ntt_fwd_core2(r, rb, twf, lm);
+#pragma unroll
+            for (int j = 0; j < 4; j++) r[j] = mulmod_true(r[j], rb[j]);
+            ntt_inv_core(r, twi, lm);
+#pragma unroll
+            for (int m = 0; m < 4; m++) mb->out[lane + 64 * m] = (int32_t)canon_small(r[m]);
         } else {                                          // MB_PW_MUL: out = in0 o in1;  MB_BRAM_MUL: ram[map(l)] *= mul_ram[l] (ntt2x2_mul.cpp:33-59)
             const int row = op == MB_BRAM_MUL ? resolve_row(mapping, lane) : lane;
 #pragma unroll
@@ -416,6 +480,14 @@ hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t*
     case OP_SUB: hipLaunchKernelGGL(pointwise_kernel<OP_SUB>, grid, 256, 0, s, c, a, b, acc, nvec4); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_polymul(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, const Tables& t, hipStream_t s)
+{
+    if (batch == 0) return hipSuccess;
+    const int grid = grid_for((batch + NTT_WPB - 1) / NTT_WPB, t.num_cus * t.ntt_blocks_per_cu * 4 / NTT_WPB);
+    hipLaunchKernelGGL(polymul_kernel, grid, 64 * NTT_WPB, 0, s, c, a, b, batch, t.fwd, t.inv_pipe);
     return hipGetLastError();
 }
 

@@ -50,7 +50,7 @@ hipError_t launch_ntt_traffic(bool inverse, int32_t* polys, size_t batch, const 
 // launch, no hipMemcpy, no stream synchronisation on the path: ~5 us a call (profiles/r04*_mailbox.txt).  The wave retires after
 // `idle_ticks` without a request (a resident kernel would otherwise hold hipDeviceSynchronize() forever) and is relaunched by the
 // next call; `state` closes the race between "retiring" and "a request just arrived" (capi.hip mailbox_call).
-enum { MB_FWD = 0, MB_INV = 1, MB_PW_MUL = 2, MB_BRAM_FWD = 3, MB_BRAM_INV = 4, MB_BRAM_MUL = 5, MB_QUIT = 6 };
+enum { MB_FWD = 0, MB_INV = 1, MB_PW_MUL = 2, MB_BRAM_FWD = 3, MB_BRAM_INV = 4, MB_BRAM_MUL = 5, MB_QUIT = 6, MB_POLYMUL = 7 };
 enum { MB_DEAD = 0, MB_ALIVE = 1, MB_EXITING = 2 };
 // The request header is ONE 32-bit word -- sequence number << 8 | op << 2 | mapping -- so that the wave's poll can never see a new
 // sequence number with the previous request's operation (a 16-byte PCIe read is not guaranteed to be untorn against the host's stores).
@@ -68,6 +68,7 @@ hipError_t launch_mailbox(Mailbox* mb_dev, uint32_t last_done, uint64_t idle_tic
 hipError_t launch_pointwise(int op, int32_t* c, const int32_t* a, const int32_t* b, const int32_t* acc, size_t batch,
                             const Tables& t, hipStream_t s);
 hipError_t launch_bram_mul(int32_t* ram, const int32_t* mul_ram, size_t batch, int mapping, const Tables& t, hipStream_t s);
+hipError_t launch_polymul(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, const Tables& t, hipStream_t s);   // c = invntt(ntt(a) o ntt(b)), fused
 // Optional key indirection of the per-item-key pipelines (the signing loop's speculative entries): entry `it` uses the
 // key material of row idx[(base + it) / S] (idx == nullptr: that row number itself).  Default = identity.
 constexpr int TICKET_PARTS = 64, TICKET_STRIDE = 32, TICKET_WORDS = TICKET_PARTS * TICKET_STRIDE;

@@ -42,6 +42,8 @@ SIGNATURES = {
     "dil_poly_add_dev": [_vp, _vp, _vp, _sz, _vp],
     "dil_poly_sub_dev": [_vp, _vp, _vp, _sz, _vp],
     "dil_pointwise_host": [_i32p, _i32p, _i32p, _sz],
+    "dil_polymul_dev": [_vp, _vp, _vp, _sz, _vp],
+    "dil_polymul_host": [_i32p, _i32p, _i32p, _sz],
     "dil_bram_fwdntt_dev": [_vp, _sz, C.c_int, _vp],
     "dil_bram_invntt_dev": [_vp, _sz, C.c_int, _vp],
     "dil_bram_mul_dev": [_vp, _vp, _sz, C.c_int, _vp],

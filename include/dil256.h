@@ -113,6 +113,16 @@ int dil_poly_add_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batc
 int dil_poly_sub_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream);
 int dil_pointwise_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batch);
 
+/* ---- the polynomial product chain in one call ------------------------------------------------
+ * c = a * b in Z_q[x] / (x^256 + 1) = invntt(pointwise_barrett(ntt(a), ntt(b))): what the reference's callers spell as four calls
+ * (hardware_code/ntt2x2_test.cpp:109-137 `polymul`; reference_code/ref_ntt.cpp:28-87), as ONE fused kernel -- both forward transforms, the
+ * product and the inverse transform of a pair in one wavefront's registers: 2 KiB read + 1 KiB written per product instead of 9 KiB over
+ * four launches.  [batch][256] each, coefficients in natural order, canonical outputs; c may alias a or b; |a|, |b| < 2^26 (the
+ * reference's (-q, q) is far inside).  The _host form is the one call that is worth a PCIe round trip for a source-compatible user:
+ * a and b go up once, c comes down (batch 1: one mailbox request instead of four). */
+int dil_polymul_dev(int32_t* c, const int32_t* a, const int32_t* b, size_t batch, void* stream);
+int dil_polymul_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batch);
+
 /* ---- H6: the hardware-model API on `bram` ([batch][64][4]) -----------------------------
  * `mapping` is the model's address translation (address_encoder_decoder.cpp:34-55).
  * fwd: NATURAL in -> AFTER_NTT out (ntt2x2_fwdntt.cpp:32-157, ntt2x2_test.cpp:41-58)

@@ -268,3 +268,91 @@ def test_host_pointer_entry_points(gpu, oracle):
     r = a.copy()
     api.ntt2x2_fwdntt(r, NATURAL)
     assert (r == oracle.bram_fwdntt(a, NATURAL)).all()
+
+
+def _negacyclic_schoolbook(a, b):
+    """a * b mod (x^256 + 1, q) by the definition, for a handful of rows (int64 exact: 256 products < 2^46 each)"""
+    a, b = a.astype(np.int64) % Q, b.astype(np.int64) % Q
+    out = np.zeros_like(a)
+    for i in range(N):
+        prod = (a[:, i:i + 1] * b) % Q                       # x^i a_i * b
+        out[:, i:] += prod[:, :N - i]
+        out[:, :i] -= prod[:, N - i:]
+    return np.mod(out, Q).astype(np.int32)
+
+
+def test_polymul_fused_vs_oracle_chain_and_the_definition(gpu, oracle):
+    """dil_polymul_dev == the reference's chain ntt, ntt, pointwise_barrett, invntt (ntt2x2_test.cpp:109-137) on 20000 + edge pairs, every
+    coefficient; == the negacyclic product by its definition on 40 rows; aliasing c = a and c = b; operands in (-q, q) as the reference's"""
+    from dilithium_amd import api
+    edge = [np.zeros(N), np.full(N, Q - 1), np.full(N, -(Q - 1)), np.full(N, 1), np.arange(N), np.full(N, (Q - 1) // 2)]
+    for idx in (0, 1, 255):
+        e = np.zeros(N)
+        e[idx] = 1
+        edge.append(e)
+    a = np.concatenate([np.array(edge, dtype=np.int32), splitmix64_polys(20000, seed=61), splitmix64_polys(500, seed=62, lo=-(Q - 1), hi=Q)])
+    b = np.concatenate([splitmix64_polys(len(edge), seed=63), splitmix64_polys(20000, seed=64), splitmix64_polys(500, seed=65, lo=-(Q - 1), hi=Q)])
+    b[:len(edge)][3] = Q - 1
+    want = oracle.invntt(oracle.pointwise(oracle.ntt(a), oracle.ntt(b)))
+    ta, tb = dev(gpu, a), dev(gpu, b)
+    tc = gpu.empty_like(ta)
+    api.polymul(tc, ta, tb)
+    got = host(tc)
+    assert (got == want).all()
+    assert (host(ta) == a).all() and (host(tb) == b).all()                 # operands untouched
+    rows = np.r_[0:len(edge), 1000:1020, 20300:20311]
+    assert (got[rows] == _negacyclic_schoolbook(a[rows], b[rows])).all()
+    api.polymul(ta, ta, tb)                                                # c aliases a
+    assert (host(ta) == want).all()
+    ta = dev(gpu, a)
+    api.polymul(tb, ta, tb)                                                # c aliases b
+    assert (host(tb) == want).all()
+    # the unfused chain through the separate entry points agrees too
+    xa, xb = dev(gpu, a), dev(gpu, b)
+    api.ntt(xa)
+    api.ntt(xb)
+    api.pointwise_barrett(xa, xa, xb)
+    api.invntt(xa)
+    assert (host(xa) == want).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 77, 4095, 4096, 9000, 20011])
+def test_polymul_host_one_round_trip(gpu, oracle, n):
+    """dil_polymul_host: host arrays in, host array out (one-shot below 4096 pairs, chunked over the streams above; batch 1 through the
+    mailbox when it is on) == the oracle chain"""
+    from dilithium_amd import api
+    a, b = splitmix64_polys(n, seed=70 + n), splitmix64_polys(n, seed=71 + n, lo=-(Q - 1), hi=Q)
+    want = oracle.invntt(oracle.pointwise(oracle.ntt(a), oracle.ntt(b)))
+    c = np.empty_like(a)
+    api.polymul(c, a, b)
+    assert (c == want).all()
+    x = a.copy()
+    api.polymul(x, x, b)                                                   # in place
+    assert (x == want).all()
+    if n == 1:
+        saved = api.get_option("host_mailbox")
+        try:
+            api.set_option("host_mailbox", 1)
+            for rep in range(50):                                          # the resident wave serves the whole chain as one request
+                c2 = np.empty_like(a)
+                api.polymul(c2, a, b)
+                assert (c2 == want).all()
+        finally:
+            api.set_option("host_mailbox", saved)
+
+
+def test_polymul_host_chunk_and_stream_options(gpu, oracle):
+    from dilithium_amd import api
+    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin")}
+    try:
+        a, b = splitmix64_polys(5000, seed=81), splitmix64_polys(5000, seed=82)
+        want = oracle.invntt(oracle.pointwise(oracle.ntt(a), oracle.ntt(b)))
+        for chunk, streams, pin in ((128, 1, 0), (600, 3, 1), (1000, 8, 0), (8192, 4, 0)):
+            for k, v in (("host_chunk", chunk), ("host_streams", streams), ("host_pin", pin)):
+                api.set_option(k, v)
+            c = np.empty_like(a)
+            api.polymul(c, a, b)
+            assert (c == want).all(), (chunk, streams, pin)
+    finally:
+        for k, v in saved.items():
+            api.set_option(k, v)
