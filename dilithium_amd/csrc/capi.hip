@@ -56,6 +56,7 @@ const OptName* option_table(int* n)
         {"fuse_challenge", "DIL_FUSE_CHALLENGE", &cfg.fuse_challenge},
         {"a24", "DIL_A24", &cfg.a24},
         {"fuse_keygen", "DIL_FUSE_KEYGEN", &cfg.fuse_keygen},
+        {"fuse_sib", "DIL_FUSE_SIB", &cfg.fuse_sib},
         {"two_lane_max_sponges", "DIL_TWO_LANE_MAX", &dil::two_lane_max_sponges},
         {"coop_max", "DIL_COOP_MAX", &dil::coop_max_sponges},
     };

@@ -37,6 +37,8 @@ struct Config {
     std::atomic<int> aux_overlap{1};       // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream
     std::atomic<int> zeroize{0};           // DIL_ZEROIZE: 1 = signing / keygen clear their device scratch before returning
     std::atomic<int> fuse_wire{1};         // DIL_FUSE_WIRE: 0 = wire-format verify runs the unfused (codec + core) sequence
+    std::atomic<int> fuse_sib{1};          // DIL_FUSE_SIB: wire-format verification with a key per item samples c inside the fused kernel (bit 0: when A is already expanded --
+                                           // dil_verify_wire_core_dev, dil_verify_sig_expanded_dev; bit 1: beside ExpandA in dil_verify_sig_dev too); 0: sample_in_ball_bits_kernel in front
     std::atomic<int> fuse_keygen{1};       // DIL_FUSE_KEYGEN: 0 = keygen's mat-vec, Power2Round and t1 / t0 packing as separate kernels
     std::atomic<int> a24{1};               // DIL_A24: 0 = the composite calls keep per-item matrices as int32 in HBM (1: 24-bit packed)
     std::atomic<int> fuse_challenge{1};    // DIL_FUSE_CHALLENGE: 1 = the signing loop hashes c~ and samples c in ONE launch (0: challenge hash, then SampleInBall)

@@ -82,7 +82,23 @@ struct SibShared {
     int32_t c[256];
 };
 
+// the points where the wave's LDS writes must be visible to its own reads: a workgroup of ONE wave uses the barrier (the stand-alone
+// kernels); a wave inside a larger workgroup (verify_wire_wpi_kernel's fused SampleInBall) only orders its own accesses -- a wave's
+// LDS instructions execute in order, the fences keep the compiler from moving them
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void sib_sync()
+{
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // sp: the SHAKE256(c~) sponge after its first squeeze permutation.  On return sh.c holds c (+1 / -1 / 0), visible to the wave.
+template <bool WAVE_LOCAL = false>
 __device__ __forceinline__ void sib_sample(Sponge<17>& sp, int tau, SibShared& sh, int lane)
 {
     const int i0 = 256 - tau;
@@ -92,7 +108,7 @@ __device__ __forceinline__ void sib_sample(Sponge<17>& sp, int tau, SibShared& s
     reinterpret_cast<int4*>(sh.c)[lane] = make_int4(0, 0, 0, 0);
     for (;;) {
         if (sp.rate_lane) sh.blk[sp.k.dword] = sp.v;
-        __syncthreads();
+        sib_sync<WAVE_LOCAL>();
         if (first) {
             s_lo = sh.blk[0];
             s_hi = sh.blk[1];
@@ -113,11 +129,11 @@ __device__ __forceinline__ void sib_sample(Sponge<17>& sp, int tau, SibShared& s
             i_next += __popcll(mask);
         }
         if (i_next >= 256) break;
-        __syncthreads();                       // the block has been read
+        sib_sync<WAVE_LOCAL>();                       // the block has been read
         sp.permute();
         start = 0;
     }
-    __syncthreads();
+    sib_sync<WAVE_LOCAL>();
     const uint32_t tb = sh.tokb[lane < tau ? lane : 0];
     uint32_t pos = tb;
 #pragma unroll 1
@@ -132,7 +148,7 @@ __device__ __forceinline__ void sib_sample(Sponge<17>& sp, int tau, SibShared& s
         const uint32_t sign = ((lane < 32 ? s_lo >> lane : s_hi >> (lane - 32)) & 1u);
         sh.c[pos] = sign ? -1 : 1;
     }
-    __syncthreads();
+    sib_sync<WAVE_LOCAL>();
 }
 
 // c~ (32 bytes, any alignment) -> the SampleInBall sponge after its first permutation

@@ -34,17 +34,17 @@ template <int LEVEL>
 struct Par;
 template <>
 struct Par<2> {
-    static constexpr int K = 4, L = 4, OMEGA = 80, BETA = 78;
+    static constexpr int K = 4, L = 4, OMEGA = 80, BETA = 78, TAU = 39;
     static constexpr int32_t GAMMA1 = 1 << 17, GAMMA2 = (Q - 1) / 88;
 };
 template <>
 struct Par<3> {
-    static constexpr int K = 6, L = 5, OMEGA = 55, BETA = 196;
+    static constexpr int K = 6, L = 5, OMEGA = 55, BETA = 196, TAU = 49;
     static constexpr int32_t GAMMA1 = 1 << 19, GAMMA2 = (Q - 1) / 32;
 };
 template <>
 struct Par<5> {
-    static constexpr int K = 8, L = 7, OMEGA = 75, BETA = 120;
+    static constexpr int K = 8, L = 7, OMEGA = 75, BETA = 120, TAU = 60;
     static constexpr int32_t GAMMA1 = 1 << 19, GAMMA2 = (Q - 1) / 32;
 };
 

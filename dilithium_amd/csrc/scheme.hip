@@ -477,9 +477,11 @@ int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t
     if (!A) return (int)hipErrorInvalidValue;
     hipStream_t s = S(stream);
     StreamScratch ws(dv, s);
+    const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
+    if (!shared_pk && (dil::rt::cfg.fuse_sib.load(std::memory_order_relaxed) & 1))      // c sampled inside the kernel: one launch, no compact c through HBM
+        return ws.close((int)dil::launch_verify_wire(level, w1_packed, verdict, A, pk, pkb, sig, sgb, nullptr, batch, 0, T, s));
     uint32_t* cbits = ws.take<uint32_t>(batch * 64);
     if (ws.rc) return ws.rc;
-    const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
     DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
     return ws.close((int)dil::launch_verify_wire(level, w1_packed, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s));
 }
@@ -510,9 +512,11 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         uint32_t* cbits = ws.take<uint32_t>(batch * 64);
         uint8_t* w1p = ws.take<uint8_t>(batch * w1b);
         if (ws.rc) return ws.rc;
-        if (A_ready) {               // the matrix is already there: SampleInBall, the fused kernel, the challenge hash
-            DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
-            DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, cbits, batch, shared_pk, T, s, dil::A_I32, t1hat_ready));
+        const int fuse_sib = dil::rt::cfg.fuse_sib.load(std::memory_order_relaxed);
+        if (A_ready) {               // the matrix is already there: SampleInBall (inside the fused kernel where that form exists), the fused kernel, the challenge hash
+            const bool sib_inside = (fuse_sib & 1) && !shared_pk && !t1hat_ready;
+            if (!sib_inside) DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
+            DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, sib_inside ? nullptr : cbits, batch, shared_pk, T, s, dil::A_I32, t1hat_ready));
             return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
         }
         // Two independent Keccak jobs: ExpandA (nk * K * L sponges) and SampleInBall (batch sponges, one lane each).
@@ -538,6 +542,11 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         //  63.1 us and ExpandA's 48-byte pieces cost 8 us more than its 64-byte ones; profiles/r02_a24.txt.  The format
         //  parameter stays for A/B runs: option a24 = 2 forces the packed form here too.)
         const int a_fmt = (!shared_pk && dil::rt::cfg.a24.load(std::memory_order_relaxed) == 2) ? matrix_format(nk, p.K, p.L) : dil::A_I32;
+        if ((fuse_sib & 2) && !shared_pk && a_fmt == dil::A_I32) {      // c inside the fused kernel: ExpandA alone in front, no helper stream
+            DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, s, a_fmt));
+            DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, nullptr, batch, 0, T, s, a_fmt));
+            return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
+        }
         hipStream_t sa = a_sponges <= batch ? ax.fork(a_sponges) : s;
         hipStream_t sc = a_sponges <= batch ? s : ax.fork(batch);
         DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, sa, a_fmt));

@@ -38,7 +38,12 @@ template <> struct WireSh<5> { static constexpr int NW = 12; static constexpr bo
 // T1H: the caller keeps t1^ = NTT(t1 2^13) of every key beside its matrix (dil_expand_t1_dev: VY_NTT_T1 of combined_top.v:1259-1313 done
 // once per key instead of once per verification): the K transforms of t1 leave the kernel -- L + 1 forward and K inverse remain --
 // for 6 KiB of int32 per key in place of 1.9 KiB of packed t1.
-template <int LEVEL, int AF, bool T1H = false>
+// SIB (round 6): c = SampleInBall(c~) is computed INSIDE the item loop by the wave that owns the item -- one SHAKE256 state over the wavefront
+// (keccak_coop.hpp: 29 VALU instructions per round) and the ballot sampler of coop_bodies.hpp, working in the wave's z^ area of LDS before
+// the forward transforms fill it -- instead of a sample_in_ball_bits_kernel launch in front (24-32 us per 8192, serial) and 256 B of
+// compact c per item through HBM.  The reference feeds c straight from the sampler into the transform too (gen_c.v:163-196,318-339 ->
+// VY_NTT_C, combined_top.v:1314).  cbits == nullptr selects it at run time (same template otherwise).
+template <int LEVEL, int AF, bool T1H = false, bool SIB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVES(LEVEL), DIL_WW_WAVES(LEVEL)))) void verify_wire_wpi_kernel(
     uint8_t* __restrict__ w1p_out, int32_t* __restrict__ verdict, const int32_t* __restrict__ A,
     const uint8_t* __restrict__ pk, size_t pk_stride, const uint8_t* __restrict__ sig, size_t sig_stride,
@@ -67,10 +72,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
     size_t it = (size_t)blockIdx.x * 4 + wv;
     RawZ<LEVEL> zr;
     uint32_t cb = 0, hb0 = 0, hb1 = 0;
+    coop::Sponge<17> sp;
+    if constexpr (SIB) sp.init(lane);
+    static_assert(sizeof(coop::SibShared) <= (size_t)L * 1024, "SampleInBall works in the wave's z^ area");
     auto load_item = [&](size_t i) {
         const uint8_t* sg = sig + i * sig_stride;
         zr.load(sg + 32, plz);
-        cb = cbits[i * 64 + lane];
+        if constexpr (SIB) {                                   // this lane's dword of c~ in the sponge's own lane order (dwords 0..7 of the state)
+            const int d = sp.k.dword;
+            cb = (d >= 0 && d < 8) ? coop::ld_u32u(sg + 4 * d) : 0u;
+        } else {
+            cb = cbits[i * 64 + lane];
+        }
         hb0 = (lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + lane] : 0;          // (61 hint bytes at level 3: never read past the signature)
         hb1 = (64 + lane < W::HINT_BYTES) ? sg[32 + W::Z_BYTES + 64 + lane] : 0;
     };
@@ -96,7 +109,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
         const bool bad = hints_to_bitmap<LEVEL>(bm, sc, hb0, hb1, lane);
         int32_t zmax = 0;
         int32_t ch[4];
-        decode_c(ch, cb);
+        if constexpr (SIB) {
+            coop::SibShared& sh = *reinterpret_cast<coop::SibShared*>(zl);     // (free until the forward transforms below store z^)
+            sp.v = cb;
+            sp.pad(4);
+            sp.permute();
+            coop::sib_sample<true>(sp, Par<LEVEL>::TAU, sh, lane);
+#pragma unroll
+            for (int m = 0; m < 4; m++) ch[m] = sh.c[lane + 64 * m];
+            coop::sib_sync<true>();                                            // ... read before z^ overwrites it
+        } else {
+            decode_c(ch, cb);
+        }
         if constexpr (DUAL) {
         // the L + 1 forward transforms two at a time (ntt_core.hpp ntt_fwd_core2: one set of twiddle reads, two dependency chains)
 #pragma unroll
@@ -501,6 +525,7 @@ static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const
                                            const Tables& t, hipStream_t s, int a_fmt, const int32_t* t1hat)
 {
     if (shared_pk && a_fmt != A_I32) return hipErrorInvalidValue;
+    if (!cbits && (shared_pk || t1hat || a_fmt != A_I32)) return hipErrorInvalidValue;      // the fused SampleInBall exists in the plain a-key-per-item form only
     if (t1hat && !shared_pk) {                    // keys whose t1^ the caller keeps beside A (a key per item; int32 A only)
         if (a_fmt != A_I32) return hipErrorInvalidValue;
         const int g = grid_for((batch + 3) / 4,
@@ -521,6 +546,12 @@ static hipError_t launch_verify_wire_level(uint8_t* w1p, int32_t* verdict, const
                                t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_P24>, 256, t.wpi_blocks_per_cu, t.device));
         note_launch("verify_wire_wpi", g, 4, batch);
         hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_P24>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
+                           t.fwd, t.inv_pipe, nullptr);
+    } else if (!cbits) {                          // SampleInBall inside the kernel
+        const int g = grid_for((batch + 3) / 4,
+                               t.num_cus * resident_blocks_per_cu(verify_wire_wpi_kernel<LEVEL, A_I32, false, true>, 256, t.wpi_blocks_per_cu, t.device));
+        note_launch("verify_wire_wpi", g, 4, batch);
+        hipLaunchKernelGGL((verify_wire_wpi_kernel<LEVEL, A_I32, false, true>), g, 256, 0, s, w1p, verdict, A, pk, pk_stride, sig, sig_stride, cbits, batch,
                            t.fwd, t.inv_pipe, nullptr);
     } else {
         const int g = grid_for((batch + 3) / 4,

@@ -70,6 +70,11 @@ int dil_shutdown(void);
  *                                   signatures is int32 [K][L][256]
  *   "fuse_keygen" (DIL_FUSE_KEYGEN) 1 (default) = large key-generation batches run t = A s1 + s2, Power2Round and the packing of
  *                                   t1 into pk / t0 into sk as ONE kernel; 0 = mat-vec, power2round and pack kernels
+ *   "fuse_sib"    (DIL_FUSE_SIB)    wire-format verification with a key per signature: c = SampleInBall(c~) is sampled INSIDE the fused
+ *                                   verify kernel by the wave that owns the signature (one SHAKE256 state over the wavefront) instead of a
+ *                                   sampling launch in front.  bit 0 (default on) = where the matrix is already expanded
+ *                                   (dil_verify_wire_core_dev, dil_verify_sig_expanded_dev), bit 1 = in dil_verify_sig_dev too (there the
+ *                                   sampler otherwise runs beside ExpandA on the helper stream).  Verdicts and w1 do not depend on it.
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it

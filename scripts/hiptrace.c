@@ -17,7 +17,7 @@
 #include <time.h>
 #include <unistd.h>
 
-#define RING 16384
+#define RING (1 << 20)      /* 64 MiB of records: the whole life of a test-suite process */
 typedef struct { uint64_t t_ns; const char* what; const void *a, *b; size_t n; const void* stream; int tid, rc; } Rec;
 static Rec ring[RING];
 static volatile uint64_t head;
@@ -79,6 +79,32 @@ int hipDeviceSynchronize(void) { REAL(hipDeviceSynchronize); Rec* r = put("hipDe
 int hipStreamDestroy(void* st) { REAL(hipStreamDestroy); Rec* r = put("hipStreamDestroy", 0, 0, 0, st); return r->rc = real(st); }
 int hipStreamCreateWithFlags(void** st, unsigned f) { REAL(hipStreamCreateWithFlags); int rc = real(st, f); Rec* r = put("hipStreamCreateWithFlags", 0, 0, f, st ? *st : 0); return r->rc = rc; }
 
+/* the thunk marks every host range it registers with the driver (a runtime-internal pin of a pageable copy, or hipHostRegister) MADV_DONTFORK and
+ * gives it back with MADV_DOFORK: these two calls ARE the life of a userptr registration, page-aligned range included */
+int madvise(void* addr, size_t len, int advice)
+{
+    static int (*real_madvise)(void*, size_t, int);
+    if (!real_madvise) real_madvise = (int (*)(void*, size_t, int))dlsym(RTLD_NEXT, "madvise");
+    if (advice == 10 || advice == 11) { Rec* r = put(advice == 10 ? "madvise DONTFORK" : "madvise DOFORK", addr, 0, len, 0); return r->rc = real_madvise(addr, len, advice); }
+    return real_madvise(addr, len, advice);
+}
+pid_t fork(void)
+{
+    static pid_t (*real_fork)(void);
+    if (!real_fork) real_fork = (pid_t (*)(void))dlsym(RTLD_NEXT, "fork");
+    Rec* r = put("fork", 0, 0, 0, 0);
+    const pid_t p = real_fork();
+    if (p != 0) r->rc = (int)p;
+    return p;
+}
+
+static int in_heap(const void* p, const uintptr_t (*heaps)[2], int nheaps)
+{
+    for (int i = 0; i < nheaps; i++)
+        if ((uintptr_t)p >= heaps[i][0] && (uintptr_t)p < heaps[i][1]) return 1;
+    return 0;
+}
+
 static void dump(int sig, siginfo_t* si)
 {
     const char* dir = getenv("HIPTRACE_OUT");
@@ -94,11 +120,26 @@ static void dump(int sig, siginfo_t* si)
     backtrace_symbols_fd(bt, n, fileno(f));
     fprintf(f, "---- /proc/self/maps ----\n");
     FILE* m = fopen("/proc/self/maps", "r");
-    if (m) { char ln[512]; while (fgets(ln, sizeof ln, m)) fputs(ln, f); fclose(m); }
+    static uintptr_t heaps[256][2];
+    int nheaps = 0;
+    if (m) {
+        char ln[512];
+        while (fgets(ln, sizeof ln, m)) {
+            fputs(ln, f);
+            unsigned long lo_, hi_;
+            if (strstr(ln, "[heap]") && nheaps < 256 && sscanf(ln, "%lx-%lx", &lo_, &hi_) == 2) { heaps[nheaps][0] = lo_; heaps[nheaps][1] = hi_; nheaps++; }
+        }
+        fclose(m);
+    }
     uint64_t h = head, lo = h > RING ? h - RING : 0;
-    fprintf(f, "---- last %llu of %llu HIP calls (t [s], tid, call, a, b, n, stream, rc) ----\n", (unsigned long long)(h - lo), (unsigned long long)h);
+    fprintf(f, "---- of the last %llu of %llu calls: every one that touches the [heap], every registration / madvise / fork / stream event, and the last 3000 of any kind "
+               "(t [s], tid, call, a, b, n, stream, rc) ----\n", (unsigned long long)(h - lo), (unsigned long long)h);
     for (uint64_t i = lo; i < h; i++) {
         Rec* r = &ring[i % RING];
+        const int keep = i + 3000 >= h || in_heap(r->a, heaps, nheaps) || in_heap(r->b, heaps, nheaps) ||
+                         (r->what && (strstr(r->what, "Register") || strstr(r->what, "madvise") || strstr(r->what, "fork") || strstr(r->what, "hipStreamCreate") ||
+                                      strstr(r->what, "hipStreamDestroy") || strstr(r->what, "Host")));
+        if (!keep) continue;
         Dl_info di;
         const char* sym = "";
         if (r->what && !strcmp(r->what, "hipLaunchKernel") && dladdr(r->a, &di) && di.dli_sname) sym = di.dli_sname;

@@ -66,6 +66,29 @@ def test_verify_wire_core_distinct_vs_oracle(gpu, oracle, level, n):
 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
+def test_verify_wire_core_sample_in_ball_inside_vs_in_front(gpu, oracle, level):
+    """option fuse_sib: c = SampleInBall(c~) sampled inside verify_wire_wpi_kernel (one SHAKE256 state per wavefront, the sampler working in the
+    wave's z^ area of LDS) against the sampling launch in front -- 4200 items (more than the 3072 resident waves: waves re-enter their item loop), every packed w1 byte
+    and verdict bit identical to each other and to the oracle; then the byte-level entry points under bit 1 of the option"""
+    from dilithium_amd import api
+    n = 4200
+    A, pk, sig, f = synth_wire(level, n, 500 + level, zmax_items=[0, 7, 4199])
+    dA, dpk, dsig = cu(gpu, A), cu(gpu, pk), cu(gpu, sig)
+    saved = api.get_option("fuse_sib")
+    try:
+        out = {}
+        for mode in (0, 1):
+            api.set_option("fuse_sib", mode)
+            w1p, v = api.verify_wire_core(dA, dpk, dsig, level)
+            out[mode] = (w1p.cpu().numpy(), v.cpu().numpy())
+        assert (out[0][0] == out[1][0]).all() and (out[0][1] == out[1][1]).all()
+    finally:
+        api.set_option("fuse_sib", saved)
+    ew1p, ev = expected(oracle, level, A, f, False)
+    assert (out[1][1] == ev).all() and (out[1][0] == ew1p).all()
+
+
+@pytest.mark.parametrize("level", [2, 3, 5])
 @pytest.mark.parametrize("n", [1, 53, 4099])
 def test_verify_wire_core_shared_vs_oracle(gpu, oracle, level, n):
     """verify_wire_shared_kernel<LEVEL, NW>: one pk (A, t1^ LDS-resident), ragged batch"""
