@@ -314,27 +314,33 @@ def system_clocks():
     return out
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), if any"""
+def _pmc_summary(family):
+    """profiles/pmc_summary.json if its stamps (git blob ids of the sources the kernel family is compiled from, written by
+    scripts/pmc_summary.py) still match the tree; None otherwise -- a committed counter figure must not outlive the kernel it was measured on"""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if not os.path.exists(p):
-        return None
     try:
-        return json.load(open(p)).get(kernel_key, {}).get("hbm_bytes_per_launch")
+        d = json.load(open(p))
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from pmc_summary import source_stamps
+        return d if d.get("_source_blobs", {}).get(family) == source_stamps()[family] else None
     except Exception:
         return None
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), if there is one measured on these kernel sources"""
+    d = _pmc_summary("ntt" if kernel_key.startswith("ntt") else "verify")
+    return d.get(kernel_key, {}).get("hbm_bytes_per_launch") if d else None
 
 
 def pmc_sign_valu():
-    """VALU instructions per level-5 sign attempt (phase 1, phase 2) from the committed SQ_INSTS_VALU passes, if any"""
-    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    """VALU instructions per level-5 sign attempt (phase 1, phase 2) from the committed SQ_INSTS_VALU passes, if any (and not stale)"""
+    d = _pmc_summary("sign")
     try:
-        v = json.load(open(p)).get("sign_valu_insts_per_attempt")
+        v = d.get("sign_valu_insts_per_attempt") if d else None
         return {"phase1": float(v["phase1"]), "phase2": float(v["phase2"])} if v else None
     except Exception:
         return None
-
-
 
 
 class Bench:

@@ -443,12 +443,8 @@ __device__ __forceinline__ void emit_matvec_row(int32_t* __restrict__ w_out, uin
 template <bool NT = true>
 __device__ __forceinline__ void load_strided(int32_t (&r)[4], const int32_t* __restrict__ a, int lane)
 {
-#ifdef DIL_LOAD_STRIDED_HOOK       // variant builds only (variants.hpp)
-    DIL_LOAD_STRIDED_HOOK(r, a, lane);
-#else
 #pragma unroll
     for (int m = 0; m < 4; m++) r[m] = NT ? ld_nt(a + lane + 64 * m) : a[lane + 64 * m];
-#endif
 }
 
 template <int L, int FMT = A_I32>
@@ -460,9 +456,6 @@ struct ARow<L, A_I32> {
     // stream = true: this row is read once (per-item A): non-temporal; false: shared A, keep it cached
     __device__ __forceinline__ void load(const int32_t* __restrict__ Arow, int lane, bool stream)
     {
-#ifdef DIL_AROW_STREAM_HOOK        // variant builds only (variants.hpp)
-        stream = DIL_AROW_STREAM_HOOK(stream);
-#endif
         if (stream) {
 #pragma unroll
             for (int l = 0; l < L; l++) v[l] = ld_nt4(Arow + l * 256 + 4 * lane);

@@ -452,15 +452,6 @@ __global__ __launch_bounds__(256) void keygen_wpi_kernel(
     }
 }
 
-// Hook points of the A/B builds (csrc/variants.hpp through scripts/build_variant.py -DDIL_VARIANT_BUILD ...): the shipped
-// build compiles exactly these defaults.
-#ifndef VW_FWD
-#define VW_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
-#define VW_INV(r, tw, x) ntt_inv_core(r, tw, x)
-#endif
-#ifndef VW_ALOAD
-#define VW_ALOAD(Ar, p, lane, st) Ar.load(p, lane, st)
-#endif
 // waves per SIMD the register allocator aims for: 4 at level 2 (118 VGPRs), 3 at levels 3 / 5 (138 / 168 VGPRs; forcing 4
 // there was measured slower in both rounds -- the HBM stream is throughput-limited, more waves only add pressure)
 #define DIL_VW_WAVES(LEVEL) ((LEVEL) == 2 ? 4 : 3)
@@ -502,7 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
         const uint8_t* hit = h + it * K * 256;
         // row 0 operands fly under the z-phase
         ARow<L> Ar;
-        VW_ALOAD(Ar, Ait, lane, true);
+        Ar.load(Ait, lane, true);
         int32_t tn[4];
         uint32_t hn;
         load_strided<false>(tn, t1it, lane);
@@ -521,7 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
 #pragma unroll
         for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;   // decoder.v:96-100
         load_strided<false>(tn, t1it + 256, lane);
-        VW_FWD(th, twf, lm);
+        ntt_fwd_core(th, twf, lm);
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
             mac_row<L>(acc, Ar, zl, lane);
@@ -531,7 +522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
             for (int m = 0; m < 4; m++) acc[m] -= (int64_t)ch[m] * th[m];
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             if (k + 1 < K) {
-                VW_ALOAD(Ar, Ait + (size_t)(k + 1) * L * 256, lane, true);
+                Ar.load(Ait + (size_t)(k + 1) * L * 256, lane, true);
                 hn = load_row_u8(hit + (k + 1) * 256, lane);
 #pragma unroll
                 for (int m = 0; m < 4; m++) th[m] = (tn[m] & 0x3FF) << 13;
@@ -540,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_VW_WAVE
                 ntt_fwd_inv_pair(th, r, twf, twi, lm);
             } else {
                 DIL_SCHED_FENCE();
-                VW_INV(r, twi, lm);
+                ntt_inv_core(r, twi, lm);
             }
             DIL_SCHED_FENCE();
             const size_t o = (it * K + k) * 256;
@@ -934,30 +925,12 @@ __device__ __forceinline__ void mac_row_lds(int64_t (&acc)[4], const uint32_t* a
 // LDS slice -- that slice (L KiB per wave) was what capped the workgroup at 12 waves = 3 per SIMD at level 5, and three waves per
 // SIMD issue no more than two (scripts/tune_xchg.hip, profiles/r03c_tune_xchg.txt: 785 / 785 / 689 cycles per transform at 2 / 3 /
 // 4 waves).  Now 16 waves = 4 per SIMD at every level, no ds_write of y^ and half the ds_read_b128 of the multiply-accumulate.
-#define MVS_XB xb
-#ifndef MVS_FWD         // hook points of the A/B builds (variants.hpp)
-#define MVS_FWD(r, tw, x) ntt_fwd_core(r, tw, x)
-#define MVS_INV(r, tw, x) ntt_inv_core(r, tw, x)
-#endif
 // Level 5: nothing is prefetched.  Three of the seven polynomials would fit beside seven transforms in flight under 128 VGPRs and
 // make the kernel 2 % faster on its own (45.5 vs 46.1 us) -- but with them bench.py's attempt (phase 1, then phase 2, over ONE set of
 // buffers: 223 MB, Infinity-Cache-resident) takes 134.7 instead of 103.9 us, while the same pair over two rotating sets (HBM-streaming)
 // is unchanged (105.9 vs 106.6): profiles/r04q_ab_pf.txt, r04r_ab_pair.txt.  Unexplained; the cache-resident regime is the one the
 // signing loop's narrow rounds run in, so the prefetch stays off where it was off.
 #define DIL_MVS_PFN(L) ((L) <= 5 ? (L) : 0)
-#ifndef MVS_FWDN
-#define MVS_FWDN(v, tw, x) ntt_fwd_coreN<L>(v, tw, x)
-#endif
-#ifndef MVS_FWD2
-#define MVS_FWD2(a, b, tw, x) ntt_fwd_core2(a, b, tw, x)
-#define MVS_INV2(a, b, tw, x) ntt_inv_core2(a, b, tw, x)
-#endif
-#ifndef MVS_AREAD
-#define MVS_AREAD(p) (*reinterpret_cast<const int4*>(p))
-#endif
-#ifndef MVS_EMIT
-#define MVS_EMIT(call, w0, o, r, lane) call
-#endif
 #define DIL_MVS_WGS 1          // 16-wave workgroups per CU the shared-key kernels are built for (8 waves per SIMD need <= 64 VGPRs)
 template <int K, int L, int LEVEL, int OUT, int NW, int YF>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS_WGS * NW / 4))) void matvec_shared_kernel(
@@ -1017,7 +990,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
         } else {
 #pragma unroll
             for (int l = 0; l < L; l++) ys.value(yh[l]);
-            MVS_FWDN(yh, twf, lm);
+            ntt_fwd_coreN<L>(yh, twf, lm);
         }
         DIL_SCHED_FENCE();
         const size_t itn = it + nwaves;
@@ -1027,8 +1000,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
             int64_t acc[4] = {0, 0, 0, 0}, acd[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int l = 0; l < L; l++) {
-                const int4 a = MVS_AREAD(Al + (k * L + l) * 256 + 4 * lane);
-                const int4 d = MVS_AREAD(Al + ((k + 1) * L + l) * 256 + 4 * lane);
+                const int4 a = (*reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane));
+                const int4 d = (*reinterpret_cast<const int4*>(Al + ((k + 1) * L + l) * 256 + 4 * lane));
                 acc[0] += (int64_t)a.x * yh[l][0];
                 acc[1] += (int64_t)a.y * yh[l][1];
                 acc[2] += (int64_t)a.z * yh[l][2];
@@ -1041,18 +1014,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             int32_t rd[4] = {mont_red64(acd[0]), mont_red64(acd[1]), mont_red64(acd[2]), mont_red64(acd[3])};
             DIL_SCHED_FENCE();
-            MVS_INV2(r, rd, twi, lm);
+            ntt_inv_core2(r, rd, twi, lm);
             DIL_SCHED_FENCE();
-            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, MVS_XB)), w0_out, (it * K + k) * 256, r, lane);
-            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k + 1) * 256, rd, sc, lane, MVS_XB)), w0_out,
-                     (it * K + k + 1) * 256, rd, lane);
+            (emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, xb));
+            (emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k + 1) * 256, rd, sc, lane, xb));
         }
         if (false)
         for (int k = 0; k < K; k++) {
             int64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int l = 0; l < L; l++) {
-                const int4 a = MVS_AREAD(Al + (k * L + l) * 256 + 4 * lane);
+                const int4 a = (*reinterpret_cast<const int4*>(Al + (k * L + l) * 256 + 4 * lane));
                 acc[0] += (int64_t)a.x * yh[l][0];
                 acc[1] += (int64_t)a.y * yh[l][1];
                 acc[2] += (int64_t)a.z * yh[l][2];
@@ -1060,9 +1032,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(DIL_MVS
             }
             int32_t r[4] = {mont_red64(acc[0]), mont_red64(acc[1]), mont_red64(acc[2]), mont_red64(acc[3])};
             DIL_SCHED_FENCE();
-            MVS_INV(r, twi, lm);
+            ntt_inv_core(r, twi, lm);
             DIL_SCHED_FENCE();
-            MVS_EMIT((emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, MVS_XB)), w0_out, (it * K + k) * 256, r, lane);
+            (emit_matvec_row<LEVEL, OUT>(w_out, w1_out, w0_out, (it * K + k) * 256, r, sc, lane, xb));
         }
     }
 }

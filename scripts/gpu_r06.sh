@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 GPU visit (round 4: gpu_r04.sh): parity tests (+ the persistent-loop step log), kernel-coverage trace, smoke, bench, rocprofv3 kernel stats of the
+# Round-6 GPU visit (round 5: gpu_r05.sh, in the history): parity tests (+ the persistent-loop step log), kernel-coverage trace, smoke, bench, rocprofv3 kernel stats of the
 # same bench command, HBM-traffic PMC passes (each its own run; kernel trace only).
-#   gpurun --timeout 2400 -- bash scripts/gpu_r05.sh [tag] [what...]     what: tests cover smoke bench prof pmc signpmc looppmc verifyprof   (default: all)
-TAG=${1:-r05z}; shift
+#   gpurun --timeout 2400 -- bash scripts/gpu_r06.sh [tag] [what...]     what: tests cover smoke bench prof pmc signpmc looppmc verifyprof   (default: all)
+TAG=${1:-r06z}; shift
 WHAT=${@:-tests cover smoke bench prof pmc signpmc looppmc verifyprof}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 if has tests; then
   rm -f $OUT/${TAG}_persistent_steps.txt
-  DIL_STEPS_LOG=$OUT/${TAG}_persistent_steps.txt timeout 1500 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1
+  DIL_STEPS_LOG=$OUT/${TAG}_persistent_steps.txt timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_pytest_gpu.log 2>&1     # -s: native stderr (ROCr's fault lines) must reach the log
   echo "pytest exit $?" >> $OUT/${TAG}_pytest_gpu.log
   tail -5 $OUT/${TAG}_pytest_gpu.log
 fi

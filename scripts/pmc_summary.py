@@ -7,9 +7,30 @@ Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZ
 on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so
 hbm_read_bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as is (calibrated here on the
 in-place NTT, which writes exactly 64 MiB per launch, and on verify's 12 MiB of w1)."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources a kernel family is compiled from: bench.py refuses a committed summary whose stamps no longer match the tree
+SOURCES = {
+    "ntt": ["kernels.hip", "ntt_core.hpp", "modarith.hpp", "device_common.hpp"],
+    "verify": ["pipelines.hip", "pipeline_common.hpp", "ntt_core.hpp", "modarith.hpp", "device_common.hpp"],
+    "sign": ["pipelines.hip", "pipeline_common.hpp", "ntt_core.hpp", "modarith.hpp", "device_common.hpp"],
+}
+
+
+def git_blob_id(path):
+    """what `git hash-object` prints for the file"""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_stamps():
+    csrc = os.path.join(ROOT, "dilithium_amd", "csrc")
+    return {fam: {f: git_blob_id(os.path.join(csrc, f)) for f in files} for fam, files in SOURCES.items()}
 
 
 def main():
@@ -47,9 +68,18 @@ def main():
             out["verify_kernel"] = out[key]
         if base(key) == "verify_wire_wpi_kernel" and "<3>" in key:
             out["verify_wire_kernel"] = out[key]
+    if os.path.exists(sys.argv[1]):                 # keys other passes put there (sign_valu_insts_per_attempt) survive a refresh of these
+        try:
+            old = json.load(open(sys.argv[1]))
+            for k in ("sign_valu_insts_per_attempt",):
+                if k in old and k not in out:
+                    out[k] = old[k]
+        except Exception:
+            pass
+    out["_source_blobs"] = source_stamps()
     json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
     for k, d in sorted(out.items()):
-        if "hbm_bytes_per_launch" in d:
+        if isinstance(d, dict) and "hbm_bytes_per_launch" in d:
             print(f"{k:28s} read {d['hbm_read_bytes_per_launch'] / 1e6:9.1f} MB  write {d['hbm_write_bytes_per_launch'] / 1e6:9.1f} MB")
 
 
