@@ -768,6 +768,27 @@ def leg_other_configs(cx, sec):
                             "transform alone reaches 0.62-0.67 of this peak in a compute-only loop (profiles/r03c_tune_xchg.txt)"}}}
     except Exception as e:  # noqa: BLE001
         sec["other_configs"] = {"error": repr(e)}
+    try:      # the reference's polymul chain (ntt, ntt, pointwise_barrett, invntt; ntt2x2_test.cpp:109-137): fused kernel vs the four launches
+        gp = torch.Generator(device="cuda").manual_seed(11)
+        NP = 32768
+        pa = [torch.randint(0, 8380417, (NP, 256), dtype=torch.int32, device="cuda", generator=gp) for _ in range(8)]      # 8 x (a, b, c) x 32 MiB = 768 MiB rotating
+        pb = [torch.randint(0, 8380417, (NP, 256), dtype=torch.int32, device="cuda", generator=gp) for _ in range(8)]
+        pc = [torch.empty((NP, 256), dtype=torch.int32, device="cuda") for _ in range(8)]
+        f_ms, _ = timed(lambda i: L.dil_polymul_dev(P(pc[i % 8]), P(pa[i % 8]), P(pb[i % 8]), NP, stream))
+
+        def chain(i):
+            a_, b_ = P(pa[i % 8]), P(pb[i % 8])
+            return (L.dil_ntt_dev(a_, NP, stream) | L.dil_ntt_dev(b_, NP, stream) | L.dil_pointwise_dev(a_, a_, b_, NP, stream)
+                    | L.dil_invntt_dev(a_, NP, stream))
+        c_ms, _ = timed(chain)
+        sec.setdefault("other_configs", {})["polymul (ntt, ntt, pointwise, invntt) batch=32768"] = {
+            "fused_products_per_s": NP / (f_ms * 1e-3), "fused_ms": f_ms, "bytes_per_product_fused": 3072,
+            "fused_GBps": 3072 * NP / (f_ms * 1e-3) / 1e9, "fused_frac_of_hbm_peak": 3072 * NP / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "four_launches_products_per_s": NP / (c_ms * 1e-3), "four_launches_ms": c_ms, "bytes_per_product_four_launches": 9216,
+            "kernel": "polymul_kernel (both forward transforms, the product and the inverse transform of a pair in one wavefront's registers)"}
+        del pa, pb, pc
+    except Exception as e:  # noqa: BLE001
+        sec.setdefault("other_configs", {})["polymul_error"] = repr(e)
 
 
 def leg_scheme(cx, sec):
@@ -938,7 +959,7 @@ def leg_end_to_end(cx):
     rng = np.random.default_rng(3)
     a = rng.integers(0, 8380417, (BATCH, 256), dtype=np.int32)
     ntt = {"workload": "BASELINE configs[1] through dil_ntt_host + dil_invntt_host: 65536 polynomials, 64 MiB up and 64 MiB down per call",
-           "options": {k: api.get_option(k) for k in ("host_chunk", "host_chunk_pinned", "host_streams", "host_threads", "host_duplex")}}
+           "options": {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin", "host_duplex")}}
     for kind in ("pageable", "page_locked"):
         keep = torch.from_numpy(a.copy()).pin_memory() if kind == "page_locked" else None
         x = keep.numpy() if keep is not None else a.copy()
@@ -962,6 +983,29 @@ def leg_end_to_end(cx):
         sweep[str(b)] = b / ((time.perf_counter() - t0) / reps)
     ntt["batch_sweep_NTT_per_s"] = sweep
     out["ntt"] = ntt
+    # the one call that is worth a PCIe round trip for a source-compatible caller: the whole polymul chain in one upload + one download
+    try:
+        NPH = 32768
+        ha, hb = a[:NPH].copy(), rng.integers(0, 8380417, (NPH, 256), dtype=np.int32)
+        hc = np.empty_like(ha)
+        api.polymul(hc, ha, hb)
+        t_f = med(lambda: api.polymul(hc, ha, hb))
+
+        def four_calls():
+            x, y = ha.copy(), hb.copy()
+            t0 = time.perf_counter()
+            api.ntt(x), api.ntt(y)
+            api.pointwise_barrett(x, x, y)
+            api.invntt(x)
+            return time.perf_counter() - t0
+        four_calls()
+        t_c = float(np.median([four_calls() for _ in range(3)]))
+        out["polymul"] = {"workload": "32768 products from pageable host arrays: dil_polymul_host (a, b up once, c down) against the chain as four *_host calls",
+                          "one_call": {"value": NPH / t_f, "unit": "products/s", "ms": t_f * 1e3, "bytes_up": 2048 * NPH, "bytes_down": 1024 * NPH,
+                                       "GBps_up": 2048 * NPH / t_f / 1e9, "frac_of_pcie": 2048 * NPH / t_f / 1e9 / one_way},
+                          "four_calls": {"value": NPH / t_c, "unit": "products/s", "ms": t_c * 1e3}}
+    except Exception as e:  # noqa: BLE001
+        out["polymul"] = {"error": repr(e)}
     # configs[3]: host A / z / c / t1 / h -> w1
     A, z, c, t1_, h = synth_verify(VBATCH, 901)
     h2 = np.ascontiguousarray(h.reshape(VBATCH, -1))

@@ -45,11 +45,10 @@ const OptName* option_table(int* n)
         {"w0w1_plane", "DIL_W0W1_PLANE", &cfg.w0w1_plane},
         {"multi_group_at_1", "DIL_MULTI_GROUP_AT_1", &cfg.multi_group_at_1},
         {"host_chunk", "DIL_HOST_CHUNK", &cfg.host_chunk},
-        {"host_chunk_pinned", "DIL_HOST_CHUNK_PINNED", &cfg.host_chunk_pinned},
+        {"host_chunk_pinned", "DIL_HOST_CHUNK_PINNED", &cfg.host_chunk},      // (rounds 4-5 kept a second chunk size for page-locked buffers: one now, both names)
         {"host_streams", "DIL_HOST_STREAMS", &cfg.host_streams},
         {"host_pin", "DIL_HOST_PIN", &cfg.host_pin},
         {"host_duplex", "DIL_HOST_DUPLEX", &cfg.host_duplex},
-        {"host_threads", "DIL_HOST_THREADS", &cfg.host_threads},
         {"host_mailbox", "DIL_HOST_MAILBOX", &cfg.host_mailbox},
         {"mailbox_idle_us", "DIL_MAILBOX_IDLE_US", &cfg.mailbox_idle_us},
         {"mailbox_resident_us", "DIL_MAILBOX_RESIDENT_US", &cfg.mailbox_resident_us},
@@ -104,7 +103,6 @@ int init_device(Device& d, int id)
 void destroy_device(Device& d)
 {
     ::mailbox_destroy(d);
-    d.helper.stop();
     d.arenas.clear();
     d.aux.destroy();
     if (d.hp.ready) {
@@ -118,6 +116,9 @@ void destroy_device(Device& d)
     }
     if (d.d_tables) (void)hipFree(d.d_tables);
     if (d.scratch) (void)hipFree(d.scratch);
+    if (d.stage) (void)hipHostFree(d.stage);
+    d.stage = nullptr;
+    d.stage_bytes = 0;
     if (d.pool) (void)hipMemPoolDestroy(d.pool);
     d.d_tables = nullptr;
     d.scratch = nullptr;
@@ -171,54 +172,6 @@ dil::Tables Device::tables() const
     t.fused_wgs_per_cu = pos(cfg.fused_wgs_per_cu.load(std::memory_order_relaxed), 4);
     t.fused_mode = cfg.fused_mode.load(std::memory_order_relaxed);
     return t;
-}
-
-bool HelperThread::submit(int device, std::function<void()> fn)
-{
-    std::unique_lock<std::mutex> lk(mu);
-    if (!started) {
-        try {
-            th = std::thread([this, device] {
-                (void)hipSetDevice(device);              // once: the thread serves this device for its whole life
-                std::unique_lock<std::mutex> l(mu);
-                for (;;) {
-                    cv.wait(l, [this] { return has_job || quit; });
-                    if (quit) return;
-                    std::function<void()> f = std::move(job);
-                    has_job = false;
-                    l.unlock();
-                    f();
-                    l.lock();
-                    job_done = true;
-                    cv.notify_all();
-                }
-            });
-        } catch (const std::exception&) {
-            return false;
-        }
-        started = true;
-    }
-    job = std::move(fn);
-    has_job = true;
-    job_done = false;
-    cv.notify_all();
-    return true;
-}
-void HelperThread::wait()
-{
-    std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [this] { return job_done; });
-}
-void HelperThread::stop()
-{
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!started) return;
-        quit = true;
-        cv.notify_all();
-    }
-    if (th.joinable()) th.join();
-    started = quit = has_job = false;
 }
 
 bool AuxStream::ensure()
@@ -445,21 +398,27 @@ int ensure_scratch(Device& d, size_t bytes)
     return 0;
 }
 
-// host wrapper: the reference's callers hold HOST buffers.  Small batches (< 8 MiB): copy in, run, copy out on the default stream.
-// Larger ones go through NS staging buffers in chunks of H2D -> kernel -> D2H, in the pattern that gets both directions of the link
-// busy at once for the kind of memory the caller holds (profiles/r05t_*.txt):
-//   pageable      the runtime stages such copies itself and blocks the copying thread meanwhile: the calling thread uploads and launches
-//                 (stream 0), a helper thread downloads (stream 1).  64 MiB + 64 MiB: 2.56 -> 1.82 ms.  (host_threads = 1: one thread)
-//   page-locked   (by the caller, or for the call by DIL_HOST_PIN=1): stream 0 carries every upload, stream 1 kernels and downloads --
-//                 one stream per direction and 8-MiB chunks is the one pattern tried in which the link runs duplex (43 - 47 GB/s each way
-//                 of 57; two big copies side by side share 57).  2.03 -> 1.80 ms.  (host_duplex = 0: chunks round-robin over NS streams)
-// Locking: these entry points share the device's staging buffers, so they are serialised by the device's
-// `host_mu` -- a lock of their own; initialisation (Device::mu) and every *_dev entry point are never blocked by it.
-// Chunk size and buffer count are options (host_chunk / host_chunk_pinned in KiB = polynomials, host_streams).
-static size_t host_chunk_polys(bool pinned = false)
+// ---- host-pointer entry points: the reference's callers hold HOST buffers (reference_code/ref_ntt.h:30-36) ----------------------------
+// RULE (round 6): the runtime never sees an unregistered caller pointer.  A copy from / to PAGEABLE memory makes the runtime page-lock
+// the range itself and KEEP that registration in a per-stream cache after the copy -- on this library's private streams, which nothing
+// else ever uses, for the life of the process.  The callee then retains something of the caller's buffer after the call has returned
+// (against the reference's contract: caller-owned, nothing retained, ref_ntt.h:30-36), and a later copy of the APPLICATION to the same
+// heap addresses can meet the stale registration: the round-5 test suite died of exactly that -- "Memory access fault by GPU ... Write
+// access to a read-only page" inside a plain torch .cpu() into heap memory that had been a pageable source of this library's chunked copies
+// 78 s earlier (profiles/r06_suite_crash_rootcause.txt).  So every host-pointer call takes one of two forms:
+//   small (<= 4 MiB per operand)   through the library's OWN page-locked staging buffer: memcpy in, DMA, kernel, DMA, memcpy out
+//   larger                          the caller's ranges are page-locked EXPLICITLY for the duration of the call (hipHostRegister at entry,
+//                                   hipHostUnregister before returning: nothing outlives the call), then chunks of H2D -> kernel -> D2H over the
+//                                   streams: one stream per direction from 64 MiB (the one pattern in which the link runs duplex: 43 - 47 GB/s
+//                                   each way of 57, profiles/r05t_pcie_duplex.txt), round-robin in 1-MiB chunks below
+//   (a range that cannot be registered -- or option host_pin = 0 --: slices of 4 MiB through the staging buffer, one after the other)
+// A buffer the caller page-locked itself (hipHostMalloc, hipHostRegister, torch pin_memory) is used as it is.
+// Locking: these entry points share the device's staging buffers, so they are serialised by the device's `host_mu` -- a lock of their
+// own; initialisation (Device::mu) and every *_dev entry point are never blocked by it.
+constexpr size_t STAGE_POLYS = 4096;                       // polynomials (KiB) per operand that go through the staging buffer in one piece
+static size_t host_chunk_polys()
 {
-    const int v = pinned ? dil::rt::cfg.host_chunk_pinned.load(std::memory_order_relaxed) : dil::rt::cfg.host_chunk.load(std::memory_order_relaxed);
-    return (size_t)std::min(std::max(v, 64), 1 << 20);
+    return (size_t)std::min(std::max(dil::rt::cfg.host_chunk.load(std::memory_order_relaxed), 64), 1 << 20);
 }
 static bool is_page_locked(const void* h, size_t bytes)          // both ends of the range: a partly registered buffer is pageable to us
 {
@@ -475,6 +434,64 @@ static bool is_page_locked(const void* h, size_t bytes)          // both ends of
     return true;
 }
 static int host_stream_count() { return std::min(std::max(dil::rt::cfg.host_streams.load(std::memory_order_relaxed), 1), HOST_STREAMS); }
+
+// The caller's operand ranges page-locked for the duration of one call.  Ranges whose PAGES touch or overlap (two arrays of the caller next
+// to each other in the heap, an output aliasing an input) are registered as ONE range: two registrations never share a page.
+struct LockSet {
+    struct R { uintptr_t lo, hi; };
+    R reg[8];
+    int nreg = 0;
+    bool ok = true;
+    LockSet(std::initializer_list<std::pair<const void*, size_t>> ops)
+    {
+        R r[8];
+        int n = 0;
+        for (const auto& o : ops)
+            if (o.first && o.second && n < 8) r[n++] = {reinterpret_cast<uintptr_t>(o.first), reinterpret_cast<uintptr_t>(o.first) + o.second};
+        std::sort(r, r + n, [](const R& x, const R& y) { return x.lo < y.lo; });
+        constexpr uintptr_t PG = 4095;
+        int m = 0;
+        for (int i = 0; i < n; i++) {                                   // merge by page-rounded extent
+            if (m && (r[i].lo & ~PG) <= ((r[m - 1].hi + PG) & ~PG)) r[m - 1].hi = std::max(r[m - 1].hi, r[i].hi);
+            else r[m++] = r[i];
+        }
+        const bool may_register = dil::rt::cfg.host_pin.load(std::memory_order_relaxed) != 0;
+        for (int i = 0; i < m && ok; i++) {
+            void* p = reinterpret_cast<void*>(r[i].lo);
+            const size_t bytes = r[i].hi - r[i].lo;
+            if (is_page_locked(p, bytes)) continue;                     // the caller's own page-locked memory
+            if (may_register && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) {
+                reg[nreg++] = r[i];
+            } else {
+                (void)hipGetLastError();
+                ok = false;
+            }
+        }
+        if (!ok) release();
+    }
+    void release()
+    {
+        for (int i = 0; i < nreg; i++) (void)hipHostUnregister(reinterpret_cast<void*>(reg[i].lo));
+        nreg = 0;
+    }
+    ~LockSet() { release(); }
+    LockSet(const LockSet&) = delete;
+    LockSet& operator=(const LockSet&) = delete;
+};
+
+// the library's own page-locked staging buffer (per device, under host_mu; grown on demand, kept)
+int ensure_stage(Device& d, size_t bytes)
+{
+    if (bytes <= d.stage_bytes) return 0;
+    if (d.stage) {
+        DIL_TRY(hipHostFree(d.stage));
+        d.stage = nullptr;
+        d.stage_bytes = 0;
+    }
+    DIL_TRY(hipHostMalloc(&d.stage, bytes, hipHostMallocDefault));
+    d.stage_bytes = bytes;
+    return 0;
+}
 
 // streams + events once; staging buffers only for the `nbuf` a call goes round, each grown to what the call needs -- and given back when a
 // run of 16 later calls needs less than a quarter of it, or not that buffer at all (one large dil_verify_core_host call must not hold
@@ -509,41 +526,43 @@ int ensure_pipe(Device& d, size_t bytes_per_buffer, int nbuf)
     }
     return 0;
 }
-// page-lock a caller's buffer for the duration of a call (option host_pin); a buffer that cannot be registered is simply copied pageable
-struct PinGuard {
-    void* p = nullptr;
-    PinGuard(const void* h, size_t bytes)
-    {
-        if (dil::rt::cfg.host_pin.load(std::memory_order_relaxed) && h && bytes &&
-            hipHostRegister(const_cast<void*>(h), bytes, hipHostRegisterDefault) == hipSuccess)
-            p = const_cast<void*>(h);
-        else (void)hipGetLastError();
-    }
-    ~PinGuard() { if (p) (void)hipHostUnregister(p); }
-};
 
-// Which pipeline a host-pointer transform call takes, and in which chunks (profiles/r05t_host_batch_sweep.txt):
-//   pageable     helper thread from two chunks of the option's size (16 MiB) up; a call of fewer than four such chunks is cut in four (>= 2 MiB
-//                each: below that a copy is latency); without the helper thread, chunks round-robin over the streams
-//   page-locked  one stream per direction pays from eight chunks of the option's size (64 MiB) up; smaller calls go round-robin over the
-//                streams in 1-MiB chunks (16 MiB: 0.50 vs 0.56 ms)
-//   below 8 MiB in all (or one chunk): one upload, one launch, one download
-enum { HOST_PIPE_ONE_SHOT = 0, HOST_PIPE_ROUND_ROBIN = 1, HOST_PIPE_DUPLEX = 2, HOST_PIPE_HELPER_THREAD = 3 };
+// Which form a host-pointer transform call takes, and in which chunks (profiles/r05t_host_batch_sweep.txt for the thresholds of the
+// page-locked pipelines): `lockable` = the caller's buffer is page-locked or may be registered for the call (option host_pin)
+enum { HOST_PIPE_ONE_SHOT = 0, HOST_PIPE_ROUND_ROBIN = 1, HOST_PIPE_DUPLEX = 2, HOST_PIPE_STAGED_SLICES = 3 };
 struct HostPlan {
     int pipeline;
     size_t chunk;      // polynomials per chunk
 };
-static HostPlan host_plan(size_t batch, bool locked)
+static HostPlan host_plan(size_t batch, bool lockable)
 {
-    const size_t opt_chunk = host_chunk_polys(locked);
+    const size_t opt_chunk = host_chunk_polys();
+    if (batch <= std::min(STAGE_POLYS, opt_chunk)) return {HOST_PIPE_ONE_SHOT, batch};
+    if (!lockable) return {HOST_PIPE_STAGED_SLICES, std::min(STAGE_POLYS, opt_chunk)};
     const bool want_duplex = dil::rt::cfg.host_duplex.load(std::memory_order_relaxed) != 0;
-    const bool duplex = locked && want_duplex && batch >= 8 * opt_chunk;
-    const bool helper_thread = !locked && dil::rt::cfg.host_threads.load(std::memory_order_relaxed) >= 2 && batch >= 2 * opt_chunk;
-    const size_t chunk = locked ? ((duplex || !want_duplex) ? opt_chunk : std::min<size_t>(opt_chunk, 1024))
-                         : (!helper_thread || batch >= 4 * opt_chunk) ? opt_chunk
-                                                                    : std::min(opt_chunk, std::max<size_t>(2048, (batch / 4 + 63) & ~(size_t)63));
-    if (batch <= chunk || batch < std::min<size_t>(8192, 2 * opt_chunk)) return {HOST_PIPE_ONE_SHOT, batch};
-    return {duplex ? HOST_PIPE_DUPLEX : helper_thread ? HOST_PIPE_HELPER_THREAD : HOST_PIPE_ROUND_ROBIN, chunk};
+    if (want_duplex && batch >= 8 * opt_chunk) return {HOST_PIPE_DUPLEX, opt_chunk};
+    return {HOST_PIPE_ROUND_ROBIN, want_duplex ? std::min<size_t>(opt_chunk, 1024) : opt_chunk};
+}
+
+// one piece of at most STAGE_POLYS polynomials per operand through the library's staging buffer: in[] are copied in one after the other
+// (device layout: operand i at polynomial i * n of the scratch), fn runs on the null stream, `n_out` polynomials from the start of
+// the scratch come back into out
+template <class F>
+int staged_piece(Device& d, const dil::Tables& T, int32_t* out, std::initializer_list<const int32_t*> in, size_t n, F&& fn)
+{
+    const size_t bytes = n * 1024, total = bytes * in.size();
+    int rc = ensure_scratch(d, total);
+    if (!rc) rc = ensure_stage(d, total);
+    if (rc) return rc;
+    char* st = static_cast<char*>(d.stage);
+    size_t k = 0;
+    for (const int32_t* p : in) memcpy(st + (k++) * bytes, p, bytes);
+    DIL_TRY(hipMemcpy(d.scratch, st, total, hipMemcpyHostToDevice));          // page-locked source: plain DMA, nothing for the runtime to register
+    rc = fn(static_cast<int32_t*>(d.scratch), n, T, (hipStream_t)0);
+    if (rc) return rc;
+    DIL_TRY(hipMemcpy(st, d.scratch, bytes, hipMemcpyDeviceToHost));          // (the null stream orders it behind the kernel)
+    memcpy(out, st, bytes);
+    return 0;
 }
 
 template <class F>
@@ -552,34 +571,28 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     if (batch == 0) return 0;
     DIL_ENTER(d, T);
     std::lock_guard<std::mutex> lk(d.host_mu);
-    int rc;
-    PinGuard pin(h, batch > 4096 ? batch * 1024 : 0);        // (option host_pin; not worth a registration for a small batch)
-    const bool locked = batch > 4096 && (pin.p || is_page_locked(h, batch * 1024));
-    const HostPlan plan = host_plan(batch, locked);
+    if (batch <= std::min(STAGE_POLYS, host_chunk_polys())) return staged_piece(d, T, h, {h}, batch, fn);
+    LockSet locks({{h, batch * 1024}});
+    const HostPlan plan = host_plan(batch, locks.ok);
     const size_t HOST_CHUNK = plan.chunk;
-    const bool duplex = plan.pipeline == HOST_PIPE_DUPLEX, helper_thread = plan.pipeline == HOST_PIPE_HELPER_THREAD;
-    const int NS = host_stream_count();
-    if (plan.pipeline == HOST_PIPE_ONE_SHOT) {
-        const size_t bytes = batch * 1024;
-        rc = ensure_scratch(d, bytes);
-        if (rc) return rc;
-        DIL_TRY(hipMemcpy(d.scratch, h, bytes, hipMemcpyHostToDevice));
-        rc = fn(static_cast<int32_t*>(d.scratch), batch, T, (hipStream_t)0);
-        if (rc) return rc;
-        DIL_TRY(hipStreamSynchronize(nullptr));
-        DIL_TRY(hipMemcpy(h, d.scratch, bytes, hipMemcpyDeviceToHost));
+    if (plan.pipeline == HOST_PIPE_STAGED_SLICES) {
+        for (size_t off = 0; off < batch; off += HOST_CHUNK) {
+            const int rc = staged_piece(d, T, h + off * 256, {h + off * 256}, std::min(HOST_CHUNK, batch - off), fn);
+            if (rc) return rc;
+        }
         return 0;
     }
-    rc = ensure_pipe(d, HOST_CHUNK * 1024, NS);
+    const int NS = host_stream_count();
+    int rc = ensure_pipe(d, HOST_CHUNK * 1024, NS);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
     int err = 0;
     size_t c = 0;
-    if (duplex) {
-        // Page-locked buffers: the link carries both directions at once only in ONE pattern of those tried (scripts/bench_pcie_duplex.py,
-        // profiles/r05t_pcie_duplex.txt): one stream per direction, chunks of 4 - 16 MiB -- 43 - 47 GB/s each way, where two large
-        // copies side by side share 57 GB/s and several streams per direction fall back to ~32.  So: stream 0 carries every upload,
-        // stream 1 the kernels and downloads, NS staging buffers go round between them on events.
+    if (plan.pipeline == HOST_PIPE_DUPLEX) {
+        // The link carries both directions at once only in ONE pattern of those tried (profiles/r05t_pcie_duplex.txt): one stream per
+        // direction, chunks of 4 - 16 MiB -- 43 - 47 GB/s each way, where two large copies side by side share 57 GB/s and several streams
+        // per direction fall back to ~32.  So: stream 0 carries every upload, stream 1 the kernels and downloads, NS staging buffers go
+        // round between them on events.
         hipStream_t up = hp.stream[0], dn = hp.stream[1];
         for (size_t off = 0; off < batch && !err; off += HOST_CHUNK, c++) {
             const int b = (int)(c % NS);
@@ -598,59 +611,7 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
             const hipError_t e = hipStreamSynchronize(hp.stream[i]);
             if (!err && e != hipSuccess) err = (int)e;
         }
-        return err;
-    }
-    if (helper_thread) {
-        // Pageable buffers: the runtime stages the copy and BLOCKS the copying thread meanwhile, so one thread gets upload and download one
-        // after the other (27 GB/s each way).  A second thread takes the downloads: 37.8 GB/s each way at 8-MiB chunks -- the rate of the
-        // page-locked pipeline above (scripts/tune_pageable_duplex.hip, profiles/r05t_pageable_duplex.txt).  The calling thread uploads
-        // and launches on stream 0; the helper waits for a chunk's event and downloads on stream 1; NS staging buffers go round.
-        hipStream_t up = hp.stream[0], dn = hp.stream[1];
-        const size_t nch = (batch + HOST_CHUNK - 1) / HOST_CHUNK;
-        std::atomic<size_t> uploaded{0}, downloaded{0};
-        std::atomic<int> err_dn{0};
-        std::atomic<bool> stop{false};
-        auto download = [&] {
-            for (size_t k = 0; k < nch; k++) {
-                while (uploaded.load(std::memory_order_acquire) <= k) {
-                    if (stop.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
-                }
-                const int b = (int)(k % NS);
-                const size_t off = k * HOST_CHUNK, n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
-                hipError_t e = hipStreamWaitEvent(dn, hp.up_done[b], 0);
-                if (e == hipSuccess) e = hipMemcpyAsync(h + off * 256, hp.dev[b], n * 1024, hipMemcpyDeviceToHost, dn);
-                if (e == hipSuccess) e = hipEventRecord(hp.dn_done[b], dn);
-                if (e != hipSuccess) { err_dn.store((int)e); return; }
-                downloaded.store(k + 1, std::memory_order_release);
-            }
-            const hipError_t e = hipStreamSynchronize(dn);
-            if (e != hipSuccess) err_dn.store((int)e);
-        };
-        const bool have_helper = d.helper.submit(d.id, download);    // false: no thread to be had -- the one-thread pipeline below
-        for (size_t k = 0; have_helper && k < nch && !err; k++) {
-            const int b = (int)(k % NS);
-            const size_t off = k * HOST_CHUNK, n = batch - off < HOST_CHUNK ? batch - off : HOST_CHUNK;
-            int32_t* dc = reinterpret_cast<int32_t*>(hp.dev[b]);
-            if (k >= (size_t)NS) {                       // the buffer's previous chunk: its download queued (host side), then done (device side)
-                while (downloaded.load(std::memory_order_acquire) + NS <= k && !err_dn.load(std::memory_order_relaxed)) std::this_thread::yield();
-                if (err_dn.load(std::memory_order_relaxed)) break;
-                err = (int)hipStreamWaitEvent(up, hp.dn_done[b], 0);
-            }
-            if (!err) err = (int)hipMemcpyAsync(dc, h + off * 256, n * 1024, hipMemcpyHostToDevice, up);
-            if (!err) err = fn(dc, n, T, up);
-            if (!err) err = (int)hipEventRecord(hp.up_done[b], up);
-            if (!err) uploaded.store(k + 1, std::memory_order_release);
-        }
-        if (have_helper) {
-            if (err || err_dn.load()) stop.store(true);
-            d.helper.wait();                             // (the job holds references to this frame: it has returned before we do)
-            const hipError_t e = hipStreamSynchronize(up);
-            if (!err) err = err_dn.load();
-            if (!err && e != hipSuccess) err = (int)e;
-            if (err) (void)hipStreamSynchronize(dn);
-            return err;
-        }
+        return err;                                   // (~LockSet unregisters after the streams have drained)
     }
     for (size_t off = 0; off < batch && !err; off += HOST_CHUNK, c++) {
         const int s = (int)(c % NS);
@@ -670,7 +631,9 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
 
 // The verify core from HOST operands (the reference's calling convention for the path: caller-owned host arrays, ref_ntt.h:30-36):
 // items in chunks round-robin over the streams, each chunk  H2D (A, z, c, t1, h) -> fused kernel -> D2H (w1)  on its own stream.
-// A key shared by the batch goes up once.  Chunk = as many items as fit the staging buffer of host_chunk KiB.
+// A key shared by the batch goes up once.  Chunk = as many items as fit the staging buffer of host_chunk KiB (at least 64 MiB).
+// The six operand arrays are page-locked for the call (LockSet); where that is not possible the chunks shrink to what the library's own
+// page-locked staging buffer holds (4 MiB) and go through it one after the other.
 int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1, const uint8_t* h, int level, size_t batch,
                      int shared_pk)
 {
@@ -681,14 +644,19 @@ int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int3
     const size_t K = level == 2 ? 4 : level == 3 ? 6 : 8, L = level == 2 ? 4 : level == 3 ? 5 : 7;
     const size_t bA = K * L * 1024, bz = L * 1024, bc = 1024, bt = K * 1024, bh = K * 256, bw = K * 256;
     const size_t key_bytes = bA + bt, item_in = bz + bc + bh + (shared_pk ? 0 : key_bytes), item_all = item_in + bw;
-    const int NS = host_stream_count();
-    const size_t budget = std::max(host_chunk_polys(), (size_t)65536) * 1024;      // upload-dominated: 64 MiB chunks reach 0.88-0.95 of the link
-    const size_t per_chunk = std::max<size_t>(1, (budget - (shared_pk ? key_bytes : 0)) / item_all);
-    int rc = ensure_pipe(d, std::max(budget, item_all + key_bytes), NS);
+    const size_t nk = shared_pk ? 1 : batch;
+    const bool small = batch * item_all + (shared_pk ? key_bytes : 0) <= STAGE_POLYS * 1024;
+    LockSet locks(small ? std::initializer_list<std::pair<const void*, size_t>>{}
+                        : std::initializer_list<std::pair<const void*, size_t>>{{A, nk * bA}, {z, batch * bz}, {c, batch * bc}, {t1, nk * bt}, {h, batch * bh}, {w1, batch * bw}});
+    const bool staged = small || !locks.ok;
+    const int NS = staged ? 1 : host_stream_count();
+    const size_t budget = staged ? STAGE_POLYS * 1024 : std::max(host_chunk_polys(), (size_t)65536) * 1024;      // upload-dominated: 64 MiB chunks reach 0.88-0.95 of the link
+    const size_t per_chunk = std::max<size_t>(1, (budget - std::min(budget - 1, shared_pk ? key_bytes : 0)) / item_all);
+    const size_t buf_bytes = std::max(budget, per_chunk * item_all + key_bytes);
+    int rc = ensure_pipe(d, buf_bytes, NS);
+    if (!rc && staged) rc = ensure_stage(d, buf_bytes);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
-    const size_t nk = shared_pk ? 1 : batch;
-    PinGuard pA(A, nk * bA), pz(z, batch * bz), pc(c, batch * bc), pt(t1, nk * bt), ph(h, batch * bh), pw(w1, batch * bw);
     int err = 0;
     bool key_up[HOST_STREAMS] = {};
     size_t ck = 0;
@@ -698,28 +666,45 @@ int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int3
         hipStream_t st = hp.stream[s];
         uint8_t* base = hp.dev[s];
         // staging layout: [A | t1 of the shared key] then per chunk A, t1 (a key per item), z, c, h, w1 -- every block 1 KiB aligned
-        int32_t* dA = reinterpret_cast<int32_t*>(base);
-        int32_t* dt = reinterpret_cast<int32_t*>(base + (shared_pk ? bA : n * bA));
-        uint8_t* q = base + (shared_pk ? key_bytes : n * key_bytes);
-        int32_t* dz = reinterpret_cast<int32_t*>(q);
-        int32_t* dc = reinterpret_cast<int32_t*>(q + n * bz);
-        uint8_t* dh = q + n * (bz + bc);
-        uint8_t* dw = dh + n * bh;
-        if (shared_pk) {
-            if (!key_up[s]) {                        // once per stream's staging buffer
-                err = (int)hipMemcpyAsync(dA, A, bA, hipMemcpyHostToDevice, st);
-                if (!err) err = (int)hipMemcpyAsync(dt, t1, bt, hipMemcpyHostToDevice, st);
-                key_up[s] = true;
+        const size_t oA = 0, ot = shared_pk ? bA : n * bA, oq = shared_pk ? key_bytes : n * key_bytes;
+        const size_t oz = oq, oc = oq + n * bz, oh = oq + n * (bz + bc), ow = oh + n * bh;
+        int32_t* dA = reinterpret_cast<int32_t*>(base + oA);
+        int32_t* dt = reinterpret_cast<int32_t*>(base + ot);
+        int32_t* dz = reinterpret_cast<int32_t*>(base + oz);
+        int32_t* dc = reinterpret_cast<int32_t*>(base + oc);
+        uint8_t* dh = base + oh;
+        uint8_t* dw = base + ow;
+        const bool key_now = shared_pk ? !key_up[s] : true;
+        const size_t kA = shared_pk ? bA : n * bA, kt = shared_pk ? bt : n * bt;
+        const int32_t* hA = shared_pk ? A : A + off * (bA / 4);
+        const int32_t* ht = shared_pk ? t1 : t1 + off * (bt / 4);
+        if (staged) {                                // the same image assembled in the library's page-locked buffer, one upload
+            char* sg = static_cast<char*>(d.stage);
+            if (key_now) {
+                memcpy(sg + oA, hA, kA);
+                memcpy(sg + ot, ht, kt);
             }
+            memcpy(sg + oz, z + off * (bz / 4), n * bz);
+            memcpy(sg + oc, c + off * (bc / 4), n * bc);
+            memcpy(sg + oh, h + off * bh, n * bh);
+            const size_t from = key_now ? 0 : oq;
+            err = (int)hipMemcpyAsync(base + from, sg + from, ow - from, hipMemcpyHostToDevice, st);
+            if (!err) err = (int)dil::launch_verify(level, dw, dA, dz, dc, dt, dh, n, shared_pk, T, st);
+            if (!err) err = (int)hipMemcpyAsync(sg + ow, dw, n * bw, hipMemcpyDeviceToHost, st);
+            if (!err) err = (int)hipStreamSynchronize(st);
+            if (!err) memcpy(w1 + off * bw, sg + ow, n * bw);
         } else {
-            err = (int)hipMemcpyAsync(dA, A + off * (bA / 4), n * bA, hipMemcpyHostToDevice, st);
-            if (!err) err = (int)hipMemcpyAsync(dt, t1 + off * (bt / 4), n * bt, hipMemcpyHostToDevice, st);
+            if (key_now) {
+                err = (int)hipMemcpyAsync(dA, hA, kA, hipMemcpyHostToDevice, st);
+                if (!err) err = (int)hipMemcpyAsync(dt, ht, kt, hipMemcpyHostToDevice, st);
+            }
+            if (!err) err = (int)hipMemcpyAsync(dz, z + off * (bz / 4), n * bz, hipMemcpyHostToDevice, st);
+            if (!err) err = (int)hipMemcpyAsync(dc, c + off * (bc / 4), n * bc, hipMemcpyHostToDevice, st);
+            if (!err) err = (int)hipMemcpyAsync(dh, h + off * bh, n * bh, hipMemcpyHostToDevice, st);
+            if (!err) err = (int)dil::launch_verify(level, dw, dA, dz, dc, dt, dh, n, shared_pk, T, st);
+            if (!err) err = (int)hipMemcpyAsync(w1 + off * bw, dw, n * bw, hipMemcpyDeviceToHost, st);
         }
-        if (!err) err = (int)hipMemcpyAsync(dz, z + off * (bz / 4), n * bz, hipMemcpyHostToDevice, st);
-        if (!err) err = (int)hipMemcpyAsync(dc, c + off * (bc / 4), n * bc, hipMemcpyHostToDevice, st);
-        if (!err) err = (int)hipMemcpyAsync(dh, h + off * bh, n * bh, hipMemcpyHostToDevice, st);
-        if (!err) err = (int)dil::launch_verify(level, dw, dA, dz, dc, dt, dh, n, shared_pk, T, st);
-        if (!err) err = (int)hipMemcpyAsync(w1 + off * bw, dw, n * bw, hipMemcpyDeviceToHost, st);
+        key_up[s] = true;
     }
     for (int i = 0; i < NS; i++) {
         const hipError_t e = hipStreamSynchronize(hp.stream[i]);
@@ -728,53 +713,34 @@ int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int3
     return err;
 }
 
-// two-operand host form (pointwise / bram mul): c <- op(a, b), one staging buffer of 2 x batch polynomials
+// two-operand host forms (pointwise / bram mul / the fused polynomial product): out <- fn(a, b).  Small: both operands through the staging
+// buffer in one piece.  Larger: operands page-locked for the call, chunks round-robin over the streams (a | b of a chunk share one
+// device staging buffer, the result overwrites a's half); not lockable: slices through the staging buffer.
 template <class F>
-int host_binary(int32_t* out, const int32_t* a, const int32_t* b, size_t batch, F&& fn)
+int host_binary(int32_t* out, const int32_t* a, const int32_t* b, size_t batch, F&& fn)      // fn(da, db, n, tables, stream) -> int, result in da
 {
     if (batch == 0) return 0;
     DIL_ENTER(d, T);
     std::lock_guard<std::mutex> lk(d.host_mu);
-    const size_t bytes = batch * 1024;
-    const int rc = ensure_scratch(d, 2 * bytes);
-    if (rc) return rc;
-    int32_t* da = static_cast<int32_t*>(d.scratch);
-    int32_t* db = da + batch * 256;
-    DIL_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
-    DIL_TRY(fn(da, db, T));
-    DIL_TRY(hipStreamSynchronize(nullptr));
-    DIL_TRY(hipMemcpy(out, da, bytes, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-// c = a * b from HOST operands (dil_polymul_host): the chain's four calls would cross the link four times (2 + 2 + 3 + 2 KiB per product);
-// here a and b go up once, the fused kernel runs, c comes down -- 2 KiB up, 1 KiB down per product, chunks round-robin over the streams.
-int host_polymul(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
-{
-    if (batch == 0) return 0;
-    DIL_ENTER(d, T);
-    std::lock_guard<std::mutex> lk(d.host_mu);
-    const size_t CH = host_chunk_polys();
-    if (batch <= CH / 2 || batch < 4096) {
-        const size_t bytes = batch * 1024;
-        const int rc = ensure_scratch(d, 2 * bytes);
-        if (rc) return rc;
-        int32_t* da = static_cast<int32_t*>(d.scratch);
-        int32_t* db = da + batch * 256;
-        DIL_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-        DIL_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
-        DIL_TRY(dil::launch_polymul(da, da, db, batch, T, 0));
-        DIL_TRY(hipStreamSynchronize(nullptr));
-        DIL_TRY(hipMemcpy(c, da, bytes, hipMemcpyDeviceToHost));
+    auto piece = [&](size_t off, size_t n) {
+        return staged_piece(d, T, out + off * 256, {a + off * 256, b + off * 256}, n,
+                            [&](int32_t* p, size_t m, const dil::Tables& t, hipStream_t s) { return fn(p, p + m * 256, m, t, s); });
+    };
+    const size_t slice = std::min(STAGE_POLYS / 2, std::max<size_t>(host_chunk_polys() / 2, 32));
+    if (batch <= slice) return piece(0, batch);
+    LockSet locks({{a, batch * 1024}, {b, batch * 1024}, {out, batch * 1024}});
+    if (!locks.ok) {
+        for (size_t off = 0; off < batch; off += slice) {
+            const int rc = piece(off, std::min(slice, batch - off));
+            if (rc) return rc;
+        }
         return 0;
     }
     const int NS = host_stream_count();
-    const size_t chunk = CH / 2;                                   // a | b of a chunk share one staging buffer of the transforms' size
+    const size_t chunk = std::max<size_t>(host_chunk_polys() / 2, 32);
     int rc = ensure_pipe(d, 2 * chunk * 1024, NS);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
-    PinGuard pa(a, batch * 1024), pb(b, batch * 1024), pc(c == a || c == b ? nullptr : c, batch * 1024);
     int err = 0;
     size_t k = 0;
     for (size_t off = 0; off < batch && !err; off += chunk, k++) {
@@ -784,8 +750,8 @@ int host_polymul(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
         int32_t* db = da + n * 256;
         err = (int)hipMemcpyAsync(da, a + off * 256, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
         if (!err) err = (int)hipMemcpyAsync(db, b + off * 256, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
-        if (!err) err = (int)dil::launch_polymul(da, da, db, n, T, hp.stream[s]);
-        if (!err) err = (int)hipMemcpyAsync(c + off * 256, da, n * 1024, hipMemcpyDeviceToHost, hp.stream[s]);
+        if (!err) err = fn(da, db, n, T, hp.stream[s]);
+        if (!err) err = (int)hipMemcpyAsync(out + off * 256, da, n * 1024, hipMemcpyDeviceToHost, hp.stream[s]);
     }
     for (int i = 0; i < NS; i++) {
         const hipError_t e = hipStreamSynchronize(hp.stream[i]);
@@ -795,6 +761,45 @@ int host_polymul(int32_t* c, const int32_t* a, const int32_t* b, size_t batch)
 }
 
 }  // namespace
+
+// plain copies between a caller's host buffer and device memory under the same rule (scheme.hip's *_host forms): small through the
+// library's page-locked staging buffer, larger from / to the caller's range page-locked for the copy, else in slices through the buffer
+namespace dil {
+namespace rt {
+static int host_copy(Device& d, void* host, void* dev, size_t bytes, bool up)
+{
+    if (bytes == 0) return 0;
+    std::lock_guard<std::mutex> lk(d.host_mu);
+    const size_t SL = STAGE_POLYS * 1024;
+    auto slice = [&](size_t off, size_t n) -> int {
+        const int rc = ensure_stage(d, std::min(bytes, SL));
+        if (rc) return rc;
+        char* h = static_cast<char*>(host) + off;
+        char* g = static_cast<char*>(dev) + off;
+        if (up) {
+            memcpy(d.stage, h, n);
+            DIL_TRY(hipMemcpy(g, d.stage, n, hipMemcpyHostToDevice));
+        } else {
+            DIL_TRY(hipMemcpy(d.stage, g, n, hipMemcpyDeviceToHost));
+            memcpy(h, d.stage, n);
+        }
+        return 0;
+    };
+    if (bytes <= SL) return slice(0, bytes);
+    {
+        LockSet locks({{host, bytes}});
+        if (locks.ok) return (int)hipMemcpy(up ? dev : host, up ? host : dev, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+    }
+    for (size_t off = 0; off < bytes; off += SL) {
+        const int rc = slice(off, std::min(SL, bytes - off));
+        if (rc) return rc;
+    }
+    return 0;
+}
+int host_upload(Device& d, void* dev, const void* host, size_t bytes) { return host_copy(d, const_cast<void*>(host), dev, bytes, true); }
+int host_download(Device& d, void* host, const void* dev, size_t bytes) { return host_copy(d, host, const_cast<void*>(dev), bytes, false); }
+}  // namespace rt
+}  // namespace dil
 
 extern "C" {
 
@@ -922,8 +927,8 @@ int dil_pointwise_host(int32_t* c, const int32_t* a, const int32_t* b, size_t ba
         const int rc = mailbox_call(dil::MB_PW_MUL, 0, a, b, c);
         if (rc != MB_FALLBACK) return rc;
     }
-    return host_binary(c, a, b, batch, [batch](int32_t* da, int32_t* db, const dil::Tables& t) {
-        return dil::launch_pointwise(dil::OP_MUL, da, da, db, nullptr, batch, t, 0);
+    return host_binary(c, a, b, batch, [](int32_t* da, int32_t* db, size_t n, const dil::Tables& t, hipStream_t st) {
+        return (int)dil::launch_pointwise(dil::OP_MUL, da, da, db, nullptr, n, t, st);
     });
 }
 
@@ -941,7 +946,9 @@ int dil_polymul_host(int32_t* c, const int32_t* a, const int32_t* b, size_t batc
         const int rc = mailbox_call(dil::MB_POLYMUL, 0, a, b, c);
         if (rc != MB_FALLBACK) return rc;
     }
-    return host_polymul(c, a, b, batch);
+    return host_binary(c, a, b, batch, [](int32_t* da, int32_t* db, size_t n, const dil::Tables& t, hipStream_t st) {
+        return (int)dil::launch_polymul(da, da, db, n, t, st);
+    });
 }
 
 // ---- bram (hardware-model API) -----------------------------------------------------------------
@@ -994,8 +1001,8 @@ int dil_bram_mul_host(int32_t* ram, const int32_t* mul_ram, size_t batch, int ma
         const int rc = mailbox_call(dil::MB_BRAM_MUL, mapping, ram, mul_ram, ram);
         if (rc != MB_FALLBACK) return rc;
     }
-    return host_binary(ram, ram, mul_ram, batch, [batch, mapping](int32_t* da, int32_t* db, const dil::Tables& t) {
-        return dil::launch_bram_mul(da, db, batch, mapping, t, 0);
+    return host_binary(ram, ram, mul_ram, batch, [mapping](int32_t* da, int32_t* db, size_t n, const dil::Tables& t, hipStream_t st) {
+        return (int)dil::launch_bram_mul(da, db, n, mapping, t, st);
     });
 }
 
@@ -1008,7 +1015,7 @@ int dil_clock_probe_dev(uint64_t* out4, unsigned spin_us, void* stream)
 
 int dil_host_plan(size_t batch, int page_locked, int* pipeline, size_t* chunk_polys)
 {
-    const HostPlan plan = host_plan(batch, batch > 4096 && page_locked != 0);
+    const HostPlan plan = host_plan(batch, page_locked != 0 || dil::rt::cfg.host_pin.load(std::memory_order_relaxed) != 0);
     if (pipeline) *pipeline = plan.pipeline;
     if (chunk_polys) *chunk_polys = plan.chunk;
     return 0;

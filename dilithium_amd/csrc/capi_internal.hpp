@@ -8,10 +8,7 @@
 #include "kernels.hpp"
 
 #include <atomic>
-#include <condition_variable>
-#include <functional>
 #include <mutex>
-#include <thread>
 
 #define DIL_TRY(expr)                          \
     do {                                       \
@@ -46,13 +43,11 @@ struct Config {
                                            // (libdil256_ref.so turns it on: its ntt() / invntt() / ... are batch-of-one calls)
     std::atomic<int> mailbox_idle_us{200}; // DIL_MAILBOX_IDLE_US: the mailbox wave retires after this long without a request
     std::atomic<int> mailbox_resident_us{20000};   // DIL_MAILBOX_RESIDENT_US: ... and after this long in all, busy or not (a device-wide sync of another thread waits at most this long)
-    std::atomic<int> host_chunk{8192};     // DIL_HOST_CHUNK: polynomials (KiB) per chunk of the *_host pipelines, pageable caller buffers
-    std::atomic<int> host_threads{2};      // DIL_HOST_THREADS: 2 = a pageable caller buffer is uploaded by the calling thread and downloaded by a second one (the runtime
-                                           // blocks the thread that copies pageable memory: one thread gets the two directions one after the other)
-    std::atomic<int> host_chunk_pinned{8192};  // DIL_HOST_CHUNK_PINNED: the same when the caller's buffer is page-locked (true asynchronous DMA: small chunks overlap better)
+    std::atomic<int> host_chunk{8192};     // DIL_HOST_CHUNK: polynomials (KiB) per chunk of the *_host pipelines
     std::atomic<int> host_streams{4};      // DIL_HOST_STREAMS: streams the chunks go round (1 .. 8)
     std::atomic<int> host_duplex{1};       // DIL_HOST_DUPLEX: 1 = page-locked caller buffers: ONE stream carries every upload, one the kernels + downloads (0: chunks round-robin over host_streams)
-    std::atomic<int> host_pin{0};          // DIL_HOST_PIN: 1 = the caller's buffers are page-locked for the duration of a *_host call
+    std::atomic<int> host_pin{1};          // DIL_HOST_PIN: 1 = a pageable caller buffer above 4 MiB is page-locked (hipHostRegister) for the duration of a *_host call; 0 = it goes through the
+                                           // library's own page-locked staging buffer in 4-MiB slices (what also happens when a range cannot be registered)
     std::atomic<int> multi_group_at_1{0};  // DIL_MULTI_GROUP_AT_1 (tests): 1 | 2 = a one-device dil_*_multi_dev job goes through the grouped collective code
     std::atomic<int> w0w1_plane{1};        // DIL_W0W1_PLANE: 1 = inside the signing loop phase 1 hands w1 to phase 2 in the top byte of the w0 dwords (0: a byte plane of its own)
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
@@ -98,20 +93,6 @@ struct HostPipe {
     bool ready = false;
 };
 
-// ONE parked helper thread per device for the pageable pipeline of the *_host entry points (the downloads of a call run on it): created on
-// the first call that needs it, bound to the device once, woken per call -- no thread creation and no fresh per-thread runtime state per call
-struct HelperThread {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::thread th;
-    std::function<void()> job;
-    bool has_job = false, job_done = false, quit = false, started = false;
-    bool submit(int device, std::function<void()> fn);   // false: no thread to be had (the caller runs its one-thread pipeline)
-    void wait();                                         // until the submitted job has returned
-    void stop();
-    ~HelperThread() { stop(); }
-};
-
 // the host mailbox of the batch-of-one drop-in calls (kernels.hpp Mailbox; capi.hip mailbox_call)
 struct MailboxHost {
     std::mutex mu;                  // one request at a time; a second caller takes the launch path instead of waiting
@@ -134,14 +115,20 @@ struct Device {
     std::mutex host_mu;             // serialises the *_host transform entry points of THIS device (they share `scratch`, `hp`)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    void* stage = nullptr;          // the library's own page-locked staging buffer of the small host-pointer calls (hipHostMalloc)
+    size_t stage_bytes = 0;
     HostPipe hp;
-    HelperThread helper;            // (used under host_mu only)
     ArenaPool arenas;
     AuxStream aux;
     MailboxHost mbox;
     // launch configuration for a call made now: device constants + the current options
     dil::Tables tables() const;
 };
+
+// copies between a caller's HOST buffer and device memory that never hand an unregistered caller pointer to the runtime (capi.hip, the rule
+// of the host-pointer entry points): synchronous on the null stream
+int host_upload(Device& d, void* dev, const void* host, size_t bytes);
+int host_download(Device& d, void* host, const void* dev, size_t bytes);
 
 // The Device record of the calling thread's CURRENT HIP device, initialised on first use.  Every entry point starts
 // here, so buffers, stream and tables always belong to one device: the one HIP itself would launch on.

@@ -922,11 +922,11 @@ int dil_keygen_host(uint8_t* pk, uint8_t* sk, const uint8_t* seed, int level, si
     uint8_t* dseed = ws.take<uint8_t>(batch * 32);
     if (ws.rc) return ws.rc;
     ws.secret = true;            // seed and the staged secret keys
-    DIL_TRY(hipMemcpy(dseed, seed, batch * 32, hipMemcpyHostToDevice));
+    if ((rc = dil::rt::host_upload(dv, dseed, seed, batch * 32))) return rc;
     rc = dil_keygen_dev(dpk, dsk, dseed, level, batch, nullptr);
     if (rc) return rc;
-    DIL_TRY(hipMemcpy(pk, dpk, batch * pkb, hipMemcpyDeviceToHost));
-    DIL_TRY(hipMemcpy(sk, dsk, batch * skb, hipMemcpyDeviceToHost));
+    if ((rc = dil::rt::host_download(dv, pk, dpk, batch * pkb))) return rc;
+    if ((rc = dil::rt::host_download(dv, sk, dsk, batch * skb))) return rc;
     return ws.close(0);
 }
 
@@ -945,13 +945,14 @@ int dil_sign_host(uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint
     uint8_t* dmu = ws.take<uint8_t>(batch * 64);
     if (ws.rc) return ws.rc;
     ws.secret = true;            // the staged secret key
-    DIL_TRY(hipMemcpy(dsk, sk, nk * skb, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(dmu, mu, batch * 64, hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = dil::rt::host_upload(dv, dsk, sk, nk * skb))) return rc;
+    if ((rc = dil::rt::host_upload(dv, dmu, mu, batch * 64))) return rc;
     const int src = dil_sign_dev(dsig, datt, dsk, dmu, level, batch, shared_sk, max_attempts, nullptr);
     if (src && src != DIL_ERR_UNFINISHED) return src;
     DIL_TRY(hipStreamSynchronize(nullptr));
-    DIL_TRY(hipMemcpy(sig, dsig, batch * sgb, hipMemcpyDeviceToHost));
-    if (attempts) DIL_TRY(hipMemcpy(attempts, datt, batch * 4, hipMemcpyDeviceToHost));
+    if ((rc = dil::rt::host_download(dv, sig, dsig, batch * sgb))) return rc;
+    if (attempts && (rc = dil::rt::host_download(dv, attempts, datt, batch * 4))) return rc;
     return ws.close(src);
 }
 
@@ -970,11 +971,11 @@ int dil_verify_sig_host(int32_t* verdict, const uint8_t* pk, const uint8_t* sig,
     uint8_t* dsig = ws.take<uint8_t>(batch * sgb);
     uint8_t* dmu = ws.take<uint8_t>(batch * 64);
     if (ws.rc) return ws.rc;
-    DIL_TRY(hipMemcpy(dpk, pk, nk * pkb, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(dsig, sig, batch * sgb, hipMemcpyHostToDevice));
-    DIL_TRY(hipMemcpy(dmu, mu, batch * 64, hipMemcpyHostToDevice));
+    if ((rc = dil::rt::host_upload(dv, dpk, pk, nk * pkb))) return rc;
+    if ((rc = dil::rt::host_upload(dv, dsig, sig, batch * sgb))) return rc;
+    if ((rc = dil::rt::host_upload(dv, dmu, mu, batch * 64))) return rc;
     rc = dil_verify_sig_dev(dverd, dpk, dsig, dmu, level, batch, shared_pk, nullptr);
     if (rc) return rc;
-    DIL_TRY(hipMemcpy(verdict, dverd, batch * 4, hipMemcpyDeviceToHost));
+    if ((rc = dil::rt::host_download(dv, verdict, dverd, batch * 4))) return rc;
     return 0;
 }

@@ -72,15 +72,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
     size_t it = (size_t)blockIdx.x * 4 + wv;
     RawZ<LEVEL> zr;
     uint32_t cb = 0, hb0 = 0, hb1 = 0;
-    coop::Sponge<17> sp;
-    if constexpr (SIB) sp.init(lane);
     static_assert(sizeof(coop::SibShared) <= (size_t)L * 1024, "SampleInBall works in the wave's z^ area");
     auto load_item = [&](size_t i) {
         const uint8_t* sg = sig + i * sig_stride;
         zr.load(sg + 32, plz);
-        if constexpr (SIB) {                                   // this lane's dword of c~ in the sponge's own lane order (dwords 0..7 of the state)
-            const int d = sp.k.dword;
-            cb = (d >= 0 && d < 8) ? coop::ld_u32u(sg + 4 * d) : 0u;
+        if constexpr (SIB) {                                   // this lane's dword of c~ in the sponge's own lane order: state words 0..3 sit in lanes
+            const int l5 = lane & 31;                          // 0..3 (low halves) and 32..35 (high halves) -- keccak_coop.hpp Lane::init
+            cb = l5 < 4 ? coop::ld_u32u(sg + 4 * (2 * l5 + (lane >> 5))) : 0u;
         } else {
             cb = cbits[i * 64 + lane];
         }
@@ -111,6 +109,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DIL_WW_WAVE
         int32_t ch[4];
         if constexpr (SIB) {
             coop::SibShared& sh = *reinterpret_cast<coop::SibShared*>(zl);     // (free until the forward transforms below store z^)
+            // the sponge's dozen per-lane constants are rebuilt per item from an opaque copy of the lane number: kept across the item loop
+            // they cost 12 VGPRs of a kernel that sits at its 168-register cap (level 5: 52 spilled dwords against 16)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            coop::Sponge<17> sp;
+            sp.init(lane_o);
             sp.v = cb;
             sp.pad(4);
             sp.permute();

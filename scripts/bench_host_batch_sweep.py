@@ -1,4 +1,5 @@
-"""dil_ntt_host by batch size: pageable (one thread / helper thread) and page-locked (round-robin / one stream per direction) caller buffers"""
+"""dil_ntt_host by batch size: a pageable caller buffer page-locked for the call (host_pin = 1, the default) or taken through the library's
+staging buffer in slices (host_pin = 0), and a buffer the caller page-locked itself (round-robin / one stream per direction)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -10,17 +11,16 @@ def med(f, reps=9):
     for _ in range(reps):
         t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
     return sorted(ts)[len(ts) // 2]
-for size in (2048, 4096, 8192, 12000, 16384, 32768, 65536, 131072):
+for size in (256, 1024, 2048, 4096, 4097, 8192, 12000, 16384, 32768, 65536, 131072):
     y = splitmix64_polys(size, seed=4); y0 = y.copy()
     pin = torch.empty((size, 256), dtype=torch.int32).pin_memory(); yp = pin.numpy(); yp[:] = y
     row = []
-    for th in (1, 2):
-        api.set_option("host_threads", th)
+    for hp in (1, 0):
+        api.set_option("host_pin", hp)
         y[:] = y0; api.ntt(y); api.invntt(y); assert (y == y0).all()
-        t = med(lambda: api.ntt(y)); row.append(f"pageable threads={th}: {t*1e3:6.3f} ms {size/t/1e6:5.1f} M/s")
+        t = med(lambda: api.ntt(y)); row.append(f"pageable host_pin={hp}: {t*1e3:6.3f} ms {size/t/1e6:5.1f} M/s")
+    api.set_option("host_pin", 1)
     for dp in (0, 1):
         api.set_option("host_duplex", dp)
-        if dp == 0: api.set_option("host_chunk_pinned", 1024)
-        else: api.set_option("host_chunk_pinned", 8192)
         t = med(lambda: api.ntt(yp)); row.append(f"locked duplex={dp}: {t*1e3:6.3f} ms {size/t/1e6:5.1f} M/s")
     print(f"batch {size:6d}: " + "  ".join(row), flush=True)

@@ -1,8 +1,8 @@
-"""The host-pointer pipelines (csrc/capi.hip host_inplace / host_verify_core: chunks of H2D -> kernel -> D2H; a helper thread for the
-downloads of a pageable buffer, one stream per direction for a page-locked one, or round-robin over streams) under every setting of
-their options -- host_chunk / host_chunk_pinned (KiB per chunk), host_streams (1 .. 8 staging buffers), host_pin, host_duplex,
-host_threads -- against
-the oracle and the device-pointer entry points.  The reference's calling convention for the path is caller-owned HOST arrays
+"""The host-pointer entry points (csrc/capi.hip host_inplace / host_binary / host_verify_core) under every setting of their options --
+host_chunk (KiB per chunk), host_streams (1 .. 8 staging buffers), host_pin (1: a pageable caller buffer is page-locked for the call;
+0: it goes through the library's own page-locked staging buffer in slices), host_duplex (one stream per direction from 8 chunks up) --
+against the oracle and the device-pointer entry points; and the round-6 rule itself: NOTHING of a caller's buffer stays registered
+with the driver after a call has returned (the runtime's cached page-locks of pageable copies killed the round-5 suite).  The reference's calling convention for the path is caller-owned HOST arrays
 (reference_code/ref_ntt.h:30-36, hardware_code/ntt2x2.h:30-34); bench.py's `end_to_end` block times these calls."""
 import numpy as np
 import pytest
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def host_opts(gpu):
     from dilithium_amd import api
-    saved = {k: api.get_option(k) for k in ("host_chunk", "host_chunk_pinned", "host_streams", "host_pin", "host_duplex", "host_threads")}
+    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin", "host_duplex")}
     yield lambda **kw: [api.set_option(k, v) for k, v in kw.items()]
     for k, v in saved.items():
         api.set_option(k, v)
@@ -35,15 +35,14 @@ def test_ntt_host_chunked(gpu, oracle, host_opts, chunk, streams, pin):
     assert (x == a).all()
 
 
-@pytest.mark.parametrize("threads,duplex,pin,locked", [(2, 1, 0, False), (1, 1, 0, False), (2, 1, 1, False), (2, 0, 1, False), (2, 1, 0, True),
-                                                       (2, 0, 0, True)])
+@pytest.mark.parametrize("duplex,pin,locked", [(1, 1, False), (0, 1, False), (1, 0, False), (1, 0, True), (0, 0, True)])
 @pytest.mark.parametrize("chunk,bufs", [(64, 1), (64, 2), (100, 4), (600, 2), (8192, 3)])
-def test_ntt_host_two_threads_and_one_stream_per_direction(gpu, oracle, host_opts, threads, duplex, pin, locked, chunk, bufs):
-    """the two pipelines of round 5 -- a helper thread downloading a pageable buffer's chunks, one stream per direction for a page-locked
-    one -- with the staging ring wrapping several times (7+ chunks over 1 .. 4 buffers) and a ragged last chunk, against the oracle and the
-    round trip; `locked`: the caller's buffer is page-locked already (torch pin_memory), pin: the library registers it for the call"""
+def test_ntt_host_pipelines_ring_wraps_and_ragged_tails(gpu, oracle, host_opts, duplex, pin, locked, chunk, bufs):
+    """one stream per direction / round-robin over the streams on a buffer page-locked for the call (pin) or by the caller (locked: torch
+    pin_memory), and the staged slices of a buffer that is neither (pin 0) -- with the staging ring wrapping several times (9+ chunks over
+    1 .. 4 buffers) and a ragged last chunk, against the oracle and the round trip"""
     from dilithium_amd import api
-    host_opts(host_chunk=chunk, host_chunk_pinned=chunk, host_streams=bufs, host_pin=pin, host_duplex=duplex, host_threads=threads)
+    host_opts(host_chunk=chunk, host_streams=bufs, host_pin=pin, host_duplex=duplex)
     n = 9 * chunk + 17 if chunk < 4096 else 20011         # (chunk 600: 5417 polynomials, past the 4096 below which a page-locked buffer
     a = splitmix64_polys(n, seed=chunk + bufs)            #  is not treated as one, and >= 8 chunks: the one-stream-per-direction pipeline)
     if locked:
@@ -87,9 +86,9 @@ def test_verify_core_host_vs_device_and_oracle(gpu, oracle, host_opts, level, sh
 
 
 def test_host_pipelines_from_concurrent_threads(gpu, oracle):
-    """three host threads in the *_host transforms at once (pageable buffers large enough for the helper-thread pipeline, a page-locked one,
-    small ones on the one-shot path) beside a fourth on the device-pointer scheme calls: the host entry points of a device serialise on
-    their own lock, the helper thread of one call never serves another, every result is the oracle's"""
+    """three host threads in the *_host transforms at once (pageable buffers large enough to be page-locked for the call, a page-locked one,
+    small ones through the staging buffer) beside a fourth on the device-pointer scheme calls: the host entry points of a device serialise on
+    their own lock, every result is the oracle's"""
     import threading
     from dilithium_amd import api
     torch = gpu
@@ -137,3 +136,58 @@ def test_host_pipelines_from_concurrent_threads(gpu, oracle):
     for t in ths:
         t.join()
     assert not errors, errors
+
+
+def _registered_with_the_driver(arr):
+    """VMAs overlapping the array that carry the `dc` (VM_DONTCOPY) flag in /proc/self/smaps: the thunk marks every host range it registers
+    with the driver MADV_DONTFORK -- a page-lock the runtime made for a pageable copy, or hipHostRegister -- and clears the mark when the
+    registration goes"""
+    lo, hi = arr.ctypes.data, arr.ctypes.data + arr.nbytes
+    hits, cur = [], None
+    for ln in open("/proc/self/smaps"):
+        head = ln.split(" ", 1)[0]
+        if "-" in head and ln[:1] in "0123456789abcdef":
+            a, b = (int(x, 16) for x in head.split("-"))
+            cur = (a, b)
+        elif ln.startswith("VmFlags:") and cur and cur[0] < hi and cur[1] > lo and " dc" in ln:
+            hits.append(cur)
+    return hits
+
+
+def test_nothing_of_the_callers_buffer_stays_registered_after_a_call(gpu, oracle, host_opts):
+    """The reference's contract -- the caller owns every buffer, the callee retains nothing (reference_code/ref_ntt.h:30-36) -- down to the
+    driver: after dil_ntt_host / dil_invntt_host / dil_pointwise_host / dil_polymul_host / dil_verify_core_host have returned, no page of the
+    caller's heap arrays is still registered (VM_DONTCOPY in /proc/self/smaps), whatever the size class and option.  Rounds 4-5 handed the
+    caller's pageable pointer to hipMemcpyAsync on the library's private streams: the runtime page-locked the range and kept the lock in
+    that stream's cache for the life of the process (this test fails on that library) -- the state in which a later copy of the application
+    to the same heap addresses faulted on the GPU (profiles/r06_suite_crash_rootcause.txt)."""
+    import ctypes
+    from dilithium_amd import api
+    libc = ctypes.CDLL("libc.so.6")
+    libc.mallopt(-3, 1 << 30)                       # M_MMAP_THRESHOLD: the arrays below come from the heap proper, like the suite's
+    for pin, duplex in ((1, 1), (1, 0), (0, 1)):
+        host_opts(host_pin=pin, host_duplex=duplex, host_chunk=8192, host_streams=4)
+        for n in (3, 300, 5000, 20000, 70000):
+            a = splitmix64_polys(n, seed=n)
+            x, b = a.copy(), splitmix64_polys(n, seed=n + 1)
+            api.ntt(x)
+            api.invntt(x)
+            assert (x == a).all()
+            c = np.empty_like(a)
+            api.pointwise_barrett(c, a, b)
+            api.polymul(c, a, b)
+            left = [r for arr in (x, a, b, c) for r in _registered_with_the_driver(arr)]
+            assert not left, (pin, duplex, n, [(hex(lo), hex(hi)) for lo, hi in left])
+    K, L, n = 6, 5, 700
+    rng = np.random.default_rng(1)
+    A = splitmix64_polys(n * K * L, seed=5).reshape(n, K, L, N)
+    z = np.mod(rng.integers(-(1 << 19) + 1, 1 << 19, (n, L, N)), Q).astype(np.int32)
+    cc = np.zeros((n, N), np.int32)
+    cc[:, ::7] = 1
+    t1 = rng.integers(0, 1024, (n, K, N)).astype(np.int32)
+    h = (rng.random((n, K * N)) < 0.03).astype(np.uint8)
+    for pin in (1, 0):
+        host_opts(host_pin=pin)
+        w1 = api.verify_core(A, z, cc, t1, h, 3)
+        left = [r for arr in (A, z, cc, t1, h, w1) for r in _registered_with_the_driver(arr)]
+        assert not left, (pin, [(hex(lo), hex(hi)) for lo, hi in left])
