@@ -478,7 +478,10 @@ int dil_verify_wire_core_dev(uint8_t* w1_packed, int32_t* verdict, const int32_t
     hipStream_t s = S(stream);
     StreamScratch ws(dv, s);
     const size_t pkb = dil_pk_bytes(level), sgb = dil_sig_bytes(level);
-    if (!shared_pk && (dil::rt::cfg.fuse_sib.load(std::memory_order_relaxed) & 1))      // c sampled inside the kernel: one launch, no compact c through HBM
+    // c sampled inside the kernel: one launch, no compact c through HBM -- levels 2 and 3 (76 - 80 against 84 - 86 us and 57 against 64 us per 8192);
+    // at level 5 the kernel sits at its 168-register cap and the sampler's registers spill (134 against 130 us): the launch in front stays
+    // (profiles/r06g_fuse_sib.txt)
+    if (!shared_pk && level != 5 && (dil::rt::cfg.fuse_sib.load(std::memory_order_relaxed) & 1))
         return ws.close((int)dil::launch_verify_wire(level, w1_packed, verdict, A, pk, pkb, sig, sgb, nullptr, batch, 0, T, s));
     uint32_t* cbits = ws.take<uint32_t>(batch * 64);
     if (ws.rc) return ws.rc;
@@ -514,7 +517,7 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         if (ws.rc) return ws.rc;
         const int fuse_sib = dil::rt::cfg.fuse_sib.load(std::memory_order_relaxed);
         if (A_ready) {               // the matrix is already there: SampleInBall (inside the fused kernel where that form exists), the fused kernel, the challenge hash
-            const bool sib_inside = (fuse_sib & 1) && !shared_pk && !t1hat_ready;
+            const bool sib_inside = (fuse_sib & 1) && !shared_pk && !t1hat_ready && level != 5;
             if (!sib_inside) DIL_TRY(dil::launch_sample_in_ball_bits(cbits, sig, sgb, level, batch, s));
             DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, sib_inside ? nullptr : cbits, batch, shared_pk, T, s, dil::A_I32, t1hat_ready));
             return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);
@@ -542,7 +545,7 @@ int verify_sig_core(Device& dv, const dil::Tables& T, StreamScratch& ws, int32_t
         //  63.1 us and ExpandA's 48-byte pieces cost 8 us more than its 64-byte ones; profiles/r02_a24.txt.  The format
         //  parameter stays for A/B runs: option a24 = 2 forces the packed form here too.)
         const int a_fmt = (!shared_pk && dil::rt::cfg.a24.load(std::memory_order_relaxed) == 2) ? matrix_format(nk, p.K, p.L) : dil::A_I32;
-        if ((fuse_sib & 2) && !shared_pk && a_fmt == dil::A_I32) {      // c inside the fused kernel: ExpandA alone in front, no helper stream
+        if ((fuse_sib & 2) && !shared_pk && a_fmt == dil::A_I32 && level != 5) {      // c inside the fused kernel: ExpandA alone in front, no helper stream
             DIL_TRY(dil::launch_expand_a(A, pk, pkb, level, nk, s, a_fmt));
             DIL_TRY(dil::launch_verify_wire(level, w1p, verdict, A, pk, pkb, sig, sgb, nullptr, batch, 0, T, s, a_fmt));
             return (int)dil::launch_challenge_hash(nullptr, verdict, mu, w1p, level, sig, batch, s, sgb);

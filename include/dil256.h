@@ -74,7 +74,8 @@ int dil_shutdown(void);
  *                                   verify kernel by the wave that owns the signature (one SHAKE256 state over the wavefront) instead of a
  *                                   sampling launch in front.  bit 0 (default on) = where the matrix is already expanded
  *                                   (dil_verify_wire_core_dev, dil_verify_sig_expanded_dev), bit 1 = in dil_verify_sig_dev too (there the
- *                                   sampler otherwise runs beside ExpandA on the helper stream).  Verdicts and w1 do not depend on it.
+ *                                   sampler otherwise runs beside ExpandA on the helper stream).  Levels 2 and 3 (level 5: the launch in front is faster and
+ *                                   stays).  Verdicts and w1 do not depend on it.
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it
