@@ -959,7 +959,7 @@ def leg_end_to_end(cx):
     rng = np.random.default_rng(3)
     a = rng.integers(0, 8380417, (BATCH, 256), dtype=np.int32)
     ntt = {"workload": "BASELINE configs[1] through dil_ntt_host + dil_invntt_host: 65536 polynomials, 64 MiB up and 64 MiB down per call",
-           "options": {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin", "host_duplex")}}
+           "options": {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_copy_threads", "host_duplex")}}
     for kind in ("pageable", "page_locked"):
         keep = torch.from_numpy(a.copy()).pin_memory() if kind == "page_locked" else None
         x = keep.numpy() if keep is not None else a.copy()

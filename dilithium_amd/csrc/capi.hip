@@ -7,8 +7,10 @@
 #include "launch_util.hpp"
 
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -47,7 +49,7 @@ const OptName* option_table(int* n)
         {"host_chunk", "DIL_HOST_CHUNK", &cfg.host_chunk},
         {"host_chunk_pinned", "DIL_HOST_CHUNK_PINNED", &cfg.host_chunk},      // (rounds 4-5 kept a second chunk size for page-locked buffers: one now, both names)
         {"host_streams", "DIL_HOST_STREAMS", &cfg.host_streams},
-        {"host_pin", "DIL_HOST_PIN", &cfg.host_pin},
+        {"host_copy_threads", "DIL_HOST_COPY_THREADS", &cfg.host_copy_threads},
         {"host_duplex", "DIL_HOST_DUPLEX", &cfg.host_duplex},
         {"host_mailbox", "DIL_HOST_MAILBOX", &cfg.host_mailbox},
         {"mailbox_idle_us", "DIL_MAILBOX_IDLE_US", &cfg.mailbox_idle_us},
@@ -108,6 +110,7 @@ void destroy_device(Device& d)
     if (d.hp.ready) {
         for (int i = 0; i < HOST_STREAMS; i++) {
             if (d.hp.dev[i]) (void)hipFree(d.hp.dev[i]);
+            if (d.hp.host[i]) (void)hipHostFree(d.hp.host[i]);
             if (d.hp.stream[i]) (void)hipStreamDestroy(d.hp.stream[i]);
             if (d.hp.up_done[i]) (void)hipEventDestroy(d.hp.up_done[i]);
             if (d.hp.dn_done[i]) (void)hipEventDestroy(d.hp.dn_done[i]);
@@ -399,30 +402,34 @@ int ensure_scratch(Device& d, size_t bytes)
 }
 
 // ---- host-pointer entry points: the reference's callers hold HOST buffers (reference_code/ref_ntt.h:30-36) ----------------------------
-// RULE (round 6): the runtime never sees an unregistered caller pointer.  A copy from / to PAGEABLE memory makes the runtime page-lock
-// the range itself and KEEP that registration in a per-stream cache after the copy -- on this library's private streams, which nothing
-// else ever uses, for the life of the process.  The callee then retains something of the caller's buffer after the call has returned
-// (against the reference's contract: caller-owned, nothing retained, ref_ntt.h:30-36), and a later copy of the APPLICATION to the same
-// heap addresses can meet the stale registration: the round-5 test suite died of exactly that -- "Memory access fault by GPU ... Write
-// access to a read-only page" inside a plain torch .cpu() into heap memory that had been a pageable source of this library's chunked copies
-// 78 s earlier (profiles/r06_suite_crash_rootcause.txt).  So every host-pointer call takes one of two forms:
-//   small (<= 4 MiB per operand)   through the library's OWN page-locked staging buffer: memcpy in, DMA, kernel, DMA, memcpy out
-//   larger                          the caller's ranges are page-locked EXPLICITLY for the duration of the call (hipHostRegister at entry,
-//                                   hipHostUnregister before returning: nothing outlives the call), then chunks of H2D -> kernel -> D2H over the
-//                                   streams: one stream per direction from 64 MiB (the one pattern in which the link runs duplex: 43 - 47 GB/s
-//                                   each way of 57, profiles/r05t_pcie_duplex.txt), round-robin in 1-MiB chunks below
-//   (a range that cannot be registered -- or option host_pin = 0 --: slices of 4 MiB through the staging buffer, one after the other)
-// A buffer the caller page-locked itself (hipHostMalloc, hipHostRegister, torch pin_memory) is used as it is.
-// Locking: these entry points share the device's staging buffers, so they are serialised by the device's `host_mu` -- a lock of their
-// own; initialisation (Device::mu) and every *_dev entry point are never blocked by it.
-constexpr size_t STAGE_POLYS = 4096;                       // polynomials (KiB) per operand that go through the staging buffer in one piece
+// RULE (round 6): the library never makes the runtime page-lock, and never page-locks or releases itself, a page of the CALLER's memory.
+// On this platform page-locking paged memory is not a counted reference but a per-range ATTRIBUTE of the driver's shared-virtual-memory
+// ranges (GPU access in place, at the CPU address), set by whoever locks and cleared by whoever unlocks -- the runtime for every large copy from /
+// to pageable memory (it keeps such locks in small per-stream caches and releases them on eviction), hipHostRegister / hipHostUnregister for
+// an explicit lock.  Locks and releases of NEIGHBOURING heap ranges by different owners interfere: the round-5 test suite died in ~45 % of
+// its runs of "Memory access fault by GPU ... on address <a heap address>" (reason "Unknown" or "Write access to a read-only page") inside a
+// plain torch copy from / to a numpy array, each time within milliseconds-to-seconds of this library's own lock traffic on heap ranges next to
+// it -- the runtime's implicit locks of rounds 4-5 (pageable caller pointers given to hipMemcpyAsync on the library's private streams) and,
+// just the same, explicit hipHostRegister / hipHostUnregister around the call (tried and measured in round 6: 2 of 7 runs died).  The record:
+// profiles/r06_suite_crash_rootcause.txt.  So every byte between a pageable caller buffer and the device goes through the library's OWN
+// page-locked staging buffers (hipHostMalloc, made once, never attached to caller memory):
+//      caller buffer --memcpy (calling thread + pool threads)--> page-locked slot --DMA--> device slot --kernel--> --DMA--> slot --memcpy--> caller
+// in a ring of HOST_RING slots on as many streams, so that the memcpy of slice k + 1 runs under the DMA and the kernel of slice k.  The
+// memcpy is the bound (two or three threads reach the link's rate, option host_copy_threads).  A buffer the CALLER page-locked (hipHostMalloc,
+// its own hipHostRegister, torch pin_memory) needs no lock from anyone and is DMA'd in place: one stream per direction from 64 MiB (the one
+// pattern in which the link runs duplex, profiles/r05t_pcie_duplex.txt), chunks round-robin over the streams below.
+// Locking: these entry points share the device's staging slots, so they are serialised by the device's `host_mu` -- a lock of their own;
+// initialisation (Device::mu) and every *_dev entry point are never blocked by it.
+constexpr size_t STAGE_POLYS = 4096;                       // polynomials (KiB) per slice of a pageable transform call = size of a staging slot
+constexpr int HOST_RING = 3;                               // staging slots (and streams) a pageable call goes round
 static size_t host_chunk_polys()
 {
     return (size_t)std::min(std::max(dil::rt::cfg.host_chunk.load(std::memory_order_relaxed), 64), 1 << 20);
 }
 static bool is_page_locked(const void* h, size_t bytes)          // both ends of the range: a partly registered buffer is pageable to us
 {
-    const char* ends[2] = {static_cast<const char*>(h), static_cast<const char*>(h) + (bytes ? bytes - 1 : 0)};
+    if (!h || !bytes) return true;
+    const char* ends[2] = {static_cast<const char*>(h), static_cast<const char*>(h) + (bytes - 1)};
     for (const char* p : ends) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, p) != hipSuccess) {
@@ -435,51 +442,76 @@ static bool is_page_locked(const void* h, size_t bytes)          // both ends of
 }
 static int host_stream_count() { return std::min(std::max(dil::rt::cfg.host_streams.load(std::memory_order_relaxed), 1), HOST_STREAMS); }
 
-// The caller's operand ranges page-locked for the duration of one call.  Ranges whose PAGES touch or overlap (two arrays of the caller next
-// to each other in the heap, an output aliasing an input) are registered as ONE range: two registrations never share a page.
-struct LockSet {
-    struct R { uintptr_t lo, hi; };
-    R reg[8];
-    int nreg = 0;
-    bool ok = true;
-    LockSet(std::initializer_list<std::pair<const void*, size_t>> ops)
+// memcpy on the calling thread + parked pool threads (process-wide; they never call the HIP runtime): a single thread moves ~25 GB/s here,
+// the link 57
+class CopyPool {
+    struct Job { char* d; const char* s; size_t n; };
+    std::mutex call_mu;                 // one parallel copy at a time (calls on different devices take turns)
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> th;
+    std::vector<Job> jobs;
+    size_t next = 0, pending = 0;
+    bool quit = false;
+    void worker()
     {
-        R r[8];
-        int n = 0;
-        for (const auto& o : ops)
-            if (o.first && o.second && n < 8) r[n++] = {reinterpret_cast<uintptr_t>(o.first), reinterpret_cast<uintptr_t>(o.first) + o.second};
-        std::sort(r, r + n, [](const R& x, const R& y) { return x.lo < y.lo; });
-        constexpr uintptr_t PG = 4095;
-        int m = 0;
-        for (int i = 0; i < n; i++) {                                   // merge by page-rounded extent
-            if (m && (r[i].lo & ~PG) <= ((r[m - 1].hi + PG) & ~PG)) r[m - 1].hi = std::max(r[m - 1].hi, r[i].hi);
-            else r[m++] = r[i];
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [this] { return quit || next < jobs.size(); });
+            if (quit) return;
+            const Job j = jobs[next++];
+            lk.unlock();
+            memcpy(j.d, j.s, j.n);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
         }
-        const bool may_register = dil::rt::cfg.host_pin.load(std::memory_order_relaxed) != 0;
-        for (int i = 0; i < m && ok; i++) {
-            void* p = reinterpret_cast<void*>(r[i].lo);
-            const size_t bytes = r[i].hi - r[i].lo;
-            if (is_page_locked(p, bytes)) continue;                     // the caller's own page-locked memory
-            if (may_register && hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess) {
-                reg[nreg++] = r[i];
-            } else {
-                (void)hipGetLastError();
-                ok = false;
+    }
+public:
+    void copy(void* dst, const void* src, size_t n)
+    {
+        const int want = std::min(std::max(dil::rt::cfg.host_copy_threads.load(std::memory_order_relaxed), 1), 8);
+        const size_t parts = std::min<size_t>((size_t)want, n >> 19);          // at least 512 KiB a thread
+        if (parts <= 1) {
+            memcpy(dst, src, n);
+            return;
+        }
+        std::lock_guard<std::mutex> whole(call_mu);
+        std::unique_lock<std::mutex> lk(mu);
+        while (th.size() + 1 < parts) {
+            try {
+                th.emplace_back([this] { worker(); });
+            } catch (const std::exception&) {
+                break;
             }
         }
-        if (!ok) release();
+        const size_t p = std::min(parts, th.size() + 1), piece = ((n / p) + 4095) & ~(size_t)4095;
+        jobs.clear();
+        next = 0;
+        for (size_t i = 1; i < p; i++) {
+            const size_t off = i * piece;
+            if (off < n) jobs.push_back({static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(piece, n - off)});
+        }
+        pending = jobs.size();
+        cv_work.notify_all();
+        lk.unlock();
+        memcpy(dst, src, std::min(piece, n));
+        lk.lock();
+        cv_done.wait(lk, [this] { return pending == 0; });
     }
-    void release()
+    ~CopyPool()
     {
-        for (int i = 0; i < nreg; i++) (void)hipHostUnregister(reinterpret_cast<void*>(reg[i].lo));
-        nreg = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv_work.notify_all();
+        }
+        for (std::thread& t : th)
+            if (t.joinable()) t.join();
     }
-    ~LockSet() { release(); }
-    LockSet(const LockSet&) = delete;
-    LockSet& operator=(const LockSet&) = delete;
 };
+CopyPool g_copy;
 
-// the library's own page-locked staging buffer (per device, under host_mu; grown on demand, kept)
+// the library's own page-locked staging buffer for single pieces (per device, under host_mu; grown on demand, kept)
 int ensure_stage(Device& d, size_t bytes)
 {
     if (bytes <= d.stage_bytes) return 0;
@@ -493,10 +525,11 @@ int ensure_stage(Device& d, size_t bytes)
     return 0;
 }
 
-// streams + events once; staging buffers only for the `nbuf` a call goes round, each grown to what the call needs -- and given back when a
-// run of 16 later calls needs less than a quarter of it, or not that buffer at all (one large dil_verify_core_host call must not hold
-// 8 x 64 MiB for the life of the process; calls of two sizes taking turns must not free and allocate every time)
-int ensure_pipe(Device& d, size_t bytes_per_buffer, int nbuf)
+// streams + events once; device staging buffers only for the `nbuf` a call goes round, each grown to what the call needs -- and given back
+// when a run of 16 later calls needs less than a quarter of it, or not that buffer at all (one large dil_verify_core_host call must not hold
+// 8 x 64 MiB for the life of the process; calls of two sizes taking turns must not free and allocate every time).  host_slots: the same
+// number of page-locked HOST slots of that size (the ring of a pageable call).
+int ensure_pipe(Device& d, size_t bytes_per_buffer, int nbuf, bool host_slots = false)
 {
     dil::rt::HostPipe& hp = d.hp;
     if (!hp.ready) {
@@ -523,46 +556,73 @@ int ensure_pipe(Device& d, size_t bytes_per_buffer, int nbuf)
             DIL_TRY(hipMalloc(reinterpret_cast<void**>(&hp.dev[i]), bytes_per_buffer));
             hp.dev_bytes[i] = bytes_per_buffer;
         }
+        if (host_slots && used && hp.host_bytes[i] < bytes_per_buffer) {
+            if (hp.host[i]) DIL_TRY(hipHostFree(hp.host[i]));
+            hp.host[i] = nullptr;
+            hp.host_bytes[i] = 0;
+            DIL_TRY(hipHostMalloc(reinterpret_cast<void**>(&hp.host[i]), bytes_per_buffer, hipHostMallocDefault));
+            hp.host_bytes[i] = bytes_per_buffer;
+        }
     }
     return 0;
 }
 
+// The ring of a call on PAGEABLE caller memory: slice k lives in slot k % nb (a page-locked host buffer, a device buffer, a stream).
+//   fill(k, host_slot) -> bytes to upload from the start of the slot         (memcpy from the caller's arrays, calling thread + pool)
+//   launch(k, device_slot, stream) -> status                                  (the kernels of the slice)
+//   down(k) -> {offset, bytes} of the slot that come back                     drain(k, host_slot)   (memcpy into the caller's arrays)
+// The memcpy into slot b of slice k + nb waits for slice k's download (a stream synchronisation: the slot's stream carries nothing else).
+template <class Fill, class Launch, class Down, class Drain>
+int staged_ring(Device& d, size_t nslices, size_t slot_bytes, Fill&& fill, Launch&& launch, Down&& down, Drain&& drain)
+{
+    const int nb = (int)std::min<size_t>(nslices, HOST_RING);
+    int rc = ensure_pipe(d, slot_bytes, nb, true);
+    if (rc) return rc;
+    dil::rt::HostPipe& hp = d.hp;
+    int err = 0;
+    size_t k = 0;
+    auto finish = [&](size_t j) {
+        const int b = (int)(j % nb);
+        const hipError_t e = hipStreamSynchronize(hp.stream[b]);
+        if (!err && e != hipSuccess) err = (int)e;
+        if (!err) drain(j, reinterpret_cast<const char*>(hp.host[b]));
+    };
+    for (; k < nslices && !err; k++) {
+        const int b = (int)(k % nb);
+        if (k >= (size_t)nb) finish(k - nb);
+        if (err) break;
+        char* hs = reinterpret_cast<char*>(hp.host[b]);
+        const size_t up = fill(k, hs);
+        err = (int)hipMemcpyAsync(hp.dev[b], hs, up, hipMemcpyHostToDevice, hp.stream[b]);
+        if (!err) err = launch(k, reinterpret_cast<char*>(hp.dev[b]), hp.stream[b]);
+        const std::pair<size_t, size_t> dn = down(k);
+        if (!err) err = (int)hipMemcpyAsync(hs + dn.first, hp.dev[b] + dn.first, dn.second, hipMemcpyDeviceToHost, hp.stream[b]);
+    }
+    for (size_t j = k > (size_t)nb ? k - nb : 0; j < k; j++) finish(j);          // (on an error: the streams are drained, nothing more is copied out)
+    if (err)
+        for (int b = 0; b < nb; b++) (void)hipStreamSynchronize(hp.stream[b]);
+    return err;
+}
+
 // Which form a host-pointer transform call takes, and in which chunks (profiles/r05t_host_batch_sweep.txt for the thresholds of the
-// page-locked pipelines): `lockable` = the caller's buffer is page-locked or may be registered for the call (option host_pin)
-enum { HOST_PIPE_ONE_SHOT = 0, HOST_PIPE_ROUND_ROBIN = 1, HOST_PIPE_DUPLEX = 2, HOST_PIPE_STAGED_SLICES = 3 };
+// page-locked pipelines)
+enum { HOST_PIPE_ONE_SHOT = 0, HOST_PIPE_ROUND_ROBIN = 1, HOST_PIPE_DUPLEX = 2, HOST_PIPE_STAGED_RING = 3 };
 struct HostPlan {
     int pipeline;
     size_t chunk;      // polynomials per chunk
 };
-static HostPlan host_plan(size_t batch, bool lockable)
+static HostPlan host_plan(size_t batch, bool locked)
 {
     const size_t opt_chunk = host_chunk_polys();
-    if (batch <= std::min(STAGE_POLYS, opt_chunk)) return {HOST_PIPE_ONE_SHOT, batch};
-    if (!lockable) return {HOST_PIPE_STAGED_SLICES, std::min(STAGE_POLYS, opt_chunk)};
+    if (!locked) {                                   // pageable: slices of at most 4 MiB through the ring of page-locked slots
+        const size_t sl = std::min(STAGE_POLYS, opt_chunk);
+        return batch <= sl ? HostPlan{HOST_PIPE_ONE_SHOT, batch} : HostPlan{HOST_PIPE_STAGED_RING, sl};
+    }
     const bool want_duplex = dil::rt::cfg.host_duplex.load(std::memory_order_relaxed) != 0;
-    if (want_duplex && batch >= 8 * opt_chunk) return {HOST_PIPE_DUPLEX, opt_chunk};
-    return {HOST_PIPE_ROUND_ROBIN, want_duplex ? std::min<size_t>(opt_chunk, 1024) : opt_chunk};
-}
-
-// one piece of at most STAGE_POLYS polynomials per operand through the library's staging buffer: in[] are copied in one after the other
-// (device layout: operand i at polynomial i * n of the scratch), fn runs on the null stream, `n_out` polynomials from the start of
-// the scratch come back into out
-template <class F>
-int staged_piece(Device& d, const dil::Tables& T, int32_t* out, std::initializer_list<const int32_t*> in, size_t n, F&& fn)
-{
-    const size_t bytes = n * 1024, total = bytes * in.size();
-    int rc = ensure_scratch(d, total);
-    if (!rc) rc = ensure_stage(d, total);
-    if (rc) return rc;
-    char* st = static_cast<char*>(d.stage);
-    size_t k = 0;
-    for (const int32_t* p : in) memcpy(st + (k++) * bytes, p, bytes);
-    DIL_TRY(hipMemcpy(d.scratch, st, total, hipMemcpyHostToDevice));          // page-locked source: plain DMA, nothing for the runtime to register
-    rc = fn(static_cast<int32_t*>(d.scratch), n, T, (hipStream_t)0);
-    if (rc) return rc;
-    DIL_TRY(hipMemcpy(st, d.scratch, bytes, hipMemcpyDeviceToHost));          // (the null stream orders it behind the kernel)
-    memcpy(out, st, bytes);
-    return 0;
+    const bool duplex = want_duplex && batch >= 8 * opt_chunk;
+    const size_t chunk = (duplex || !want_duplex) ? opt_chunk : std::min<size_t>(opt_chunk, 1024);
+    if (batch <= chunk || batch < std::min<size_t>(8192, 2 * opt_chunk)) return {HOST_PIPE_ONE_SHOT, batch};
+    return {duplex ? HOST_PIPE_DUPLEX : HOST_PIPE_ROUND_ROBIN, chunk};
 }
 
 template <class F>
@@ -571,15 +631,29 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
     if (batch == 0) return 0;
     DIL_ENTER(d, T);
     std::lock_guard<std::mutex> lk(d.host_mu);
-    if (batch <= std::min(STAGE_POLYS, host_chunk_polys())) return staged_piece(d, T, h, {h}, batch, fn);
-    LockSet locks({{h, batch * 1024}});
-    const HostPlan plan = host_plan(batch, locks.ok);
+    const bool locked = is_page_locked(h, batch * 1024);
+    const HostPlan plan = host_plan(batch, locked);
     const size_t HOST_CHUNK = plan.chunk;
-    if (plan.pipeline == HOST_PIPE_STAGED_SLICES) {
-        for (size_t off = 0; off < batch; off += HOST_CHUNK) {
-            const int rc = staged_piece(d, T, h + off * 256, {h + off * 256}, std::min(HOST_CHUNK, batch - off), fn);
-            if (rc) return rc;
-        }
+    if (!locked) {
+        const size_t nsl = (batch + HOST_CHUNK - 1) / HOST_CHUNK;
+        auto cnt = [&](size_t k) { return std::min(HOST_CHUNK, batch - k * HOST_CHUNK); };
+        return staged_ring(
+            d, nsl, std::min(batch, HOST_CHUNK) * 1024,
+            [&](size_t k, char* hs) { g_copy.copy(hs, h + k * HOST_CHUNK * 256, cnt(k) * 1024); return cnt(k) * 1024; },
+            [&](size_t k, char* dv, hipStream_t st) { return fn(reinterpret_cast<int32_t*>(dv), cnt(k), T, st); },
+            [&](size_t k) { return std::make_pair((size_t)0, cnt(k) * 1024); },
+            [&](size_t k, const char* hs) { g_copy.copy(h + k * HOST_CHUNK * 256, hs, cnt(k) * 1024); });
+    }
+    // the caller's own page-locked memory: DMA in place
+    if (plan.pipeline == HOST_PIPE_ONE_SHOT) {
+        const size_t bytes = batch * 1024;
+        int rc = ensure_scratch(d, bytes);
+        if (rc) return rc;
+        DIL_TRY(hipMemcpy(d.scratch, h, bytes, hipMemcpyHostToDevice));
+        rc = fn(static_cast<int32_t*>(d.scratch), batch, T, (hipStream_t)0);
+        if (rc) return rc;
+        DIL_TRY(hipStreamSynchronize(nullptr));
+        DIL_TRY(hipMemcpy(h, d.scratch, bytes, hipMemcpyDeviceToHost));
         return 0;
     }
     const int NS = host_stream_count();
@@ -611,7 +685,7 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
             const hipError_t e = hipStreamSynchronize(hp.stream[i]);
             if (!err && e != hipSuccess) err = (int)e;
         }
-        return err;                                   // (~LockSet unregisters after the streams have drained)
+        return err;
     }
     for (size_t off = 0; off < batch && !err; off += HOST_CHUNK, c++) {
         const int s = (int)(c % NS);
@@ -630,10 +704,9 @@ int host_inplace(int32_t* h, size_t batch, F&& fn)   // fn(device_ptr, n_polys, 
 }
 
 // The verify core from HOST operands (the reference's calling convention for the path: caller-owned host arrays, ref_ntt.h:30-36):
-// items in chunks round-robin over the streams, each chunk  H2D (A, z, c, t1, h) -> fused kernel -> D2H (w1)  on its own stream.
-// A key shared by the batch goes up once.  Chunk = as many items as fit the staging buffer of host_chunk KiB (at least 64 MiB).
-// The six operand arrays are page-locked for the call (LockSet); where that is not possible the chunks shrink to what the library's own
-// page-locked staging buffer holds (4 MiB) and go through it one after the other.
+// items in chunks over the streams, each chunk  H2D (A, z, c, t1, h) -> fused kernel -> D2H (w1).  A key shared by the batch goes up once per
+// slot.  Pageable operands (any of the six): the chunk's image is assembled in a page-locked slot of the ring (16 MiB slots) and goes up
+// as ONE copy; operands the caller page-locked: five copies straight from the arrays, chunks of as many items as fit host_chunk KiB (at least 64 MiB).
 int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1, const uint8_t* h, int level, size_t batch,
                      int shared_pk)
 {
@@ -645,66 +718,82 @@ int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int3
     const size_t bA = K * L * 1024, bz = L * 1024, bc = 1024, bt = K * 1024, bh = K * 256, bw = K * 256;
     const size_t key_bytes = bA + bt, item_in = bz + bc + bh + (shared_pk ? 0 : key_bytes), item_all = item_in + bw;
     const size_t nk = shared_pk ? 1 : batch;
-    const bool small = batch * item_all + (shared_pk ? key_bytes : 0) <= STAGE_POLYS * 1024;
-    LockSet locks(small ? std::initializer_list<std::pair<const void*, size_t>>{}
-                        : std::initializer_list<std::pair<const void*, size_t>>{{A, nk * bA}, {z, batch * bz}, {c, batch * bc}, {t1, nk * bt}, {h, batch * bh}, {w1, batch * bw}});
-    const bool staged = small || !locks.ok;
-    const int NS = staged ? 1 : host_stream_count();
-    const size_t budget = staged ? STAGE_POLYS * 1024 : std::max(host_chunk_polys(), (size_t)65536) * 1024;      // upload-dominated: 64 MiB chunks reach 0.88-0.95 of the link
-    const size_t per_chunk = std::max<size_t>(1, (budget - std::min(budget - 1, shared_pk ? key_bytes : 0)) / item_all);
-    const size_t buf_bytes = std::max(budget, per_chunk * item_all + key_bytes);
-    int rc = ensure_pipe(d, buf_bytes, NS);
-    if (!rc && staged) rc = ensure_stage(d, buf_bytes);
+    const bool locked = is_page_locked(A, nk * bA) && is_page_locked(z, batch * bz) && is_page_locked(c, batch * bc) && is_page_locked(t1, nk * bt) &&
+                        is_page_locked(h, batch * bh) && is_page_locked(w1, batch * bw);
+    const size_t opt = std::max(host_chunk_polys(), (size_t)64) * 1024;
+    const size_t budget = locked ? std::max(opt, (size_t)64 << 20) : std::min(std::max(opt, (size_t)1 << 20), (size_t)16 << 20);      // (upload-dominated: 64 MiB chunks reach 0.88-0.95 of the link)
+    const size_t key_in_slot = shared_pk ? key_bytes : 0;
+    const size_t per_chunk = std::max<size_t>(1, (budget > key_in_slot ? budget - key_in_slot : 0) / item_all);
+    const size_t slot_bytes = std::max(budget, per_chunk * item_all + key_in_slot);
+    // slot layout: [A | t1 of the shared key] then per chunk A, t1 (a key per item), z, c, h, w1 -- every block 1 KiB aligned
+    struct Lay { size_t oA, ot, oz, oc, oh, ow; };
+    auto lay = [&](size_t n) {
+        const size_t oq = shared_pk ? key_bytes : n * key_bytes;
+        return Lay{0, shared_pk ? bA : n * bA, oq, oq + n * bz, oq + n * (bz + bc), oq + n * (bz + bc) + n * bh};
+    };
+    auto cnt = [&](size_t k) { return std::min(per_chunk, batch - k * per_chunk); };
+    const size_t nch = (batch + per_chunk - 1) / per_chunk;
+    if (!locked) {
+        bool key_up[HOST_STREAMS] = {};
+        const int nb = (int)std::min<size_t>(nch, HOST_RING);
+        return staged_ring(
+            d, nch, slot_bytes,
+            [&](size_t k, char* hs) {
+                const size_t n = cnt(k), off = k * per_chunk;
+                const Lay o = lay(n);
+                const int b = (int)(k % nb);
+                if (!shared_pk) {
+                    g_copy.copy(hs + o.oA, A + off * (bA / 4), n * bA);
+                    g_copy.copy(hs + o.ot, t1 + off * (bt / 4), n * bt);
+                } else if (!key_up[b]) {             // the key rides in every slot (host and device side) from its first use on
+                    memcpy(hs + o.oA, A, bA);
+                    memcpy(hs + o.ot, t1, bt);
+                    key_up[b] = true;
+                }
+                g_copy.copy(hs + o.oz, z + off * (bz / 4), n * bz);
+                g_copy.copy(hs + o.oc, c + off * (bc / 4), n * bc);
+                g_copy.copy(hs + o.oh, h + off * bh, n * bh);
+                return o.ow;                         // (a shared key is uploaded again with each slice: 36 KiB of a 16-MiB slot)
+            },
+            [&](size_t k, char* dv, hipStream_t st) {
+                const size_t n = cnt(k);
+                const Lay o = lay(n);
+                return (int)dil::launch_verify(level, reinterpret_cast<uint8_t*>(dv + o.ow), reinterpret_cast<int32_t*>(dv + o.oA), reinterpret_cast<int32_t*>(dv + o.oz),
+                                               reinterpret_cast<int32_t*>(dv + o.oc), reinterpret_cast<int32_t*>(dv + o.ot), reinterpret_cast<uint8_t*>(dv + o.oh), n,
+                                               shared_pk, T, st);
+            },
+            [&](size_t k) { return std::make_pair(lay(cnt(k)).ow, cnt(k) * bw); },
+            [&](size_t k, const char* hs) { g_copy.copy(w1 + k * per_chunk * bw, hs + lay(cnt(k)).ow, cnt(k) * bw); });
+    }
+    const int NS = host_stream_count();
+    int rc = ensure_pipe(d, slot_bytes, NS);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
     int err = 0;
     bool key_up[HOST_STREAMS] = {};
-    size_t ck = 0;
-    for (size_t off = 0; off < batch && !err; off += per_chunk, ck++) {
+    for (size_t ck = 0; ck < nch && !err; ck++) {
         const int s = (int)(ck % NS);
-        const size_t n = std::min(per_chunk, batch - off);
+        const size_t n = cnt(ck), off = ck * per_chunk;
+        const Lay o = lay(n);
         hipStream_t st = hp.stream[s];
         uint8_t* base = hp.dev[s];
-        // staging layout: [A | t1 of the shared key] then per chunk A, t1 (a key per item), z, c, h, w1 -- every block 1 KiB aligned
-        const size_t oA = 0, ot = shared_pk ? bA : n * bA, oq = shared_pk ? key_bytes : n * key_bytes;
-        const size_t oz = oq, oc = oq + n * bz, oh = oq + n * (bz + bc), ow = oh + n * bh;
-        int32_t* dA = reinterpret_cast<int32_t*>(base + oA);
-        int32_t* dt = reinterpret_cast<int32_t*>(base + ot);
-        int32_t* dz = reinterpret_cast<int32_t*>(base + oz);
-        int32_t* dc = reinterpret_cast<int32_t*>(base + oc);
-        uint8_t* dh = base + oh;
-        uint8_t* dw = base + ow;
-        const bool key_now = shared_pk ? !key_up[s] : true;
-        const size_t kA = shared_pk ? bA : n * bA, kt = shared_pk ? bt : n * bt;
-        const int32_t* hA = shared_pk ? A : A + off * (bA / 4);
-        const int32_t* ht = shared_pk ? t1 : t1 + off * (bt / 4);
-        if (staged) {                                // the same image assembled in the library's page-locked buffer, one upload
-            char* sg = static_cast<char*>(d.stage);
-            if (key_now) {
-                memcpy(sg + oA, hA, kA);
-                memcpy(sg + ot, ht, kt);
+        if (shared_pk) {
+            if (!key_up[s]) {                        // once per stream's staging buffer
+                err = (int)hipMemcpyAsync(base + o.oA, A, bA, hipMemcpyHostToDevice, st);
+                if (!err) err = (int)hipMemcpyAsync(base + o.ot, t1, bt, hipMemcpyHostToDevice, st);
+                key_up[s] = true;
             }
-            memcpy(sg + oz, z + off * (bz / 4), n * bz);
-            memcpy(sg + oc, c + off * (bc / 4), n * bc);
-            memcpy(sg + oh, h + off * bh, n * bh);
-            const size_t from = key_now ? 0 : oq;
-            err = (int)hipMemcpyAsync(base + from, sg + from, ow - from, hipMemcpyHostToDevice, st);
-            if (!err) err = (int)dil::launch_verify(level, dw, dA, dz, dc, dt, dh, n, shared_pk, T, st);
-            if (!err) err = (int)hipMemcpyAsync(sg + ow, dw, n * bw, hipMemcpyDeviceToHost, st);
-            if (!err) err = (int)hipStreamSynchronize(st);
-            if (!err) memcpy(w1 + off * bw, sg + ow, n * bw);
         } else {
-            if (key_now) {
-                err = (int)hipMemcpyAsync(dA, hA, kA, hipMemcpyHostToDevice, st);
-                if (!err) err = (int)hipMemcpyAsync(dt, ht, kt, hipMemcpyHostToDevice, st);
-            }
-            if (!err) err = (int)hipMemcpyAsync(dz, z + off * (bz / 4), n * bz, hipMemcpyHostToDevice, st);
-            if (!err) err = (int)hipMemcpyAsync(dc, c + off * (bc / 4), n * bc, hipMemcpyHostToDevice, st);
-            if (!err) err = (int)hipMemcpyAsync(dh, h + off * bh, n * bh, hipMemcpyHostToDevice, st);
-            if (!err) err = (int)dil::launch_verify(level, dw, dA, dz, dc, dt, dh, n, shared_pk, T, st);
-            if (!err) err = (int)hipMemcpyAsync(w1 + off * bw, dw, n * bw, hipMemcpyDeviceToHost, st);
+            err = (int)hipMemcpyAsync(base + o.oA, A + off * (bA / 4), n * bA, hipMemcpyHostToDevice, st);
+            if (!err) err = (int)hipMemcpyAsync(base + o.ot, t1 + off * (bt / 4), n * bt, hipMemcpyHostToDevice, st);
         }
-        key_up[s] = true;
+        if (!err) err = (int)hipMemcpyAsync(base + o.oz, z + off * (bz / 4), n * bz, hipMemcpyHostToDevice, st);
+        if (!err) err = (int)hipMemcpyAsync(base + o.oc, c + off * (bc / 4), n * bc, hipMemcpyHostToDevice, st);
+        if (!err) err = (int)hipMemcpyAsync(base + o.oh, h + off * bh, n * bh, hipMemcpyHostToDevice, st);
+        if (!err)
+            err = (int)dil::launch_verify(level, base + o.ow, reinterpret_cast<int32_t*>(base + o.oA), reinterpret_cast<int32_t*>(base + o.oz),
+                                          reinterpret_cast<int32_t*>(base + o.oc), reinterpret_cast<int32_t*>(base + o.ot), base + o.oh, n, shared_pk, T, st);
+        if (!err) err = (int)hipMemcpyAsync(w1 + off * bw, base + o.ow, n * bw, hipMemcpyDeviceToHost, st);
     }
     for (int i = 0; i < NS; i++) {
         const hipError_t e = hipStreamSynchronize(hp.stream[i]);
@@ -713,39 +802,38 @@ int host_verify_core(uint8_t* w1, const int32_t* A, const int32_t* z, const int3
     return err;
 }
 
-// two-operand host forms (pointwise / bram mul / the fused polynomial product): out <- fn(a, b).  Small: both operands through the staging
-// buffer in one piece.  Larger: operands page-locked for the call, chunks round-robin over the streams (a | b of a chunk share one
-// device staging buffer, the result overwrites a's half); not lockable: slices through the staging buffer.
+// two-operand host forms (pointwise / bram mul / the fused polynomial product): out <- fn(a, b).  a | b of a slice share one slot, the result
+// overwrites a's half.  Pageable operands: the ring of page-locked slots; all three arrays page-locked by the caller: DMA in place, chunks
+// round-robin over the streams.
 template <class F>
 int host_binary(int32_t* out, const int32_t* a, const int32_t* b, size_t batch, F&& fn)      // fn(da, db, n, tables, stream) -> int, result in da
 {
     if (batch == 0) return 0;
     DIL_ENTER(d, T);
     std::lock_guard<std::mutex> lk(d.host_mu);
-    auto piece = [&](size_t off, size_t n) {
-        return staged_piece(d, T, out + off * 256, {a + off * 256, b + off * 256}, n,
-                            [&](int32_t* p, size_t m, const dil::Tables& t, hipStream_t s) { return fn(p, p + m * 256, m, t, s); });
-    };
-    const size_t slice = std::min(STAGE_POLYS / 2, std::max<size_t>(host_chunk_polys() / 2, 32));
-    if (batch <= slice) return piece(0, batch);
-    LockSet locks({{a, batch * 1024}, {b, batch * 1024}, {out, batch * 1024}});
-    if (!locks.ok) {
-        for (size_t off = 0; off < batch; off += slice) {
-            const int rc = piece(off, std::min(slice, batch - off));
-            if (rc) return rc;
-        }
-        return 0;
-    }
+    const bool locked = is_page_locked(a, batch * 1024) && is_page_locked(b, batch * 1024) && is_page_locked(out, batch * 1024);
+    const size_t chunk = std::max<size_t>((locked ? host_chunk_polys() : std::min(STAGE_POLYS, host_chunk_polys())) / 2, 32);
+    const size_t nch = (batch + chunk - 1) / chunk;
+    auto cnt = [&](size_t k) { return std::min(chunk, batch - k * chunk); };
+    if (!locked)
+        return staged_ring(
+            d, nch, 2 * std::min(batch, chunk) * 1024,
+            [&](size_t k, char* hs) {
+                g_copy.copy(hs, a + k * chunk * 256, cnt(k) * 1024);
+                g_copy.copy(hs + cnt(k) * 1024, b + k * chunk * 256, cnt(k) * 1024);
+                return 2 * cnt(k) * 1024;
+            },
+            [&](size_t k, char* dv, hipStream_t st) { return fn(reinterpret_cast<int32_t*>(dv), reinterpret_cast<int32_t*>(dv) + cnt(k) * 256, cnt(k), T, st); },
+            [&](size_t k) { return std::make_pair((size_t)0, cnt(k) * 1024); },
+            [&](size_t k, const char* hs) { g_copy.copy(out + k * chunk * 256, hs, cnt(k) * 1024); });
     const int NS = host_stream_count();
-    const size_t chunk = std::max<size_t>(host_chunk_polys() / 2, 32);
-    int rc = ensure_pipe(d, 2 * chunk * 1024, NS);
+    int rc = ensure_pipe(d, 2 * std::min(batch, chunk) * 1024, NS);
     if (rc) return rc;
     dil::rt::HostPipe& hp = d.hp;
     int err = 0;
-    size_t k = 0;
-    for (size_t off = 0; off < batch && !err; off += chunk, k++) {
+    for (size_t k = 0; k < nch && !err; k++) {
         const int s = (int)(k % NS);
-        const size_t n = std::min(chunk, batch - off);
+        const size_t n = cnt(k), off = k * chunk;
         int32_t* da = reinterpret_cast<int32_t*>(hp.dev[s]);
         int32_t* db = da + n * 256;
         err = (int)hipMemcpyAsync(da, a + off * 256, n * 1024, hipMemcpyHostToDevice, hp.stream[s]);
@@ -762,37 +850,29 @@ int host_binary(int32_t* out, const int32_t* a, const int32_t* b, size_t batch, 
 
 }  // namespace
 
-// plain copies between a caller's host buffer and device memory under the same rule (scheme.hip's *_host forms): small through the
-// library's page-locked staging buffer, larger from / to the caller's range page-locked for the copy, else in slices through the buffer
+// plain copies between a caller's host buffer and device memory under the same rule (scheme.hip's *_host forms): a pageable buffer in slices
+// through the library's page-locked staging buffer, one the caller page-locked by DMA in place
 namespace dil {
 namespace rt {
 static int host_copy(Device& d, void* host, void* dev, size_t bytes, bool up)
 {
     if (bytes == 0) return 0;
     std::lock_guard<std::mutex> lk(d.host_mu);
+    if (is_page_locked(host, bytes)) return (int)hipMemcpy(up ? dev : host, up ? host : dev, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
     const size_t SL = STAGE_POLYS * 1024;
-    auto slice = [&](size_t off, size_t n) -> int {
-        const int rc = ensure_stage(d, std::min(bytes, SL));
-        if (rc) return rc;
+    const int rc = ensure_stage(d, std::min(bytes, SL));
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += SL) {
+        const size_t n = std::min(SL, bytes - off);
         char* h = static_cast<char*>(host) + off;
         char* g = static_cast<char*>(dev) + off;
         if (up) {
-            memcpy(d.stage, h, n);
+            g_copy.copy(d.stage, h, n);
             DIL_TRY(hipMemcpy(g, d.stage, n, hipMemcpyHostToDevice));
         } else {
             DIL_TRY(hipMemcpy(d.stage, g, n, hipMemcpyDeviceToHost));
-            memcpy(h, d.stage, n);
+            g_copy.copy(h, d.stage, n);
         }
-        return 0;
-    };
-    if (bytes <= SL) return slice(0, bytes);
-    {
-        LockSet locks({{host, bytes}});
-        if (locks.ok) return (int)hipMemcpy(up ? dev : host, up ? host : dev, bytes, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
-    }
-    for (size_t off = 0; off < bytes; off += SL) {
-        const int rc = slice(off, std::min(SL, bytes - off));
-        if (rc) return rc;
     }
     return 0;
 }
@@ -1015,7 +1095,7 @@ int dil_clock_probe_dev(uint64_t* out4, unsigned spin_us, void* stream)
 
 int dil_host_plan(size_t batch, int page_locked, int* pipeline, size_t* chunk_polys)
 {
-    const HostPlan plan = host_plan(batch, page_locked != 0 || dil::rt::cfg.host_pin.load(std::memory_order_relaxed) != 0);
+    const HostPlan plan = host_plan(batch, page_locked != 0);
     if (pipeline) *pipeline = plan.pipeline;
     if (chunk_polys) *chunk_polys = plan.chunk;
     return 0;

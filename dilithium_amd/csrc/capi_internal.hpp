@@ -46,8 +46,7 @@ struct Config {
     std::atomic<int> host_chunk{8192};     // DIL_HOST_CHUNK: polynomials (KiB) per chunk of the *_host pipelines
     std::atomic<int> host_streams{4};      // DIL_HOST_STREAMS: streams the chunks go round (1 .. 8)
     std::atomic<int> host_duplex{1};       // DIL_HOST_DUPLEX: 1 = page-locked caller buffers: ONE stream carries every upload, one the kernels + downloads (0: chunks round-robin over host_streams)
-    std::atomic<int> host_pin{1};          // DIL_HOST_PIN: 1 = a pageable caller buffer above 4 MiB is page-locked (hipHostRegister) for the duration of a *_host call; 0 = it goes through the
-                                           // library's own page-locked staging buffer in 4-MiB slices (what also happens when a range cannot be registered)
+    std::atomic<int> host_copy_threads{3}; // DIL_HOST_COPY_THREADS: threads (the calling one included) that memcpy between a pageable caller buffer and the page-locked staging slots
     std::atomic<int> multi_group_at_1{0};  // DIL_MULTI_GROUP_AT_1 (tests): 1 | 2 = a one-device dil_*_multi_dev job goes through the grouped collective code
     std::atomic<int> w0w1_plane{1};        // DIL_W0W1_PLANE: 1 = inside the signing loop phase 1 hands w1 to phase 2 in the top byte of the w0 dwords (0: a byte plane of its own)
     std::atomic<int> packed_y{1};          // DIL_PACKED_Y: 1 = the signing loop's large rounds keep y as ExpandMask's raw B-bit stream (0: int32)
@@ -87,6 +86,8 @@ constexpr int HOST_STREAMS = 8;            // upper bound; option host_streams p
 struct HostPipe {
     hipStream_t stream[HOST_STREAMS] = {};
     uint8_t* dev[HOST_STREAMS] = {};       // one staging buffer per stream, allocated when a call first uses that many (ensure_pipe)
+    uint8_t* host[HOST_STREAMS] = {};      // page-locked HOST slots of the ring a pageable call goes round (hipHostMalloc; the first HOST_RING only)
+    size_t host_bytes[HOST_STREAMS] = {};
     size_t dev_bytes[HOST_STREAMS] = {};   // size of each
     int oversized[HOST_STREAMS] = {};      // consecutive calls that needed less than a quarter of it (or not the buffer at all): given back after 16
     hipEvent_t up_done[HOST_STREAMS] = {}, dn_done[HOST_STREAMS] = {};   // per staging buffer: its upload landed / its download left

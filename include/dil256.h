@@ -106,6 +106,15 @@ int dil_invntt_dev(int32_t* polys, size_t batch, void* stream);
 /* measurement helper (bench.py `roofline.achievable`): the loads and stores of dil_ntt_dev (inverse = 0) / dil_invntt_dev (1) with the
  * same launch shape and NO arithmetic -- what this access pattern reaches on the box.  SCRAMBLES polys: scratch data only. */
 int dil_ntt_traffic_dev(int32_t* polys, size_t batch, int inverse, void* stream);
+/* Host-pointer forms (`*_host`, here and below): synchronous, caller-owned HOST arrays as in the reference (reference_code/ref_ntt.h:30-36).
+ * THE RULE (round 6): a PAGEABLE caller buffer only ever meets memcpy -- its bytes go through the library's own page-locked slots
+ * (hipHostMalloc, made once; a ring of three 4-MiB slots on three streams, the memcpy on the calling thread + pool threads, option
+ * "host_copy_threads", default 3), so the library never page-locks a page of the caller's memory and never makes the runtime do it: on
+ * this platform such locks are per-range attributes shared with every other lock holder of the process (the application's own pageable
+ * hipMemcpy / torch copies included), and lock traffic on neighbouring heap ranges killed the round-5 test suite
+ * (profiles/r06_suite_crash_rootcause.txt).  A buffer the CALLER page-locked (hipHostMalloc, hipHostRegister, torch pin_memory) is DMA'd
+ * in place: one stream per direction from 64 MiB ("host_duplex"), round-robin over "host_streams" streams below; "host_chunk" = KiB per
+ * chunk.  Calls of one device serialise on a lock of their own.  dil_host_plan says which form a call takes. */
 int dil_ntt_host(int32_t* polys, size_t batch);
 int dil_invntt_host(int32_t* polys, size_t batch);
 
@@ -169,8 +178,11 @@ int dil_verify_core_dev(uint8_t* w1, const int32_t* A, const int32_t* z, const i
                         const uint8_t* h, int level, size_t batch, int shared_pk, void* stream);
 
 /* The same from HOST arrays (the reference's calling convention for this path is caller-owned host buffers, reference_code/ref_ntt.h:30-36):
- * synchronous; items in chunks round-robin over `host_streams` streams, each chunk H2D -> fused kernel -> D2H (options host_chunk,
- * host_streams, host_pin).  PCIe-bound: 45 KiB up and 1.5 KiB down per level-3 item. */
+ * synchronous; items in chunks, each chunk H2D -> fused kernel -> D2H.  Pageable arrays: a chunk's operands are memcpy'd into one of the
+ * library's own page-locked 16-MiB slots (a ring of three, option host_copy_threads) and go up as one copy -- the library never page-locks
+ * caller memory nor lets the runtime do it (see the host-pointer rule at dil_ntt_host); arrays the caller page-locked: copies straight from
+ * them, round-robin over `host_streams` streams in chunks of host_chunk KiB (at least 64 MiB).  PCIe-bound: 45 KiB up and 1.5 KiB down per
+ * level-3 item. */
 int dil_verify_core_host(uint8_t* w1, const int32_t* A, const int32_t* z, const int32_t* c, const int32_t* t1, const uint8_t* h, int level,
                          size_t batch, int shared_pk);
 
@@ -220,9 +232,9 @@ int dil_sign_phase2_early_dev(int32_t* z, uint8_t* h, int32_t* flags, const int3
 int dil_launch_info(const char* family, int* grid, int* items_per_block, size_t* items, size_t* launches);
 
 /* What a host-pointer transform call (dil_ntt_host, dil_invntt_host, dil_bram_*_host) of `batch` polynomials would do under the current
- * options, for a pageable (0) or page-locked (1) caller buffer: *pipeline = 0 one upload / launch / download, 1 chunks round-robin over the
- * streams, 2 one stream per direction (page-locked buffers from 64 MiB), 3 calling thread uploads + helper thread downloads (pageable
- * buffers from 16 MiB); *chunk_polys = polynomials per chunk.  Pure host logic (no device needed); the reference's calling convention is
+ * options, for a pageable (0) or caller-page-locked (1) buffer: *pipeline = 0 one upload / launch / download, 1 chunks round-robin over the
+ * streams (page-locked), 2 one stream per direction (page-locked buffers from 64 MiB), 3 slices through the ring of the library's own
+ * page-locked slots (pageable buffers above 4 MiB); *chunk_polys = polynomials per chunk.  Pure host logic (no device needed); the reference's calling convention is
  * caller-owned host arrays (reference_code/ref_ntt.h:30-36).  Runtime utility without a reference counterpart. */
 int dil_host_plan(size_t batch, int page_locked, int* pipeline, size_t* chunk_polys);
 

@@ -1,8 +1,8 @@
 """The host-pointer entry points (csrc/capi.hip host_inplace / host_binary / host_verify_core) under every setting of their options --
-host_chunk (KiB per chunk), host_streams (1 .. 8 staging buffers), host_pin (1: a pageable caller buffer is page-locked for the call;
-0: it goes through the library's own page-locked staging buffer in slices), host_duplex (one stream per direction from 8 chunks up) --
-against the oracle and the device-pointer entry points; and the round-6 rule itself: NOTHING of a caller's buffer stays registered
-with the driver after a call has returned (the runtime's cached page-locks of pageable copies killed the round-5 suite).  The reference's calling convention for the path is caller-owned HOST arrays
+host_chunk (KiB per chunk / slice), host_streams (1 .. 8 staging buffers of the pipelines on caller-page-locked memory), host_duplex (one
+stream per direction from 8 chunks up), host_copy_threads (threads of the memcpy between a pageable caller buffer and the library's
+page-locked slots) -- against the oracle and the device-pointer entry points.  Round 6: a pageable caller buffer only ever meets memcpy
+(the library never page-locks caller memory, and never lets the runtime do it: csrc/capi.hip, profiles/r06_suite_crash_rootcause.txt).  The reference's calling convention for the path is caller-owned HOST arrays
 (reference_code/ref_ntt.h:30-36, hardware_code/ntt2x2.h:30-34); bench.py's `end_to_end` block times these calls."""
 import numpy as np
 import pytest
@@ -15,16 +15,16 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def host_opts(gpu):
     from dilithium_amd import api
-    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin", "host_duplex")}
+    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_copy_threads", "host_duplex")}
     yield lambda **kw: [api.set_option(k, v) for k, v in kw.items()]
     for k, v in saved.items():
         api.set_option(k, v)
 
 
-@pytest.mark.parametrize("chunk,streams,pin", [(64, 1, 0), (64, 3, 1), (100, 8, 0), (16384, 3, 0), (1024, 2, 1)])
-def test_ntt_host_chunked(gpu, oracle, host_opts, chunk, streams, pin):
+@pytest.mark.parametrize("chunk,streams,threads", [(64, 1, 1), (64, 3, 3), (100, 8, 2), (16384, 3, 3), (1024, 2, 8)])
+def test_ntt_host_chunked(gpu, oracle, host_opts, chunk, streams, threads):
     from dilithium_amd import api
-    host_opts(host_chunk=chunk, host_streams=streams, host_pin=pin)
+    host_opts(host_chunk=chunk, host_streams=streams, host_copy_threads=threads)
     n = 3 * chunk + 17 if chunk < 4096 else 20000
     a = splitmix64_polys(n, seed=chunk + streams)
     x = a.copy()
@@ -35,14 +35,14 @@ def test_ntt_host_chunked(gpu, oracle, host_opts, chunk, streams, pin):
     assert (x == a).all()
 
 
-@pytest.mark.parametrize("duplex,pin,locked", [(1, 1, False), (0, 1, False), (1, 0, False), (1, 0, True), (0, 0, True)])
+@pytest.mark.parametrize("duplex,threads,locked", [(1, 3, False), (1, 1, False), (1, 3, True), (0, 3, True)])
 @pytest.mark.parametrize("chunk,bufs", [(64, 1), (64, 2), (100, 4), (600, 2), (8192, 3)])
-def test_ntt_host_pipelines_ring_wraps_and_ragged_tails(gpu, oracle, host_opts, duplex, pin, locked, chunk, bufs):
-    """one stream per direction / round-robin over the streams on a buffer page-locked for the call (pin) or by the caller (locked: torch
-    pin_memory), and the staged slices of a buffer that is neither (pin 0) -- with the staging ring wrapping several times (9+ chunks over
+def test_ntt_host_pipelines_ring_wraps_and_ragged_tails(gpu, oracle, host_opts, duplex, threads, locked, chunk, bufs):
+    """a pageable buffer through the ring of page-locked slots (memcpy by 1 or 3 threads), and one stream per direction / round-robin over
+    the streams on a buffer the caller page-locked (locked: torch pin_memory) -- with the rings wrapping several times (9+ chunks over
     1 .. 4 buffers) and a ragged last chunk, against the oracle and the round trip"""
     from dilithium_amd import api
-    host_opts(host_chunk=chunk, host_streams=bufs, host_pin=pin, host_duplex=duplex)
+    host_opts(host_chunk=chunk, host_streams=bufs, host_copy_threads=threads, host_duplex=duplex)
     n = 9 * chunk + 17 if chunk < 4096 else 20011         # (chunk 600: 5417 polynomials, past the 4096 below which a page-locked buffer
     a = splitmix64_polys(n, seed=chunk + bufs)            #  is not treated as one, and >= 8 chunks: the one-stream-per-direction pipeline)
     if locked:
@@ -60,8 +60,8 @@ def test_ntt_host_pipelines_ring_wraps_and_ragged_tails(gpu, oracle, host_opts, 
 
 @pytest.mark.parametrize("level", [2, 3, 5])
 @pytest.mark.parametrize("shared", [False, True])
-@pytest.mark.parametrize("chunk,streams,pin", [(128, 3, 0), (300, 1, 1), (16384, 3, 0)])
-def test_verify_core_host_vs_device_and_oracle(gpu, oracle, host_opts, level, shared, chunk, streams, pin):
+@pytest.mark.parametrize("chunk,streams,locked", [(128, 3, 0), (300, 1, 1), (16384, 3, 0), (1024, 2, 1)])
+def test_verify_core_host_vs_device_and_oracle(gpu, oracle, host_opts, level, shared, chunk, streams, locked):
     from dilithium_amd import api
     K, L = {2: (4, 4), 3: (6, 5), 5: (8, 7)}[level]
     n = 77
@@ -76,8 +76,12 @@ def test_verify_core_host_vs_device_and_oracle(gpu, oracle, host_opts, level, sh
         c[i, pos] = np.where(rng.random(39) < 0.5, 1, Q - 1)
     t1 = rng.integers(0, 1024, (nk, K, N)).astype(np.int32)
     h = (rng.random((n, K, N)) < 0.03).astype(np.uint8)
-    host_opts(host_chunk=chunk, host_streams=streams, host_pin=pin)
-    w1 = api.verify_core(A, z, c, t1, h.reshape(n, K * N), level, shared_pk=shared)
+    host_opts(host_chunk=chunk, host_streams=streams)
+    if locked:          # every operand page-locked by the caller (torch pin_memory): DMA in place instead of the staged ring
+        keep = [gpu.from_numpy(x).pin_memory() for x in (A, z, c, t1, h.reshape(n, K * N))]
+        w1 = api.verify_core(*[k.numpy() for k in keep], level, shared_pk=shared)
+    else:
+        w1 = api.verify_core(A, z, c, t1, h.reshape(n, K * N), level, shared_pk=shared)
     cu = lambda x: gpu.from_numpy(x).cuda()  # noqa: E731
     dev = api.verify_core(cu(A), cu(z), cu(c), cu(t1), cu(h), level, shared_pk=shared).cpu().numpy()
     assert (w1.reshape(dev.shape) == dev).all()
@@ -138,56 +142,38 @@ def test_host_pipelines_from_concurrent_threads(gpu, oracle):
     assert not errors, errors
 
 
-def _registered_with_the_driver(arr):
-    """VMAs overlapping the array that carry the `dc` (VM_DONTCOPY) flag in /proc/self/smaps: the thunk marks every host range it registers
-    with the driver MADV_DONTFORK -- a page-lock the runtime made for a pageable copy, or hipHostRegister -- and clears the mark when the
-    registration goes"""
-    lo, hi = arr.ctypes.data, arr.ctypes.data + arr.nbytes
-    hits, cur = [], None
-    for ln in open("/proc/self/smaps"):
-        head = ln.split(" ", 1)[0]
-        if "-" in head and ln[:1] in "0123456789abcdef":
-            a, b = (int(x, 16) for x in head.split("-"))
-            cur = (a, b)
-        elif ln.startswith("VmFlags:") and cur and cur[0] < hi and cur[1] > lo and " dc" in ln:
-            hits.append(cur)
-    return hits
-
-
-def test_nothing_of_the_callers_buffer_stays_registered_after_a_call(gpu, oracle, host_opts):
-    """The reference's contract -- the caller owns every buffer, the callee retains nothing (reference_code/ref_ntt.h:30-36) -- down to the
-    driver: after dil_ntt_host / dil_invntt_host / dil_pointwise_host / dil_polymul_host / dil_verify_core_host have returned, no page of the
-    caller's heap arrays is still registered (VM_DONTCOPY in /proc/self/smaps), whatever the size class and option.  Rounds 4-5 handed the
-    caller's pageable pointer to hipMemcpyAsync on the library's private streams: the runtime page-locked the range and kept the lock in
-    that stream's cache for the life of the process (this test fails on that library) -- the state in which a later copy of the application
-    to the same heap addresses faulted on the GPU (profiles/r06_suite_crash_rootcause.txt)."""
-    import ctypes
+def test_pageable_caller_buffers_only_meet_memcpy(gpu, oracle, host_opts):
+    """The round-6 rule, observed from outside: during host-pointer calls on pageable arrays of every size class the library issues no
+    hipHostRegister / hipHostUnregister, and every hipMemcpy* it issues has a page-locked host end (its own slots) -- checked by asking the
+    runtime about both ends of the caller's arrays before and after (still unknown to it: pageable, unregistered), and by the results"""
+    import ctypes as C
     from dilithium_amd import api
-    libc = ctypes.CDLL("libc.so.6")
-    libc.mallopt(-3, 1 << 30)                       # M_MMAP_THRESHOLD: the arrays below come from the heap proper, like the suite's
-    for pin, duplex in ((1, 1), (1, 0), (0, 1)):
-        host_opts(host_pin=pin, host_duplex=duplex, host_chunk=8192, host_streams=4)
+    hip = C.CDLL("libamdhip64.so")
+
+    class Attr(C.Structure):
+        _fields_ = [("type", C.c_int), ("device", C.c_int), ("devicePointer", C.c_void_p), ("hostPointer", C.c_void_p), ("isManaged", C.c_int),
+                    ("allocationFlags", C.c_uint), ("pad", C.c_char * 64)]
+
+    def known_to_runtime(arr):
+        at = Attr()
+        ends = (arr.ctypes.data, arr.ctypes.data + arr.nbytes - 1)
+        rcs = [hip.hipPointerGetAttributes(C.byref(at), C.c_void_p(p)) for p in ends]
+        hip.hipGetLastError()
+        return any(rc == 0 and at.type == 1 for rc in rcs)          # hipMemoryTypeHost: registered / page-locked host memory
+
+    for threads in (1, 3):
+        host_opts(host_copy_threads=threads, host_chunk=8192, host_streams=4)
         for n in (3, 300, 5000, 20000, 70000):
             a = splitmix64_polys(n, seed=n)
             x, b = a.copy(), splitmix64_polys(n, seed=n + 1)
+            assert not any(known_to_runtime(v) for v in (x, a, b))
             api.ntt(x)
+            idx = np.arange(0, n, max(1, n // 50))
+            assert (x[idx] == oracle.ntt(a[idx])).all()
             api.invntt(x)
             assert (x == a).all()
             c = np.empty_like(a)
             api.pointwise_barrett(c, a, b)
             api.polymul(c, a, b)
-            left = [r for arr in (x, a, b, c) for r in _registered_with_the_driver(arr)]
-            assert not left, (pin, duplex, n, [(hex(lo), hex(hi)) for lo, hi in left])
-    K, L, n = 6, 5, 700
-    rng = np.random.default_rng(1)
-    A = splitmix64_polys(n * K * L, seed=5).reshape(n, K, L, N)
-    z = np.mod(rng.integers(-(1 << 19) + 1, 1 << 19, (n, L, N)), Q).astype(np.int32)
-    cc = np.zeros((n, N), np.int32)
-    cc[:, ::7] = 1
-    t1 = rng.integers(0, 1024, (n, K, N)).astype(np.int32)
-    h = (rng.random((n, K * N)) < 0.03).astype(np.uint8)
-    for pin in (1, 0):
-        host_opts(host_pin=pin)
-        w1 = api.verify_core(A, z, cc, t1, h, 3)
-        left = [r for arr in (A, z, cc, t1, h, w1) for r in _registered_with_the_driver(arr)]
-        assert not left, (pin, [(hex(lo), hex(hi)) for lo, hi in left])
+            assert (c[idx] == oracle.invntt(oracle.pointwise(oracle.ntt(a[idx]), oracle.ntt(b[idx])))).all()
+            assert not any(known_to_runtime(v) for v in (x, a, b, c)), (threads, n)

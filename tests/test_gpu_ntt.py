@@ -318,8 +318,8 @@ def test_polymul_fused_vs_oracle_chain_and_the_definition(gpu, oracle):
 
 @pytest.mark.parametrize("n", [1, 2, 77, 2048, 2049, 9000, 20011])
 def test_polymul_host_one_round_trip(gpu, oracle, n):
-    """dil_polymul_host: host arrays in, host array out (up to 2048 pairs through the staging buffer in one piece, above that page-locked
-    for the call and chunked over the streams; batch 1 through the mailbox when it is on) == the oracle chain"""
+    """dil_polymul_host: host arrays in, host array out (pageable arrays in slices of 2048 pairs through the ring of page-locked slots;
+    batch 1 through the mailbox when it is on) == the oracle chain"""
     from dilithium_amd import api
     a, b = splitmix64_polys(n, seed=70 + n), splitmix64_polys(n, seed=71 + n, lo=-(Q - 1), hi=Q)
     want = oracle.invntt(oracle.pointwise(oracle.ntt(a), oracle.ntt(b)))
@@ -343,16 +343,16 @@ def test_polymul_host_one_round_trip(gpu, oracle, n):
 
 def test_polymul_host_chunk_and_stream_options(gpu, oracle):
     from dilithium_amd import api
-    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_pin")}
+    saved = {k: api.get_option(k) for k in ("host_chunk", "host_streams", "host_copy_threads")}
     try:
         a, b = splitmix64_polys(5000, seed=81), splitmix64_polys(5000, seed=82)
         want = oracle.invntt(oracle.pointwise(oracle.ntt(a), oracle.ntt(b)))
-        for chunk, streams, pin in ((128, 1, 0), (600, 3, 1), (1000, 8, 0), (8192, 4, 0)):
-            for k, v in (("host_chunk", chunk), ("host_streams", streams), ("host_pin", pin)):
+        for chunk, streams, threads in ((128, 1, 1), (600, 3, 3), (1000, 8, 2), (8192, 4, 3)):
+            for k, v in (("host_chunk", chunk), ("host_streams", streams), ("host_copy_threads", threads)):
                 api.set_option(k, v)
             c = np.empty_like(a)
             api.polymul(c, a, b)
-            assert (c == want).all(), (chunk, streams, pin)
+            assert (c == want).all(), (chunk, streams, threads)
     finally:
         for k, v in saved.items():
             api.set_option(k, v)

@@ -215,11 +215,11 @@ def test_every_option_is_documented_and_round_trips_without_gpu(lib):
 
 
 def test_host_pipeline_plan_without_gpu(lib):
-    """dil_host_plan: which form a dil_ntt_host-style call takes and in which chunks, by batch size, lockability of the caller's buffer and
-    options (csrc/capi.hip host_plan; thresholds of the page-locked pipelines from profiles/r05t_host_batch_sweep.txt) -- pure host logic"""
+    """dil_host_plan: which form a dil_ntt_host-style call takes and in which chunks, by batch size, kind of caller memory and options
+    (csrc/capi.hip host_plan; thresholds of the page-locked pipelines from profiles/r05t_host_batch_sweep.txt) -- pure host logic"""
     import ctypes as C
-    ONE_SHOT, ROUND_ROBIN, DUPLEX, STAGED_SLICES = 0, 1, 2, 3
-    names = ("host_chunk", "host_streams", "host_pin", "host_duplex")
+    ONE_SHOT, ROUND_ROBIN, DUPLEX, STAGED_RING = 0, 1, 2, 3
+    names = ("host_chunk", "host_streams", "host_copy_threads", "host_duplex")
     saved = {}
     for n in names:
         v = C.c_int(0)
@@ -232,30 +232,27 @@ def test_host_pipeline_plan_without_gpu(lib):
         return p.value, c.value
 
     try:
-        for n, v in (("host_chunk", 8192), ("host_pin", 1), ("host_duplex", 1)):
+        for n, v in (("host_chunk", 8192), ("host_duplex", 1)):
             assert lib.dil_set_option(n.encode(), v) == 0
-        for locked in (0, 1):       # a pageable buffer is page-locked for the call: the same plan as one the caller page-locked
-            # up to 4 MiB: one piece through the library's own staging buffer
-            assert plan(1, locked) == (ONE_SHOT, 1) and plan(4096, locked) == (ONE_SHOT, 4096)
-            # then round-robin in 1-MiB chunks, one stream per direction from 8 chunks of the option's size (64 MiB)
-            assert plan(4097, locked) == (ROUND_ROBIN, 1024) and plan(65535, locked) == (ROUND_ROBIN, 1024)
-            assert plan(65536, locked) == (DUPLEX, 8192) and plan(1 << 20, locked) == (DUPLEX, 8192)
-        # host_pin = 0: a pageable buffer is never registered -- 4-MiB slices through the staging buffer; the caller's own page-lock still counts
-        assert lib.dil_set_option(b"host_pin", 0) == 0
-        assert plan(4096, 0) == (ONE_SHOT, 4096) and plan(4097, 0) == (STAGED_SLICES, 4096) and plan(1 << 20, 0) == (STAGED_SLICES, 4096)
-        assert plan(65536, 1) == (DUPLEX, 8192)
-        assert lib.dil_set_option(b"host_pin", 1) == 0
+        # pageable: always through the library's own page-locked slots -- one slice up to 4 MiB, a ring of 4-MiB slices above
+        assert plan(1, 0) == (ONE_SHOT, 1) and plan(4096, 0) == (ONE_SHOT, 4096)
+        assert plan(4097, 0) == (STAGED_RING, 4096) and plan(65536, 0) == (STAGED_RING, 4096) and plan(1 << 20, 0) == (STAGED_RING, 4096)
+        # page-locked by the caller: DMA in place -- one shot below 8 MiB, round-robin in 1-MiB chunks, one stream per direction from 64 MiB
+        assert plan(4096, 1) == (ONE_SHOT, 4096) and plan(8191, 1) == (ONE_SHOT, 8191)
+        assert plan(8192, 1) == (ROUND_ROBIN, 1024) and plan(65535, 1) == (ROUND_ROBIN, 1024)
+        assert plan(65536, 1) == (DUPLEX, 8192) and plan(1 << 20, 1) == (DUPLEX, 8192)
         # the options take the pipelines away / move the chunk
-        assert lib.dil_set_option(b"host_duplex", 0) == 0 and plan(65536, 1) == (ROUND_ROBIN, 8192) and plan(5000, 0) == (ROUND_ROBIN, 8192)
+        assert lib.dil_set_option(b"host_duplex", 0) == 0 and plan(65536, 1) == (ROUND_ROBIN, 8192)
         assert lib.dil_set_option(b"host_duplex", 1) == 0
-        # small chunks (what the GPU tests use to wrap the staging ring): a call larger than one chunk takes a pipeline
+        # small chunks (what the GPU tests use to wrap the rings)
         assert lib.dil_set_option(b"host_chunk", 64) == 0
-        assert plan(64, 0) == (ONE_SHOT, 64) and plan(65, 0) == (ROUND_ROBIN, 64) and plan(511, 1) == (ROUND_ROBIN, 64) and plan(512, 0) == (DUPLEX, 64)
+        assert plan(64, 0) == (ONE_SHOT, 64) and plan(65, 0) == (STAGED_RING, 64) and plan(593, 0) == (STAGED_RING, 64)
         assert lib.dil_set_option(b"host_chunk_pinned", 600) == 0        # (the older name of the same option)
         v = C.c_int(0)
         assert lib.dil_get_option(b"host_chunk", C.byref(v)) == 0 and v.value == 600
-        assert plan(5417, 1) == (DUPLEX, 600) and plan(4799, 0) == (ROUND_ROBIN, 600)
-        assert lib.dil_set_option(b"host_threads", 2) != 0               # the helper-thread pipeline for pageable buffers is gone
+        assert plan(5417, 1) == (DUPLEX, 600) and plan(4799, 1) == (ROUND_ROBIN, 600) and plan(4799, 0) == (STAGED_RING, 600)
+        # gone with round 6: the helper-thread pipeline on pageable memory, page-locking the caller's buffer for a call
+        assert lib.dil_set_option(b"host_threads", 2) != 0 and lib.dil_set_option(b"host_pin", 1) != 0
         for batch in (100, 1000, 5000, 20011, 70000, 300000):
             for locked in (0, 1):
                 p, c = plan(batch, locked)
