@@ -911,8 +911,8 @@ def leg_scheme(cx, sec):
 def leg_end_to_end(cx):
     """"exclude H2D/D2H from kernel figures but report end-to-end separately".  The reference's calling convention for the
     path is caller-owned HOST arrays (reference_code/ref_ntt.h:30-36, hardware_code/ntt2x2.h:30-34); these are the same two workloads
-    through the host-pointer entry points (csrc/capi.hip: chunks of H2D -> kernel -> D2H; a helper thread downloads a pageable buffer, a
-    page-locked one gets one stream per direction), with the caller's buffers pageable and page-locked, against the link's own copy rate
+    through the host-pointer entry points (csrc/capi.hip: chunks of H2D -> kernel -> D2H; a pageable buffer goes through the library's ring of
+    page-locked slots by memcpy, a page-locked one is DMA'd in place with one stream per direction), with the caller's buffers pageable and page-locked, against the link's own copy rate
     measured here -- one direction at a time, and both at once in the best pattern found (scripts/bench_pcie_duplex.py).  PCIe-bound by two orders of magnitude: never `value`."""
     api = cx.api
 

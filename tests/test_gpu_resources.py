@@ -1,5 +1,5 @@
 """Nothing accumulates: device memory, host memory, threads and open file descriptors of the process after hundreds of calls of every
-kind of entry point -- transforms on device and host pointers (all three host pipelines, the helper thread of the pageable one included),
+kind of entry point -- transforms on device and host pointers (the ring of page-locked slots a pageable buffer goes through, both in-place pipelines of a page-locked one),
 the fused cores, the byte-level scheme (whose signing loop reads a count back every round), the batch-of-one mailbox calls.  The
 reference is stateless and allocation-free (ref_ntt.h:30-36: caller-owned buffers, nothing retained); the drop-in keeps grow-only scratch
 per stream and device, so a steady workload must reach a steady state."""
@@ -37,7 +37,7 @@ def _steady(torch, body, warm=3, reps=40, dev_slack=8 << 20, rss_slack=48 << 20)
 def test_transforms_and_host_pipelines_reach_a_steady_state(gpu):
     from dilithium_amd import api
     torch = gpu
-    n = 40000                                             # pageable: helper-thread pipeline; page-locked: round-robin below 64 MiB
+    n = 40000                                             # pageable: the ring of page-locked slots; page-locked: round-robin below 64 MiB
     a = splitmix64_polys(n, seed=9)
     pageable = a.copy()
     keep = torch.empty((70000, 256), dtype=torch.int32).pin_memory()     # >= 64 MiB: one stream per direction
