@@ -40,6 +40,7 @@ const OptName* option_table(int* n)
         {"sign_waste", "DIL_SIGN_WASTE", &cfg.sign_waste},
         {"sign_skip", "DIL_SIGN_SKIP", &cfg.sign_skip},
         {"sign_cap", "DIL_SIGN_CAP", &cfg.sign_cap},
+        {"sign_wake", "DIL_SIGN_WAKE", &cfg.sign_wake},
         {"aux_overlap", "DIL_AUX_OVERLAP", &cfg.aux_overlap},
         {"zeroize", "DIL_ZEROIZE", &cfg.zeroize},
         {"fuse_wire", "DIL_FUSE_WIRE", &cfg.fuse_wire},

@@ -30,6 +30,7 @@ struct Config {
     std::atomic<int> sign_early{1};        // DIL_SIGN_EARLY: 0 = the signing loop evaluates every check of every attempt
     std::atomic<int> sign_skip{3};         // DIL_SIGN_SKIP: bit 0 = phase 2 of a speculative round drops the attempts behind an accepted one, bit 1 = its waves draw entries from a queue
     std::atomic<int> sign_waste{6144};     // DIL_SIGN_WASTE: speculative entries a round may expect to waste
+    std::atomic<int> sign_wake{1};         // DIL_SIGN_WAKE: how a signing round's pending count reaches the host: 1 = posted into mapped host words by the collect kernel (polled), 0 = copy + event
     std::atomic<int> sign_cap{0};          // DIL_SIGN_CAP: entries in flight per signing round (0 = default 16384)
     std::atomic<int> aux_overlap{1};       // DIL_AUX_OVERLAP: 0 = composite calls never use the helper stream
     std::atomic<int> zeroize{0};           // DIL_ZEROIZE: 1 = signing / keygen clear their device scratch before returning

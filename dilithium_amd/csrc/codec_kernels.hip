@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void sign_round_setup_kernel(uint4* __restrict
                                                                size_t entries, int gather)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < 2) counts[g] = 0;          // pending, winners
+    if (g < 3) counts[g] = 0;          // pending, winners, workgroups of the collect kernel that are through
     for (size_t i = g; i < (size_t)TICKET_WORDS; i += (size_t)gridDim.x * blockDim.x) tickets[i] = 0;      // phase 2's work queues (KeyMap::ticket)
     const size_t e = g >> 2, w = g & 3;
     if (e >= entries) return;
@@ -351,35 +351,53 @@ __global__ __launch_bounds__(256) void sign_round_setup_kernel(uint4* __restrict
 // (entry, item) pair goes on the winners list (packed into the item's signature slot by the RowMap-driven codec launches
 // that follow), the attempt count is recorded and the winner's c~ (32 bytes, any alignment) is copied into its signature
 // slot; none accepted -> the item goes on the next pending list.  counts[0] = pending, counts[1] = winners.
+// host_words != nullptr: the LAST workgroup through (counts[2]) posts the two counts and then `seq` into the host's mapped, coherent
+// words -- the host sizes the next round from them the moment this kernel is done, without a copy, an event or a wake-up in between
+// (scheme.hip sign_core; the FPGA's FSM never leaves the device between attempts either, combined_top.v:1823-1934).
 __global__ __launch_bounds__(256) void sign_collect_ct_kernel(int32_t* __restrict__ attempts, int32_t* __restrict__ next_idx,
                                                               int32_t* __restrict__ win_entry, int32_t* __restrict__ win_item,
                                                               int32_t* __restrict__ counts, const int32_t* __restrict__ flags,
                                                               const int32_t* __restrict__ idx, int a0, int S, size_t n,
-                                                              uint8_t* __restrict__ sig, size_t sig_stride, const uint8_t* __restrict__ ct)
+                                                              uint8_t* __restrict__ sig, size_t sig_stride, const uint8_t* __restrict__ ct,
+                                                              int32_t* host_words, uint32_t seq)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t item = idx ? idx[i] : (int32_t)i;
-    int win = -1;
-    for (int j = 0; j < S; j++)
-        if (flags[i * (size_t)S + j] == 0) {
-            win = j;
-            break;
-        }
-    if (win < 0) {
-        next_idx[atomicAdd(&counts[0], 1)] = item;
-    } else {
-        const int w = atomicAdd(&counts[1], 1);
-        const size_t entry = i * (size_t)S + win;
-        win_entry[w] = (int32_t)entry;
-        win_item[w] = item;
-        attempts[item] = a0 + win + 1;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(ct + entry * 32);      // scratch: 4-byte aligned
-        uint8_t* dst = sig + (size_t)item * sig_stride;
+    if (i < n) {
+        const int32_t item = idx ? idx[i] : (int32_t)i;
+        int win = -1;
+        for (int j = 0; j < S; j++)
+            if (flags[i * (size_t)S + j] == 0) {
+                win = j;
+                break;
+            }
+        if (win < 0) {
+            next_idx[atomicAdd(&counts[0], 1)] = item;
+        } else {
+            const int w = atomicAdd(&counts[1], 1);
+            const size_t entry = i * (size_t)S + win;
+            win_entry[w] = (int32_t)entry;
+            win_item[w] = item;
+            attempts[item] = a0 + win + 1;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ct + entry * 32);      // scratch: 4-byte aligned
+            uint8_t* dst = sig + (size_t)item * sig_stride;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const uint32_t v = src[q];
-            __builtin_memcpy(dst + 4 * q, &v, 4);
+            for (int q = 0; q < 8; q++) {
+                const uint32_t v = src[q];
+                __builtin_memcpy(dst + 4 * q, &v, 4);
+            }
+        }
+    }
+    if (!host_words) return;
+    __syncthreads();                                     // this workgroup's additions to counts[0..1] are issued
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&counts[2], 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            const int32_t pending = __hip_atomic_load(&counts[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t winners = __hip_atomic_load(&counts[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&host_words[0], pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_words[1], winners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(&host_words[2]), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -468,11 +486,11 @@ hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa
 
 hipError_t launch_sign_collect_ct(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
                                   const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, uint8_t* sig, size_t sig_stride,
-                                  const uint8_t* ct, hipStream_t s)
+                                  const uint8_t* ct, hipStream_t s, int32_t* host_words, uint32_t seq)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(sign_collect_ct_kernel, (int)((n + 255) / 256), 256, 0, s, attempts, next_idx, win_entry, win_item, counts, flags,
-                       idx, a0, S, n, sig, sig_stride, ct);
+                       idx, a0, S, n, sig, sig_stride, ct, host_words, seq);
     return hipGetLastError();
 }
 

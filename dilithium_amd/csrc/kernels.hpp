@@ -202,7 +202,7 @@ hipError_t launch_sign_round_setup(uint8_t* mu_c, uint8_t* rp_c, uint32_t* kappa
                                    const int32_t* idx, uint32_t a0, uint32_t L, uint32_t S, size_t entries, bool gather, hipStream_t s);
 hipError_t launch_sign_collect_ct(int32_t* attempts, int32_t* next_idx, int32_t* win_entry, int32_t* win_item, int32_t* counts,
                                   const int32_t* flags, const int32_t* idx, int a0, int S, size_t n, uint8_t* sig, size_t sig_stride,
-                                  const uint8_t* ct, hipStream_t s);
+                                  const uint8_t* ct, hipStream_t s, int32_t* host_words = nullptr, uint32_t seq = 0);
 hipError_t launch_copy_field(uint8_t* dst, size_t dst_stride, size_t dst_off, const uint8_t* src, size_t src_stride, size_t src_off,
                              int nbytes, size_t nitems, const Tables& t, hipStream_t s, RowMap map = RowMap());
 

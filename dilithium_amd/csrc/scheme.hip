@@ -135,14 +135,19 @@ struct StreamScratch {
         }
         return static_cast<T*>(q);
     }
-    // two pinned host words (per arena; a private allocation when the call has no arena)
+    // four page-locked host words, mapped and coherent (per arena; a private allocation when the call has no arena): the signing loop's
+    // [0] pending, [1] winners, [2] the sequence number the device posts behind them, [3] the host's own sequence counter
     int32_t* own_pinned = nullptr;
     int32_t* pinned_words()
     {
         int32_t** slot = arena ? &arena->pinned : &own_pinned;
-        if (!*slot && hipHostMalloc(reinterpret_cast<void**>(slot), 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
-            *slot = nullptr;
-            rc = rc ? rc : (int)hipErrorOutOfMemory;
+        if (!*slot) {
+            if (hipHostMalloc(reinterpret_cast<void**>(slot), 4 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+                *slot = nullptr;
+                rc = rc ? rc : (int)hipErrorOutOfMemory;
+            } else {
+                for (int i = 0; i < 4; i++) (*slot)[i] = 0;
+            }
         }
         return *slot;
     }
@@ -690,6 +695,26 @@ int sign_round_width(size_t pending, size_t cap, int attempts_left)
     return S_;
 }
 
+// Poll the mapped words for the sequence number the collect kernel posts behind its counts.  Every ~16 k polls the stream is asked
+// whether it is still busy: a stream that has drained (or failed) without the number means the post never comes -- then the counts are
+// fetched by an ordinary blocking copy (or the stream's error is returned), so a lost post costs time, never a hang.
+int await_round_count(int32_t* host_words, const int32_t* counts, uint32_t seq, hipStream_t s)
+{
+    const uint32_t* posted = reinterpret_cast<const uint32_t*>(host_words + 2);
+    for (unsigned polls = 1;; polls++) {
+        if (__atomic_load_n(posted, __ATOMIC_ACQUIRE) == seq) return 0;
+        if ((polls & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(posted, __ATOMIC_ACQUIRE) == seq) return 0;
+                return (int)hipMemcpy(host_words, counts, 8, hipMemcpyDeviceToHost);
+            }
+            if (q != hipErrorNotReady) return (int)q;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig, int32_t* attempts, const uint8_t* sk, const uint8_t* mu,
               int level, const LevelPar& p, size_t batch, int shared_sk, int max_attempts, hipStream_t s)
 {
@@ -713,7 +738,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     int32_t* wine = ws.take<int32_t>(batch);             // winners of a round: entry, item
     int32_t* wini = ws.take<int32_t>(batch);
     int32_t* own_attempts = attempts ? nullptr : ws.take<int32_t>(batch);
-    int32_t* counts = ws.take<int32_t>(2);               // [0] pending, [1] winners
+    int32_t* counts = ws.take<int32_t>(4);               // [0] pending, [1] winners, [2] workgroups of the collect kernel that are through
     uint32_t* tickets = ws.take<uint32_t>(dil::TICKET_WORDS);      // phase 2's work queues (KeyMap::ticket)
     // per entry
     uint32_t* kap = ws.take<uint32_t>(cap);
@@ -744,11 +769,15 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         DIL_TRY(dil::launch_sign_setup(level, A, few, s1h, s2h, t0h, sk, nk, rp, attempts, mu, sk_stride, batch, T, s));
     }
 
+    // How a round's pending count reaches the host (option sign_wake): 1 = the collect kernel's last workgroup posts it into mapped host words
+    // and the host polls them -- no copy, no event, no wake-up, so the next round's launches are queued while the winners are still being
+    // packed; 0 = an 8-byte copy behind the collect kernel + an event (rounds 2 - 5).
+    const bool wake_flag = dil::rt::cfg.sign_wake.load(std::memory_order_relaxed) != 0;
     struct EventGuard {
         hipEvent_t ev = nullptr;
         ~EventGuard() { if (ev) (void)hipEventDestroy(ev); }
     } counted;
-    DIL_TRY(hipEventCreateWithFlags(&counted.ev, hipEventDisableTiming));
+    if (!wake_flag) DIL_TRY(hipEventCreateWithFlags(&counted.ev, hipEventDisableTiming));
     int32_t *idx_cur = nullptr, *idx_next = idx0;
     size_t n = batch;
     int a0 = 0;                                          // attempts every pending item has already failed
@@ -773,25 +802,37 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
                 DIL_TRY(dil::launch_gather_rows(rp_c, rp, idx_cur, 64, (uint32_t)S_, E, T, s));
             }
             DIL_TRY(dil::launch_sign_kappa(kap, fl, (uint32_t)a0, (uint32_t)p.L, (uint32_t)S_, E, s));
-            DIL_TRY(hipMemsetAsync(counts, 0, 8, s));
+            DIL_TRY(hipMemsetAsync(counts, 0, 16, s));
             DIL_TRY(hipMemsetAsync(tickets, 0, dil::TICKET_WORDS * 4, s));
         }
         // (Two stream-level overlaps of a round's latency-bound hash kernels with its polynomial kernels were built in rounds 2 / 3 and
         //  measured slower -- 1.42 -> 1.77 ms per 8192 level-3 signatures, profiles/r03j_sign_overlap.txt -- and are gone.)
         if ((rc = sign_attempt_impl(T, att, ct, z, h, fl, A, mur, rpr, kap, s1h, s2h, t0h, level, E, shared_sk, s, keys, sign_early))) return rc;
         // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
-        DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s));
-        // the pending count goes home NOW, marked by an event; the winners' packing is queued behind it, so the host wakes up,
-        // sizes the next round and has its launches in the queue while the packing kernels still run
-        DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
-        DIL_TRY(hipEventRecord(counted.ev, s));
+        uint32_t seq = 0;
+        if (wake_flag) {
+            seq = (uint32_t)++host_counts[3];
+            if (seq == 0) seq = (uint32_t)++host_counts[3];          // (0 is what a fresh allocation shows)
+        }
+        DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s,
+                                            wake_flag ? host_counts : nullptr, seq));
+        // the pending count goes home NOW; the winners' packing is queued behind it, so the host sizes the next round and has its
+        // launches in the queue while the packing kernels still run
+        if (!wake_flag) {
+            DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
+            DIL_TRY(hipEventRecord(counted.ev, s));
+        }
         dil::RowMap win;
         win.src_row = wine;
         win.dst_row = wini;
         win.count = counts + 1;
         DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, T, s, win));
         DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n, s, win));
-        DIL_TRY(hipEventSynchronize(counted.ev));
+        if (wake_flag) {
+            if ((rc = await_round_count(host_counts, counts, seq, s))) return rc;
+        } else {
+            DIL_TRY(hipEventSynchronize(counted.ev));
+        }
         n = (size_t)host_counts[0];
         a0 += S_;
         idx_cur = idx_next;

@@ -76,6 +76,10 @@ int dil_shutdown(void);
  *                                   (dil_verify_wire_core_dev, dil_verify_sig_expanded_dev), bit 1 = in dil_verify_sig_dev too (there the
  *                                   sampler otherwise runs beside ExpandA on the helper stream).  Levels 2 and 3 (level 5: the launch in front is faster and
  *                                   stays).  Verdicts and w1 do not depend on it.
+ *   "sign_wake"   (DIL_SIGN_WAKE)   how the pending count of a signing round reaches the host, which sizes the next round from it:
+ *                                   1 (default) = the round's last kernel posts it into mapped page-locked words of the library and the
+ *                                   calling thread polls them (no copy, no event: the next round is queued while the winners are packed),
+ *                                   0 = an 8-byte copy + an event behind that kernel.  Signatures and attempt counts do not depend on it.
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it

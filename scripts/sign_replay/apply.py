@@ -5,7 +5,7 @@ A loop whose rounds size themselves from a count in device memory could at best 
 in advance: no read-back, no wake-up, every launch queued behind the previous one, grids and kernel forms exactly as the host-sized loop
 picks them.  This script builds that bound as a VARIANT library (never shipped): a copy of csrc/scheme.hip in which sign_core takes the
 pending counts of the rounds from the environment (DIL_SIGN_REPLAY="n1,n2,...": signing is deterministic, so a first ordinary call of the
-same inputs gives them) instead of reading them back, and checks the device's count once, after the last round.
+same inputs gives them) instead of waiting for them, and checks the device's count once, after the last round (option sign_wake = 1 assumed: the default).
 
     python scripts/sign_replay/apply.py            ->  scripts/bin/libdil256_replay.so   (other objects: dilithium_amd/build/*.o)
 """
@@ -17,27 +17,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "dilithium_amd", "csrc")
 src = open(os.path.join(CSRC, "scheme.hip")).read()
 
-OLD_COPY = """        DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
-        DIL_TRY(hipEventRecord(counted.ev, s));
-"""
-NEW_COPY = """        const bool replayed = round_no < replay.size();
-        if (!replayed) {
-        DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
-        DIL_TRY(hipEventRecord(counted.ev, s));
+OLD_SYNC = """        if (wake_flag) {
+            if ((rc = await_round_count(host_counts, counts, seq, s))) return rc;
+        } else {
+            DIL_TRY(hipEventSynchronize(counted.ev));
         }
-"""
-OLD_SYNC = """        DIL_TRY(hipEventSynchronize(counted.ev));
         n = (size_t)host_counts[0];
 """
-NEW_SYNC = """        if (replayed) {
+NEW_SYNC = """        if (round_no < replay.size()) {
             n = replay[round_no];
-            if (round_no + 1 == replay.size()) {          // the one read-back a host-free loop keeps: the count after its last queued round
-                DIL_TRY(hipMemcpyAsync(host_counts, counts, 8, hipMemcpyDeviceToHost, s));
-                DIL_TRY(hipStreamSynchronize(s));
+            if (round_no + 1 == replay.size()) {          // the one wait a host-free loop keeps: the count after its last queued round
+                if ((rc = await_round_count(host_counts, counts, seq, s))) return rc;
                 if ((size_t)host_counts[0] != n) return (int)hipErrorAssert;          // the replayed schedule was not this input's
             }
         } else {
-            DIL_TRY(hipEventSynchronize(counted.ev));
+            if ((rc = await_round_count(host_counts, counts, seq, s))) return rc;
             n = (size_t)host_counts[0];
         }
         round_no++;
@@ -54,7 +48,7 @@ NEW_LOOP = OLD_LOOP + """    std::vector<size_t> replay;
             if (end == q && *q) break;
         }
 """
-for old, new in ((OLD_COPY, NEW_COPY), (OLD_SYNC, NEW_SYNC), (OLD_LOOP, NEW_LOOP)):
+for old, new in ((OLD_SYNC, NEW_SYNC), (OLD_LOOP, NEW_LOOP)):
     assert src.count(old) == 1, old
     src = src.replace(old, new)
 src = src.replace('#include "capi_internal.hpp"', '#include <vector>\n#include <cstdlib>\n#include "capi_internal.hpp"', 1)

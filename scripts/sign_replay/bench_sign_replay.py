@@ -2,7 +2,7 @@
 """The signing loop as it is against its host-free UPPER BOUND (scripts/sign_replay/apply.py builds the variant library):
     DIL_LIB_PATH=scripts/bin/libdil256_replay.so python scripts/sign_replay/bench_sign_replay.py [n]
 Per level: one ordinary call gives attempts[] and with the exported speculation rule (dil_sign_round_plan) the pending count after every
-round; then the same call is timed with the read-backs (DIL_SIGN_REPLAY unset) and with every round queued back to back (set)."""
+round; then the same call is timed with the count read back by copy + event (sign_wake 0), posted into mapped words and polled (sign_wake 1, shipped) and with every round queued back to back (DIL_SIGN_REPLAY set: the bound)."""
 import ctypes as C
 import os
 import sys
@@ -54,12 +54,15 @@ for level in (2, 3, 5):
         os.environ.pop("DIL_SIGN_REPLAY", None)
         sig0, att = api.sign(sk, mu, level, shared_sk=bool(shared))
         sch = schedule(level, att)
+        api.set_option("sign_wake", 0)
+        t_event = timeit(lambda: api.sign(sk, mu, level, shared_sk=bool(shared)))
+        api.set_option("sign_wake", 1)
         t_host = timeit(lambda: api.sign(sk, mu, level, shared_sk=bool(shared)))
         os.environ["DIL_SIGN_REPLAY"] = ",".join(str(p) for _, _, p in sch)
         sig1, att1 = api.sign(sk, mu, level, shared_sk=bool(shared))
         same = bool((sig0 == sig1).all()) and bool((att == att1).all())
         t_free = timeit(lambda: api.sign(sk, mu, level, shared_sk=bool(shared)))
         os.environ.pop("DIL_SIGN_REPLAY", None)
-        print(f"L{level} n={n} {'one key' if shared else 'key/item'}: rounds (S, entries, pending after) {sch} | host-sized {t_host * 1e6:8.1f} us "
-              f"{n / t_host / 1e6:5.2f} M/s | queued back to back {t_free * 1e6:8.1f} us {n / t_free / 1e6:5.2f} M/s | {100 * (t_host / t_free - 1):+.1f} % | "
+        print(f"L{level} n={n} {'one key' if shared else 'key/item'}: rounds (S, entries, pending after) {sch} | copy + event {t_event * 1e6:8.1f} us {n / t_event / 1e6:5.2f} M/s | "
+              f"posted count (shipped) {t_host * 1e6:8.1f} us {n / t_host / 1e6:5.2f} M/s | queued back to back {t_free * 1e6:8.1f} us {n / t_free / 1e6:5.2f} M/s | {100 * (t_host / t_free - 1):+.1f} % | "
               f"identical {same}", flush=True)
