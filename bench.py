@@ -810,6 +810,12 @@ def leg_scheme(cx, sec):
         vd = torch.empty((VBATCH,), dtype=torch.int32, device="cuda")
         kg_ms, _ = timed(lambda i: L.dil_keygen_dev(P(pk), P(sk), P(seed), 3, VBATCH, stream))
         sg_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, VBATCH, 1, 512, stream))
+        # the same with the round's count fetched by copy + event (rounds 2-5's form, option sign_wake = 0)
+        cx.api.set_option("sign_wake", 0)
+        try:
+            sg0_ms, _ = timed(lambda i: L.dil_sign_dev(P(sig), P(att), P(sk), P(mu), 3, VBATCH, 1, 512, stream))
+        finally:
+            cx.api.set_option("sign_wake", 1)
         mean_att = float(att.float().mean())
         sgd_ms, _ = timed(lambda i: L.dil_sign_dev(P(sigd), P(att), P(sk), P(mu), 3, VBATCH, 0, 512, stream))
         vf_ms, _ = timed(lambda i: L.dil_verify_sig_dev(P(vd), P(pk), P(sig), P(mu), 3, VBATCH, 1, stream))
@@ -858,11 +864,12 @@ def leg_scheme(cx, sec):
             "note": "pk/sk/sig bytes in HBM -> bytes in HBM; SHAKE, samplers, codecs, rejection loop all on the device; "
                     "verification reads the packed fields inside the fused kernel (no int32 temporaries).  Rates are whole calls "
                     "timed with HIP events around back-to-back calls on one stream (the median of three regions of >= 25 ms); the sign rates are therefore HOST-INCLUSIVE: "
-                    "dil_sign_dev synchronises the stream once per rejection round (an 8-byte count read back, ~10 us per round)",
-            "keygen_per_s": per_s(kg_ms), "sign_shared_key_per_s": per_s(sg_ms), "sign_distinct_keys_per_s": per_s(sgd_ms),
+                    "dil_sign_dev sizes every rejection round on the host from the count the round's last kernel posts into mapped host words (option sign_wake)",
+            "keygen_per_s": per_s(kg_ms), "sign_shared_key_per_s": per_s(sg_ms), "sign_shared_key_copy_event_per_s": per_s(sg0_ms),
+            "sign_distinct_keys_per_s": per_s(sgd_ms),
             "verify_shared_pk_per_s": per_s(vf_ms), "verify_distinct_pk_per_s": per_s(vfd_ms),
-            "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "sample_in_ball_bits_kernel + "
-                                             "verify_wire_wpi_kernel<3>", "wire_bytes_per_verify": 30 * 1024 + 3200 + 61 + 1920 + 256 + 768},
+            "verify_wire_core_distinct_pk": {"per_s": per_s(wk_ms), "ms": wk_ms, "kernel": "verify_wire_wpi_kernel<3> with SampleInBall "
+                                             "inside (option fuse_sib; rounds 1-5: sample_in_ball_bits_kernel in front)", "wire_bytes_per_verify": 30 * 1024 + 3200 + 61 + 1920 + 256 + 768},
             "verify_expanded_keys": {"distinct_pk_per_s": per_s(vxd_ms), "shared_pk_per_s": per_s(vxs_ms),
                                      "distinct_pk_with_t1hat_per_s": per_s(vx2_ms),
                                      "note": "A = ExpandA(rho) expanded once by the caller and kept across calls"},

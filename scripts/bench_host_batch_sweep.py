@@ -15,7 +15,7 @@ for size in (256, 1024, 2048, 4096, 4097, 8192, 12000, 16384, 32768, 65536, 1310
     y = splitmix64_polys(size, seed=4); y0 = y.copy()
     pin = torch.empty((size, 256), dtype=torch.int32).pin_memory(); yp = pin.numpy(); yp[:] = y
     row = []
-    for ct in (1, 3):
+    for ct in (1, 3, 5, 8):
         api.set_option("host_copy_threads", ct)
         y[:] = y0; api.ntt(y); api.invntt(y); assert (y == y0).all()
         t = med(lambda: api.ntt(y)); row.append(f"pageable copy_threads={ct}: {t*1e3:6.3f} ms {size/t/1e6:5.1f} M/s")
