@@ -16,7 +16,7 @@ OBJ_DIR = os.path.join(PKG, "build")       # git-ignored
 REF_LIB_BUILT = os.path.join(PKG, "libdil256_ref.so")                      # what build_ref() writes
 REF_LIB = os.environ.get("DIL_REF_LIB_PATH", REF_LIB_BUILT)              # what the tests load
 SOURCES = ["kernels.hip", "pipelines.hip", "hash_kernels.hip", "coop_kernels.hip", "codec_kernels.hip", "wire_kernels.hip", "capi.hip", "scheme.hip", "multi_gpu.hip"]
-HEADERS = ["capi_internal.hpp", "modarith.hpp", "ntt_core.hpp", "kernels.hpp", "device_common.hpp", "pipeline_common.hpp", "launch_util.hpp", "keccak.hpp", "keccak_coop.hpp", "coop_bodies.hpp", "wire_common.hpp", "sampler_bodies.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
+HEADERS = ["capi_internal.hpp", "modarith.hpp", "ntt_core.hpp", "kernels.hpp", "device_common.hpp", "pipeline_common.hpp", "launch_util.hpp", "keccak.hpp", "keccak_coop.hpp", "coop_bodies.hpp", "wire_common.hpp", "sampler_bodies.hpp", "copy_pool.hpp", "ref_api.cpp", os.path.join("..", "..", "include", "dil256.h"),
            os.path.join("..", "..", "include", "dil256_ref.hpp")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall", "-pthread"]
 

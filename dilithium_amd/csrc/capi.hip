@@ -5,6 +5,7 @@
 // point launches a HIP kernel and returns the hipError_t if that is not possible.
 #include "capi_internal.hpp"
 #include "launch_util.hpp"
+#include "copy_pool.hpp"
 
 #include <algorithm>
 #include <condition_variable>
@@ -443,74 +444,12 @@ static bool is_page_locked(const void* h, size_t bytes)          // both ends of
 }
 static int host_stream_count() { return std::min(std::max(dil::rt::cfg.host_streams.load(std::memory_order_relaxed), 1), HOST_STREAMS); }
 
-// memcpy on the calling thread + parked pool threads (process-wide; they never call the HIP runtime): a single thread moves ~25 GB/s here,
-// the link 57
-class CopyPool {
-    struct Job { char* d; const char* s; size_t n; };
-    std::mutex call_mu;                 // one parallel copy at a time (calls on different devices take turns)
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::vector<std::thread> th;
-    std::vector<Job> jobs;
-    size_t next = 0, pending = 0;
-    bool quit = false;
-    void worker()
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            cv_work.wait(lk, [this] { return quit || next < jobs.size(); });
-            if (quit) return;
-            const Job j = jobs[next++];
-            lk.unlock();
-            memcpy(j.d, j.s, j.n);
-            lk.lock();
-            if (--pending == 0) cv_done.notify_all();
-        }
-    }
-public:
-    void copy(void* dst, const void* src, size_t n)
-    {
-        const int want = std::min(std::max(dil::rt::cfg.host_copy_threads.load(std::memory_order_relaxed), 1), 8);
-        const size_t parts = std::min<size_t>((size_t)want, n >> 19);          // at least 512 KiB a thread
-        if (parts <= 1) {
-            memcpy(dst, src, n);
-            return;
-        }
-        std::lock_guard<std::mutex> whole(call_mu);
-        std::unique_lock<std::mutex> lk(mu);
-        while (th.size() + 1 < parts) {
-            try {
-                th.emplace_back([this] { worker(); });
-            } catch (const std::exception&) {
-                break;
-            }
-        }
-        const size_t p = std::min(parts, th.size() + 1), piece = ((n / p) + 4095) & ~(size_t)4095;
-        jobs.clear();
-        next = 0;
-        for (size_t i = 1; i < p; i++) {
-            const size_t off = i * piece;
-            if (off < n) jobs.push_back({static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(piece, n - off)});
-        }
-        pending = jobs.size();
-        cv_work.notify_all();
-        lk.unlock();
-        memcpy(dst, src, std::min(piece, n));
-        lk.lock();
-        cv_done.wait(lk, [this] { return pending == 0; });
-    }
-    ~CopyPool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit = true;
-            cv_work.notify_all();
-        }
-        for (std::thread& t : th)
-            if (t.joinable()) t.join();
-    }
+// memcpy on the calling thread + pool threads that never call the HIP runtime (copy_pool.hpp), option host_copy_threads
+struct HostCopy {
+    dil::CopyPool pool;
+    void copy(void* dst, const void* src, size_t n) { pool.copy(dst, src, n, dil::rt::cfg.host_copy_threads.load(std::memory_order_relaxed)); }
 };
-CopyPool g_copy;
+HostCopy g_copy;
 
 // the library's own page-locked staging buffer for single pieces (per device, under host_mu; grown on demand, kept)
 int ensure_stage(Device& d, size_t bytes)
