@@ -15,21 +15,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# (round 5 ran the cyclic collector only between tests to mask an intermittent crash; DIL_TEST_GC_BETWEEN=1 brings that back for A/B runs
-#  of scripts/stress_suite.sh -- the default is Python's own collector, as in any user process)
-if os.environ.get("DIL_TEST_GC_BETWEEN") == "1":
-    @pytest.fixture(autouse=True, scope="session")
-    def _collect_garbage_between_tests_only():
-        import gc
-        gc.disable()
-        yield
-        gc.enable()
-
-    @pytest.fixture(autouse=True)
-    def _gc_after_each_test():
-        yield
-        import gc
-        gc.collect()
+# (round 5 ran the cyclic collector only between tests to mask an intermittent crash; the cause is gone from the product -- profiles/r06_suite_crash_rootcause.txt --
+#  and so are the fixtures: Python's own collector, as in any user process)
 
 
 @pytest.fixture(scope="session")
