@@ -5,6 +5,7 @@
 // pageable arrays 18.4 -> 19.1 M NTT/s, within noise -- and a loss under a tight CPU quota, where polling threads eat the copy's own cycles;
 // the pool parks at once.)  Tested without a GPU under ThreadSanitizer: tests/cpp/test_copy_pool.cpp (tests/test_copy_pool.py).
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstring>

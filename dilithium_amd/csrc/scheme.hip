@@ -811,8 +811,9 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         // winners (first accepted attempt per item) -> packed straight into their signature slots; c~ rides in the collect kernel
         uint32_t seq = 0;
         if (wake_flag) {
-            seq = (uint32_t)++host_counts[3];
-            if (seq == 0) seq = (uint32_t)++host_counts[3];          // (0 is what a fresh allocation shows)
+            uint32_t* host_seq = reinterpret_cast<uint32_t*>(host_counts + 3);          // the host's own counter (unsigned: wraps, never overflows)
+            seq = ++*host_seq;
+            if (seq == 0) seq = ++*host_seq;                         // (0 is what a fresh allocation shows)
         }
         DIL_TRY(dil::launch_sign_collect_ct(attempts, idx_next, wine, wini, counts, fl, idx_cur, a0, S_, n, sig, sgb, ct, s,
                                             wake_flag ? host_counts : nullptr, seq));
