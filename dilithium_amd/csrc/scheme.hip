@@ -772,7 +772,9 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
     // How a round's pending count reaches the host (option sign_wake): 1 = the collect kernel's last workgroup posts it into mapped host words
     // and the host polls them -- no copy, no event, no wake-up, so the next round's launches are queued while the winners are still being
     // packed; 0 = an 8-byte copy behind the collect kernel + an event (rounds 2 - 5).
-    const bool wake_flag = dil::rt::cfg.sign_wake.load(std::memory_order_relaxed) != 0;
+    const int sign_wake = dil::rt::cfg.sign_wake.load(std::memory_order_relaxed);
+    const bool wake_flag = sign_wake != 0;
+    const bool lose_post = sign_wake == 2;      // tests only: the host waits for a number the kernel never posts -- the stream drains, the counts come by the blocking copy
     struct EventGuard {
         hipEvent_t ev = nullptr;
         ~EventGuard() { if (ev) (void)hipEventDestroy(ev); }
@@ -830,7 +832,7 @@ int sign_core(Device& dv, const dil::Tables& T, StreamScratch& ws, uint8_t* sig,
         DIL_TRY(dil::launch_pack(p.zbits, sig, sgb, 32, z, p.L, dil::XF_OFFSET_MINUS, p.gamma1, n, T, s, win));
         DIL_TRY(dil::launch_hint_pack(sig, sgb, 32 + zb, h, p.K, p.omega, n, s, win));
         if (wake_flag) {
-            if ((rc = await_round_count(host_counts, counts, seq, s))) return rc;
+            if ((rc = await_round_count(host_counts, counts, lose_post ? seq ^ 0x80000000u : seq, s))) return rc;
         } else {
             DIL_TRY(hipEventSynchronize(counted.ev));
         }

@@ -79,7 +79,9 @@ int dil_shutdown(void);
  *   "sign_wake"   (DIL_SIGN_WAKE)   how the pending count of a signing round reaches the host, which sizes the next round from it:
  *                                   1 (default) = the round's last kernel posts it into mapped page-locked words of the library and the
  *                                   calling thread polls them (no copy, no event: the next round is queued while the winners are packed),
- *                                   0 = an 8-byte copy + an event behind that kernel.  Signatures and attempt counts do not depend on it.
+ *                                   0 = an 8-byte copy + an event behind that kernel; 2 (tests only) = as 1, but the host waits for a number
+ *                                   that is never posted: the wait notices the drained stream and fetches the counts by a blocking copy
+ *                                   (the no-hang path).  Signatures and attempt counts do not depend on it.
  *   "zeroize"     (DIL_ZEROIZE)     1 = dil_sign_* / dil_keygen_* clear their device scratch (secret key in NTT
  *                                   form, rho', y, rejected z ...) before returning; 0 (default) = the scratch stays
  *                                   in the per-stream arena until the next call on that stream overwrites it

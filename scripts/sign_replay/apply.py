@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "dilithium_amd", "csrc")
 src = open(os.path.join(CSRC, "scheme.hip")).read()
 
 OLD_SYNC = """        if (wake_flag) {
-            if ((rc = await_round_count(host_counts, counts, seq, s))) return rc;
+            if ((rc = await_round_count(host_counts, counts, lose_post ? seq ^ 0x80000000u : seq, s))) return rc;
         } else {
             DIL_TRY(hipEventSynchronize(counted.ev));
         }

@@ -18,6 +18,7 @@ OPTION_SETS = {
     "a24=0,fuse_keygen=0": {"a24": 0, "fuse_keygen": 0},
     "fuse_sib=0": {"fuse_sib": 0},                       # round 6: SampleInBall as a launch of its own in front of the wire-format verify kernel
     "fuse_sib=3": {"fuse_sib": 3},                       # ... and inside that kernel in dil_verify_sig_dev too
+    "sign_wake=2": {"sign_wake": 2},                     # ... and with the post "lost": the wait sees the drained stream and falls back to a blocking copy (no hang)
     "sign_wake=0": {"sign_wake": 0},                     # round 6: a signing round's count by copy + event instead of the collect kernel's post into mapped words
     "coop_max=0": {"coop_max": 0},                       # round 5: the lane-per-sponge / two-lane Keccak forms everywhere
     "coop_max=2^30,sign_early=0": {"coop_max": 1 << 30, "sign_early": 0},
