@@ -3,10 +3,10 @@
 #   pass 1 (gcc runtime):   oracle/dil_oracle.c, dilithium_amd/csrc/ref_api.cpp      -> the oracle / KAT / drop-in CPU tests
 #   pass 2 (clang runtime): the HOST code of libdil256.so (capi.hip, scheme.hip, multi_gpu.hip ... compiled by hipcc with
 #                           -fsanitize=address,undefined; device code unchanged)     -> the C-ABI / options / sharding CPU tests
-# usage: scripts/san_check.sh [logfile]      (default profiles/r05_sanitizers.txt)
+# usage: scripts/san_check.sh [logfile]      (default profiles/r06_sanitizers.txt)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$ROOT/profiles/r05_sanitizers.txt}
+LOG=${1:-$ROOT/profiles/r06_sanitizers.txt}
 SAN=$ROOT/oracle/_san
 mkdir -p $SAN
 cd $ROOT
